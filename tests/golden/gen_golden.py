@@ -1,0 +1,450 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the REAL reference.
+
+Runs only in the build container (needs /root/reference); the .npz files it
+writes are committed and are the only thing that travels to the GPU box.
+
+The reference targets Python >= 3.11 with gymnasium/PyQt6/pyqtgraph installed;
+this container has Python 3.10 and none of them, so a small import shim
+ provides the typing names and inert stand-ins for the
+GUI / space modules.  No reference arithmetic is replaced: worlds, env, policy,
+memory and agents below are the reference's own classes, driven by
+``oracle.philox.TapeRNG`` so that they consume the build's Philox streams.
+
+    python tests/golden/gen_golden.py            # rewrite every fixture
+"""
+from __future__ import annotations
+
+import importlib.metadata as md
+import os
+import sys
+import types
+import typing
+
+import numpy as np
+import typing_extensions as te
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def load_reference():
+    typing.NotRequired, typing.Self = te.NotRequired, te.Self
+    real = md.distribution
+    md.distribution = (
+        lambda n: types.SimpleNamespace(version='3.0.1') if n == 'cobel' else real(n)
+    )
+    gym, sp = types.ModuleType('gymnasium'), types.ModuleType('gymnasium.spaces')
+
+    class Space:
+        pass
+
+    class Discrete(Space):
+        def __init__(self, n):
+            self.n = np.int64(n)
+
+    class Box(Space):
+        def __init__(self, low, high, shape=None, dtype=np.float64):
+            self.low, self.high = np.asarray(low), np.asarray(high)
+            self.shape = tuple(shape) if shape is not None else self.low.shape
+            self.dtype = dtype
+
+    class Dict(Space, dict):
+        def __init__(self, d=None):
+            dict.__init__(self, d or {})
+            self.spaces = self
+
+    class Tuple(Space):
+        def __init__(self, s):
+            self.spaces = list(s)
+
+    class Env:
+        pass
+
+    for k, v in dict(Space=Space, Discrete=Discrete, Box=Box, Dict=Dict, Tuple=Tuple).items():
+        setattr(sp, k, v)
+    gym.spaces, gym.Space, gym.Env = sp, Space, Env
+    sys.modules.update({'gymnasium': gym, 'gymnasium.spaces': sp})
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return type(k, (), {})
+
+    for name in ['pyqtgraph', 'pyqtgraph.Qt', 'PyQt6', 'PyQt6.QtGui', 'PyQt6.QtCore',
+                 'PyQt6.QtWidgets', 'shapely', 'shapely.ops', 'shapely.affinity', 'cv2']:
+        m = _Any(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.path.insert(0, '/root/reference/src')
+    import cobel  # noqa: F401
+    return cobel
+
+
+load_reference()
+
+from cobel.agent import DynaQ  # noqa: E402
+from cobel.agent.q import QAgent  # noqa: E402
+from cobel.agent.sr import SR  # noqa: E402
+from cobel.analysis.behavior_spatial import get_occupancy_map  # noqa: E402
+from cobel.interface import Gridworld  # noqa: E402
+from cobel.misc import gridworld_tools as gt  # noqa: E402
+from cobel.monitor import EscapeLatencyMonitor  # noqa: E402
+from cobel.policy import EpsilonGreedy  # noqa: E402
+
+from oracle.philox import (STREAM_ENV, STREAM_MEMORY, STREAM_POLICY,  # noqa: E402
+                           TapeRNG)
+
+SEED = 0xC0BE1
+
+
+def compact(world) -> dict:
+    """Compact tables of a reference WorldDict (argmax over the one-hot sas)."""
+    return dict(
+        height=np.int64(world['height']), width=np.int64(world['width']),
+        next=np.argmax(world['sas'], axis=2).astype(np.uint16),
+        reward=np.asarray(world['rewards'], dtype=np.float64),
+        terminal=np.asarray(world['terminals']).astype(np.uint8),
+        starts=np.asarray(world['starting_states']).astype(np.uint16),
+        coordinates=np.asarray(world['coordinates'], dtype=np.float64),
+        invalid_states=np.asarray(sorted(world['invalid_states']), dtype=np.int64),
+    )
+
+
+def walls_8x8():
+    inv_states = [10, 11, 12, 20, 28, 36, 44, 45, 50]
+    inv_trans = [(0, 1), (1, 0), (62, 63), (63, 62), (33, 34)]
+    return gt.make_gridworld(
+        8, 8, terminals=[7, 56], rewards=np.array([[7, 1.0], [56, -0.5], [30, 0.25]]),
+        goals=[7], invalid_states=inv_states, invalid_transitions=inv_trans,
+        starting_states=[63, 32, 3, 27],
+    )
+
+
+def maze_cells(seed: int, h: int = 32, w: int = 32, p: float = 0.20):
+    """SURVEY.md §8d C3 obstacle recipe: wall cells ~ Bernoulli(p), goal 0,
+    redrawn until the goal is reachable from >= 50 % of the free cells."""
+    rng = np.random.default_rng(seed)
+    while True:
+        wall = rng.random(h * w) < p
+        wall[0] = False
+        free = ~wall
+        seen = np.zeros(h * w, dtype=bool)
+        seen[0] = True
+        stack = [0]
+        while stack:
+            s = stack.pop()
+            y, x = divmod(s, w)
+            for ny, nx in ((y, x - 1), (y - 1, x), (y, x + 1), (y + 1, x)):
+                if 0 <= ny < h and 0 <= nx < w:
+                    t = ny * w + nx
+                    if free[t] and not seen[t]:
+                        seen[t] = True
+                        stack.append(t)
+        if seen.sum() >= 0.5 * free.sum():
+            return [int(i) for i in np.flatnonzero(wall)]
+
+
+def gen_worlds():
+    out = {}
+    worlds = {
+        'open_5x5': gt.make_open_field(5, 5, 0, 1),
+        'kat_5x5': gt.make_gridworld(5, 5, [0], np.array([[0, 10.]]), starting_states=[24]),
+        'open_4x7_goal9': gt.make_open_field(4, 7, 9, 2.5),
+        'empty_3x3': gt.make_empty_field(3, 3),
+        'walls_8x8': walls_8x8(),
+        'windy_7x10_up': gt.make_windy_gridworld(
+            7, 10, np.array([0, 0, 0, 1, 1, 1, 2, 2, 1, 0]), 37, 1.0, 'up'),
+        'windy_5x6_down': gt.make_windy_gridworld(
+            5, 6, np.array([0, 1, 2, 1, 0, 3]), 3, 1.0, 'down'),
+        'open_32x32': gt.make_open_field(32, 32, 0, 1),
+    }
+    for seed in (1234, 1235):
+        walls = maze_cells(seed)
+        free_nt = [s for s in range(1024) if s not in set(walls) and s != 0]
+        worlds['maze_32x32_%d' % seed] = gt.make_gridworld(
+            32, 32, terminals=[0], rewards=np.array([[0, 1.0]]), goals=[0],
+            invalid_states=walls, starting_states=free_nt)
+    for name, w in worlds.items():
+        for k, v in compact(w).items():
+            out['%s/%s' % (name, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'worlds.npz'), **out)
+    return worlds
+
+
+def gen_gridworld_kat():
+    """unit_tests/test_gridworld.py:16-41 replayed through the reference."""
+    world = gt.make_gridworld(5, 5, [0], np.array([[0, 10.]]), starting_states=[24])
+    env = Gridworld(world)
+    state, _ = env.reset()
+    actions = [0, 0, 0, 0, 0, 1, 1, 1, 1]
+    states, rewards, terms = [], [], []
+    for a in actions:
+        s, r, t, _, _ = env.step(a)
+        states.append(s), rewards.append(r), terms.append(t)
+    assert states == [23, 22, 21, 20, 20, 15, 10, 5, 0]
+    assert rewards == [0] * 8 + [10.] and terms == [False] * 8 + [True]
+    np.savez_compressed(
+        os.path.join(HERE, 'gridworld_kat.npz'), start=np.int64(state),
+        actions=np.array(actions), states=np.array(states),
+        rewards=np.array(rewards, dtype=np.float64), terminals=np.array(terms),
+        n_obs=np.int64(env.observation_space.n), n_act=np.int64(env.action_space.n))
+
+
+def gen_eps_greedy():
+    """policy/greedy.py:40-88: probabilities and injected-u selections."""
+    rows = []
+    vs = [
+        [0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [0.5, 0.5, 0, 0], [0.1, 0.7, 0.7, 0.2],
+        [-1, -1, -2, -1], [3, 3, 3, 2], [1e-8, 0, 1e-8, 0], [0.25, 0.5, 0.75, 1.0],
+        [-0.5, -0.25, -0.125, -1.0],
+    ]
+    masks = [None, [1, 1, 1, 1], [1, 0, 1, 0], [0, 1, 1, 1], [0, 0, 0, 1], [1, 1, 0, 0]]
+    us = [0.0, 0.024999, 0.025, 0.0250001, 0.05, 0.1, 0.25, 0.3, 0.5, 0.74999, 0.75,
+          0.9, 0.925, 0.95, 0.975, 0.999999999, 1.0 - 2.0 ** -53]
+    for dt in (np.float64, np.float32):
+        for eps in (0.0, 0.1, 0.3, 1.0):
+            pol = EpsilonGreedy(eps, rng=TapeRNG(SEED, 0, STREAM_POLICY))
+            for v in vs:
+                v = np.array(v, dtype=dt)
+                for m in masks:
+                    mm = None if m is None else np.array(m, dtype=bool)
+                    p = pol.get_action_probs(v, mm)
+                    for u in us:
+                        pol.rng.random = lambda u=u: u
+                        a = int(pol.select_action(v, mm))
+                        rows.append((dt == np.float32, eps, *[float(x) for x in v],
+                                     0xF if m is None else sum(b << i for i, b in enumerate(m)),
+                                     u, a, *p))
+    rows = np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'eps_greedy_kat.npz'), rows=rows, columns=np.array(
+        ['is_f32', 'eps', 'v0', 'v1', 'v2', 'v3', 'mask', 'u', 'action', 'p0', 'p1', 'p2', 'p3']))
+
+
+class Tracer:
+    """Collects the per-step experience the reference hands to its callbacks."""
+
+    def __init__(self, agent=None):
+        self.agent = agent
+        self.sarsn, self.td, self.steps, self.trial_reward, self.Q_trial = [], [], [], [], []
+        self.q = []
+
+    def on_step_end(self, logs):
+        first = lambda x: x[0] if isinstance(x, tuple) else x  # QAgent keys states as tuples
+        self.sarsn.append((first(logs['state']), logs['action'], logs['reward'],
+                           first(logs['next_state']), logs['terminal']))
+        td = logs.get('td', 0.0)  # test() logs carry no TD error
+        self.td.append(float(td) if np.ndim(td) == 0 else 0.0)
+
+    def on_trial_end(self, logs):
+        self.steps.append(logs['steps'])
+        self.trial_reward.append(float(logs['trial_reward']))
+        if self.agent is not None and hasattr(self.agent, 'Q') and isinstance(self.agent.Q, np.ndarray):
+            self.Q_trial.append(np.array(self.agent.Q, dtype=np.float64))
+
+    def callbacks(self):
+        return {'on_step_end': [self.on_step_end], 'on_trial_end': [self.on_trial_end]}
+
+    def pack(self) -> dict:
+        a = np.array(self.sarsn, dtype=np.float64).reshape(-1, 5)
+        d = dict(
+            state=a[:, 0].astype(np.int16), action=a[:, 1].astype(np.int8), reward=a[:, 2],
+            next_state=a[:, 3].astype(np.int16), nonterminal=a[:, 4].astype(np.int8),
+            td=np.array(self.td), steps=np.array(self.steps, dtype=np.int32),
+            trial_reward=np.array(self.trial_reward))
+        if self.Q_trial:
+            d['Q_trial'] = np.array(self.Q_trial)
+        return d
+
+
+def _env(world, inst):
+    return Gridworld(world, rng=TapeRNG(SEED, inst, STREAM_ENV))
+
+
+def bump_mask(world):
+    """Action mask that forbids moves which leave the state unchanged."""
+    nxt = np.argmax(world['sas'], axis=2)
+    m = nxt != np.arange(world['states'])[:, None]
+    m[~m.any(axis=1)] = True
+    return m
+
+
+def gen_dynaq(worlds):
+    cases = {
+        # name: (world, instance, f32, trials, steps, B, kwargs)
+        'open5_b32_f64': ('open_5x5', 0, False, 30, 50, 32, {}),
+        'open5_b32_f32': ('open_5x5', 0, True, 30, 50, 32, {}),
+        'open5_b50_f32_i7': ('open_5x5', 7, True, 12, 50, 50, {}),
+        'open5_noreplay_f32': ('open_5x5', 1, True, 40, 50, 32, {'no_replay': True}),
+        'open5_episodic_f32': ('open_5x5', 2, True, 25, 50, 16, {'episodic': True}),
+        'walls8_b8_f64': ('walls_8x8', 3, False, 25, 60, 8, {}),
+        'walls8_b8_f32': ('walls_8x8', 3, True, 25, 60, 8, {}),
+        'walls8_mask_f32': ('walls_8x8', 4, True, 25, 60, 8, {'mask': True}),
+        'walls8_traintest_f32': ('walls_8x8', 5, True, 20, 40, 12, {'test_trials': 10}),
+        'maze32_b50_f32': ('maze_32x32_1234', 6, True, 3, 200, 50, {}),
+    }
+    out = {}
+    for name, (wname, inst, f32, trials, steps, B, kw) in cases.items():
+        world = worlds[wname]
+        env = _env(world, inst)
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        ag = DynaQ(env.observation_space, env.action_space, pol)
+        ag.M.rng = TapeRNG(SEED, inst, STREAM_MEMORY)
+        if f32:
+            ag.Q = ag.Q.astype(np.float32)
+            ag.M.rewards = ag.M.rewards.astype(np.float32)
+        if kw.get('mask'):
+            ag.mask_actions = True
+            ag.action_mask = bump_mask(world)
+        ag.episodic_replay = bool(kw.get('episodic'))
+        tr = Tracer(ag)
+        ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            ag.callbacks.custom_callbacks.setdefault(k, [])
+        ag.train(env, trials, steps, B, bool(kw.get('no_replay')))
+        n_train_steps = len(tr.sarsn)
+        if kw.get('test_trials'):
+            ag.test(env, kw['test_trials'], steps)
+        d = tr.pack()
+        d.update(Q=np.array(ag.Q, dtype=np.float64), M_rewards=np.array(ag.M.rewards, dtype=np.float64),
+                 M_states=ag.M.states.astype(np.int16), M_terminals=ag.M.terminals.astype(np.int8),
+                 cfg=np.array([inst, f32, trials, steps, B, bool(kw.get('no_replay')),
+                               bool(kw.get('episodic')), bool(kw.get('mask')),
+                               kw.get('test_trials', 0), n_train_steps], dtype=np.int64),
+                 alpha=np.float64(ag.learning_rate), gamma=np.float64(ag.gamma),
+                 eps=np.float64(0.1), model_lr=np.float64(ag.M.learning_rate))
+        if kw.get('mask'):
+            d['action_mask'] = ag.action_mask
+        if 'Q_trial' in d and name.startswith('maze32'):
+            del d['Q_trial']
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+        out['%s/world' % name] = np.array(wname)
+    out['cfg_columns'] = np.array(['instance', 'f32', 'trials', 'steps', 'B', 'no_replay',
+                                   'episodic', 'mask', 'test_trials', 'n_train_steps'])
+    np.savez_compressed(os.path.join(HERE, 'dynaq_traces.npz'), **out)
+
+
+def gen_qagent(worlds):
+    cases = {
+        'open5_b0_f32': ('open_5x5', 0, True, 40, 50, 0),
+        'open5_b0_f64': ('open_5x5', 0, False, 40, 50, 0),
+        'open5_b8_f32': ('open_5x5', 1, True, 30, 50, 8),
+        'walls8_b16_f32': ('walls_8x8', 2, True, 20, 60, 16),
+        'walls8_b16_f64': ('walls_8x8', 2, False, 20, 60, 16),
+    }
+    out = {}
+    for name, (wname, inst, f32, trials, steps, B) in cases.items():
+        world = worlds[wname]
+        env = _env(world, inst)
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        ag = QAgent(env.observation_space, env.action_space, pol,
+                    rng=TapeRNG(SEED, inst, STREAM_MEMORY))
+        if f32:  # rows are otherwise created lazily as float64 (q.py:197-204)
+            for s in range(world['states']):
+                ag.Q[(s,)] = np.zeros(4, dtype=np.float32)
+        tr = Tracer(None)
+        ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            ag.callbacks.custom_callbacks.setdefault(k, [])
+        ag.train(env, trials, steps, B)
+        d = tr.pack()
+        Q = np.zeros((world['states'], 4))
+        for (s,), row in ag.Q.items():
+            Q[s] = row
+        d.update(Q=Q, cfg=np.array([inst, f32, trials, steps, B], dtype=np.int64),
+                 alpha=np.float64(ag.learning_rate), gamma=np.float64(ag.gamma), eps=np.float64(0.1),
+                 log_len=np.int64(len(ag.M)))
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+        out['%s/world' % name] = np.array(wname)
+    np.savez_compressed(os.path.join(HERE, 'qagent_traces.npz'), **out)
+
+
+def gen_sr(worlds):
+    cases = {
+        'open5_f64': ('open_5x5', 0, False, 30, 50, False),
+        'open5_f32': ('open_5x5', 0, True, 30, 50, False),
+        'walls8_f32': ('walls_8x8', 1, True, 20, 60, False),
+        'walls8_f64': ('walls_8x8', 1, False, 20, 60, False),
+        'walls8_mask_f32': ('walls_8x8', 2, True, 15, 60, True),
+    }
+    out = {}
+    for name, (wname, inst, f32, trials, steps, mask) in cases.items():
+        world = worlds[wname]
+        env = _env(world, inst)
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        ag = SR(env.observation_space, env.action_space, pol)
+        if f32:
+            ag.SR = ag.SR.astype(np.float32)
+            ag.rewards = ag.rewards.astype(np.float32)
+        if mask:
+            ag.mask_actions = True
+            ag.action_mask = bump_mask(world)
+        tr = Tracer(None)
+        qs = []
+        orig = ag.retrieve_q
+
+        def spy(state, orig=orig, qs=qs):
+            q = orig(state)
+            qs.append(np.asarray(q, dtype=np.float64))
+            return q
+
+        ag.retrieve_q = spy
+        ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            ag.callbacks.custom_callbacks.setdefault(k, [])
+        ag.train(env, trials, steps)
+        d = tr.pack()
+        del d['td']
+        d.update(SR=np.array(ag.SR, dtype=np.float64), rewards=np.array(ag.rewards, dtype=np.float64),
+                 T=np.argmax(ag.transitions, axis=-1).astype(np.int16), q=np.array(qs),
+                 cfg=np.array([inst, f32, trials, steps, mask], dtype=np.int64),
+                 alpha=np.float64(ag.learning_rate), gamma=np.float64(ag.gamma), eps=np.float64(0.1))
+        if mask:
+            d['action_mask'] = ag.action_mask
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+        out['%s/world' % name] = np.array(wname)
+    np.savez_compressed(os.path.join(HERE, 'sr_traces.npz'), **out)
+
+
+def gen_monitor(worlds):
+    """monitor/behavior.py:73-97 and analysis/behavior_spatial.py:9-73."""
+    rng = np.random.default_rng(7)
+    trials, max_steps = 40, 50
+    mon = EscapeLatencyMonitor(trials, max_steps)
+    steps = rng.integers(0, max_steps, trials)
+    order = [t for t in range(trials) if t not in (5, 6, 17)]  # leave NaN gaps
+    for t in order:
+        mon.update({'trial': t, 'steps': int(steps[t])})
+    world = worlds['walls_8x8']
+    traj_states = [rng.integers(0, 64, n) for n in (30, 1, 77)]
+    trajs = [world['coordinates'][s] for s in traj_states]
+    occ = {m: get_occupancy_map(trajs, 8, 8, 1.0, m) for m in ('expand', 'include', 'ignore')}
+    occ2 = get_occupancy_map(trajs, 8, 8, 2.0, 'expand')
+    np.savez_compressed(
+        os.path.join(HERE, 'monitor_kat.npz'), steps=steps, order=np.array(order),
+        latency=mon.latency_trace, latency_avg=mon.latency_trace_avg, max_steps=np.int64(max_steps),
+        traj_states=np.concatenate(traj_states), traj_len=np.array([30, 1, 77]),
+        occ_expand=occ['expand'], occ_include=occ['include'], occ_ignore=occ['ignore'],
+        occ_bin2=occ2)
+
+
+def main():
+    worlds = gen_worlds()
+    gen_gridworld_kat()
+    gen_eps_greedy()
+    gen_dynaq(worlds)
+    gen_qagent(worlds)
+    gen_sr(worlds)
+    gen_monitor(worlds)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print('%-24s %8d B' % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == '__main__':
+    main()
