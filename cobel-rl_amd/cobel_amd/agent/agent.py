@@ -1,0 +1,286 @@
+"""Agent base class, callbacks and the per-instance device state shared by all fused agents.
+
+Surface of the reference's ``cobel.agent.agent`` (agent/agent.py:19-243): ``Agent.train /
+test / predict_on_batch``, attributes ``current_trial``, ``stop``, ``callbacks``; ``Callbacks``
+with the four hooks, each shallow-copying ``logs``, adding ``logs['agent']`` and merging dicts
+returned by user callbacks.
+
+Device hooks cannot call Python, so host callbacks fire at launch boundaries:
+  * ``n_envs == 1`` and step callbacks registered  -> one launch per env step
+    (``step_budget = 1``), logs identical in keys to the reference's;
+  * ``n_envs == 1`` otherwise                      -> one launch per trial;
+  * ``n_envs > 1``                                 -> one launch per ``train()`` call; monitors are
+    reduced on device and ``on_trial_end`` then fires once per trial index with the mean
+    ``steps`` / ``trial_reward`` over instances (and ``'count'`` = instances that ran it).
+"""
+from __future__ import annotations
+
+import abc
+import copy
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class Callbacks:
+    def __init__(self, agent, custom_callbacks=None) -> None:
+        self.agent = agent
+        self.custom_callbacks = {} if custom_callbacks is None else custom_callbacks
+
+    def _fire(self, name: str, logs: dict) -> dict:
+        out = copy.copy(logs)
+        out['agent'] = self.agent
+        for cb in self.custom_callbacks.get(name, []):
+            ret = cb(out)
+            if type(ret) is dict:
+                out.update(ret)
+        return out
+
+    def on_step_begin(self, logs: dict) -> dict:
+        return self._fire('on_step_begin', logs)
+
+    def on_step_end(self, logs: dict) -> dict:
+        return self._fire('on_step_end', logs)
+
+    def on_trial_begin(self, logs: dict) -> dict:
+        return self._fire('on_trial_begin', logs)
+
+    def on_trial_end(self, logs: dict) -> dict:
+        return self._fire('on_trial_end', logs)
+
+    def has(self, *names: str) -> bool:
+        return any(len(self.custom_callbacks.get(n, [])) > 0 for n in names)
+
+
+class Agent(abc.ABC):
+    def __init__(self, observation_space, action_space, custom_callbacks=None) -> None:
+        self.observation_space = observation_space
+        self.action_space = action_space
+        self.callbacks = Callbacks(self, custom_callbacks)
+        self.current_trial = 0
+        self.stop = False
+
+    @abc.abstractmethod
+    def train(self, interface, trials: int, steps: int) -> None:
+        ...
+
+    @abc.abstractmethod
+    def test(self, interface, trials: int, steps: int) -> None:
+        ...
+
+    @abc.abstractmethod
+    def predict_on_batch(self, batch):
+        ...
+
+
+class DeviceMonitors:
+    """Per-trial reductions written by the kernels: escape latency (``logs['steps']``,
+    monitor/behavior.py:82), trial reward, and per-state visit counts."""
+
+    def __init__(self, device, n_worlds: int, n_states: int, occupancy: bool = False) -> None:
+        self.device = device
+        self.cap = 0
+        self.lat_sum = self.lat_cnt = self.reward_sum = None
+        self.occupancy = (torch.zeros((n_worlds, n_states), dtype=torch.int64, device=device)
+                          if occupancy else None)
+        self.steps_done = torch.zeros(1, dtype=torch.int64, device=device)
+        self.lat_trace = None
+
+    def reserve(self, trials: int, n_envs: int = 0, per_instance: bool = False) -> None:
+        if trials > self.cap:
+            def grow(t, dtype):
+                new = torch.zeros(trials, dtype=dtype, device=self.device)
+                if t is not None:
+                    new[: t.numel()] = t
+                return new
+            self.lat_sum = grow(self.lat_sum, torch.int64)
+            self.lat_cnt = grow(self.lat_cnt, torch.int64)
+            self.reward_sum = grow(self.reward_sum, torch.float64)
+            if per_instance or self.lat_trace is not None:
+                new = torch.full((n_envs, trials), -1, dtype=torch.int32, device=self.device)
+                if self.lat_trace is not None:
+                    new[:, : self.lat_trace.shape[1]] = self.lat_trace
+                self.lat_trace = new
+            self.cap = trials
+        elif per_instance and self.lat_trace is None:
+            self.lat_trace = torch.full((n_envs, self.cap), -1, dtype=torch.int32,
+                                        device=self.device)
+
+    def all_reduce(self) -> None:
+        """Sum the monitor buffers over all ranks (the only collective of the path; RCCL)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        bufs = [b for b in (self.lat_sum, self.lat_cnt, self.occupancy, self.steps_done)
+                if b is not None]
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.all_reduce(flat)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off: off + b.numel()].reshape(b.shape))
+            off += b.numel()
+        if self.reward_sum is not None:
+            dist.all_reduce(self.reward_sum)
+
+    def mean_latency(self) -> np.ndarray:
+        s, c = self.lat_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return np.where(c > 0, s / np.maximum(c, 1), np.nan)
+
+    def mean_reward(self) -> np.ndarray:
+        s, c = self.reward_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return np.where(c > 0, s / np.maximum(c, 1), np.nan)
+
+
+class FusedAgent(Agent):
+    """Plumbing common to the agents whose whole loop runs in one kernel."""
+
+    def __init__(self, observation_space, action_space, policy, policy_test, custom_callbacks):
+        super().__init__(observation_space, action_space, custom_callbacks)
+        self.policy = policy
+        self.policy_test = policy if policy_test is None else policy_test
+        self.n_states = int(observation_space.n)
+        self.n_actions = int(action_space.n)
+        assert self.n_actions == 4, 'the fused kernels cover 4-action worlds'
+        self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
+        self.mask_actions = False
+        self.track_occupancy = False
+        self.track_instances = False   # keep per-instance latency traces [N, trials]
+        self.device = None
+        self.n_envs = None
+        self.inst = None
+        self.monitors = None
+        self._last_exp = None
+
+    # -- device state -------------------------------------------------------------------------
+    def _bind(self, interface) -> None:
+        """Allocate per-instance state on first contact with an environment."""
+        if self.inst is not None:
+            assert interface.n_envs == self.n_envs and interface.device == self.device, \
+                'an agent stays bound to the instance count / device it first trained on'
+            return
+        self.n_envs, self.device = interface.n_envs, interface.device
+        assert int(interface.observation_space.n) == self.n_states
+        self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)
+        self.monitors = DeviceMonitors(self.device, interface.handle.n_worlds, self.n_states,
+                                       self.track_occupancy)
+        self._last_exp = torch.zeros((self.n_envs, 6), dtype=torch.int32, device=self.device)
+        self._alloc_tables()
+
+    @abc.abstractmethod
+    def _alloc_tables(self) -> None:
+        ...
+
+    @abc.abstractmethod
+    def _launch(self, interface, pol, flags: int, trials_target: int, steps: int, budget: int,
+                batch: int) -> None:
+        ...
+
+    def _mask_bits(self):
+        m = np.asarray(self.action_mask, dtype=bool).reshape(self.n_states, 4)
+        assert m.any(axis=1).all(), 'The action mask masks all actions!'
+        bits = (m * np.array([1, 2, 4, 8])).sum(axis=1).astype(np.uint8)
+        return torch.as_tensor(bits, device=self.device)
+
+    def _policy_in(self, pol, interface, test: bool) -> int:
+        """Adopt the policy's stream + counter for a run; returns extra flags."""
+        if pol.seed is None:
+            pol.seed = interface.seed
+        assert pol.seed == interface.seed, \
+            'all streams of an instance derive from the environment seed'
+        if pol.stream is None:
+            pol.stream = (_lib.STREAM_POLICY_TEST if (test and pol is not self.policy)
+                          else _lib.STREAM_POLICY)
+        if pol.counter is None or pol.counter.numel() != self.n_envs:
+            pol.counter = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        self.inst[:, _lib.I_CTR_POLICY] = pol.counter
+        return _lib.F_TEST_STREAM if pol.stream == _lib.STREAM_POLICY_TEST else 0
+
+    def _policy_out(self, pol) -> None:
+        pol.counter.copy_(self.inst[:, _lib.I_CTR_POLICY])
+
+    def _env_in(self, interface) -> None:
+        self.inst[:, _lib.I_STATE] = interface.state
+        self.inst[:, _lib.I_CTR_ENV] = interface.env_ctr
+        self.inst[:, _lib.I_FLAGS] = 0
+        self.inst[:, _lib.I_STEP] = 0
+        self.inst[:, _lib.I_TRIAL] = self.current_trial
+
+    def _env_out(self, interface) -> None:
+        interface.state.copy_(self.inst[:, _lib.I_STATE])
+        interface.env_ctr.copy_(self.inst[:, _lib.I_CTR_ENV])
+
+    def _trial_reward(self) -> np.ndarray:
+        return self.inst[:, _lib.I_REWARD_LO:_lib.I_REWARD_HI + 1].contiguous().view(
+            torch.float64).reshape(-1).cpu().numpy()
+
+    def env_steps(self) -> int:
+        """Env steps executed by this agent's kernels so far (this rank)."""
+        return int(self.monitors.steps_done.item()) if self.monitors is not None else 0
+
+    # -- the shared trial driver ----------------------------------------------------------------
+    def _session(self, interface, trials: int, steps: int, batch: int, learn: bool,
+                 extra_flags: int = 0) -> None:
+        self._bind(interface)
+        pol = self.policy if learn else self.policy_test
+        flags = extra_flags | (_lib.F_LEARN if learn else 0)
+        if self.mask_actions:
+            flags |= _lib.F_MASK_ACTIONS
+        self._env_in(interface)
+        flags |= self._policy_in(pol, interface, not learn)
+        first = self.current_trial
+        self.monitors.reserve(first + trials, self.n_envs, self.track_instances)
+        per_step = self.n_envs == 1 and self.callbacks.has('on_step_begin', 'on_step_end')
+        per_trial = self.n_envs == 1 and (per_step or self.callbacks.has('on_trial_begin',
+                                                                         'on_trial_end'))
+        if not per_trial:
+            for t in range(trials):
+                self.callbacks.on_trial_begin({'trial_reward': 0.0, 'trial': first + t,
+                                               'trial_session': t})
+            self._launch(interface, pol, flags, first + trials, steps, 0, batch)
+            self.current_trial = first + trials
+            if self.callbacks.has('on_trial_end'):
+                lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()
+                cnt = self.monitors.lat_cnt.cpu().numpy()
+                for t in range(trials):
+                    self.callbacks.on_trial_end({
+                        'trial_reward': float(rew[first + t]), 'trial': first + t,
+                        'trial_session': t, 'steps': float(lat[first + t]),
+                        'count': int(cnt[first + t])})
+        else:
+            for t in range(trials):
+                logs = self.callbacks.on_trial_begin({'trial_reward': 0.0,
+                                                      'trial': self.current_trial,
+                                                      'trial_session': t})
+                target = self.current_trial + 1
+                if per_step:
+                    step = 0
+                    while int(self.inst[0, _lib.I_TRIAL].item()) < target:
+                        logs['step'] = step
+                        logs = self.callbacks.on_step_begin(logs)
+                        self._launch(interface, pol, flags, target, steps, 1, batch)
+                        e = self._last_exp[0].cpu().numpy()
+                        r = float(e[4:5].view(np.float32)[0])
+                        logs['trial_reward'] += r
+                        logs.update({'state': int(e[0]), 'action': int(e[1]), 'reward': r,
+                                     'next_state': int(e[2]), 'terminal': int(e[3])})
+                        if learn:
+                            logs['td'] = float(e[5:6].view(np.float32)[0])
+                        logs = self.callbacks.on_step_end(logs)
+                        step += 1
+                    logs['steps'] = step - 1
+                else:
+                    self._launch(interface, pol, flags, target, steps, 0, batch)
+                    lat = self.monitors.lat_sum[self.current_trial].item()
+                    logs['steps'] = int(lat)
+                    logs['trial_reward'] = float(
+                        self.monitors.reward_sum[self.current_trial].item())
+                self.current_trial += 1
+                logs = self.callbacks.on_trial_end(logs)
+                if self.stop:
+                    break
+        self._policy_out(pol)
+        self._env_out(interface)

@@ -1,0 +1,52 @@
+"""Tabular Dyna-Q — ``cobel.agent.DynaQ`` (agent/dyna_q.py:17-330) on the fused HIP kernel.
+
+Same constructor, ``train(interface, trials, steps, batch_size=32, no_replay=False)``,
+``test``, ``predict_on_batch`` and attributes (``Q``, ``M``, ``learning_rate``, ``gamma``,
+``action_mask``, ``mask_actions``, ``episodic_replay``, ``current_trial``, ``stop``).  Tables are
+float32; see include/cobel_hip.h for the exact arithmetic (bit-exact against the reference run
+with float32 tables).  ``batch_size`` is limited to 62 (one wavefront plans one batch).
+"""
+from __future__ import annotations
+
+from .. import _lib
+from ..memory.dyna_q import DynaQMemory
+from ..spaces import Discrete
+from .tabular import TabularAgent
+
+
+class DynaQ(TabularAgent):
+    agent_kind = _lib.AGENT_DYNAQ
+
+    def __init__(self, observation_space, action_space, policy, policy_test=None,
+                 learning_rate: float = 0.99, gamma: float = 0.99, memory=None,
+                 custom_callbacks=None) -> None:
+        assert type(observation_space) is Discrete, 'DynaQ requires a discrete observation space!'
+        assert type(action_space) is Discrete, 'DynaQ requires a discrete action space!'
+        super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
+                         gamma, custom_callbacks)
+        self.M = DynaQMemory(self.n_states, self.n_actions) if memory is None else memory
+        self.episodic_replay = False
+
+    def _alloc_tables(self) -> None:
+        super()._alloc_tables()
+        self.M._bind(self.n_envs, self.device)
+
+    def _extra(self, run) -> None:
+        run.model = _lib.ptr(self.M.table)
+        run.model_lr = float(self.M.learning_rate)
+        self.inst[:, _lib.I_CTR_MEMORY] = self.M.counter
+
+    def _launch(self, *args) -> None:
+        super()._launch(*args)
+        self.M.counter.copy_(self.inst[:, _lib.I_CTR_MEMORY])
+
+    def train(self, interface, trials: int, steps: int, batch_size: int = 32,
+              no_replay: bool = False) -> None:
+        assert 0 <= batch_size <= _lib.MAX_BATCH, \
+            'batch_size above %d is not supported by the planning kernel' % _lib.MAX_BATCH
+        extra = (_lib.F_NO_REPLAY if no_replay else 0) | \
+                (_lib.F_EPISODIC if self.episodic_replay else 0)
+        self._session(interface, trials, steps, batch_size, True, extra)
+
+    def test(self, interface, trials: int, steps: int) -> None:
+        self._session(interface, trials, steps, 0, False)

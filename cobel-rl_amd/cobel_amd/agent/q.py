@@ -1,0 +1,68 @@
+"""Tabular Q-learning with experience replay — ``cobel.agent.QAgent`` (agent/q.py:26-354).
+
+Discrete observations only (the gridworld case): the reference's lazily created dict rows are a
+dense zero table here.  The replay memory is the per-instance log of experienced transitions
+(q.py:143,213), kept on device; its capacity must be announced with ``reserve_replay`` (or is
+sized from the first ``train`` call).  ``batch_size=0`` disables replay (demo/topology/demo.py:76).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from ..spaces import Discrete
+from .tabular import TabularAgent
+
+
+class QAgent(TabularAgent):
+    agent_kind = _lib.AGENT_Q
+
+    def __init__(self, observation_space, action_space, policy, policy_test=None,
+                 learning_rate: float = 0.9, gamma: float = 0.8, custom_callbacks=None,
+                 rng=None) -> None:
+        assert type(observation_space) is Discrete, 'only Discrete observations are accelerated'
+        assert type(action_space) is Discrete, 'Wrong action space!'
+        super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
+                         gamma, custom_callbacks)
+        self.rng = rng
+        self.nb_actions = self.n_actions
+        self._log = None
+        self._log_cap = 0
+
+    def reserve_replay(self, entries: int) -> None:
+        """Make room for ``entries`` logged experiences per instance (8 B each)."""
+        if entries <= self._log_cap:
+            return
+        new = torch.zeros((self.n_envs, entries), dtype=torch.int64, device=self.device)
+        if self._log is not None:
+            new[:, : self._log_cap] = self._log
+        self._log, self._log_cap = new, entries
+
+    @property
+    def M(self):
+        """Logged experiences of instance 0 as ``(state, action, reward, next_state, terminal)``."""
+        if self._log is None:
+            return []
+        n = int(self.inst[0, _lib.I_LOG_LEN].item())
+        raw = self._log[0, :n].cpu().numpy()
+        lo = (raw & 0xFFFFFFFF).astype('uint32').view('float32')
+        hi = (raw >> 32) & 0xFFFFFFFF
+        return [{'state': (int(h & 0x3FFF),), 'action': int((h >> 28) & 3), 'reward': float(r),
+                 'next_state': (int((h >> 14) & 0x3FFF),), 'terminal': int((h >> 30) & 1)}
+                for r, h in zip(lo, hi)]
+
+    def _extra(self, run) -> None:
+        run.replay_log = _lib.ptr(self._log)
+        run.log_cap = self._log_cap
+
+    def train(self, interface, trials: int, steps: int = 32, batch_size: int = 32) -> None:
+        assert 0 <= batch_size <= _lib.MAX_BATCH, \
+            'batch_size above %d is not supported by the replay kernel' % _lib.MAX_BATCH
+        self._bind(interface)
+        if batch_size > 0:
+            used = int(self.inst[:, _lib.I_LOG_LEN].max().item())
+            self.reserve_replay(used + trials * steps)
+        self._session(interface, trials, steps, batch_size, True)
+
+    def test(self, interface, trials: int, steps: int = 32) -> None:
+        self._session(interface, trials, steps, 0, False)

@@ -1,0 +1,89 @@
+"""Shared implementation of the two tabular TD agents on ``cobel_tab_run``."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .agent import FusedAgent
+
+
+class TabularAgent(FusedAgent):
+    """Q table [N, S, 4] float32 on device + launch plumbing for ``cobel_tab_run``."""
+
+    agent_kind = _lib.AGENT_Q
+
+    def __init__(self, observation_space, action_space, policy, policy_test, learning_rate,
+                 gamma, custom_callbacks) -> None:
+        super().__init__(observation_space, action_space, policy, policy_test, custom_callbacks)
+        self.learning_rate = learning_rate
+        self.gamma = gamma
+        self._q = None
+        self._q_host = np.zeros((self.n_states, self.n_actions), dtype=np.float32)
+
+    # -- tables -----------------------------------------------------------------------------
+    def _alloc_tables(self) -> None:
+        lds, per_block = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().cobel_tab_query(self.n_states, self.agent_kind, 0, C.byref(lds),
+                                              C.byref(per_block)))
+        self._q = torch.zeros((self.n_envs, self.n_states, 4), dtype=torch.float32,
+                              device=self.device)
+        self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
+
+    @property
+    def Q(self):
+        """``(S, 4)`` float32 NumPy snapshot for one instance (the reference's ``agent.Q``), the
+        device tensor ``[N, S, 4]`` when vectorised.  Assigning broadcasts to all instances."""
+        if self._q is None:
+            return self._q_host
+        return self._q[0].cpu().numpy() if self.n_envs == 1 else self._q
+
+    @Q.setter
+    def Q(self, value) -> None:
+        if self._q is None:
+            self._q_host = np.array(value, dtype=np.float32).reshape(self.n_states, 4)
+        else:
+            v = torch.as_tensor(np.asarray(value, dtype=np.float32) if not torch.is_tensor(value)
+                                else value, device=self.device).to(torch.float32)
+            self._q.copy_(v.expand_as(self._q) if v.dim() == 2 else v)
+
+    def predict_on_batch(self, batch):
+        """Q-values of a batch of observations, ``[len(batch), 4]`` (dyna_q.py:303-317)."""
+        idx = np.array(batch).astype(int)
+        if self._q is None:
+            return self._q_host[idx]
+        if self.n_envs == 1:
+            return self._q[0][torch.as_tensor(idx, device=self.device)].cpu().numpy()
+        return self._q[:, torch.as_tensor(idx, device=self.device)]
+
+    # -- launch -----------------------------------------------------------------------------
+    def _extra(self, run: _lib.TabRun) -> None:
+        pass
+
+    def _launch(self, interface, pol, flags, trials_target, steps, budget, batch) -> None:
+        mon = self.monitors
+        run = _lib.TabRun()
+        run.q = _lib.ptr(self._q)
+        run.inst = _lib.ptr(self.inst)
+        self._mask_dev = self._mask_bits() if (flags & _lib.F_MASK_ACTIONS) else None
+        run.action_mask = _lib.ptr(self._mask_dev)
+        run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
+        run.reward_sum = _lib.ptr(mon.reward_sum)
+        run.lat_trace = _lib.ptr(mon.lat_trace)
+        run.occupancy = _lib.ptr(mon.occupancy)
+        run.steps_done = _lib.ptr(mon.steps_done)
+        run.last_exp = _lib.ptr(self._last_exp)
+        run.n, run.trial_cap = self.n_envs, mon.cap
+        run.instance_base = interface.instance_base
+        run.agent, run.flags = self.agent_kind, flags
+        run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
+        run.batch = batch
+        run.alpha, run.gamma = float(self.learning_rate), float(self.gamma)
+        run.epsilon = float(pol.epsilon)
+        run.model_lr = 0.9
+        run.seed = interface.seed
+        self._extra(run)
+        _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
+                                            _lib.current_stream(self.device)))

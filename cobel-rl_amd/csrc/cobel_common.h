@@ -1,0 +1,58 @@
+// Internal declarations shared by the translation units of libcobel_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cobel_hip.h"
+#include "cobel_rng.h"
+
+// World record, one per state, 16 B so that a single dwordx4 load returns everything the
+// loop needs about a state: where each action leads, and what entering the state pays.
+struct __attribute__((aligned(16))) cobel_wrec {
+  uint16_t next[4];
+  float reward;
+  uint32_t terminal;  // 0 / 1
+};
+static_assert(sizeof(cobel_wrec) == 16, "world record must be 16 bytes");
+
+struct cobel_world {
+  int32_t n_states, n_worlds, device;
+  cobel_wrec* rec;       // [dev] [n_worlds][S]
+  uint16_t* starts;      // [dev] concatenated
+  int32_t* start_off;    // [dev] [n_worlds + 1]
+  int32_t* h_start_off;  // [host] copy for argument checks
+};
+
+int cobel_fail(int code, const char* fmt, ...);
+
+#define COBEL_HIP_TRY(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return cobel_fail(COBEL_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+  } while (0)
+
+#define COBEL_REQUIRE(cond, code, ...) \
+  do {                                 \
+    if (!(cond)) return cobel_fail(code, __VA_ARGS__); \
+  } while (0)
+
+// Packed 8-byte records.
+//   model entry  : lo = f32 reward estimate, hi = next_state | nonterminal << 16
+//   replay entry : lo = f32 reward,          hi = state | next_state << 14 | action << 28 | nonterminal << 30
+__host__ __device__ __forceinline__ uint64_t cobel_model_pack(float r, uint32_t ns, uint32_t nt) {
+  return (uint64_t)__builtin_bit_cast(uint32_t, r) | ((uint64_t)(ns | (nt << 16)) << 32);
+}
+__host__ __device__ __forceinline__ uint64_t cobel_log_pack(float r, uint32_t s, uint32_t a,
+                                                            uint32_t ns, uint32_t nt) {
+  return (uint64_t)__builtin_bit_cast(uint32_t, r) |
+         ((uint64_t)(s | (ns << 14) | (a << 28) | (nt << 30)) << 32);
+}
+
+// Device-side view of the epsilon-greedy CDF table (cobel_policy_table), passed by value.
+struct cobel_cdf_table {
+  double cdf[16][16][4];
+};

@@ -1,0 +1,95 @@
+// Epsilon-greedy action selection, restating policy/greedy.py:40-88 of the reference plus the
+// numpy Generator.choice draw it ends in:
+//     probs[allowed] = eps / n_allowed
+//     probs[allowed] += (1 - eps) * ties / n_ties        ties = (max(v[allowed]) == v[allowed])
+//     action = searchsorted(cumsum(probs) / cumsum(probs)[-1], u, side='right')
+// The probabilities are float64 whatever the table dtype; ties are detected with exact equality
+// in the table dtype (float32 here).  eps / n and (1 - eps) / n_ties are formed on the host in
+// float64 (cobel_eps_consts) so the device only adds, divides (IEEE, correctly rounded) and
+// compares.
+#pragma once
+#include <stdint.h>
+
+struct cobel_eps_consts {
+  double base[5];  // base[n]  = eps / n                 n = 1..4
+  double bonus[5]; // bonus[t] = ((1 - eps) * 1.0) / t   t = 1..4
+};
+
+// Constant lookup written as selects: a runtime index into a by-value kernel argument would send
+// the struct to scratch memory.
+#if defined(__HIPCC__)
+__device__ __forceinline__ double cobel_pick(const double* t, int n) {
+  return n <= 1 ? t[1] : (n == 2 ? t[2] : (n == 3 ? t[3] : t[4]));
+}
+#endif
+
+static inline cobel_eps_consts cobel_make_eps_consts(double eps) {
+  cobel_eps_consts c;
+  c.base[0] = c.bonus[0] = 0.0;
+  for (int n = 1; n <= 4; ++n) {
+    c.base[n] = eps / (double)n;
+    c.bonus[n] = ((1.0 - eps) * 1.0) / (double)n;
+  }
+  return c;
+}
+
+#if defined(__HIPCC__)
+// All arguments wave-uniform or per-lane alike; every lane returns the same answer it would get
+// alone.  mask: 4-bit set of allowed actions (non-zero).  probs (optional): 4 doubles out.
+__device__ __forceinline__ int cobel_eps_greedy_select(float v0, float v1, float v2, float v3,
+                                                       uint32_t mask, double u,
+                                                       const cobel_eps_consts& k,
+                                                       double* probs = nullptr) {
+  const float ninf = -__builtin_huge_valf();
+  const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
+  float m = ninf;
+  m = a0 ? fmaxf(m, v0) : m;
+  m = a1 ? fmaxf(m, v1) : m;
+  m = a2 ? fmaxf(m, v2) : m;
+  m = a3 ? fmaxf(m, v3) : m;
+  const bool t0 = a0 && v0 == m, t1 = a1 && v1 == m, t2 = a2 && v2 == m, t3 = a3 && v3 == m;
+  const int n = __popc(mask & 15u);
+  const int nt = (int)t0 + (int)t1 + (int)t2 + (int)t3;
+  const double base = cobel_pick(k.base, n), bonus = cobel_pick(k.bonus, nt);
+  const double p0 = a0 ? base + (t0 ? bonus : 0.0) : 0.0;
+  const double p1 = a1 ? base + (t1 ? bonus : 0.0) : 0.0;
+  const double p2 = a2 ? base + (t2 ? bonus : 0.0) : 0.0;
+  const double p3 = a3 ? base + (t3 ? bonus : 0.0) : 0.0;
+  if (probs) {
+    probs[0] = p0;
+    probs[1] = p1;
+    probs[2] = p2;
+    probs[3] = p3;
+  }
+  const double c0 = p0, c1 = c0 + p1, c2 = c1 + p2, c3 = c2 + p3;
+  // c3 / c3 == 1 > u always, so at most three thresholds can be passed.
+  return (int)(c0 / c3 <= u) + (int)(c1 / c3 <= u) + (int)(c2 / c3 <= u);
+}
+
+// Same selection when the whole wave holds identical arguments: lanes 0..2 each take one of the
+// three float64 divisions, a ballot counts the thresholds passed.  Returns a wave-uniform value.
+__device__ __forceinline__ int cobel_eps_greedy_select_wave(float v0, float v1, float v2,
+                                                            float v3, uint32_t mask, double u,
+                                                            const cobel_eps_consts& k,
+                                                            int lane) {
+  const float ninf = -__builtin_huge_valf();
+  const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
+  float m = ninf;
+  m = a0 ? fmaxf(m, v0) : m;
+  m = a1 ? fmaxf(m, v1) : m;
+  m = a2 ? fmaxf(m, v2) : m;
+  m = a3 ? fmaxf(m, v3) : m;
+  const bool t0 = a0 && v0 == m, t1 = a1 && v1 == m, t2 = a2 && v2 == m, t3 = a3 && v3 == m;
+  const int n = __popc(mask & 15u);
+  const int nt = (int)t0 + (int)t1 + (int)t2 + (int)t3;
+  const double base = cobel_pick(k.base, n), bonus = cobel_pick(k.bonus, nt);
+  const double p0 = a0 ? base + (t0 ? bonus : 0.0) : 0.0;
+  const double p1 = a1 ? base + (t1 ? bonus : 0.0) : 0.0;
+  const double p2 = a2 ? base + (t2 ? bonus : 0.0) : 0.0;
+  const double p3 = a3 ? base + (t3 ? bonus : 0.0) : 0.0;
+  const double c0 = p0, c1 = c0 + p1, c2 = c1 + p2, c3 = c2 + p3;
+  const double mine = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+  const bool pass = lane < 3 && (mine / c3 <= u);
+  return __popcll(__ballot(pass));
+}
+#endif

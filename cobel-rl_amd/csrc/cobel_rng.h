@@ -1,0 +1,52 @@
+// Counter-based random streams shared by every kernel (and the host-side tests).
+// Philox-4x32-10 (Salmon et al., SC'11).  Layout, also restated in oracle/philox.py:
+//   key = (seed lo, seed hi)   ctr = (index, sub, instance, stream)
+// A draw is a pure function of (seed, global instance id, stream, index, sub): results do not
+// depend on how instances are sharded over GPUs or chunked over launches.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define COBEL_HD __host__ __device__ __forceinline__
+#else
+#define COBEL_HD static inline
+#endif
+
+struct cobel_u4 {
+  uint32_t x, y, z, w;
+};
+
+COBEL_HD uint32_t cobel_mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+COBEL_HD cobel_u4 cobel_philox(uint32_t index, uint32_t sub, uint32_t instance, uint32_t stream,
+                               uint64_t seed) {
+  uint32_t c0 = index, c1 = sub, c2 = instance, c3 = stream;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = cobel_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = cobel_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  cobel_u4 o = {c0, c1, c2, c3};
+  return o;
+}
+
+// k in [0, n): Lemire multiply-shift without rejection (bias <= n / 2^32).
+COBEL_HD uint32_t cobel_bounded(uint32_t x, uint32_t n) { return cobel_mulhi32(x, n); }
+
+// 53-bit double in [0, 1) from two words, NumPy's recipe.
+COBEL_HD double cobel_u01(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}

@@ -1,0 +1,548 @@
+// Successor-representation agent — one 256-thread workgroup per agent–env instance (gfx950).
+//
+// The SR matrix (S x S float32, 4 MiB at 32x32) stays in HBM; a step streams whole rows:
+//   * wave a (a = 0..3) loads row T[s][a] with coalesced 16-byte loads into LDS and reduces
+//     V_a = sum_k SR[T[s][a]][k] * R[k].  The reduction reproduces NumPy's pairwise summation
+//     (np.sum(SR * rewards, axis=1), sr.py:302) exactly: per-element float32 products, leaves of
+//     <= 128 elements with 8 strided accumulators (8 lanes per leaf), then the halving tree — so
+//     the epsilon-greedy tie pattern matches the reference bit for bit for any reward layout;
+//   * the rows needed by the TD update (SR[s], SR[ns]) are taken from those four LDS copies when
+//     T[s][.] already points at them (always, once (s, a) has been visited) and fetched only
+//     otherwise; the updated row is written back with coalesced 16-byte stores;
+//   * the reward estimate R (4 B per state) and the agent's transition table T (8 B per state)
+//     live in LDS for the whole call and are written through to HBM as they change.
+//
+// Reference behaviour restated (paths relative to /root/reference/src/cobel):
+//   agent/sr.py:155-197 (train loop), :267-284 (update), :302-308 (retrieve_q)
+// Row TD error in float64, one rounding on store (np.eye is float64, sr.py:276-284); the
+// gamma * SR[ns] product is float32 (weak Python scalar times a float32 row), gamma * e_ns is
+// float64; the reward estimate is updated in float32.
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+namespace {
+
+constexpr int kMaxLeaves = 64;
+constexpr int kRows = 6;  // four value rows + two spare rows for the update
+
+struct sr_args {
+  const cobel_wrec* rec;
+  const uint16_t* starts;
+  const int32_t* start_off;
+  int32_t S, n_worlds;
+  cobel_sr_run_t r;
+  cobel_eps_consts eps;
+  float alpha_f, gamma_f;
+};
+
+// Padded LDS position of row element e: 8 floats of padding per 128 keep the four leaves a
+// half-wave reads at once on different banks.
+__device__ __forceinline__ int phys(int e) { return e + ((e >> 7) << 3); }
+__host__ __device__ __forceinline__ int padded(int S) {
+  return (S + (((S + 127) >> 7) << 3) + 3) & ~3;
+}
+
+struct sr_plan {
+  uint16_t leaf_start[kMaxLeaves];
+  uint8_t leaf_len[kMaxLeaves];
+  uint8_t op_dst[kMaxLeaves], op_src[kMaxLeaves];
+  int n_leaves, n_ops;
+};
+
+// NumPy pairwise_sum recursion (n <= 128: leaf; else split at n/2 rounded down to a multiple
+// of 8), flattened: leaves in address order plus the post-order list of "dst += src" combines.
+__device__ void build_plan(sr_plan* p, int S, int* stack /* 64 ints of LDS scratch */) {
+  int* const st_start = stack;
+  int* const st_n = stack + 16;
+  int* const st_phase = stack + 32;
+  int* const st_left = stack + 48;
+  int top = 0, nl = 0, no = 0, ret = 0;
+  st_start[0] = 0;
+  st_n[0] = S;
+  st_phase[0] = 0;
+  st_left[0] = 0;
+  while (top >= 0) {
+    const int start = st_start[top], n = st_n[top];
+    if (n <= 128) {
+      p->leaf_start[nl] = (uint16_t)start;
+      p->leaf_len[nl] = (uint8_t)n;
+      ret = nl++;
+      --top;
+      continue;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    if (st_phase[top] == 0) {
+      st_phase[top] = 1;
+      ++top;
+      st_start[top] = start;
+      st_n[top] = n2;
+      st_phase[top] = 0;
+    } else if (st_phase[top] == 1) {
+      st_left[top] = ret;
+      st_phase[top] = 2;
+      ++top;
+      st_start[top] = start + n2;
+      st_n[top] = n - n2;
+      st_phase[top] = 0;
+    } else {
+      p->op_dst[no] = (uint8_t)st_left[top];
+      p->op_src[no] = (uint8_t)ret;
+      ++no;
+      ret = st_left[top];
+      --top;
+    }
+  }
+  p->n_leaves = nl;
+  p->n_ops = no;
+}
+
+// V = pairwise_sum_k(row[k] * rw[k]) by one wave; row and rw are in padded LDS layout.
+// Returns the value in every lane.
+__device__ __forceinline__ float wave_pairwise_dot(const float* row, const float* rw,
+                                                   const sr_plan* plan, float* leafsum,
+                                                   int lane) {
+  const int k = lane & 7;
+  const int nl = plan->n_leaves;
+  for (int l0 = 0; l0 < nl; l0 += 8) {
+    const int l = l0 + (lane >> 3);
+    float res = 0.0f;
+    const bool live = l < nl;
+    const int start = live ? plan->leaf_start[l] : 0;
+    const int m = live ? plan->leaf_len[l] : 0;
+    if (m >= 8) {
+      const int body = m - (m & 7);
+      int e = start + k;
+      float acc = row[phys(e)] * rw[phys(e)];
+      for (int o = 8; o < body; o += 8) {
+        e = start + o + k;
+        const float prod = row[phys(e)] * rw[phys(e)];
+        acc = acc + prod;
+      }
+      res = acc;
+    }
+    // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): butterflies over the 8-lane group
+    res = res + __shfl_xor(res, 1);
+    res = res + __shfl_xor(res, 2);
+    res = res + __shfl_xor(res, 4);
+    if (live && k == 0) {
+      if (m < 8) {
+        res = 0.0f;
+        for (int e = start; e < start + m; ++e) res = res + row[phys(e)] * rw[phys(e)];
+      } else {
+        for (int e = start + (m - (m & 7)); e < start + m; ++e)
+          res = res + row[phys(e)] * rw[phys(e)];
+      }
+      leafsum[l] = res;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  float v = 0.0f;
+  if (lane == 0) {
+    for (int o = 0; o < plan->n_ops; ++o)
+      leafsum[plan->op_dst[o]] = leafsum[plan->op_dst[o]] + leafsum[plan->op_src[o]];
+    v = leafsum[0];
+  }
+  return __shfl(v, 0);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load_row(float* dst, const float* __restrict__ src, int S, int t,
+                                         int nthreads) {
+  if (VEC) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int e = t * 4; e < S; e += nthreads * 4)
+      *reinterpret_cast<float4*>(dst + phys(e)) = s4[e >> 2];
+  } else {
+    for (int e = t; e < S; e += nthreads) dst[phys(e)] = src[e];
+  }
+}
+
+struct sr_lds {
+  float* rw;
+  uint16_t* T;
+  float* rows;
+  sr_plan* plan;
+  float* leafsum;  // [4][kMaxLeaves]
+  float* V;        // [4]
+  int PS;
+};
+
+__device__ __forceinline__ sr_lds carve(unsigned char* base, int S) {
+  sr_lds L;
+  L.PS = padded(S);
+  size_t off = 0;
+  L.rows = reinterpret_cast<float*>(base + off);
+  off += (size_t)kRows * L.PS * 4;
+  L.rw = reinterpret_cast<float*>(base + off);
+  off += (size_t)L.PS * 4;
+  L.leafsum = reinterpret_cast<float*>(base + off);
+  off += 4 * kMaxLeaves * 4;
+  L.V = reinterpret_cast<float*>(base + off);
+  off += 16;
+  L.plan = reinterpret_cast<sr_plan*>(base + off);
+  off += (sizeof(sr_plan) + 15) & ~(size_t)15;
+  L.T = reinterpret_cast<uint16_t*>(base + off);
+  return L;
+}
+
+size_t sr_lds_bytes(int S, bool with_T) {
+  size_t b = (size_t)(kRows + 1) * padded(S) * 4 + 4 * kMaxLeaves * 4 + 16 +
+             ((sizeof(sr_plan) + 15) & ~(size_t)15);
+  if (with_T) b += (size_t)S * 8;
+  return (b + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
+  const uint32_t w = (a & 2) ? w1 : w0;
+  return (a & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <bool VEC, bool OCC>
+__global__ __launch_bounds__(256) void k_sr(const sr_args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int S = A.S;
+  const sr_lds L = carve(lds_raw, S);
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = (int)blockIdx.x;
+  const uint32_t g = A.r.instance_base + (uint32_t)i;
+  const int world = (int)(g % (uint32_t)A.n_worlds);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
+  float* const SRg = A.r.sr + (size_t)i * S * S;
+  uint16_t* const Tg = A.r.trans + (size_t)i * S * 4;
+  float* const Rg = A.r.rewards + (size_t)i * S;
+  uint32_t* const occ = reinterpret_cast<uint32_t*>(L.T + (size_t)S * 4);  // only if OCC
+
+  for (int e = t; e < S; e += 256) {
+    L.rw[phys(e)] = Rg[e];
+    if (OCC) occ[e] = 0u;
+  }
+  for (int e = t; e < S * 4; e += 256) L.T[e] = Tg[e];
+  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.leafsum));
+  __syncthreads();
+
+  int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
+  int state = inst[COBEL_I_STATE];
+  int step = inst[COBEL_I_STEP];
+  int trial = inst[COBEL_I_TRIAL];
+  uint32_t ce = (uint32_t)inst[COBEL_I_CTR_ENV];
+  uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
+  uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
+  unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
+
+  const uint32_t flags = A.r.flags;
+  const bool learn = flags & COBEL_F_LEARN;
+  const uint32_t pol_stream =
+      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
+  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const uint64_t seed = A.r.seed;
+  const int start_lo = A.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
+  const double alpha = A.r.alpha, gamma = A.r.gamma;
+  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f;
+
+  uint32_t cw0 = 0, cw1 = 0;
+  uint4 cand = {0, 0, 0, 0};
+  uint32_t mask_cur = 15u;
+  auto enter_state = [&](int s) {
+    const uint4 c = W4[s];
+    cw0 = rfl(c.x);
+    cw1 = rfl(c.y);
+    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
+  };
+  if (iflags & 1u) enter_state(state);
+
+  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  unsigned long long executed = 0;
+
+  while (true) {
+    if (!(iflags & 1u)) {
+      if (trial >= A.r.trials_target) break;
+      const cobel_u4 x = cobel_philox(ce, 0u, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      state = (int)A.starts[start_lo + (int)cobel_bounded(x.x, start_cnt)];
+      step = 0;
+      trew = 0.0;
+      iflags |= 1u;
+      enter_state(state);
+    }
+    if (budget == 0) break;
+    budget -= 1;
+
+    // ---- retrieve_q (sr.py:302-306): wave a evaluates V[T[s][a]] ----------------------------
+    const int my_row = (int)L.T[state * 4 + wave];
+    float* const my_buf = L.rows + (size_t)wave * L.PS;
+    load_row<VEC>(my_buf, SRg + (size_t)my_row * S, S, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * kMaxLeaves, lane);
+    if (lane == 0) L.V[wave] = v;
+    __syncthreads();
+    const float4 q = *reinterpret_cast<const float4*>(L.V);
+
+    // ---- select + env.step -------------------------------------------------------------------
+    const cobel_u4 px = cobel_philox(cp, 0u, g, pol_stream, seed);
+    cp += 1u;
+    const double u = cobel_u01(px.x, px.y);
+    const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
+                                                                  A.eps, lane));
+    const int ns = (int)next_of(cw0, cw1, a);
+    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
+    const float r = __builtin_bit_cast(float, rl(cand.z, a));
+    const uint32_t end = rl(cand.w, a);
+    const uint32_t nt = 1u - end;
+
+    if (learn) {
+      // rows already in LDS? (T[s][.] as it was when the value rows were loaded)
+      int src_s = -1, src_ns = -1;
+#pragma unroll
+      for (int k2 = 3; k2 >= 0; --k2) {
+        const int rowk = (int)L.T[state * 4 + k2];
+        if (rowk == state) src_s = k2;
+        if (rowk == ns) src_ns = k2;
+      }
+      if (ns == state && src_ns < 0) src_ns = 4;  // shares the spare row with SR[s]
+      const bool need_ns = nt != 0u;
+      __syncthreads();  // every wave has read T[s][.] before it changes
+      if (src_s < 0) {
+        load_row<VEC>(L.rows + (size_t)4 * L.PS, SRg + (size_t)state * S, S, t, 256);
+        src_s = 4;
+      }
+      if (need_ns && src_ns < 0) {
+        load_row<VEC>(L.rows + (size_t)5 * L.PS, SRg + (size_t)ns * S, S, t, 256);
+        src_ns = 5;
+      }
+      if (t == 0) {
+        // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
+        const float old = L.rw[phys(ns)];
+        const float d = r - old;
+        const float upd = old + d * alpha_f;
+        L.rw[phys(ns)] = upd;
+        Rg[ns] = upd;
+        L.T[state * 4 + a] = (uint16_t)ns;
+        Tg[state * 4 + a] = (uint16_t)ns;
+      }
+      __syncthreads();
+      // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
+      const float* const row_s = L.rows + (size_t)src_s * L.PS;
+      const float* const row_n = L.rows + (size_t)(need_ns ? src_ns : src_s) * L.PS;
+      float* const out = SRg + (size_t)state * S;
+      auto upd1 = [&](int e, float cs, float cn) -> float {
+        double td = (e == state) ? 1.0 : 0.0;
+        if (need_ns) {
+          const float gs = gamma_f * cn;
+          td = td + (double)gs;
+        } else {
+          td = td + gamma * ((e == ns) ? 1.0 : 0.0);
+        }
+        td = td - (double)cs;
+        return (float)((double)cs + alpha * td);
+      };
+      if (VEC) {
+        for (int e = t * 4; e < S; e += 1024) {
+          const float4 cs = *reinterpret_cast<const float4*>(row_s + phys(e));
+          const float4 cn = *reinterpret_cast<const float4*>(row_n + phys(e));
+          float4 o;
+          o.x = upd1(e + 0, cs.x, cn.x);
+          o.y = upd1(e + 1, cs.y, cn.y);
+          o.z = upd1(e + 2, cs.z, cn.z);
+          o.w = upd1(e + 3, cs.w, cn.w);
+          reinterpret_cast<float4*>(out)[e >> 2] = o;
+        }
+      } else {
+        for (int e = t; e < S; e += 256) out[e] = upd1(e, row_s[phys(e)], row_n[phys(e)]);
+      }
+    }
+
+    if (A.r.last_exp && t == 0) {
+      int32_t* const e = A.r.last_exp + (size_t)i * 6;
+      e[0] = state;
+      e[1] = a;
+      e[2] = ns;
+      e[3] = (int32_t)nt;
+      e[4] = __builtin_bit_cast(int32_t, r);
+      e[5] = 0;
+    }
+    trew += (double)r;
+    nsteps += 1ull;
+    executed += 1ull;
+    if (OCC && t == 0) occ[ns] += 1u;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    state = ns;
+    cw0 = nw0;
+    cw1 = nw1;
+    if (!trial_over) {
+      if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+      mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
+      step += 1;
+    } else {
+      if (t == 0 && trial >= 0 && trial < A.r.trial_cap) {
+        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
+        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
+        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
+        if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
+      }
+      trial += 1;
+      iflags &= ~1u;
+    }
+    // the row just stored must be visible to the loads of the next step, and the LDS rows it
+    // was computed from must not be overwritten before every thread is done with them
+    __syncthreads();
+  }
+
+  if (OCC) {
+    __syncthreads();
+    for (int e = t; e < S; e += 256) {
+      const uint32_t c = occ[e];
+      if (c && A.r.occupancy) atomicAdd(A.r.occupancy + (size_t)world * S + e, (unsigned long long)c);
+    }
+  }
+  if (t == 0) {
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
+    if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
+  }
+}
+
+// q[i][a] = V[T[s_i][a]] for given states — predict_on_batch (sr.py:310-324).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_sr_q(const float* __restrict__ sr,
+                                              const uint16_t* __restrict__ trans,
+                                              const float* __restrict__ rewards,
+                                              const int32_t* __restrict__ states,
+                                              float* __restrict__ q_out, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const sr_lds L = carve(lds_raw, S);
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = (int)blockIdx.x;
+  const float* const SRg = sr + (size_t)i * S * S;
+  for (int e = t; e < S; e += 256) L.rw[phys(e)] = rewards[(size_t)i * S + e];
+  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.leafsum));
+  __syncthreads();
+  const int s = states[i];
+  const int row = (int)trans[((size_t)i * S + s) * 4 + wave];
+  float* const buf = L.rows + (size_t)wave * L.PS;
+  load_row<VEC>(buf, SRg + (size_t)row * S, S, lane, 64);
+  __builtin_amdgcn_wave_barrier();
+  const float v = wave_pairwise_dot(buf, L.rw, L.plan, L.leafsum + wave * kMaxLeaves, lane);
+  if (lane == 0) q_out[(size_t)i * 4 + wave] = v;
+}
+
+__global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
+                                                 uint16_t* __restrict__ trans,
+                                                 float* __restrict__ rewards, size_t n, int S) {
+  const size_t SS = (size_t)S * S;
+  const size_t total = n * SS;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t within = e % SS;
+    sr[e] = (within / S == within % S) ? 1.0f : 0.0f;
+    if (within < (size_t)S * 4) trans[(e / SS) * S * 4 + within] = (uint16_t)(within >> 2);
+    if (within < (size_t)S) rewards[(e / SS) * S + within] = 0.0f;
+  }
+}
+
+template <bool VEC, bool OCC>
+int launch_sr(const sr_args& A, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL((k_sr<VEC, OCC>), dim3(A.r.n), dim3(256), lds, st, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+}  // namespace
+
+static const size_t kLdsLimit = 160 * 1024;
+
+extern "C" int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n,
+                             int32_t n_states, void* stream) {
+  COBEL_REQUIRE(sr && trans && rewards, COBEL_E_ARG, "cobel_sr_init: NULL table");
+  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 4096, COBEL_E_RANGE,
+                "cobel_sr_init: bad sizes n=%d S=%d", n, n_states);
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_sr_init, dim3(8192), dim3(256), 0, (hipStream_t)stream, sr, trans, rewards,
+                     (size_t)n, n_states);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* run, void* stream) {
+  COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sr_run: NULL world/run");
+  const cobel_sr_run_t& r = *run;
+  COBEL_REQUIRE(r.sr && r.trans && r.rewards && r.inst, COBEL_E_ARG,
+                "cobel_sr_run: sr, trans, rewards and inst are required");
+  COBEL_REQUIRE(((uintptr_t)r.sr & 15u) == 0 && ((uintptr_t)r.inst & 7u) == 0, COBEL_E_ARG,
+                "cobel_sr_run: sr must be 16-byte and inst 8-byte aligned");
+  COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_sr_run: n = %d", r.n);
+  COBEL_REQUIRE(r.steps_per_trial > 0, COBEL_E_RANGE, "cobel_sr_run: steps_per_trial = %d",
+                r.steps_per_trial);
+  COBEL_REQUIRE(r.epsilon >= 0.0 && r.epsilon <= 1.0, COBEL_E_ARG,
+                "cobel_sr_run: epsilon %g outside [0, 1]", r.epsilon);
+  COBEL_REQUIRE(!(r.flags & COBEL_F_MASK_ACTIONS) || r.action_mask, COBEL_E_ARG,
+                "cobel_sr_run: mask_actions set without an action mask");
+  const int S = world->n_states;
+  const bool occ = r.occupancy != nullptr;
+  const size_t lds = sr_lds_bytes(S, true) + (occ ? (size_t)S * 4 : 0);
+  COBEL_REQUIRE(S <= 4096 && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
+                "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu)", S, lds,
+                kLdsLimit);
+  if (r.n == 0) return COBEL_OK;
+  sr_args A;
+  A.rec = world->rec;
+  A.starts = world->starts;
+  A.start_off = world->start_off;
+  A.S = S;
+  A.n_worlds = world->n_worlds;
+  A.r = r;
+  A.eps = cobel_make_eps_consts(r.epsilon);
+  A.alpha_f = (float)r.alpha;
+  A.gamma_f = (float)r.gamma;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (S % 4) == 0;
+  if (vec) return occ ? launch_sr<true, true>(A, lds, st) : launch_sr<true, false>(A, lds, st);
+  return occ ? launch_sr<false, true>(A, lds, st) : launch_sr<false, false>(A, lds, st);
+}
+
+extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const float* rewards,
+                                   const int32_t* states, float* q_out, int32_t n,
+                                   int32_t n_states, void* stream) {
+  COBEL_REQUIRE(sr && trans && rewards && states && q_out, COBEL_E_ARG,
+                "cobel_sr_retrieve_q: NULL argument");
+  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 4096, COBEL_E_RANGE,
+                "cobel_sr_retrieve_q: bad sizes");
+  if (n == 0) return COBEL_OK;
+  const size_t lds = sr_lds_bytes(n_states, false);
+  COBEL_REQUIRE(lds <= kLdsLimit, COBEL_E_UNSUPPORTED, "cobel_sr_retrieve_q: LDS %zu", lds);
+  hipStream_t st = (hipStream_t)stream;
+  if ((n_states % 4) == 0 && ((uintptr_t)sr & 15u) == 0) {
+    if (lds > 64 * 1024)
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_q<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_sr_q<true>), dim3(n), dim3(256), lds, st, sr, trans, rewards, states,
+                       q_out, n_states);
+  } else {
+    if (lds > 64 * 1024)
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_q<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_sr_q<false>), dim3(n), dim3(256), lds, st, sr, trans, rewards, states,
+                       q_out, n_states);
+  }
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

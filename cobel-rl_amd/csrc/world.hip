@@ -1,0 +1,286 @@
+// World handle, stand-alone vectorised env step/reset and the epsilon-greedy KAT entry point.
+// Reference behaviour restated (paths relative to /root/reference/src/cobel):
+//   interface/gridworld.py:115-126  step  = next-state lookup, reward/terminal of the state entered
+//   interface/gridworld.py:142      reset = uniform draw from starting_states
+//   interface/topology.py:146-157   same shape of step on a neighbour table
+//   policy/greedy.py:40-88          epsilon-greedy
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+static thread_local char g_err[512] = "";
+
+int cobel_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* cobel_last_error(void) { return g_err; }
+extern "C" int cobel_abi_version(void) { return 1000; }
+
+extern "C" uint64_t cobel_pack_model(float reward, uint16_t next_state, uint8_t nonterminal) {
+  return cobel_model_pack(reward, next_state, nonterminal ? 1u : 0u);
+}
+extern "C" void cobel_unpack_model(uint64_t rec, float* reward, uint16_t* next_state,
+                                   uint8_t* nonterminal) {
+  const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+  if (reward) *reward = __builtin_bit_cast(float, lo);
+  if (next_state) *next_state = (uint16_t)(hi & 0xffffu);
+  if (nonterminal) *nonterminal = (uint8_t)((hi >> 16) & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
+                                  const uint8_t* terminal, const uint16_t* starts,
+                                  const int32_t* start_offsets, int32_t n_states,
+                                  int32_t n_worlds, int32_t device, cobel_world_t** out) {
+  COBEL_REQUIRE(next && reward && terminal && starts && start_offsets && out, COBEL_E_ARG,
+                "cobel_world_create: NULL argument");
+  COBEL_REQUIRE(n_states > 0 && n_states <= 16384, COBEL_E_RANGE,
+                "cobel_world_create: n_states %d outside 1..16384", n_states);
+  COBEL_REQUIRE(n_worlds > 0, COBEL_E_RANGE, "cobel_world_create: n_worlds %d", n_worlds);
+  COBEL_REQUIRE(start_offsets[0] == 0, COBEL_E_ARG, "cobel_world_create: start_offsets[0] != 0");
+  for (int w = 0; w < n_worlds; ++w)
+    COBEL_REQUIRE(start_offsets[w + 1] > start_offsets[w], COBEL_E_ARG,
+                  "cobel_world_create: world %d has no starting state", w);
+  const size_t total = (size_t)n_worlds * (size_t)n_states;
+  std::vector<cobel_wrec> rec(total);
+  for (size_t i = 0; i < total; ++i) {
+    for (int a = 0; a < 4; ++a) {
+      COBEL_REQUIRE(next[i * 4 + a] < n_states, COBEL_E_RANGE,
+                    "cobel_world_create: next[%zu][%d] = %u >= n_states", i, a,
+                    (unsigned)next[i * 4 + a]);
+      rec[i].next[a] = next[i * 4 + a];
+    }
+    rec[i].reward = reward[i];
+    rec[i].terminal = terminal[i] ? 1u : 0u;
+  }
+  const int32_t n_starts = start_offsets[n_worlds];
+  for (int32_t i = 0; i < n_starts; ++i)
+    COBEL_REQUIRE(starts[i] < n_states, COBEL_E_RANGE, "cobel_world_create: start %u >= n_states",
+                  (unsigned)starts[i]);
+
+  COBEL_HIP_TRY(hipSetDevice(device));
+  cobel_world* w = (cobel_world*)calloc(1, sizeof(cobel_world));
+  COBEL_REQUIRE(w, COBEL_E_ARG, "cobel_world_create: out of host memory");
+  w->n_states = n_states;
+  w->n_worlds = n_worlds;
+  w->device = device;
+  w->h_start_off = (int32_t*)malloc(sizeof(int32_t) * (n_worlds + 1));
+  memcpy(w->h_start_off, start_offsets, sizeof(int32_t) * (n_worlds + 1));
+  hipError_t e = hipMalloc((void**)&w->rec, total * sizeof(cobel_wrec));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->starts, sizeof(uint16_t) * n_starts);
+  if (e == hipSuccess) e = hipMalloc((void**)&w->start_off, sizeof(int32_t) * (n_worlds + 1));
+  if (e == hipSuccess)
+    e = hipMemcpy(w->rec, rec.data(), total * sizeof(cobel_wrec), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(w->starts, starts, sizeof(uint16_t) * n_starts, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(w->start_off, start_offsets, sizeof(int32_t) * (n_worlds + 1),
+                  hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    cobel_world_destroy(w);
+    return cobel_fail(COBEL_E_HIP, "cobel_world_create: %s", hipGetErrorString(e));
+  }
+  *out = w;
+  return COBEL_OK;
+}
+
+extern "C" int cobel_world_destroy(cobel_world_t* w) {
+  if (!w) return COBEL_OK;
+  if (w->rec) (void)hipFree(w->rec);
+  if (w->starts) (void)hipFree(w->starts);
+  if (w->start_off) (void)hipFree(w->start_off);
+  free(w->h_start_off);
+  free(w);
+  return COBEL_OK;
+}
+
+extern "C" int cobel_world_info(const cobel_world_t* w, int32_t* n_states, int32_t* n_worlds,
+                                int32_t* device) {
+  COBEL_REQUIRE(w, COBEL_E_ARG, "cobel_world_info: NULL world");
+  if (n_states) *n_states = w->n_states;
+  if (n_worlds) *n_worlds = w->n_worlds;
+  if (device) *device = w->device;
+  return COBEL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One lane per instance; state/action/reward/done are SoA so every access is coalesced, the world
+// records are shared and stay in L2.
+__global__ __launch_bounds__(256) void k_env_step(const cobel_wrec* __restrict__ rec, int S,
+                                                  int n_worlds, int32_t* __restrict__ state,
+                                                  const uint8_t* __restrict__ action,
+                                                  float* __restrict__ reward_out,
+                                                  uint8_t* __restrict__ done_out, int n,
+                                                  uint32_t base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cobel_wrec* w = rec + (size_t)((base + (uint32_t)i) % (uint32_t)n_worlds) * S;
+  const int s = state[i];
+  const int a = action[i] & 3;
+  const int ns = w[s].next[a];
+  const cobel_wrec r = w[ns];
+  state[i] = ns;
+  if (reward_out) reward_out[i] = r.reward;
+  if (done_out) done_out[i] = (uint8_t)r.terminal;
+}
+
+__global__ __launch_bounds__(256) void k_env_reset(const uint16_t* __restrict__ starts,
+                                                   const int32_t* __restrict__ start_off,
+                                                   int n_worlds, int32_t* __restrict__ state,
+                                                   const uint8_t* __restrict__ reset_mask,
+                                                   uint32_t* __restrict__ env_ctr, uint64_t seed,
+                                                   int n, uint32_t base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (reset_mask && !reset_mask[i]) return;
+  const uint32_t g = base + (uint32_t)i;
+  const int w = (int)(g % (uint32_t)n_worlds);
+  const int lo = start_off[w], cnt = start_off[w + 1] - lo;
+  const uint32_t idx = env_ctr[i];
+  const cobel_u4 x = cobel_philox(idx, 0u, g, COBEL_STREAM_ENV, seed);
+  state[i] = starts[lo + (int)cobel_bounded(x.x, (uint32_t)cnt)];
+  env_ctr[i] = idx + 1u;
+}
+
+static int check_states_dev(const cobel_world_t* w, const char* who) {
+  COBEL_REQUIRE(w, COBEL_E_ARG, "%s: NULL world", who);
+  return COBEL_OK;
+}
+
+extern "C" int cobel_env_step(const cobel_world_t* world, int32_t* state, const uint8_t* action,
+                              float* reward_out, uint8_t* done_out, int32_t n,
+                              uint32_t instance_base, void* stream) {
+  if (int rc = check_states_dev(world, "cobel_env_step")) return rc;
+  COBEL_REQUIRE(state && action, COBEL_E_ARG, "cobel_env_step: NULL state/action");
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_env_step: n = %d", n);
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_env_step, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     world->rec, world->n_states, world->n_worlds, state, action, reward_out,
+                     done_out, n, instance_base);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_env_reset(const cobel_world_t* world, int32_t* state,
+                               const uint8_t* reset_mask, uint32_t* env_ctr, uint64_t seed,
+                               int32_t n, uint32_t instance_base, void* stream) {
+  if (int rc = check_states_dev(world, "cobel_env_reset")) return rc;
+  COBEL_REQUIRE(state && env_ctr, COBEL_E_ARG, "cobel_env_reset: NULL state/env_ctr");
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_env_reset: n = %d", n);
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_env_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     world->starts, world->start_off, world->n_worlds, state, reset_mask, env_ctr,
+                     seed, n, instance_base);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eps_greedy(const float4* __restrict__ values,
+                                                    const uint8_t* __restrict__ mask,
+                                                    const double* __restrict__ u,
+                                                    cobel_eps_consts k,
+                                                    uint8_t* __restrict__ action_out,
+                                                    double* __restrict__ probs_out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = values[i];
+  const uint32_t m = mask ? (mask[i] & 15u) : 15u;
+  double p[4];
+  const int a = cobel_eps_greedy_select(v.x, v.y, v.z, v.w, m, u[i], k, p);
+  action_out[i] = (uint8_t)a;
+  if (probs_out) {
+    probs_out[4 * i + 0] = p[0];
+    probs_out[4 * i + 1] = p[1];
+    probs_out[4 * i + 2] = p[2];
+    probs_out[4 * i + 3] = p[3];
+  }
+}
+
+extern "C" int cobel_eps_greedy(const float* values, const uint8_t* mask, const double* u,
+                                double epsilon, uint8_t* action_out, double* probs_out,
+                                int32_t n, void* stream) {
+  COBEL_REQUIRE(values && u && action_out, COBEL_E_ARG, "cobel_eps_greedy: NULL argument");
+  COBEL_REQUIRE(epsilon >= 0.0 && epsilon <= 1.0, COBEL_E_ARG,
+                "cobel_eps_greedy: epsilon %g outside [0, 1]", epsilon);
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_eps_greedy: n = %d", n);
+  COBEL_REQUIRE(((uintptr_t)values & 15u) == 0, COBEL_E_ARG,
+                "cobel_eps_greedy: values must be 16-byte aligned");
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_eps_greedy, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)values, mask, u, cobel_make_eps_consts(epsilon), action_out,
+                     probs_out, n);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rng_uniform(uint32_t* __restrict__ index, uint64_t seed,
+                                                     uint32_t stream, uint32_t base,
+                                                     double* __restrict__ out, int n,
+                                                     int advance) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t idx = index[i];
+  const cobel_u4 x = cobel_philox(idx, 0u, base + (uint32_t)i, stream, seed);
+  out[i] = cobel_u01(x.x, x.y);
+  if (advance) index[i] = idx + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_rng_bounded(uint32_t* __restrict__ index, uint64_t seed,
+                                                     uint32_t stream, uint32_t base,
+                                                     uint32_t bound, int32_t* __restrict__ out,
+                                                     int n, int per, int advance) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * per) return;
+  const int i = t / per, j = t % per;
+  const uint32_t idx = index[i];
+  const cobel_u4 x = cobel_philox(idx, (uint32_t)j, base + (uint32_t)i, stream, seed);
+  out[t] = (int32_t)cobel_bounded(x.x, bound);
+}
+
+__global__ __launch_bounds__(256) void k_rng_advance(uint32_t* __restrict__ index, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) index[i] += 1u;
+}
+
+extern "C" int cobel_rng_uniform(uint32_t* index, uint64_t seed, uint32_t stream,
+                                 uint32_t instance_base, double* out, int32_t n, int32_t advance,
+                                 void* sh) {
+  COBEL_REQUIRE(index && out, COBEL_E_ARG, "cobel_rng_uniform: NULL argument");
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_rng_uniform: n = %d", n);
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_rng_uniform, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)sh, index,
+                     seed, stream, instance_base, out, n, advance);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_rng_bounded(uint32_t* index, uint64_t seed, uint32_t stream,
+                                 uint32_t instance_base, uint32_t bound, int32_t* out, int32_t n,
+                                 int32_t per_instance, int32_t advance, void* sh) {
+  COBEL_REQUIRE(index && out, COBEL_E_ARG, "cobel_rng_bounded: NULL argument");
+  COBEL_REQUIRE(n >= 0 && per_instance >= 0, COBEL_E_RANGE, "cobel_rng_bounded: bad sizes");
+  COBEL_REQUIRE(bound > 0, COBEL_E_RANGE, "cobel_rng_bounded: bound must be positive");
+  if (n == 0) return COBEL_OK;
+  const long long total = (long long)n * per_instance;
+  COBEL_REQUIRE(total < (1ll << 31), COBEL_E_RANGE, "cobel_rng_bounded: too many draws");
+  if (total > 0)
+    hipLaunchKernelGGL(k_rng_bounded, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)sh, index, seed, stream, instance_base, bound, out, n,
+                       per_instance, advance);
+  if (advance)
+    hipLaunchKernelGGL(k_rng_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)sh, index,
+                       n);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

@@ -1,0 +1,252 @@
+/*
+ * cobel_hip.h — C ABI of libcobel_hip.so, the MI355X (gfx950) hot path of the
+ * vectorised navigation-RL loop.
+ *
+ * The reference (sencheng/CoBeL-RL) is pure Python and has no FFI layer; its
+ * boundary for this path is the duck-typed Python API.  Each entry point below
+ * names the reference interface it replaces (paths relative to
+ * /root/reference/src/cobel).  The binding a maintainer would add is a ctypes
+ * stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked [dev] is DEVICE memory owned by the
+ *     caller (e.g. a torch tensor's data_ptr()), [host] is host memory;
+ *   - every call returns 0 on success or a negative COBEL_E_* code and never
+ *     throws; cobel_last_error() returns a thread-local message;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and calls return without synchronising;
+ *   - the library keeps no global mutable state besides the last-error string; a
+ *     world handle is immutable after creation and may be shared by any number of
+ *     runs on its device.
+ */
+#ifndef COBEL_HIP_H
+#define COBEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COBEL_API __attribute__((visibility("default")))
+
+#define COBEL_OK 0
+#define COBEL_E_ARG (-1)         /* NULL / malformed argument            (reference: AssertionError) */
+#define COBEL_E_RANGE (-2)       /* index or size out of range            (reference: IndexError)     */
+#define COBEL_E_HIP (-3)         /* HIP runtime failure (message has hipGetErrorString)               */
+#define COBEL_E_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. table exceeds LDS)   */
+
+#define COBEL_ACTIONS 4 /* gridworld / 4-neighbour topology action count (gridworld.py:86) */
+
+/* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (index, sub, instance, stream). */
+#define COBEL_STREAM_ENV 0u    /* index = resets so far            (gridworld.py:142)     */
+#define COBEL_STREAM_POLICY 1u /* index = select_action calls      (greedy.py:58)         */
+#define COBEL_STREAM_MEMORY 2u /* index = replay batches, sub = j  (memory/dyna_q.py:137) */
+#define COBEL_STREAM_POLICY_TEST 3u
+
+COBEL_API const char* cobel_last_error(void);
+/* ABI version of this header: major * 1000 + minor. */
+COBEL_API int cobel_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Raw stream access (used by the host facade for single calls of Policy.select_action /
+ * Interface.reset, and by the parity tests of the generator itself).
+ *   uniform: out[i] = 53-bit double of block (index[i], sub, instance_base + i, stream)
+ *   bounded: out[i][j] = mulhi32(x0 of block (index[i], j, instance_base + i, stream), bound),
+ *            j < per_instance
+ * If advance != 0, index[i] += 1 afterwards.
+ * ------------------------------------------------------------------------------------------ */
+COBEL_API int cobel_rng_uniform(uint32_t* index /* [dev] [N] */, uint64_t seed, uint32_t stream,
+                                uint32_t instance_base, double* out /* [dev] [N] */, int32_t n,
+                                int32_t advance, void* stream_handle);
+COBEL_API int cobel_rng_bounded(uint32_t* index /* [dev] [N] */, uint64_t seed, uint32_t stream,
+                                uint32_t instance_base, uint32_t bound,
+                                int32_t* out /* [dev] [N][per_instance] */, int32_t n,
+                                int32_t per_instance, int32_t advance, void* stream_handle);
+
+/* ------------------------------------------------------------------------------------------
+ * World tables.  Replaces WorldDict (interface/gridworld.py:17-30) as produced by
+ * make_gridworld (misc/gridworld_tools.py:10-136) and Topology's node dict
+ * (interface/topology.py:21-26): the dense one-hot sas[S,4,S] becomes next[S,4].
+ * n_worlds distinct worlds of the same state count can live in one handle; instance g uses
+ * world (g % n_worlds).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cobel_world cobel_world_t;
+
+COBEL_API int cobel_world_create(const uint16_t* next /* [host] [n_worlds][S][4] */,
+                       const float* reward /* [host] [n_worlds][S] reward on ENTERING the state */,
+                       const uint8_t* terminal /* [host] [n_worlds][S] */,
+                       const uint16_t* starts /* [host] concatenated start lists */,
+                       const int32_t* start_offsets /* [host] [n_worlds + 1] into starts */,
+                       int32_t n_states, int32_t n_worlds, int32_t device, cobel_world_t** out);
+COBEL_API int cobel_world_destroy(cobel_world_t* world);
+COBEL_API int cobel_world_info(const cobel_world_t* world, int32_t* n_states, int32_t* n_worlds,
+                     int32_t* device);
+
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone vectorised environment.  Replaces Gridworld.step / Gridworld.reset
+ * (interface/gridworld.py:92-129, :131-145) and Topology.step / reset
+ * (interface/topology.py:126-172) for N instances at once.
+ *   step : ns = next[s][a]; reward_out = reward[ns]; done_out = terminal[ns]; state <- ns
+ *   reset: where reset_mask[i] != 0 (or reset_mask == NULL):
+ *          state[i] = starts[mulhi32(philox(seed, instance_base + i, env_ctr[i]).x0, n_starts)];
+ *          env_ctr[i] += 1
+ * ------------------------------------------------------------------------------------------ */
+COBEL_API int cobel_env_step(const cobel_world_t* world, int32_t* state /* [dev] [N] in/out */,
+                   const uint8_t* action /* [dev] [N] */, float* reward_out /* [dev] [N] */,
+                   uint8_t* done_out /* [dev] [N] */, int32_t n, uint32_t instance_base,
+                   void* stream);
+COBEL_API int cobel_env_reset(const cobel_world_t* world, int32_t* state /* [dev] [N] */,
+                    const uint8_t* reset_mask /* [dev] [N] or NULL */,
+                    uint32_t* env_ctr /* [dev] [N] in/out */, uint64_t seed, int32_t n,
+                    uint32_t instance_base, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Epsilon-greedy.  Replaces EpsilonGreedy.get_action_probs / select_action
+ * (policy/greedy.py:40-88) incl. the Generator.choice draw
+ * searchsorted(cumsum(p) / cumsum(p)[-1], u, 'right').
+ *
+ * Probabilities are float64 as in the reference (probs = np.zeros(v.shape)); ties are
+ * detected with exact equality on the float32 values.
+ * cobel_eps_greedy selects actions for N rows of 4 values with injected uniforms (KAT entry
+ * point; the fused run kernels draw u from COBEL_STREAM_POLICY instead) and optionally
+ * returns get_action_probs().
+ * ------------------------------------------------------------------------------------------ */
+COBEL_API int cobel_eps_greedy(const float* values /* [dev] [N][4], 16-byte aligned */,
+                               const uint8_t* mask /* [dev] [N] 4-bit masks, or NULL = all */,
+                               const double* u /* [dev] [N] in [0,1) */, double epsilon,
+                               uint8_t* action_out /* [dev] [N] */,
+                               double* probs_out /* [dev] [N][4] or NULL */, int32_t n,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused tabular agents.  One call advances every instance through
+ *   select -> env.step -> [model store] -> TD update -> [B planning / replay TD updates]
+ * with per-instance auto-reset at trial ends, entirely on device.
+ *
+ * Replaces the loops DynaQ.train / DynaQ.test (agent/dyna_q.py:140-273) with update_q
+ * (:275-301), replay (:319-330), DynaQMemory.store / retrieve_batch (memory/dyna_q.py:77-96,
+ * :122-157); QAgent.train / update_q / replay (agent/q.py:160-228, :289-315, :344-354); and
+ * the on_trial_end monitors EscapeLatencyMonitor / RewardMonitor (monitor/behavior.py:73-97,
+ * :111-) plus the visit counts behind get_occupancy_map (analysis/behavior_spatial.py:9-73).
+ *
+ * Numerics ("f32 tables"): tables are float32; the arithmetic follows what the reference
+ * itself computes when its tables are cast to float32 under NumPy >= 2 promotion — online TD
+ * and QAgent replay in float32, Dyna-Q planning TD in float64 rounded once on store, model
+ * reward update in float32 — so results are bit-exact against that run of the reference.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Per-instance scalar state: 12 x 32-bit words, caller-owned [dev] [N][12]. */
+enum {
+  COBEL_I_STATE = 0,      /* int32  current env state                                        */
+  COBEL_I_STEP = 1,       /* int32  steps taken in the running trial                         */
+  COBEL_I_TRIAL = 2,      /* int32  trials finished (agent.current_trial, agent.py:58)       */
+  COBEL_I_CTR_ENV = 3,    /* uint32 next index on COBEL_STREAM_ENV                           */
+  COBEL_I_CTR_POLICY = 4, /* uint32 next index on the policy stream                          */
+  COBEL_I_CTR_MEMORY = 5, /* uint32 next index on COBEL_STREAM_MEMORY                        */
+  COBEL_I_LOG_LEN = 6,    /* uint32 QAgent: experiences logged so far                        */
+  COBEL_I_FLAGS = 7,      /* bit 0: a trial is in progress                                   */
+  COBEL_I_REWARD_LO = 8,  /* float64 reward collected in the running trial (2 words)         */
+  COBEL_I_REWARD_HI = 9,
+  COBEL_I_STEPS_LO = 10,  /* uint64 env steps executed over the instance's lifetime (2 words) */
+  COBEL_I_STEPS_HI = 11,
+  COBEL_I_WORDS = 12
+};
+
+enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
+
+#define COBEL_F_LEARN 1u          /* 0 = Agent.test(): act only                              */
+#define COBEL_F_NO_REPLAY 2u      /* DynaQ.train(no_replay=True)                             */
+#define COBEL_F_EPISODIC 4u       /* DynaQ.episodic_replay: one batch per trial              */
+#define COBEL_F_MASK_ACTIONS 8u   /* agent.mask_actions                                      */
+#define COBEL_F_TEST_STREAM 16u   /* draw u from COBEL_STREAM_POLICY_TEST (separate policy)  */
+
+typedef struct {
+  /* tables, all caller-owned device memory */
+  float* q;              /* [N][S][4] float32 Q                                              */
+  uint64_t* model;       /* DYNAQ: [N][S][4] packed {f32 R; u16 NS; u8 nonterminal; u8 0}    */
+  uint64_t* replay_log;  /* Q with batch > 0: [N][log_cap] packed experiences (q.py:213), or NULL:
+                            lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30 */
+  int32_t* inst;         /* [N][COBEL_I_WORDS]                                               */
+  const uint8_t* action_mask; /* [S] 4-bit masks shared by all instances, or NULL            */
+  /* monitors (any may be NULL) */
+  unsigned long long* lat_sum;  /* [trial_cap] sum over instances of logs['steps']           */
+  unsigned long long* lat_cnt;  /* [trial_cap] instances that finished that trial            */
+  double* reward_sum;           /* [trial_cap] sum of trial rewards                          */
+  int32_t* lat_trace;           /* [N][trial_cap] per-instance logs['steps'], or NULL        */
+  unsigned long long* occupancy;/* [n_worlds][S] visits of next_state                        */
+  unsigned long long* steps_done; /* [1] env steps executed by this call (added)             */
+  int32_t* last_exp;     /* [N][6] last experience {s, a, ns, nonterminal, f32 r, f32 td} for
+                            per-step host callbacks (use with step_budget = 1), or NULL       */
+  /* sizes */
+  int32_t n;             /* instances on this device                                         */
+  int32_t log_cap;       /* entries per instance in replay_log                               */
+  int32_t trial_cap;     /* length of the monitor arrays                                     */
+  uint32_t instance_base;/* global id of local instance 0 (sharding; keeps draws G-independent) */
+  /* run parameters */
+  int32_t agent;         /* COBEL_AGENT_*                                                    */
+  uint32_t flags;        /* COBEL_F_*                                                        */
+  int32_t trials_target; /* stop an instance when inst[TRIAL] reaches this                   */
+  int32_t steps_per_trial;
+  int32_t step_budget;   /* max env steps per instance in this call; <= 0 = unlimited        */
+  int32_t batch;         /* B: planning / replay updates per step (0..COBEL_MAX_BATCH)       */
+  double alpha, gamma, epsilon, model_lr;
+  uint64_t seed;
+} cobel_tab_run_t;
+
+#define COBEL_MAX_BATCH 62
+
+/* 0 = this (S, agent, batch) combination is supported; fills *lds_bytes with the LDS per instance. */
+COBEL_API int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch, int32_t* lds_bytes,
+                    int32_t* instances_per_block);
+COBEL_API int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream);
+
+/* Host helpers for the packed 8-byte records (so bindings never re-derive the layout). */
+COBEL_API uint64_t cobel_pack_model(float reward, uint16_t next_state, uint8_t nonterminal);
+COBEL_API void cobel_unpack_model(uint64_t rec, float* reward, uint16_t* next_state, uint8_t* nonterminal);
+/* Initialise a model table the way DynaQMemory.__init__ does (memory/dyna_q.py:72-75):
+ * R = 0, NS[s][a] = s, nonterminal = 0. */
+COBEL_API int cobel_model_init(uint64_t* model /* [dev] [N][S][4] */, int32_t n, int32_t n_states,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Successor-representation agent.  Replaces SR.train / SR.update / SR.retrieve_q
+ * (agent/sr.py:142-197, :255-286, :288-308).  Tables: SR f32 [N][S][S] (= eye at init),
+ * agent transition table T u16 [N][S][4] (= s at init, sr.py:131-135), reward estimate
+ * f32 [N][S].  The row TD error is evaluated in float64 and rounded once on store, as the
+ * reference does with a float32 SR (np.eye is float64, sr.py:276-284).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  float* sr;          /* [N][S][S] */
+  uint16_t* trans;    /* [N][S][4] */
+  float* rewards;     /* [N][S]    */
+  int32_t* inst;      /* [N][COBEL_I_WORDS] */
+  const uint8_t* action_mask;
+  unsigned long long* lat_sum;
+  unsigned long long* lat_cnt;
+  double* reward_sum;
+  int32_t* lat_trace;
+  unsigned long long* occupancy;
+  unsigned long long* steps_done;
+  int32_t* last_exp;  /* [N][6] {s, a, ns, nonterminal, f32 r, 0} or NULL */
+  int32_t n, trial_cap;
+  uint32_t instance_base;
+  uint32_t flags;
+  int32_t trials_target, steps_per_trial, step_budget;
+  double alpha, gamma, epsilon;
+  uint64_t seed;
+} cobel_sr_run_t;
+
+COBEL_API int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n, int32_t n_states,
+                  void* stream);
+COBEL_API int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* run, void* stream);
+/* q[i][a] = V[T[s_i][a]], V[j] = sum_k SR[j][k] * rewards[k] (sr.py:302-306) for given states. */
+COBEL_API int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const float* rewards,
+                        const int32_t* states /* [dev] [N] */, float* q_out /* [dev] [N][4] */,
+                        int32_t n, int32_t n_states, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COBEL_HIP_H */

@@ -1,0 +1,52 @@
+"""Shared fixtures.  ``-m gpu`` tests need an MI355X and run the HIP library through its C ABI;
+everything else runs on CPU (oracle vs golden vectors, host logic, symbol checks)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'cobel-rl_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+SEED = 0xC0BE1
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + '.npz'))
+    return load
+
+
+@pytest.fixture(scope='session')
+def golden_worlds(golden):
+    data = golden('worlds')
+
+    def get(name):
+        return {k: data['%s/%s' % (name, k)] for k in
+                ('next', 'reward', 'terminal', 'starts', 'coordinates', 'height', 'width')}
+    return get
+
+
+def cases(npz):
+    return sorted({k.split('/')[0] for k in npz.files if '/' in k})
+
+
+def as_world(tab):
+    """Golden compact tables -> the WorldDict shape the host classes take."""
+    from cobel_amd.misc.gridworld_tools import World
+    w = World()
+    h, wd = int(tab['height']), int(tab['width'])
+    w.update(height=h, width=wd, states=h * wd, next=tab['next'], rewards=tab['reward'],
+             terminals=tab['terminal'].astype(int), starting_states=tab['starts'].astype(int),
+             coordinates=tab['coordinates'], deterministic=True, invalid_states=[],
+             invalid_transitions=[], goals=[], wind=np.zeros((h * wd, 2), dtype=int))
+    return w
