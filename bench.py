@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gridworld env-steps/s over tens of thousands of parallel agent-env instances.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C4] [--instances n]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One bench "step" = ONE launch of the fused agent kernel that advances every instance on the GPU
+by `env_steps_per_launch` env steps (select -> env.step -> learn -> B planning updates, with
+per-instance auto-reset).  W untimed warm-up launches, then exactly K launches timed between
+barrier + torch.cuda.synchronize() pairs; the max over ranks is used and rank 0 prints one JSON
+line.  Instances are independent, so each rank runs its own `instances` (weak scaling; global
+instance ids keep the random streams disjoint) and the only collective is the all-reduce of the
+monitor buffers after the last launch (inside the timed region).
+
+Workloads, all synthetic, tables zero-initialised as the reference does:
+  C3 (default, the configuration the metric is quoted on): 65 536 instances over 64 distinct
+     32x32 obstacle mazes, Dyna-Q alpha .99 gamma .99 eps .1 model-lr .9, B = 50 planning
+     updates per step, 200 steps per trial.
+  C2: 65 536 x 5x5 open field, Q-learning alpha .9 gamma .8 eps .1, no replay, 50 steps/trial.
+  C4: 16 384 x 32x32 open field, SR alpha .1 gamma .99 eps .1, 200 steps/trial (64 GiB of SR).
+
+`roofline.achieved` = algorithmic bytes per env step (C2 67 B, C3 1 628 B,
+C4 32 817 B) x env steps per launch / mean launch duration, the latter measured with HIP events
+on the launch stream.  `cpu_baseline` = the NumPy restatement of the reference's single-instance
+loop (oracle/ref_loop.py), one core, on a bounded sample of the same workload (rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'cobel-rl_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    'C2': dict(instances=65536, env_steps_per_launch=1024, steps_per_trial=50, batch=0,
+               bytes_per_step=67, agent='q',
+               desc='65536 x 5x5 open gridworld, tabular Q-learning (alpha .9, gamma .8, eps .1, '
+                    'no replay), 50 steps/trial'),
+    'C3': dict(instances=65536, env_steps_per_launch=256, steps_per_trial=200, batch=50,
+               bytes_per_step=1628, agent='dynaq',
+               desc='65536 instances over 64 32x32 obstacle mazes (p_wall .20, seeds 1234..1297), '
+                    'Dyna-Q (alpha .99, gamma .99, eps .1, model lr .9), 50 planning updates/step, '
+                    '200 steps/trial'),
+    'C4': dict(instances=16384, env_steps_per_launch=128, steps_per_trial=200, batch=0,
+               bytes_per_step=32817, agent='sr',
+               desc='16384 x 32x32 open gridworld, successor representation (alpha .1, gamma .99, '
+                    'eps .1), 200 steps/trial'),
+}
+SEED = 0xC0BE1
+
+
+def make_worlds(cfg_name):
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze, make_open_field
+    if cfg_name == 'C2':
+        return [make_open_field(5, 5, 0, 1)]
+    if cfg_name == 'C3':
+        return [make_obstacle_maze(32, 32, 1234 + k) for k in range(64)]
+    return [make_open_field(32, 32, 0, 1)]
+
+
+def build_agent(cfg_name, cfg, n, rank, device):
+    from cobel_amd.agent import SR, DynaQ, QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld(make_worlds(cfg_name), n_envs=n, seed=SEED, device=device,
+                    instance_base=rank * n)
+    pol = EpsilonGreedy(0.1)
+    if cfg['agent'] == 'q':
+        agent = QAgent(env.observation_space, env.action_space, pol)
+    elif cfg['agent'] == 'dynaq':
+        agent = DynaQ(env.observation_space, env.action_space, pol)
+    else:
+        agent = SR(env.observation_space, env.action_space, pol)
+    return env, agent
+
+
+class Runner:
+    """Drives the fused kernel in fixed-size launches (the façade's train() runs whole trials)."""
+
+    def __init__(self, cfg, env, agent):
+        from cobel_amd import _lib
+        self.cfg, self.env, self.agent, self._lib = cfg, env, agent, _lib
+        agent._bind(env)
+        agent._env_in(env)
+        self.flags = _lib.F_LEARN | agent._policy_in(agent.policy, env, False)
+        agent.monitors.reserve(4096, agent.n_envs, False)
+
+    def launch(self):
+        c = self.cfg
+        self.agent._launch(self.env, self.agent.policy, self.flags, 0x7fffffff,
+                           c['steps_per_trial'], c['env_steps_per_launch'], c['batch'])
+
+
+def cpu_baseline(cfg_name, cfg, seconds=12.0):
+    """NumPy restatement of the reference loop, 1 core, bounded sample of the same workload."""
+    from oracle import philox, ref_loop
+    world = make_worlds(cfg_name)[0]
+    tabs = world.compact()
+    S = int(world['states'])
+    env = ref_loop.RefGridworld(tabs, philox.TapeRNG(SEED, 0, philox.STREAM_ENV))
+    pol = ref_loop.RefEpsilonGreedy(0.1, philox.TapeRNG(SEED, 0, philox.STREAM_POLICY))
+    mem = philox.TapeRNG(SEED, 0, philox.STREAM_MEMORY)
+    if cfg['agent'] == 'q':
+        ag = ref_loop.RefQAgent(S, 4, pol, mem, dtype=np.float32)
+        run = lambda: ag.train(env, 4, cfg['steps_per_trial'], 0, trace=tr)  # noqa: E731
+    elif cfg['agent'] == 'dynaq':
+        ag = ref_loop.RefDynaQ(S, 4, pol, mem, dtype=np.float32)
+        run = lambda: ag.train(env, 1, cfg['steps_per_trial'], cfg['batch'], trace=tr)  # noqa: E731
+    else:
+        ag = ref_loop.RefSR(S, 4, pol, dtype=np.float32)
+        run = lambda: ag.train(env, 1, cfg['steps_per_trial'], trace=tr)  # noqa: E731
+    tr = ref_loop.new_trace()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run()
+    dt = time.perf_counter() - t0
+    steps = len(tr['sarsn'])
+    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle/ref_loop.py (NumPy restatement of the reference single-instance '
+                      'loop, float32 tables), instance 0 of the same workload, %d env steps in '
+                      '%.1f s on 1 of %d host cores' % (steps, dt, os.cpu_count() or 1)}
+
+
+def run_config(cfg_name, args, rank, world_size, device, dist):
+    cfg = dict(CONFIGS[cfg_name])
+    if args.instances:
+        cfg['instances'] = args.instances
+    if args.env_steps:
+        cfg['env_steps_per_launch'] = args.env_steps
+    n = cfg['instances']
+    env, agent = build_agent(cfg_name, cfg, n, rank, device)
+    runner = Runner(cfg, env, agent)
+    for _ in range(args.warmup):
+        runner.launch()
+    torch.cuda.synchronize(device)
+    before = agent.env_steps()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(args.steps):
+        runner.launch()
+        ev[k + 1].record()
+    agent.monitors.all_reduce()          # the path's only collective: monitor buffers
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    steps_rank = (agent.env_steps() - before) if dist is None else None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # steps_done was summed over ranks by monitors.all_reduce()
+        total_steps = agent.env_steps() - before * world_size
+    else:
+        total_steps = steps_rank
+    expect = n * cfg['env_steps_per_launch'] * args.steps * world_size
+    assert total_steps == expect, 'kernel executed %d env steps, expected %d' % (total_steps, expect)
+    mean_launch_s = float(np.mean(launch_ms)) * 1e-3
+    alg_bytes_per_launch = cfg['bytes_per_step'] * n * cfg['env_steps_per_launch']
+    achieved = alg_bytes_per_launch / mean_launch_s / 1e9
+    res = {
+        'metric': 'gridworld env-steps/sec (whole job)',
+        'value': total_steps / elapsed,
+        'unit': 'env-steps/s',
+        'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg_name + ': ' + cfg['desc'], 'instances_per_gpu': n,
+                   'env_steps_per_launch': cfg['env_steps_per_launch'],
+                   'parallelism': 'instances sharded x%d, no data-path collective' % world_size},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': {'q': 'k_tab_wpi<Q>', 'dynaq': 'k_tab_wpi<DYNAQ>',
+                                'sr': 'k_sr'}[cfg['agent']],
+                     'algorithmic_bytes_per_env_step': cfg['bytes_per_step'],
+                     'launch_ms_mean': mean_launch_s * 1e3,
+                     'launch_ms_all': [round(x, 4) for x in launch_ms]},
+    }
+    return res, cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='C3', choices=sorted(CONFIGS))
+    ap.add_argument('--also', default='C2,C4', help='extra configs reported under "other_configs"')
+    ap.add_argument('--instances', type=int, default=0)
+    ap.add_argument('--env-steps', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+    assert args.gpus == world_size, '--gpus must equal the number of launched ranks'
+
+    res, cfg = run_config(args.config, args, rank, world_size, device, dist)
+    others = {}
+    if world_size == 1 and not args.instances and args.also:
+        for name in [c for c in args.also.split(',') if c and c != args.config]:
+            try:
+                r, _ = run_config(name, args, rank, world_size, device, dist)
+                others[name] = {'value': r['value'], 'unit': r['unit'],
+                                'ms_per_step': r['ms_per_step'], 'config': r['config'],
+                                'roofline': r['roofline']}
+            except Exception as e:  # e.g. not enough HBM for C4 on a shared device
+                others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0:
+        if world_size == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.config, cfg)
+        if others:
+            res['other_configs'] = others
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
