@@ -1,0 +1,175 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls: there is no GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """libcobel_hip.so loads on a GPU-less host and exports exactly what include/cobel_hip.h
+    declares."""
+    from cobel_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'cobel_hip.h')).read()
+    declared = set(re.findall(r'COBEL_API\s+[\w\s\*]+?\b(cobel_\w+)\s*\(', header))
+    assert declared, 'no declarations found'
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), 'missing export ' + name
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert lib.cobel_abi_version() == 1000
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r'\bT (cobel_\w+)', out))
+    assert exported == declared
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors of the run structs have the size the C compiler gives them."""
+    from cobel_amd import _lib
+    src = ('#include "cobel_hip.h"\n#include <stdio.h>\n'
+           'int main(){printf("%zu %zu\\n", sizeof(cobel_tab_run_t), sizeof(cobel_sr_run_t));}')
+    exe = '/tmp/cobel_sizeof_%d' % os.getpid()
+    subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe],
+                   input=src.encode(), check=True)
+    a, b = subprocess.check_output([exe]).split()
+    os.remove(exe)
+    assert int(a) == C.sizeof(_lib.TabRun) and int(b) == C.sizeof(_lib.SRRun)
+
+
+def test_argument_errors_map_to_reference_exceptions():
+    """Bad arguments are rejected before any HIP call, with the exception the reference raises."""
+    from cobel_amd import _lib
+    lib = _lib.lib()
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_world_create(None, None, None, None, None, 25, 1, 0, None))
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_tab_run(None, None, None))
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_tab_query(1000000, 1, 10, None, None))
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_tab_query(25, 1, 63, None, None))
+    lds = C.c_int32()
+    _lib.check(lib.cobel_tab_query(1024, 1, 50, C.byref(lds), None))
+    assert lds.value == 1024 * 20
+    r, s, t = C.c_float(), C.c_uint16(), C.c_uint8()
+    rec = lib.cobel_pack_model(C.c_float(0.75), 321, 1)
+    lib.cobel_unpack_model(rec, C.byref(r), C.byref(s), C.byref(t))
+    assert (r.value, s.value, t.value) == (0.75, 321, 1)
+
+
+def test_world_builders_match_reference_tables(golden_worlds):
+    """cobel_amd.misc.gridworld_tools == tables derived from the reference's make_* builders."""
+    from cobel_amd.misc import gridworld_tools as gt
+    built = {
+        'open_5x5': gt.make_open_field(5, 5, 0, 1),
+        'kat_5x5': gt.make_gridworld(5, 5, [0], np.array([[0, 10.]]), starting_states=[24]),
+        'open_4x7_goal9': gt.make_open_field(4, 7, 9, 2.5),
+        'empty_3x3': gt.make_empty_field(3, 3),
+        'walls_8x8': gt.make_gridworld(
+            8, 8, terminals=[7, 56], rewards=np.array([[7, 1.0], [56, -0.5], [30, 0.25]]),
+            goals=[7], invalid_states=[10, 11, 12, 20, 28, 36, 44, 45, 50],
+            invalid_transitions=[(0, 1), (1, 0), (62, 63), (63, 62), (33, 34)],
+            starting_states=[63, 32, 3, 27]),
+        'windy_7x10_up': gt.make_windy_gridworld(
+            7, 10, np.array([0, 0, 0, 1, 1, 1, 2, 2, 1, 0]), 37, 1.0, 'up'),
+        'windy_5x6_down': gt.make_windy_gridworld(5, 6, np.array([0, 1, 2, 1, 0, 3]), 3, 1.0, 'down'),
+        'open_32x32': gt.make_open_field(32, 32, 0, 1),
+        'maze_32x32_1234': gt.make_obstacle_maze(32, 32, 1234),
+        'maze_32x32_1235': gt.make_obstacle_maze(32, 32, 1235),
+    }
+    for name, w in built.items():
+        g = golden_worlds(name)
+        assert np.array_equal(w['next'], g['next']), name
+        assert np.array_equal(w['rewards'], g['reward']), name
+        assert np.array_equal(w['terminals'], g['terminal']), name
+        assert np.array_equal(w['starting_states'], g['starts']), name
+        assert np.array_equal(w['coordinates'], g['coordinates']), name
+        c = w.compact()
+        assert c['next'].dtype == np.uint16 and c['reward'].dtype == np.float32
+    sas = built['open_5x5']['sas']          # dense form is still there for whoever asks
+    assert sas.shape == (25, 4, 25) and np.array_equal(np.argmax(sas, axis=2),
+                                                       built['open_5x5']['next'])
+    assert np.array_equal(sas.sum(axis=2), np.ones((25, 4)))
+
+
+def test_monitors_match_reference(golden):
+    from cobel_amd.monitor import EscapeLatencyMonitor
+    k = golden('monitor_kat')
+    mon = EscapeLatencyMonitor(len(k['steps']), int(k['max_steps']))
+    for t in k['order']:
+        mon.update({'trial': int(t), 'steps': int(k['steps'][t])})
+    assert np.array_equal(mon.latency_trace, k['latency'], equal_nan=True)
+    assert np.array_equal(mon.latency_trace_avg, k['latency_avg'], equal_nan=True)
+    assert mon.get_trace() is mon.latency_trace
+
+
+def test_occupancy_map_matches_reference(golden, golden_worlds):
+    from cobel_amd.analysis import get_occupancy_map, occupancy_from_counts
+    k = golden('monitor_kat')
+    coords = golden_worlds('walls_8x8')['coordinates']
+    cuts = np.cumsum(k['traj_len'])[:-1]
+    trajs = [coords[s] for s in np.split(k['traj_states'], cuts)]
+    for m in ('expand', 'include', 'ignore'):
+        assert np.array_equal(get_occupancy_map(trajs, 8, 8, 1.0, m), k['occ_' + m])
+    assert np.array_equal(get_occupancy_map(trajs, 8, 8, 2.0, 'expand'), k['occ_bin2'])
+    counts = np.bincount(k['traj_states'], minlength=64)
+    assert np.array_equal(occupancy_from_counts(counts, coords, 8, 8, 1.0), k['occ_expand'])
+    assert np.array_equal(occupancy_from_counts(counts, coords, 8, 8, 2.0), k['occ_bin2'])
+    with pytest.raises(AssertionError):
+        get_occupancy_map(trajs, 8, 8, 0.0)
+
+
+def test_callbacks_semantics():
+    """agent/agent.py:145-243: shallow copy, 'agent' key, dict returns are merged."""
+    from cobel_amd.agent import Callbacks
+    seen = []
+    cb = Callbacks('AGENT', {'on_trial_end': [lambda logs: seen.append(dict(logs)) or {'x': 1},
+                                              lambda logs: None]})
+    logs = {'trial': 3}
+    out = cb.on_trial_end(logs)
+    assert out == {'trial': 3, 'agent': 'AGENT', 'x': 1} and logs == {'trial': 3}
+    assert seen[0]['agent'] == 'AGENT'
+    assert cb.has('on_trial_end') and not cb.has('on_step_end')
+    assert cb.on_step_begin({'a': 1}) == {'a': 1, 'agent': 'AGENT'}
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'cobel-rl_amd'))
+import numpy as np, torch, torch.distributed as dist
+from cobel_amd.agent.agent import DeviceMonitors
+from cobel_amd.monitor import EscapeLatencyMonitor
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo')
+# each rank owns half of 8 instances: per-trial latencies are rank-local partial sums
+lat = np.array([[3, 5, 7], [4, 6, 8], [1, 1, 1], [9, 9, 9], [2, 4, 6], [0, 0, 0], [5, 5, 5], [7, 8, 9]])
+mine = lat[rank * 4:(rank + 1) * 4]
+mon = DeviceMonitors(torch.device('cpu'), 1, 4, occupancy=True)
+mon.reserve(3)
+mon.lat_sum += torch.as_tensor(mine.sum(axis=0)); mon.lat_cnt += 4
+mon.reward_sum += float(rank + 1); mon.occupancy += rank + 1; mon.steps_done += 100 * (rank + 1)
+el = EscapeLatencyMonitor(3, 10)
+el.update_from_device(mon)            # all-reduces, then fills the trace with per-trial means
+assert np.allclose(el.latency_trace, lat.mean(axis=0)), el.latency_trace
+assert int(mon.steps_done.item()) == 300 and int(mon.occupancy.sum().item()) == 12
+assert np.allclose(mon.reward_sum.numpy(), 3.0)
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_monitor_allreduce_two_ranks_gloo(tmp_path):
+    """The N > 1 path's only collective (monitor reduction), world_size 2 on the gloo backend."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)
