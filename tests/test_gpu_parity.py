@@ -302,3 +302,145 @@ def test_sr_golden(torch_cuda, golden, golden_worlds, name):
     assert np.array_equal(agent.T[inst].cpu().numpy(), D[name + '/T'])
     assert np.array_equal(agent.rewards[inst].cpu().numpy().astype(np.float64), D[name + '/rewards'])
     assert np.array_equal(agent.SR[inst].cpu().numpy().astype(np.float64), D[name + '/SR'])
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity against the C oracle on the benchmark workloads themselves (same seeded inputs, sizes the
+# oracle finishes in seconds), launched exactly like bench.py launches them.
+def _bench_like(torch, cfg_name, n, launches, budget, base=0):
+    import bench
+    cfg = dict(bench.CONFIGS[cfg_name], instances=n, env_steps_per_launch=budget)
+    env, agent = bench.build_agent(cfg_name, cfg, n, 0, torch.device('cuda', 0))
+    env.instance_base = base
+    env.env_ctr.zero_()
+    env.reset()
+    agent.track_occupancy = True
+    runner = bench.Runner(cfg, env, agent)
+    for _ in range(launches):
+        runner.launch()
+    torch.cuda.synchronize()
+    return cfg, env, agent
+
+
+def _oracle_world(worlds):
+    from oracle import c_oracle
+    return c_oracle.OracleWorld([dict(next=w['next'], reward=w['rewards'],
+                                      terminal=w['terminals'], starts=w['starting_states'])
+                                 for w in worlds])
+
+
+def _inst_fields(agent):
+    a = agent.inst.cpu().numpy()
+    return {'state': a[:, 0], 'step': a[:, 1], 'trial': a[:, 2], 'ctr_env': a[:, 3],
+            'ctr_policy': a[:, 4], 'ctr_memory': a[:, 5], 'log_len': a[:, 6], 'flags': a[:, 7]}
+
+
+def _cmp_inst(agent, oracle, keys):
+    got = _inst_fields(agent)
+    for k in keys:
+        assert np.array_equal(got[k].astype(np.int64), oracle.inst[k].astype(np.int64)), k
+    rew = agent.inst[:, 8:10].contiguous().view(torch_mod().float64).reshape(-1).cpu().numpy()
+    assert np.array_equal(rew, oracle.inst['trial_reward'])
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
+def test_c3_dynaq_mazes_vs_oracle(torch_cuda):
+    """C3: 64 obstacle mazes, Dyna-Q with 50 planning updates per step, 3 launches of 40 steps."""
+    from oracle import c_oracle
+    n, launches, budget = 512, 3, 40
+    cfg, env, agent = _bench_like(torch_cuda, 'C3', n, launches, budget, base=1000)
+    o = c_oracle.TabOracle(_oracle_world(env.worlds), n, c_oracle.AG_DYNAQ, env.seed, True,
+                           instance_base=1000, trial_cap=64, occupancy=True)
+    for _ in range(launches):
+        o.run(0x7fffffff, cfg['steps_per_trial'], cfg['batch'], step_budget=budget)
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(agent.M.rewards.astype(np.float64), o.MR)
+    assert np.array_equal(agent.M.states, o.MS) and np.array_equal(agent.M.terminals, o.MT)
+    _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'ctr_memory', 'flags'])
+    assert np.array_equal(agent.monitors.lat_sum.cpu().numpy()[:64], o.lat_sum.astype(np.int64))
+    assert np.array_equal(agent.monitors.lat_cnt.cpu().numpy()[:64], o.lat_cnt.astype(np.int64))
+    assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
+    assert agent.env_steps() == n * launches * budget == int(o.inst['steps'].sum())
+
+
+def test_c2_qlearning_vs_oracle(torch_cuda):
+    """C2: 5x5 open field, online Q-learning only, many short trials with auto-reset."""
+    from oracle import c_oracle
+    n, launches, budget = 4096, 2, 300
+    cfg, env, agent = _bench_like(torch_cuda, 'C2', n, launches, budget)
+    o = c_oracle.TabOracle(_oracle_world(env.worlds), n, c_oracle.AG_Q, env.seed, True,
+                           alpha=0.9, gamma=0.8, trial_cap=4096, occupancy=True)
+    for _ in range(launches):
+        o.run(0x7fffffff, cfg['steps_per_trial'], 0, step_budget=budget)
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+    _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'flags'])
+    assert np.array_equal(agent.monitors.lat_sum.cpu().numpy(), o.lat_sum.astype(np.int64))
+    assert np.array_equal(agent.monitors.lat_cnt.cpu().numpy(), o.lat_cnt.astype(np.int64))
+    assert np.allclose(agent.monitors.reward_sum.cpu().numpy(), o.reward_sum, rtol=0, atol=1e-9)
+    assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
+
+
+def test_c4_sr_32x32_vs_oracle(torch_cuda):
+    """C4: 32x32 open field, successor representation (4 MiB SR per instance)."""
+    from oracle import c_oracle
+    n, launches, budget = 24, 2, 150
+    cfg, env, agent = _bench_like(torch_cuda, 'C4', n, launches, budget, base=5)
+    o = c_oracle.SROracle(_oracle_world(env.worlds), n, env.seed, True, instance_base=5,
+                          trial_cap=16, occupancy=True)
+    for _ in range(launches):
+        o.run(0x7fffffff, cfg['steps_per_trial'], step_budget=budget)
+    assert np.array_equal(agent._T.cpu().numpy().astype(np.int64), o.T)
+    assert np.array_equal(agent._rw.cpu().numpy().astype(np.float64), o.RW)
+    assert np.array_equal(agent._sr.cpu().numpy().astype(np.float64), o.SR)
+    _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'flags'])
+    assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
+
+
+def test_sr_retrieve_q_matches_numpy_sum(torch_cuda):
+    """retrieve_q / predict_on_batch: V = np.sum(SR * rewards, axis=1) bit for bit on a table with
+    many non-zero reward estimates (the summation ORDER matters here), S = 100 (not a multiple of
+    the 128-element leaf) and S = 1024."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    for S in (100, 1024, 200):
+        rng = np.random.default_rng(S)
+        n = 3
+        sr = (rng.standard_normal((n, S, S)) * rng.random((n, S, S)) ** 4).astype(np.float32)
+        rw = rng.standard_normal((n, S)).astype(np.float32)
+        T = rng.integers(0, S, (n, S, 4)).astype(np.int16)
+        st = rng.integers(0, S, n).astype(np.int32)
+        d = lambda a: torch.as_tensor(a, device='cuda').contiguous()  # noqa: E731
+        dsr, drw, dT, dst = d(sr), d(rw), d(T), d(st)
+        q = torch.empty((n, 4), dtype=torch.float32, device='cuda')
+        _lib.check(_lib.lib().cobel_sr_retrieve_q(_lib.ptr(dsr), _lib.ptr(dT), _lib.ptr(drw),
+                                                  _lib.ptr(dst), _lib.ptr(q), n, S, None))
+        for i in range(n):
+            v = np.sum(sr[i] * rw[i], axis=1)
+            assert np.array_equal(q[i].cpu().numpy(), v[T[i, st[i]]])
+
+
+def test_qagent_replay_vs_oracle(torch_cuda, golden_worlds):
+    """QAgent with replay over the experience log (B = 24), 256 instances, two train() calls."""
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    world = as_world(golden_worlds('walls_8x8'))
+    n = 256
+    env = Gridworld(world, n_envs=n, seed=4242)
+    agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2))
+    agent.track_instances = True
+    agent.train(env, 6, 30, 24)
+    agent.train(env, 4, 30, 24)
+    o = c_oracle.TabOracle(_oracle_world([world]), n, c_oracle.AG_Q, 4242, True, alpha=0.9,
+                           gamma=0.8, epsilon=0.2, trial_cap=10, log_cap=300)
+    o.run(6, 30, 24)
+    o.run(10, 30, 24)
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(agent.monitors.lat_trace.cpu().numpy(), o.lat_trace)
+    assert np.array_equal(agent.inst[:, 6].cpu().numpy(), o.inst['log_len'].astype(np.int32))
+    assert len(agent.M) == int(o.inst['log_len'][0])
