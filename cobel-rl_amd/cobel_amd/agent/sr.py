@@ -73,7 +73,7 @@ class SR(FusedAgent):
         run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
         run.reward_sum, run.lat_trace = _lib.ptr(mon.reward_sum), _lib.ptr(mon.lat_trace)
         run.occupancy, run.steps_done = _lib.ptr(mon.occupancy), _lib.ptr(mon.steps_done)
-        run.last_exp = _lib.ptr(self._last_exp)
+        run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base, run.flags = interface.instance_base, flags
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget

@@ -74,7 +74,7 @@ class TabularAgent(FusedAgent):
         run.lat_trace = _lib.ptr(mon.lat_trace)
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done = _lib.ptr(mon.steps_done)
-        run.last_exp = _lib.ptr(self._last_exp)
+        run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base = interface.instance_base
         run.agent, run.flags = self.agent_kind, flags

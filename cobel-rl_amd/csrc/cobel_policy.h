@@ -8,11 +8,18 @@
 // float64 (cobel_eps_consts) so the device only adds, divides (IEEE, correctly rounded) and
 // compares.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 struct cobel_eps_consts {
   double base[5];  // base[n]  = eps / n                 n = 1..4
   double bonus[5]; // bonus[t] = ((1 - eps) * 1.0) / t   t = 1..4
+  // Unmasked case, per tie pattern t (bit a set = action a attains the maximum): the three
+  // thresholds of the normalised CDF as integers, thr[t][k] = ceil(cdf_k * 2^53).  With
+  // u = K * 2^-53 (K the 53-bit integer the draw is built from) cdf_k <= u  <=>  thr <= K, so
+  // the selection needs no floating point at all.  Scaling by 2^53 is exact and K is an integer,
+  // hence the ceil.
+  uint64_t thr[16][3];
 };
 
 // Constant lookup written as selects: a runtime index into a by-value kernel argument would send
@@ -29,6 +36,23 @@ static inline cobel_eps_consts cobel_make_eps_consts(double eps) {
   for (int n = 1; n <= 4; ++n) {
     c.base[n] = eps / (double)n;
     c.bonus[n] = ((1.0 - eps) * 1.0) / (double)n;
+  }
+  for (int t = 0; t < 16; ++t) {
+    int nt = 0;
+    for (int a = 0; a < 4; ++a) nt += (t >> a) & 1;
+    double cum[4], run = 0.0;
+    for (int a = 0; a < 4; ++a) {
+      // probs[a] = eps / 4; probs[a] += (1 - eps) * tie_a / n_ties      (greedy.py:83-86)
+      double p = eps / 4.0;
+      if (nt) p += ((1.0 - eps) * (((t >> a) & 1) ? 1.0 : 0.0)) / (double)nt;
+      run = (a == 0) ? p : run + p;
+      cum[a] = run;
+    }
+    for (int k = 0; k < 3; ++k) {
+      const double cdf = nt ? cum[k] / cum[3] : 2.0;   // t = 0 cannot occur; never selected
+      const double scaled = ceil(ldexp(cdf, 53));
+      c.thr[t][k] = scaled >= 18446744073709551615.0 ? ~0ull : (uint64_t)scaled;
+    }
   }
   return c;
 }
@@ -91,5 +115,16 @@ __device__ __forceinline__ int cobel_eps_greedy_select_wave(float v0, float v1, 
   const double mine = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
   const bool pass = lane < 3 && (mine / c3 <= u);
   return __popcll(__ballot(pass));
+}
+
+// Unmasked fast path: thresholds from the table (staged in LDS as thr[t * 3 + k]), K = 53-bit draw.
+__device__ __forceinline__ int cobel_eps_greedy_select_thr(float v0, float v1, float v2, float v3,
+                                                           uint64_t K, const uint64_t* thr_lds,
+                                                           int lane) {
+  const float m = fmaxf(fmaxf(fmaxf(v0, v1), v2), v3);
+  const int t = (int)(v0 == m) | ((int)(v1 == m) << 1) | ((int)(v2 == m) << 2) |
+                ((int)(v3 == m) << 3);
+  const uint64_t T = lane < 3 ? thr_lds[t * 3 + lane] : ~0ull;
+  return __popcll(__ballot(lane < 3 && T <= K));
 }
 #endif

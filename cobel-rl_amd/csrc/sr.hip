@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   uint32_t cw0 = 0, cw1 = 0;
   uint4 cand = {0, 0, 0, 0};
   uint32_t mask_cur = 15u;
+  cobel_u4 pblk = {0, 0, 0, 0};
+  uint32_t pb_idx = ~0u;
   auto enter_state = [&](int s) {
     const uint4 c = W4[s];
     cw0 = rfl(c.x);
@@ -266,9 +268,9 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   while (true) {
     if (!(iflags & 1u)) {
       if (trial >= A.r.trials_target) break;
-      const cobel_u4 x = cobel_philox(ce, 0u, g, COBEL_STREAM_ENV, seed);
+      state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                               start_cnt)];
       ce += 1u;
-      state = (int)A.starts[start_lo + (int)cobel_bounded(x.x, start_cnt)];
       step = 0;
       trew = 0.0;
       iflags |= 1u;
@@ -288,9 +290,12 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     const float4 q = *reinterpret_cast<const float4*>(L.V);
 
     // ---- select + env.step -------------------------------------------------------------------
-    const cobel_u4 px = cobel_philox(cp, 0u, g, pol_stream, seed);
+    if ((cp >> 1) != pb_idx) {   // one Philox block serves two action draws
+      pb_idx = cp >> 1;
+      pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
+    }
+    const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
     cp += 1u;
-    const double u = cobel_u01(px.x, px.y);
     const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
                                                                   A.eps, lane));
     const int ns = (int)next_of(cw0, cw1, a);

@@ -36,6 +36,7 @@ struct tab_args {
   cobel_tab_run_t r;
   cobel_eps_consts eps;
   float alpha_f, gamma_f, model_lr_f;
+  int32_t use_hash;  // LDS holds the replay dependency hash table
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -52,30 +53,84 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
   return (a & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-template <int AGENT, bool OCC>
+// LDS carve-up (bytes): Q 16*S | eps thresholds 384 | M16 8*S (Dyna-Q) | H 2048 (replay) |
+//                        world 16*S (WLDS) | occ 4*S
+struct tab_lds {
+  float4* Qs;
+  float* Qf;
+  uint16_t* M16;
+  unsigned long long* H;
+  uint64_t* thr;
+  uint4* Wl;
+  uint32_t* occ;
+};
+constexpr int kThrBytes = 16 * 3 * 8;
+constexpr int kHashBuckets = 256;
+
+__host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool replay, bool wlds,
+                                                         bool occ) {
+  size_t b = (size_t)S * 16 + kThrBytes;
+  if (agent == COBEL_AGENT_DYNAQ) b += (size_t)S * 8;
+  if (replay) b += kHashBuckets * 8;
+  if (wlds) b += (size_t)S * 16;
+  if (occ) b += (size_t)S * 4;
+  return b;
+}
+
+template <int AGENT, bool OCC, bool WLDS>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  float4* const Qs = reinterpret_cast<float4*>(lds_raw);
-  float* const Qf = reinterpret_cast<float*>(lds_raw);
-  uint32_t* const occ = reinterpret_cast<uint32_t*>(lds_raw + (size_t)A.S * 16);
+  const int S = A.S;
+  tab_lds L;
+  {
+    size_t off = 0;
+    L.Qs = reinterpret_cast<float4*>(lds_raw);
+    L.Qf = reinterpret_cast<float*>(lds_raw);
+    off += (size_t)S * 16;
+    L.thr = reinterpret_cast<uint64_t*>(lds_raw + off);
+    off += kThrBytes;
+    L.M16 = reinterpret_cast<uint16_t*>(lds_raw + off);
+    if (AGENT == COBEL_AGENT_DYNAQ) off += (size_t)S * 8;
+    L.H = reinterpret_cast<unsigned long long*>(lds_raw + off);
+    if (A.use_hash) off += kHashBuckets * 8;
+    L.Wl = reinterpret_cast<uint4*>(lds_raw + off);
+    if (WLDS) off += (size_t)S * 16;
+    L.occ = reinterpret_cast<uint32_t*>(lds_raw + off);
+  }
+  float4* const Qs = L.Qs;
+  float* const Qf = L.Qf;
 
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x;
-  const int S = A.S;
   const uint32_t g = A.r.instance_base + (uint32_t)i;
   const int world = (int)(g % (uint32_t)A.n_worlds);
-  const cobel_wrec* const W = A.rec + (size_t)world * S;
-  const uint4* const W4 = reinterpret_cast<const uint4*>(W);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
   float4* const Qg = reinterpret_cast<float4*>(A.r.q) + (size_t)i * S;
   uint64_t* const model = (AGENT == COBEL_AGENT_DYNAQ) ? A.r.model + (size_t)i * S * 4 : nullptr;
+  const uint32_t* const model32 = reinterpret_cast<const uint32_t*>(model);
   uint64_t* const rlog =
       (AGENT == COBEL_AGENT_Q && A.r.replay_log) ? A.r.replay_log + (size_t)i * A.r.log_cap
                                                  : nullptr;
+  const uint32_t SA = (uint32_t)S * 4u;
 
+  // ---- stage the instance: Q, compact model, world records --------------------------------
   for (int s = lane; s < S; s += 64) {
     Qs[s] = Qg[s];
-    if (OCC) occ[s] = 0u;
+    if (WLDS) L.Wl[s] = W4[s];
+    if (OCC) L.occ[s] = 0u;
   }
+  if (AGENT == COBEL_AGENT_DYNAQ) {
+    // 16-bit model entry: next state | nonterminal << 14 | (reward estimate != +0.0f) << 15.
+    // The float32 reward estimates stay in HBM and are fetched only for flagged entries.
+    for (uint32_t e = (uint32_t)lane; e < SA; e += 64u) {
+      const uint64_t rec = model[e];
+      const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+      L.M16[e] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
+    }
+  }
+  if (A.use_hash)
+    for (int b = lane; b < kHashBuckets; b += 64) L.H[b] = 0ull;
+  if (lane < 48) L.thr[lane] = A.eps.thr[lane / 3][lane % 3];
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -102,7 +157,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
   const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
   const uint64_t seed = A.r.seed;
-  const uint32_t SA = (uint32_t)S * 4u;
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   const double alpha = A.r.alpha, gamma = A.r.gamma;
@@ -110,66 +164,71 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
   // ---- values carried from one step to the next ------------------------------------------
   uint32_t cw0 = 0, cw1 = 0;   // next[0..3] of the current state (uniform)
-  uint4 cand = {0, 0, 0, 0};   // lane k < 4: world record of next[state][k]
-  uint64_t mrow = 0;           // lane k < 4: model[state][k]            (Dyna-Q)
+  uint4 cand = {0, 0, 0, 0};   // !WLDS: lane k < 4 holds the world record of next[state][k]
   uint32_t mask_cur = 15u;
-  double u_cur = 0.0;          // policy draw of the upcoming step
-  uint32_t mx = 0;             // lane j < B: memory draw of the upcoming step
-  uint64_t gm = 0;             // lane j < B: record that draw selects, gathered ahead
+  // Cached Philox output: lanes < B hold memory block mb_idx (four consecutive batches), lanes 62
+  // and 63 hold policy blocks pb_idx and pb_idx + 1 (four consecutive action draws).
+  cobel_u4 blk = {0, 0, 0, 0};
+  uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
+  uint32_t qx = 0;             // QAgent replay: memory draw of the upcoming batch
+  uint64_t qrec = 0;           // ... and the logged experience it selects, gathered ahead
 
-  auto draw_u = [&](uint32_t index) -> double {
-    const cobel_u4 x = cobel_philox(index, 0u, g, pol_stream, seed);
-    return cobel_u01(x.x, x.y);
+  auto draw_m = [&](uint32_t counter) -> uint32_t {   // uncached memory draw (QAgent log replay)
+    const cobel_u4 b = cobel_philox(counter >> 2, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed);
+    return cobel_word(b, counter & 3u);
   };
-  auto draw_m = [&](uint32_t index) -> uint32_t {
-    return cobel_philox(index, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed).x;
+  const bool cached_mem = AGENT == COBEL_AGENT_DYNAQ && B > 0;
+  auto refresh_draws = [&]() {   // one Philox evaluation refills both caches
+    const uint32_t pi = cp >> 1, mi = cm >> 2;
+    const bool hit = (pi - pb_idx) <= 1u && (!cached_mem || mi == mb_idx);
+    if (hit) return;
+    const bool p0 = lane == 62, p1 = lane == 63;
+    blk = cobel_philox(p1 ? pi + 1u : (p0 ? pi : mi), (p0 || p1) ? 0u : (uint32_t)lane, g,
+                       (p0 || p1) ? pol_stream : COBEL_STREAM_MEMORY, seed);
+    pb_idx = pi;
+    mb_idx = mi;
   };
-  // Start the gather of the records the batch drawn with `x` will use.  `bound` = number of
-  // sampleable records at the time the batch runs; records with index >= `have` do not exist
-  // yet and are patched in later.
-  auto gather = [&](uint32_t x, uint32_t bound, uint32_t have) -> uint64_t {
+  auto log_gather = [&](uint32_t x, uint32_t bound, uint32_t have) -> uint64_t {
     uint64_t rec = 0;
     if (lane < B && bound > 0u) {
       const uint32_t idx = cobel_bounded(x, bound);
-      if (AGENT == COBEL_AGENT_DYNAQ) rec = model[idx];
-      else if (idx < have) rec = rlog[idx];
+      if (idx < have) rec = rlog[idx];
     }
     return rec;
   };
-  auto enter_state = [&](int s) {  // prefetches that depend only on the state being entered
-    const uint4 c = W4[s];
+  auto enter_state = [&](int s) {  // what depends only on the state being entered
+    const uint4 c = WLDS ? L.Wl[s] : W4[s];
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
-    if (lane < 4) {
-      cand = W4[next_of(cw0, cw1, lane)];
-      if (AGENT == COBEL_AGENT_DYNAQ && learn) mrow = model[(uint32_t)s * 4u + (uint32_t)lane];
-    }
+    if (!WLDS && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
   };
-  const bool log_room0 = loglen < (uint32_t)A.r.log_cap;
 
-  // ---- the B sequential TD updates of one batch, run as conflict-free prefixes -------------
-  auto run_batch = [&](uint32_t x, uint64_t rec, uint32_t bound) {
-    if (bound == 0u) return;
+  // ---- B sequential TD updates, executed as conflict-free prefixes --------------------------
+  // Lane j < B holds replay j = (idx -> (s, a), r, ns, nt).  The reference applies them in order
+  // (agent/dyna_q.py:329-330); j may run once every earlier lane that writes a cell j reads —
+  // s_i == ns_j (row of the max) or idx_i == idx_j (the cell itself) — has written.
+  auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
     const bool on = lane < B;
-    const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
-    uint32_t idx, ns, nt;
-    const float r = __builtin_bit_cast(float, lo);
-    if (AGENT == COBEL_AGENT_DYNAQ) {
-      idx = cobel_bounded(x, bound);
-      ns = hi & 0xffffu;
-      nt = (hi >> 16) & 1u;
-    } else {
-      idx = (hi & 0x3fffu) * 4u + ((hi >> 28) & 3u);
-      ns = (hi >> 14) & 0x3fffu;
-      nt = (hi >> 30) & 1u;
-    }
     const uint32_t sj = idx >> 2;
+    // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
+    const uint32_t bs = sj & (kHashBuckets - 1), bn = ns & (kHashBuckets - 1);
+    if (on) atomicOr(&L.H[bs], 1ull << lane);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long cnd = on ? ((L.H[bn] | L.H[bs]) & ((1ull << lane) - 1ull)) : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (on) L.H[bs] = 0ull;
     int dep = -1;  // latest earlier lane this lane must wait for
-    for (int e = 0; e + 1 < B; ++e) {
-      const uint32_t se = rl(sj, e), ie = rl(idx, e);
-      const bool hit = (lane > e) && (ns == se || idx == ie);
-      dep = hit ? e : dep;
+    while (__ballot(cnd != 0ull)) {
+      const int e = cnd ? (63 - __clzll((long long)cnd)) : 0;
+      const uint32_t se = (uint32_t)__shfl((int)sj, e), ie = (uint32_t)__shfl((int)idx, e);
+      const bool hit = cnd && (ns == se || idx == ie);
+      if (hit) {
+        dep = e;
+        cnd = 0ull;
+      } else if (cnd) {
+        cnd &= ~(1ull << e);
+      }
     }
     int first = 0;
     while (first < B) {
@@ -182,7 +241,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         float qn;
         if (AGENT == COBEL_AGENT_DYNAQ) {
           // planning TD in float64, one rounding on store (NumPy promotion of the reference's
-          // expression with a float32 table; see header)
+          // expression with a float32 table; see include/cobel_hip.h)
           const double gnt = gamma * (double)nt;
           double td = (double)r + gnt * (double)m;
           td = td - (double)q;
@@ -199,14 +258,33 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       first = stop;
     }
   };
+  // Dyna-Q batch drawn with x: model entries from LDS, reward estimates from HBM where flagged.
+  // (fresh_idx, fresh_r): the entry this step wrote, whose HBM copy may still be in flight.
+  auto plan_dynaq = [&](uint32_t x, uint32_t fresh_idx, float fresh_r) {
+    uint32_t idx = 0, ns = 0, nt = 0;
+    float r = 0.0f;
+    if (lane < B) {
+      idx = cobel_bounded(x, SA);
+      const uint32_t m = L.M16[idx];
+      ns = m & 0x3fffu;
+      nt = (m >> 14) & 1u;
+      if (m & 0x8000u) r = __builtin_bit_cast(float, model32[2u * idx]);
+      if (idx == fresh_idx) r = fresh_r;
+    }
+    run_batch(idx, ns, nt, r);
+  };
+  auto replay_log = [&](uint64_t rec) {
+    const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+    run_batch((hi & 0x3fffu) * 4u + ((hi >> 28) & 3u), (hi >> 14) & 0x3fffu, (hi >> 30) & 1u,
+              __builtin_bit_cast(float, lo));
+  };
 
-  // ---- prologue: draws and prefetches for the first step of this call -----------------------
-  u_cur = draw_u(cp);
+  // ---- prologue -----------------------------------------------------------------------------
   if (iflags & 1u) enter_state(state);
-  if (replay_each_step) {
-    mx = draw_m(cm);
-    const uint32_t bound = (AGENT == COBEL_AGENT_DYNAQ) ? SA : loglen + (log_room0 ? 1u : 0u);
-    gm = gather(mx, bound, loglen);
+  if (AGENT == COBEL_AGENT_Q && replay_each_step) {
+    qx = draw_m(cm);
+    const uint32_t room = loglen < (uint32_t)A.r.log_cap ? 1u : 0u;
+    qrec = log_gather(qx, loglen + room, loglen);
   }
 
   int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
@@ -215,9 +293,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   while (true) {
     if (!(iflags & 1u)) {
       if (trial >= A.r.trials_target) break;
-      const cobel_u4 x = cobel_philox(ce, 0u, g, COBEL_STREAM_ENV, seed);
+      state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                               start_cnt)];
       ce += 1u;
-      state = (int)A.starts[start_lo + (int)cobel_bounded(x.x, start_cnt)];
       step = 0;
       trew = 0.0;
       iflags |= 1u;
@@ -226,35 +304,76 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (budget == 0) break;
     budget -= 1;
 
-    // ---- select (policy/greedy.py) --------------------------------------------------------
+    // ---- draws of this step (cached blocks; one Philox evaluation per ~4 steps) ---------------
+    refresh_draws();
+    const int src_lane = 62 + (int)((cp >> 1) - pb_idx);
+    const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
+    const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
+    const uint32_t mdraw = cobel_word(blk, cm & 3u);   // lanes < B: this step's batch
+    cp += 1u;
+
+    // ---- select (policy/greedy.py:40-88) ------------------------------------------------------
     const float4 qrow = Qs[state];
-    const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w,
-                                                                  mask_cur, u_cur, A.eps, lane));
-    // ---- env.step (interface/gridworld.py:115-126) ------------------------------------------
+    int a;
+    if (mask_cur == 15u) {
+      a = cobel_eps_greedy_select_thr(qrow.x, qrow.y, qrow.z, qrow.w, cobel_u53(w0, w1), L.thr,
+                                      lane);
+    } else {
+      a = cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
+                                       cobel_u01(w0, w1), A.eps, lane);
+    }
+    a = (int)rfl((uint32_t)a);
+    // ---- env.step (interface/gridworld.py:115-126) ----------------------------------------------
     const int ns = (int)next_of(cw0, cw1, a);
-    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
-    const float r = __builtin_bit_cast(float, rl(cand.z, a));
-    const uint32_t end = rl(cand.w, a);
+    uint32_t nw0, nw1, end;
+    float r;
+    if (WLDS) {
+      const uint4 nrec = L.Wl[ns];
+      nw0 = rfl(nrec.x);
+      nw1 = rfl(nrec.y);
+      r = __builtin_bit_cast(float, rfl(nrec.z));
+      end = rfl(nrec.w);
+    } else {
+      nw0 = rl(cand.x, a);
+      nw1 = rl(cand.y, a);
+      r = __builtin_bit_cast(float, rl(cand.z, a));
+      end = rl(cand.w, a);
+    }
     const uint32_t nt = 1u - end;
     const uint32_t sa = (uint32_t)state * 4u + (uint32_t)a;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    // Successor records for the next step: issued before this step's stores (a wave's memory
+    // operations retire in order, so a load issued behind a store would also wait for the
+    // store's acknowledgement) and consumed one step later, behind the planning.
+    if (!trial_over) {
+      if (!WLDS && lane < 4) cand = W4[next_of(nw0, nw1, lane)];
+      mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
+    }
 
-    uint64_t written = 0;       // the record this step adds to the model / log
-    uint32_t written_at = ~0u;  // its index
+    uint32_t fresh_idx = ~0u;   // model / log entry written by this step
+    float fresh_r = 0.0f;
+    uint64_t fresh_rec = 0;
     float td_online = 0.0f;
     if (learn) {
       if (AGENT == COBEL_AGENT_DYNAQ) {
-        // memory/dyna_q.py:92-96 (float32 arithmetic)
-        const float R = __builtin_bit_cast(float, rl((uint32_t)mrow, a));
+        // memory/dyna_q.py:92-96 (float32): rewards[s,a] += lr * (r - rewards[s,a])
+        const uint32_t old = L.M16[sa];
+        float R = 0.0f;
+        if (old & 0x8000u) R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
         const float d = r - R;
         const float Rn = R + mlr_f * d;
-        written = cobel_model_pack(Rn, (uint32_t)ns, nt);
-        written_at = sa;
-        if (lane == 0) model[sa] = written;
+        const uint32_t rbits = __builtin_bit_cast(uint32_t, Rn);
+        fresh_idx = sa;
+        fresh_r = Rn;
+        if (lane == 0) {
+          model[sa] = cobel_model_pack(Rn, (uint32_t)ns, nt);
+          L.M16[sa] = (uint16_t)((uint32_t)ns | (nt << 14) | (rbits ? 0x8000u : 0u));
+        }
       } else if (rlog) {
         if (loglen < (uint32_t)A.r.log_cap) {
-          written = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
-          written_at = loglen;
-          if (lane == 0) rlog[loglen] = written;
+          fresh_rec = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
+          fresh_idx = loglen;
+          if (lane == 0) rlog[loglen] = fresh_rec;
           loglen += 1u;
         }
       }
@@ -279,51 +398,38 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       e[5] = __builtin_bit_cast(int32_t, td_online);
     }
 
-    // ---- bookkeeping ----------------------------------------------------------------------
+    // ---- bookkeeping --------------------------------------------------------------------------
     trew += (double)r;
     nsteps += 1ull;
     executed += 1ull;
-    if (OCC && lane == 0) occ[ns] += 1u;
-    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
-    const int prev_state = state;
+    if (OCC && lane == 0) L.occ[ns] += 1u;
     state = ns;
     cw0 = nw0;
     cw1 = nw1;
-    cp += 1u;
-    u_cur = draw_u(cp);
 
-    // ---- prefetch for the next step, then this step's planning -------------------------------
-    uint32_t mx_next = 0;
-    uint64_t gm_next = 0;
-    uint32_t bound_now = 0, bound_next = 0;
+    // ---- planning / replay ----------------------------------------------------------------------
     if (replay_each_step) {
-      bound_now = (AGENT == COBEL_AGENT_DYNAQ) ? SA : loglen;
-      mx_next = draw_m(cm + 1u);
-      const uint32_t room = (loglen < (uint32_t)A.r.log_cap) ? 1u : 0u;
-      bound_next = (AGENT == COBEL_AGENT_DYNAQ) ? SA : loglen + room;
-      gm_next = gather(mx_next, bound_next, loglen);
-    }
-    if (!trial_over) {
-      if (lane < 4) {
-        cand = W4[next_of(cw0, cw1, lane)];
-        if (AGENT == COBEL_AGENT_DYNAQ && learn) {
-          mrow = model[(uint32_t)state * 4u + (uint32_t)lane];
-          // the load may pass the store above: forward the record just written
-          if (state == prev_state && lane == a) mrow = written;
+      if (AGENT == COBEL_AGENT_DYNAQ) {
+        plan_dynaq(mdraw, fresh_idx, fresh_r);
+        cm += 1u;
+      } else {
+        // experiences of the next batch are gathered now, behind this batch's updates
+        const uint32_t bound_now = loglen;
+        const uint32_t qx_next = draw_m(cm + 1u);
+        const uint32_t room = loglen < (uint32_t)A.r.log_cap ? 1u : 0u;
+        const uint32_t bound_next = loglen + room;
+        uint64_t qrec_next = log_gather(qx_next, bound_next, loglen);
+        if (bound_now > 0u) {
+          if (lane < B && cobel_bounded(qx, bound_now) == fresh_idx) qrec = fresh_rec;
+          replay_log(qrec);
         }
+        cm += 1u;
+        qx = qx_next;
+        // the gather may have passed this step's own append
+        if (lane < B && bound_next > 0u && cobel_bounded(qx, bound_next) == fresh_idx)
+          qrec_next = fresh_rec;
+        qrec = qrec_next;
       }
-      mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
-    }
-    if (replay_each_step) {
-      // the record gathered ahead for this batch predates this step's own write
-      if (lane < B && bound_now > 0u && cobel_bounded(mx, bound_now) == written_at) gm = written;
-      run_batch(mx, gm, bound_now);
-      cm += 1u;
-      mx = mx_next;
-      gm = gm_next;
-      // ... and the gather for the next batch may have passed this step's store as well
-      if (lane < B && bound_next > 0u && cobel_bounded(mx, bound_next) == written_at)
-        gm = written;
     }
 
     if (trial_over) {
@@ -337,10 +443,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       trial += 1;
       iflags &= ~1u;
       if (episodic && B > 0) {
-        const uint32_t x = draw_m(cm);
-        uint64_t rec = gather(x, SA, 0u);
-        if (lane < B && cobel_bounded(x, SA) == written_at) rec = written;
-        run_batch(x, rec, SA);
+        refresh_draws();
+        plan_dynaq(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
         cm += 1u;
       }
     } else {
@@ -353,7 +457,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   for (int s = lane; s < S; s += 64) {
     Qg[s] = Qs[s];
     if (OCC) {
-      const uint32_t c = occ[s];
+      const uint32_t c = L.occ[s];
       if (c && A.r.occupancy) atomicAdd(A.r.occupancy + (size_t)world * S + s, (unsigned long long)c);
     }
   }
@@ -372,6 +476,236 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lane-per-instance variant for runs without planning (QAgent with batch 0, or Agent.test()):
+// with nothing to spread over the lanes of a wave, 64 instances share one wavefront and every
+// instruction of the select -> step -> TD chain serves 64 env steps.  Each lane keeps its
+// instance's Q table in its own LDS column (row s of lane l at ((s * 64 + l) * 16) bytes, so a
+// 16-byte row read is bank-conflict free across the wave), plus its own stream counters and
+// cached Philox blocks.  Usable while 1 KiB * S fits in LDS.
+//
+// Per-trial monitors: thousands of lanes finishing trials every step would serialise on global
+// atomics, so each wave keeps a direct-mapped, write-back cache of per-trial accumulators in LDS
+// (slot = trial & (kMonSlots - 1), tagged with the trial index).  Lanes whose slot carries their
+// trial add to it with LDS atomics; a lane that finds another trial there evicts it (adds it to
+// the global arrays) and claims the slot.  The 64 instances of a wave pass through the same trial
+// indices at different times, so each global address is touched about once per wave instead of
+// once per instance.
+constexpr int kMonSlots = 256;
+constexpr int kMonBytes = kMonSlots * 20;
+
+template <bool ONE_WORLD, bool MON>
+__global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int S = A.S;
+  float4* const Ql = reinterpret_cast<float4*>(lds_raw);
+  float* const Qlf = reinterpret_cast<float*>(lds_raw);
+  uint64_t* const thr = reinterpret_cast<uint64_t*>(lds_raw + (size_t)S * 1024);
+  uint4* const Wl = reinterpret_cast<uint4*>(lds_raw + (size_t)S * 1024 + kThrBytes);
+  unsigned char* const mon_raw = lds_raw + (size_t)S * 1024 + kThrBytes + (size_t)S * 16;
+  double* const wrew = reinterpret_cast<double*>(mon_raw);                      // [kMonSlots]
+  uint32_t* const wsum = reinterpret_cast<uint32_t*>(mon_raw + kMonSlots * 8);  // [kMonSlots]
+  uint32_t* const wcnt = wsum + kMonSlots;                                      // [kMonSlots]
+  int32_t* const wtag = reinterpret_cast<int32_t*>(wcnt + kMonSlots);           // [kMonSlots]
+
+  const int lane = (int)threadIdx.x;
+  const int i = (int)blockIdx.x * 64 + lane;
+  const bool active = i < A.r.n;
+  const int ii = active ? i : 0;
+  const uint32_t g = A.r.instance_base + (uint32_t)ii;
+  const int world = ONE_WORLD ? 0 : (int)(g % (uint32_t)A.n_worlds);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
+  float4* const Qg = reinterpret_cast<float4*>(A.r.q) + (size_t)ii * S;
+
+  for (int s = 0; s < S; ++s) Ql[s * 64 + lane] = Qg[s];
+  if (ONE_WORLD)
+    for (int s = lane; s < S; s += 64) Wl[s] = W4[s];
+  if (lane < 48) thr[lane] = A.eps.thr[lane / 3][lane % 3];
+  if (MON)
+    for (int k = lane; k < kMonSlots; k += 64) {
+      wrew[k] = 0.0;
+      wsum[k] = 0u;
+      wcnt[k] = 0u;
+      wtag[k] = -1;
+    }
+  __syncthreads();
+  auto wrec = [&](int s) -> uint4 { return ONE_WORLD ? Wl[s] : W4[s]; };
+  // write one cached accumulator back to the global monitors
+  auto evict = [&](int k) {
+    const int t = wtag[k];
+    const uint32_t c = wcnt[k];
+    if (c && t >= 0 && t < A.r.trial_cap) {
+      if (A.r.lat_sum) atomicAdd(A.r.lat_sum + t, (unsigned long long)wsum[k]);
+      if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + t, (unsigned long long)c);
+      if (A.r.reward_sum) atomicAdd(A.r.reward_sum + t, wrew[k]);
+    }
+    wrew[k] = 0.0;
+    wsum[k] = 0u;
+    wcnt[k] = 0u;
+  };
+
+  int32_t* const inst = A.r.inst + (size_t)ii * COBEL_I_WORDS;
+  int state = inst[COBEL_I_STATE];
+  int step = inst[COBEL_I_STEP];
+  int trial = inst[COBEL_I_TRIAL];
+  uint32_t ce = (uint32_t)inst[COBEL_I_CTR_ENV];
+  uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
+  uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
+  unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
+
+  const uint32_t flags = A.r.flags;
+  const bool learn = flags & COBEL_F_LEARN;
+  const uint32_t pol_stream =
+      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
+  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const uint64_t seed = A.r.seed;
+  const int start_lo = A.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
+  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f;
+
+  cobel_u4 pblk = {0, 0, 0, 0}, eblk = {0, 0, 0, 0};
+  uint32_t pb_idx = ~0u, eb_idx = ~0u;
+  uint32_t cw0 = 0, cw1 = 0;
+  if (iflags & 1u) {
+    const uint4 c = wrec(state);
+    cw0 = c.x;
+    cw1 = c.y;
+  }
+  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  unsigned long long executed = 0;
+  bool done = !active;
+
+  for (;;) {
+    if (!done && !(iflags & 1u)) {
+      if (trial >= A.r.trials_target) {
+        done = true;
+      } else {
+        if ((ce >> 2) != eb_idx) {
+          eb_idx = ce >> 2;
+          eblk = cobel_philox(eb_idx, 0u, g, COBEL_STREAM_ENV, seed);
+        }
+        state = (int)A.starts[start_lo + (int)cobel_bounded(cobel_word(eblk, ce & 3u), start_cnt)];
+        ce += 1u;
+        step = 0;
+        trew = 0.0;
+        iflags |= 1u;
+        const uint4 c = wrec(state);
+        cw0 = c.x;
+        cw1 = c.y;
+      }
+    }
+    if (!done && budget == 0) done = true;
+    if (!__any(!done)) break;
+    bool ended = false;
+    if (!done) {
+      budget -= 1;
+      if ((cp >> 1) != pb_idx) {
+        pb_idx = cp >> 1;
+        pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
+      }
+      const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x, w1 = (cp & 1u) ? pblk.w : pblk.y;
+      cp += 1u;
+      const float4 q = Ql[state * 64 + lane];
+      const uint32_t mask = amask ? (uint32_t)amask[state] & 15u : 15u;
+      int a;
+      if (mask == 15u) {
+        const float m = max4(q);
+        const int t = (int)(q.x == m) | ((int)(q.y == m) << 1) | ((int)(q.z == m) << 2) |
+                      ((int)(q.w == m) << 3);
+        const uint64_t K = cobel_u53(w0, w1);
+        a = (int)(thr[t * 3] <= K) + (int)(thr[t * 3 + 1] <= K) + (int)(thr[t * 3 + 2] <= K);
+      } else {
+        a = cobel_eps_greedy_select(q.x, q.y, q.z, q.w, mask, cobel_u01(w0, w1), A.eps);
+      }
+      const int ns = (int)next_of(cw0, cw1, a);
+      const uint4 nrec = wrec(ns);
+      const float r = __builtin_bit_cast(float, nrec.z);
+      const uint32_t end = nrec.w, nt = 1u - end;
+      float td_online = 0.0f;
+      if (learn) {   // online TD (agent/q.py:305-313), float32
+        const float4 nrow = Ql[ns * 64 + lane];
+        const int cell = (state * 64 + lane) * 4 + a;
+        const float qsa = Qlf[cell];
+        const float gnt = nt ? gamma_f : 0.0f;
+        float td = r + gnt * max4(nrow);
+        td = td - qsa;
+        Qlf[cell] = qsa + alpha_f * td;
+        td_online = td;
+      }
+      if (A.r.last_exp) {
+        int32_t* const e = A.r.last_exp + (size_t)ii * 6;
+        e[0] = state;
+        e[1] = a;
+        e[2] = ns;
+        e[3] = (int32_t)nt;
+        e[4] = __builtin_bit_cast(int32_t, r);
+        e[5] = __builtin_bit_cast(int32_t, td_online);
+      }
+      trew += (double)r;
+      nsteps += 1ull;
+      executed += 1ull;
+      const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+      state = ns;
+      cw0 = nrec.x;
+      cw1 = nrec.y;
+      ended = trial_over;
+      if (!trial_over) step += 1;
+    }
+    // ---- trial ends (agent/q.py:222-224: current_trial += 1; logs['steps'] = step) ------------
+    if (__any(ended)) {
+      if (MON) {
+        bool pending = ended;
+        const int slot = trial & (kMonSlots - 1);
+        while (__any(pending)) {
+          if (pending && wtag[slot] == trial) {
+            atomicAdd(&wsum[slot], (uint32_t)step);
+            atomicAdd(&wcnt[slot], 1u);
+            atomicAdd(&wrew[slot], trew);
+            pending = false;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const unsigned long long left = __ballot(pending);
+          if (left && lane == __ffsll((long long)left) - 1) {   // first waiting lane claims its slot
+            evict(slot);
+            wtag[slot] = trial;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (ended) {
+        if (A.r.lat_trace && trial >= 0 && trial < A.r.trial_cap)
+          A.r.lat_trace[(size_t)ii * A.r.trial_cap + trial] = step;
+        trial += 1;
+        iflags &= ~1u;
+      }
+    }
+  }
+  if (MON) {
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < kMonSlots; k += 64) evict(k);
+  }
+
+  __syncthreads();
+  if (active) {
+    if (learn)
+      for (int s = 0; s < S; ++s) Qg[s] = Ql[s * 64 + lane];
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
+  }
+  if (A.r.steps_done) {   // one atomic per wave
+    unsigned long long tot = executed;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0 && tot) atomicAdd(A.r.steps_done, tot);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_model_init(uint64_t* __restrict__ model, size_t total,
                                                     int S4) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,20 +714,27 @@ __global__ __launch_bounds__(256) void k_model_init(uint64_t* __restrict__ model
   model[t] = cobel_model_pack(0.0f, s, 0u);
 }
 
-template <int AGENT, bool OCC>
+template <int AGENT, bool OCC, bool WLDS>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC>),
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
+}
+
+template <int AGENT>
+int dispatch_wpi(const tab_args& A, bool occ, bool wlds, size_t lds, hipStream_t st) {
+  if (occ) return wlds ? launch_wpi<AGENT, true, true>(A, lds, st) : launch_wpi<AGENT, true, false>(A, lds, st);
+  return wlds ? launch_wpi<AGENT, false, true>(A, lds, st) : launch_wpi<AGENT, false, false>(A, lds, st);
 }
 
 }  // namespace
 
 static const int kLdsLimit = 160 * 1024;
+static const int kWorldLdsStates = 256;  // worlds up to this size keep their records in LDS
 
 extern "C" int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch,
                                int32_t* lds_bytes, int32_t* instances_per_block) {
@@ -402,7 +743,8 @@ extern "C" int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch,
                 "cobel_tab_query: unknown agent %d", agent);
   COBEL_REQUIRE(batch >= 0 && batch <= COBEL_MAX_BATCH, COBEL_E_UNSUPPORTED,
                 "cobel_tab_query: batch %d outside 0..%d", batch, COBEL_MAX_BATCH);
-  const long long lds = (long long)n_states * 20;  // Q row + visit counter per state
+  // worst case: replay hash table and visit counters present
+  const long long lds = (long long)tab_lds_bytes(n_states, agent, true, n_states <= kWorldLdsStates, true);
   COBEL_REQUIRE(lds <= kLdsLimit && n_states <= 16384, COBEL_E_UNSUPPORTED,
                 "cobel_tab_query: %d states need %lld B of LDS per instance (limit %d)", n_states,
                 lds, kLdsLimit);
@@ -410,7 +752,6 @@ extern "C" int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch,
   if (instances_per_block) *instances_per_block = 1;
   return COBEL_OK;
 }
-
 extern "C" int cobel_model_init(uint64_t* model, int32_t n, int32_t n_states, void* stream) {
   COBEL_REQUIRE(model, COBEL_E_ARG, "cobel_model_init: NULL model");
   COBEL_REQUIRE(n >= 0 && n_states > 0, COBEL_E_RANGE, "cobel_model_init: bad sizes");
@@ -445,8 +786,8 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   COBEL_REQUIRE(r.trial_cap >= 0 && r.log_cap >= 0, COBEL_E_RANGE, "cobel_tab_run: negative cap");
   COBEL_REQUIRE(r.agent != COBEL_AGENT_Q || world->n_states <= 16384, COBEL_E_UNSUPPORTED,
                 "cobel_tab_run: replay records address at most 16384 states");
-  int32_t lds = 0;
-  if (int rc = cobel_tab_query(world->n_states, r.agent, r.batch, &lds, nullptr)) return rc;
+  int32_t lds_max = 0;
+  if (int rc = cobel_tab_query(world->n_states, r.agent, r.batch, &lds_max, nullptr)) return rc;
   if (r.n == 0) return COBEL_OK;
 
   tab_args A;
@@ -461,11 +802,38 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
   const bool occ = r.occupancy != nullptr;
-  const size_t lds_q = (size_t)world->n_states * 16;
+  const bool wlds = world->n_states <= kWorldLdsStates;
+  const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
+                      (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
+  A.use_hash = replay ? 1 : 0;
+  const size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ);
   hipStream_t st = (hipStream_t)stream;
-  if (r.agent == COBEL_AGENT_DYNAQ)
-    return occ ? launch_wpi<COBEL_AGENT_DYNAQ, true>(A, (size_t)lds, st)
-               : launch_wpi<COBEL_AGENT_DYNAQ, false>(A, lds_q, st);
-  return occ ? launch_wpi<COBEL_AGENT_Q, true>(A, (size_t)lds, st)
-             : launch_wpi<COBEL_AGENT_Q, false>(A, lds_q, st);
+  // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
+  const bool learn = (r.flags & COBEL_F_LEARN) != 0;
+  const size_t lds_lpi = (size_t)world->n_states * 1024 + kThrBytes + (size_t)world->n_states * 16;
+  if (!replay && !occ && (!learn || r.agent == COBEL_AGENT_Q) &&
+      lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
+      r.n >= 64 && !(r.flags & COBEL_F_FORCE_WAVE)) {
+    const bool one = world->n_worlds == 1;
+    const bool mon = r.lat_sum || r.lat_cnt || r.reward_sum;
+    const size_t bytes = lds_lpi + (mon ? (size_t)kMonBytes : 0);
+    const dim3 grid((unsigned)((r.n + 63) / 64));
+#define COBEL_LPI(ONE, MON)                                                                    \
+  do {                                                                                         \
+    if (bytes > 64 * 1024)                                                                     \
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_lpi<ONE, MON>),   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                        (int)bytes));                                          \
+    hipLaunchKernelGGL((k_tab_lpi<ONE, MON>), grid, dim3(64), bytes, st, A);                   \
+  } while (0)
+    if (one && mon) COBEL_LPI(true, true);
+    else if (one) COBEL_LPI(true, false);
+    else if (mon) COBEL_LPI(false, true);
+    else COBEL_LPI(false, false);
+#undef COBEL_LPI
+    COBEL_HIP_TRY(hipGetLastError());
+    return COBEL_OK;
+  }
+  if (r.agent == COBEL_AGENT_DYNAQ) return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, lds, st);
+  return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, lds, st);
 }

@@ -146,8 +146,7 @@ __global__ __launch_bounds__(256) void k_env_reset(const uint16_t* __restrict__ 
   const int w = (int)(g % (uint32_t)n_worlds);
   const int lo = start_off[w], cnt = start_off[w + 1] - lo;
   const uint32_t idx = env_ctr[i];
-  const cobel_u4 x = cobel_philox(idx, 0u, g, COBEL_STREAM_ENV, seed);
-  state[i] = starts[lo + (int)cobel_bounded(x.x, (uint32_t)cnt)];
+  state[i] = starts[lo + (int)cobel_draw_bounded(idx, 0u, g, COBEL_STREAM_ENV, seed, (uint32_t)cnt)];
   env_ctr[i] = idx + 1u;
 }
 
@@ -231,8 +230,7 @@ __global__ __launch_bounds__(256) void k_rng_uniform(uint32_t* __restrict__ inde
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t idx = index[i];
-  const cobel_u4 x = cobel_philox(idx, 0u, base + (uint32_t)i, stream, seed);
-  out[i] = cobel_u01(x.x, x.y);
+  out[i] = cobel_draw_u01(idx, 0u, base + (uint32_t)i, stream, seed);
   if (advance) index[i] = idx + 1u;
 }
 
@@ -244,8 +242,7 @@ __global__ __launch_bounds__(256) void k_rng_bounded(uint32_t* __restrict__ inde
   if (t >= n * per) return;
   const int i = t / per, j = t % per;
   const uint32_t idx = index[i];
-  const cobel_u4 x = cobel_philox(idx, (uint32_t)j, base + (uint32_t)i, stream, seed);
-  out[t] = (int32_t)cobel_bounded(x.x, bound);
+  out[t] = (int32_t)cobel_draw_bounded(idx, (uint32_t)j, base + (uint32_t)i, stream, seed, bound);
 }
 
 __global__ __launch_bounds__(256) void k_rng_advance(uint32_t* __restrict__ index, int n) {

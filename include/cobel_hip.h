@@ -39,10 +39,13 @@ extern "C" {
 
 #define COBEL_ACTIONS 4 /* gridworld / 4-neighbour topology action count (gridworld.py:86) */
 
-/* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (index, sub, instance, stream). */
-#define COBEL_STREAM_ENV 0u    /* index = resets so far            (gridworld.py:142)     */
-#define COBEL_STREAM_POLICY 1u /* index = select_action calls      (greedy.py:58)         */
-#define COBEL_STREAM_MEMORY 2u /* index = replay batches, sub = j  (memory/dyna_q.py:137) */
+/* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (block, sub, instance, stream).
+ * Each stream is consumed through a per-instance draw counter c:
+ *   bounded integer c = mulhi32(word (c & 3) of block (c >> 2), n)
+ *   uniform double  c = 53-bit double from words 2(c & 1), 2(c & 1) + 1 of block (c >> 1)      */
+#define COBEL_STREAM_ENV 0u    /* c = resets so far                (gridworld.py:142)     */
+#define COBEL_STREAM_POLICY 1u /* c = select_action calls          (greedy.py:58)         */
+#define COBEL_STREAM_MEMORY 2u /* c = replay batches, sub = j      (memory/dyna_q.py:137) */
 #define COBEL_STREAM_POLICY_TEST 3u
 
 COBEL_API const char* cobel_last_error(void);
@@ -52,9 +55,8 @@ COBEL_API int cobel_abi_version(void);
 /* ------------------------------------------------------------------------------------------
  * Raw stream access (used by the host facade for single calls of Policy.select_action /
  * Interface.reset, and by the parity tests of the generator itself).
- *   uniform: out[i] = 53-bit double of block (index[i], sub, instance_base + i, stream)
- *   bounded: out[i][j] = mulhi32(x0 of block (index[i], j, instance_base + i, stream), bound),
- *            j < per_instance
+ *   uniform: out[i]    = double draw number index[i] (sub 0) of instance instance_base + i
+ *   bounded: out[i][j] = integer draw number index[i], sub j, j < per_instance
  * If advance != 0, index[i] += 1 afterwards.
  * ------------------------------------------------------------------------------------------ */
 COBEL_API int cobel_rng_uniform(uint32_t* index /* [dev] [N] */, uint64_t seed, uint32_t stream,
@@ -90,7 +92,7 @@ COBEL_API int cobel_world_info(const cobel_world_t* world, int32_t* n_states, in
  * (interface/topology.py:126-172) for N instances at once.
  *   step : ns = next[s][a]; reward_out = reward[ns]; done_out = terminal[ns]; state <- ns
  *   reset: where reset_mask[i] != 0 (or reset_mask == NULL):
- *          state[i] = starts[mulhi32(philox(seed, instance_base + i, env_ctr[i]).x0, n_starts)];
+ *          state[i] = starts[bounded draw number env_ctr[i] of COBEL_STREAM_ENV, n = n_starts];
  *          env_ctr[i] += 1
  * ------------------------------------------------------------------------------------------ */
 COBEL_API int cobel_env_step(const cobel_world_t* world, int32_t* state /* [dev] [N] in/out */,
@@ -161,6 +163,7 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
 #define COBEL_F_EPISODIC 4u       /* DynaQ.episodic_replay: one batch per trial              */
 #define COBEL_F_MASK_ACTIONS 8u   /* agent.mask_actions                                      */
 #define COBEL_F_TEST_STREAM 16u   /* draw u from COBEL_STREAM_POLICY_TEST (separate policy)  */
+#define COBEL_F_FORCE_WAVE 32u    /* always use the wave-per-instance kernel (testing)       */
 
 typedef struct {
   /* tables, all caller-owned device memory */

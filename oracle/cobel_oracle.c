@@ -83,6 +83,18 @@ static uint32_t bounded(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x
 static double u01(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
+/* draw counter c -> value (see oracle/philox.py for the stream layout) */
+static uint32_t draw_bounded(uint32_t c, uint32_t sub, uint32_t g, uint32_t stream, uint64_t seed,
+                             uint32_t n) {
+  uint32_t x[4];
+  philox(c >> 2, sub, g, stream, seed, x);
+  return bounded(x[c & 3u], n);
+}
+static double draw_u01(uint32_t c, uint32_t g, uint32_t stream, uint64_t seed) {
+  uint32_t x[4];
+  philox(c >> 1, 0, g, stream, seed, x);
+  return (c & 1u) ? u01(x[2], x[3]) : u01(x[0], x[1]);
+}
 void orc_philox(uint32_t index, uint32_t sub, uint32_t instance, uint32_t stream, uint64_t seed,
                 uint32_t* out) { philox(index, sub, instance, stream, seed, out); }
 
@@ -150,7 +162,6 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
   const int B = (learn && !(c->flags & F_NO_REPLAY) && (c->agent == AG_DYNAQ || LS)) ? c->batch : 0;
   const uint32_t pol_stream = (c->flags & F_TEST_STREAM) ? STREAM_POLICY_TEST : STREAM_POLICY;
   const double mlr = f32 ? (double)(float)c->model_lr : c->model_lr;
-  uint32_t x[4];
   if (trace_len) *trace_len = 0;
   for (int i = 0; i < c->n; ++i) {
     const uint32_t g = c->instance_base + (uint32_t)i;
@@ -170,8 +181,7 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
     for (;;) {
       if (!(in->flags & 1u)) {
         if (in->trial >= c->trials_target) break;
-        philox(in->ctr_env++, 0, g, STREAM_ENV, c->seed, x);
-        in->state = starts[bounded(x[0], n_starts)];
+        in->state = starts[draw_bounded(in->ctr_env++, 0, g, STREAM_ENV, c->seed, n_starts)];
         in->step = 0;
         in->trial_reward = 0.0;
         in->flags |= 1u;
@@ -179,9 +189,9 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
       if (budget == 0) break;
       --budget;
       const int s = in->state;
-      philox(in->ctr_policy++, 0, g, pol_stream, c->seed, x);
+      const double u = draw_u01(in->ctr_policy++, g, pol_stream, c->seed);
       const uint32_t mask = (c->flags & F_MASK) ? (action_mask[s] & 15u) : 15u;
-      const int a = orc_eps_greedy(q + 4 * s, mask, c->epsilon, u01(x[0], x[1]), NULL);
+      const int a = orc_eps_greedy(q + 4 * s, mask, c->epsilon, u, NULL);
       const int ns = next[4 * s + a];
       const double r = rnd(reward[ns], f32);
       const int end = terminal[ns] != 0, nt = 1 - end;
@@ -210,15 +220,15 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
       if (B > 0 && !episodic) {
         if (c->agent == AG_DYNAQ) {
           for (int j = 0; j < B; ++j) {
-            philox(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, x);
-            const uint32_t idx = bounded(x[0], (uint32_t)S * 4u);
+            const uint32_t idx =
+                draw_bounded(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, (uint32_t)S * 4u);
             td_planning(q, (int)(idx >> 2), (int)(idx & 3u), mr[idx], ms[idx], mt[idx], c->alpha,
                         c->gamma, f32);
           }
         } else if (in->log_len > 0) {
           for (int j = 0; j < B; ++j) {
-            philox(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, x);
-            const size_t k = lo + bounded(x[0], in->log_len);
+            const size_t k =
+                lo + draw_bounded(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, in->log_len);
             td_table_dtype(q, LS[k], LA[k], LR[k], LNS[k], LNT[k], c->alpha, c->gamma, f32);
           }
         }
@@ -236,8 +246,8 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
         in->flags &= ~1u;
         if (episodic && B > 0) {
           for (int j = 0; j < B; ++j) {
-            philox(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, x);
-            const uint32_t idx = bounded(x[0], (uint32_t)S * 4u);
+            const uint32_t idx =
+                draw_bounded(in->ctr_memory, (uint32_t)j, g, STREAM_MEMORY, c->seed, (uint32_t)S * 4u);
             td_planning(q, (int)(idx >> 2), (int)(idx & 3u), mr[idx], ms[idx], mt[idx], c->alpha,
                         c->gamma, f32);
           }
@@ -290,7 +300,6 @@ int orc_sr_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* SR,
   const uint32_t pol_stream = (c->flags & F_TEST_STREAM) ? STREAM_POLICY_TEST : STREAM_POLICY;
   const double al_t = f32 ? (double)(float)c->alpha : c->alpha;   /* table-dtype alpha */
   const double ga_t = f32 ? (double)(float)c->gamma : c->gamma;
-  uint32_t x[4];
   if (trace_len) *trace_len = 0;
   for (int i = 0; i < c->n; ++i) {
     const uint32_t g = c->instance_base + (uint32_t)i;
@@ -308,8 +317,7 @@ int orc_sr_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* SR,
     for (;;) {
       if (!(in->flags & 1u)) {
         if (in->trial >= c->trials_target) break;
-        philox(in->ctr_env++, 0, g, STREAM_ENV, c->seed, x);
-        in->state = starts[bounded(x[0], n_starts)];
+        in->state = starts[draw_bounded(in->ctr_env++, 0, g, STREAM_ENV, c->seed, n_starts)];
         in->step = 0;
         in->trial_reward = 0.0;
         in->flags |= 1u;
@@ -319,9 +327,9 @@ int orc_sr_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* SR,
       const int s = in->state;
       double q[4];
       for (int a = 0; a < 4; ++a) q[a] = pw_dot(sr + (size_t)tt[4 * s + a] * S, rw, S, f32);
-      philox(in->ctr_policy++, 0, g, pol_stream, c->seed, x);
+      const double u = draw_u01(in->ctr_policy++, g, pol_stream, c->seed);
       const uint32_t mask = (c->flags & F_MASK) ? (action_mask[s] & 15u) : 15u;
-      const int a = orc_eps_greedy(q, mask, c->epsilon, u01(x[0], x[1]), NULL);
+      const int a = orc_eps_greedy(q, mask, c->epsilon, u, NULL);
       const int ns = next[4 * s + a];
       const double r = rnd(reward[ns], f32);
       const int end = terminal[ns] != 0, nt = 1 - end;

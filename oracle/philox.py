@@ -16,13 +16,15 @@ the reference consume exactly the draws the HIP kernels generate on device.
 Stream layout (shared with ``cobel-rl_amd/csrc/cobel_rng.h`` — keep in sync):
 
     key = (seed & 0xffffffff, seed >> 32)
-    ctr = (index, sub, instance, stream)
-    STREAM_ENV    = 0  index = number of resets so far     -> k = mulhi32(x0, n)
-    STREAM_POLICY = 1  index = number of select_action()s  -> u = 53-bit double
-    STREAM_MEMORY = 2  index = number of replay batches, sub = position in the
-                       batch                                -> k = mulhi32(x0, n)
+    ctr = (block, sub, instance, stream)
+    a stream is consumed through a draw counter c:
+      bounded integer c : word (c & 3) of block (c >> 2)              -> mulhi32(word, n)
+      uniform double  c : words 2(c & 1), 2(c & 1) + 1 of block (c >> 1)
+    STREAM_ENV    = 0  c = number of resets so far
+    STREAM_POLICY = 1  c = number of select_action()s
+    STREAM_MEMORY = 2  c = number of replay batches, sub = position in the batch
 
-Bounded integers are ``(x0 * n) >> 32`` (Lemire multiply-shift without the
+Bounded integers are ``(word * n) >> 32`` (Lemire multiply-shift without the
 rejection step; bias <= n / 2**32).  Uniform doubles follow NumPy's recipe
 ``(a >> 5, b >> 6) -> (a * 2**26 + b) / 2**53``.
 """
@@ -76,16 +78,23 @@ def _block(seed: int, instance, index, sub, stream: int):
 
 
 def draw_bounded(seed: int, instance, index, sub, stream: int, n):
-    """``mulhi32(x0, n)`` for the addressed block; ``n`` may be an array."""
-    x0 = _block(seed, instance, index, sub, stream)[..., 0].astype(np.uint64)
-    return ((x0 * np.asarray(n, dtype=np.uint64)) >> _S32).astype(np.int64)
+    """Integer draw number ``index`` (array-like allowed) in [0, n); ``n`` may be an array."""
+    index = np.asarray(index, dtype=np.uint64)
+    b = _block(seed, instance, index >> np.uint64(2), sub, stream)
+    w = np.take_along_axis(b, np.broadcast_to(index & np.uint64(3), b.shape[:-1])[..., None]
+                           .astype(np.int64), axis=-1)[..., 0].astype(np.uint64)
+    return ((w * np.asarray(n, dtype=np.uint64)) >> _S32).astype(np.int64)
 
 
 def draw_double(seed: int, instance, index, sub, stream: int):
-    """53-bit uniform double in [0, 1) from words x0, x1 of the addressed block."""
-    b = _block(seed, instance, index, sub, stream)
-    a = (b[..., 0] >> np.uint32(5)).astype(np.float64)
-    c = (b[..., 1] >> np.uint32(6)).astype(np.float64)
+    """Double draw number ``index``: 53-bit uniform in [0, 1)."""
+    index = np.asarray(index, dtype=np.uint64)
+    b = _block(seed, instance, index >> np.uint64(1), sub, stream)
+    k = (np.broadcast_to(index & np.uint64(1), b.shape[:-1]) * np.uint64(2)).astype(np.int64)
+    hi = np.take_along_axis(b, k[..., None], axis=-1)[..., 0]
+    lo = np.take_along_axis(b, k[..., None] + 1, axis=-1)[..., 0]
+    a = (hi >> np.uint32(5)).astype(np.float64)
+    c = (lo >> np.uint32(6)).astype(np.float64)
     return (a * 67108864.0 + c) / 9007199254740992.0
 
 

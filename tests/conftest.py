@@ -50,3 +50,17 @@ def as_world(tab):
              coordinates=tab['coordinates'], deterministic=True, invalid_states=[],
              invalid_transitions=[], goals=[], wind=np.zeros((h * wd, 2), dtype=int))
     return w
+
+
+def coinciding_trials(D, a, b):
+    """Number of leading trials in which two recorded runs visit exactly the same (s, a) pairs."""
+    sa, sb = D[a + '/steps'], D[b + '/steps']
+    pa = np.stack([D[a + '/state'], D[a + '/action']], axis=1)
+    pb = np.stack([D[b + '/state'], D[b + '/action']], axis=1)
+    same, oa, ob = 0, 0, 0
+    for t in range(min(len(sa), len(sb))):
+        na, nb = int(sa[t]) + 1, int(sb[t]) + 1
+        if na != nb or not np.array_equal(pa[oa:oa + na], pb[ob:ob + nb]):
+            break
+        same, oa, ob = same + 1, oa + na, ob + nb
+    return same

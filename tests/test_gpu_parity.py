@@ -8,7 +8,7 @@ legitimately forks them — SURVEY.md §8c)."""
 import numpy as np
 import pytest
 
-from conftest import SEED, as_world, cases
+from conftest import SEED, as_world, cases, coinciding_trials
 
 pytestmark = pytest.mark.gpu
 
@@ -220,10 +220,9 @@ def test_dynaq_float32_vs_float64_reference(torch_cuda, golden, golden_worlds, p
     D = golden('dynaq_traces')
     inst = int(D[f32 + '/cfg'][0])
     _dynaq(golden, golden_worlds, f32, 1, inst, {'on_trial_end': [spy.trial_end]})
-    ref_steps, ref_q = D[f64 + '/steps'], D[f64 + '/Q_trial']
-    same = 0
-    while same < min(len(ref_steps), len(spy.steps)) and spy.steps[same] == ref_steps[same]:
-        same += 1
+    ref_q = D[f64 + '/Q_trial']
+    assert np.array_equal(spy.steps, D[f32 + '/steps'])      # the kernel IS the float32 run
+    same = coinciding_trials(D, f32, f64)
     assert same >= 3
     for t in range(same):
         assert np.max(np.abs(spy.q[t] - ref_q[t]) / np.maximum(1.0, np.abs(ref_q[t]))) <= tol
@@ -444,3 +443,70 @@ def test_qagent_replay_vs_oracle(torch_cuda, golden_worlds):
     assert np.array_equal(agent.monitors.lat_trace.cpu().numpy(), o.lat_trace)
     assert np.array_equal(agent.inst[:, 6].cpu().numpy(), o.inst['log_len'].astype(np.int32))
     assert len(agent.M) == int(o.inst['log_len'][0])
+
+
+@pytest.mark.parametrize('n,worlds', [(4100, 1), (200, 3)])
+def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds):
+    """Runs without planning take the lane-per-instance kernel (64 instances per wave): Q-learning
+    with batch 0 over several budgeted launches (partial last wave, 1 or 3 worlds), then a
+    greedy test() phase with an action mask — all against the C oracle, and against the
+    wave-per-instance kernel forced on the same inputs."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    ws = [make_open_field(5, 5, g, 1.0 + g) for g in (0, 12, 24)][:worlds]
+
+    def run(force_wave):
+        env = Gridworld(ws, n_envs=n, seed=77, instance_base=9)
+        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1), EpsilonGreedy(0.0))
+        ag.track_instances = True
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False) | \
+            (_lib.F_FORCE_WAVE if force_wave else 0)
+        ag.monitors.reserve(64, n, True)
+        for _ in range(3):
+            ag._launch(env, ag.policy, flags, 64, 30, 37, 0)
+        ag._policy_out(ag.policy)
+        ag._env_out(env)
+        ag.current_trial = 64
+        ag.inst[:, _lib.I_TRIAL] = 64          # start the test phase at a common trial index
+        ag.mask_actions = True
+        ag.action_mask = np.ones((25, 4), dtype=bool)
+        ag.action_mask[:, 0] = False           # never move left
+        ag.action_mask[0] = True
+        ag.test(env, 3, 20)
+        torch.cuda.synchronize()
+        return ag
+
+    lpi, wpi = run(False), run(True)
+    assert torch.equal(lpi._q, wpi._q) and torch.equal(lpi.inst, wpi.inst)
+    assert torch.equal(lpi.monitors.lat_trace, wpi.monitors.lat_trace)
+    assert torch.equal(lpi.monitors.lat_sum, wpi.monitors.lat_sum)
+
+    tabs = [dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'],
+                 starts=w['starting_states']) for w in ws]
+    mask = np.ones((25, 4), dtype=bool)
+    mask[:, 0] = False
+    mask[0] = True
+    o = c_oracle.TabOracle(c_oracle.OracleWorld(tabs), n, c_oracle.AG_Q, 77, True, instance_base=9,
+                           alpha=0.9, gamma=0.8, trial_cap=67)
+    for _ in range(3):
+        o.run(64, 30, 0, step_budget=37)
+    assert np.array_equal(lpi._q.cpu().numpy().astype(np.float64), o.Q)
+    o.inst['trial'] = 64
+    o.inst['flags'] = 0
+    o.inst['step'] = 0
+    # separate test policy -> its own stream and counter
+    saved = o.inst['ctr_policy'].copy()
+    o.inst['ctr_policy'] = 0
+    o.mask = (mask * np.array([1, 2, 4, 8])).sum(axis=1).astype(np.uint8)
+    o.run(67, 20, 0, flags=c_oracle.F_TEST_STREAM, epsilon=0.0)
+    o.inst['ctr_policy'] = saved
+    assert np.array_equal(lpi.monitors.lat_trace.cpu().numpy()[:, 64:67], o.lat_trace[:, 64:67])
+    got = lpi.inst.cpu().numpy()
+    assert np.array_equal(got[:, 0], o.inst['state']) and np.array_equal(got[:, 3], o.inst['ctr_env'].astype(np.int32))

