@@ -77,7 +77,25 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
   return b;
 }
 
-template <int AGENT, bool OCC, bool WLDS>
+#if defined(COBEL_STAMPS)
+// Diagnostic build only: per-phase cycle sums, written to last_exp[i][0..5] (never to an output).
+#define STAMP(k)                                                                          \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long now_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    stamp_sum[k] += now_ - stamp_last;                                                    \
+    stamp_last = now_;                                                                    \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+// FAST: the run is the plain training case — learning on, planning after every step, no action
+// mask, no per-step host log — so those run-time switches become constants (fewer live scalar
+// registers and branches in the step loop; the generic instantiation spills SGPRs).
+template <int AGENT, bool OCC, bool WLDS, bool FAST>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -146,22 +164,30 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
 
   const uint32_t flags = A.r.flags;
-  const bool learn = flags & COBEL_F_LEARN;
-  const bool episodic = (AGENT == COBEL_AGENT_DYNAQ) && (flags & COBEL_F_EPISODIC);
-  const int B = (learn && !(flags & COBEL_F_NO_REPLAY) &&
-                 (AGENT == COBEL_AGENT_DYNAQ || rlog != nullptr))
-                    ? A.r.batch
-                    : 0;
-  const bool replay_each_step = B > 0 && !episodic;
-  const uint32_t pol_stream =
-      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
-  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const bool learn = FAST || (flags & COBEL_F_LEARN);
+  const bool episodic = !FAST && (AGENT == COBEL_AGENT_DYNAQ) && (flags & COBEL_F_EPISODIC);
+  const int B = FAST ? A.r.batch
+                     : ((learn && !(flags & COBEL_F_NO_REPLAY) &&
+                         (AGENT == COBEL_AGENT_DYNAQ || rlog != nullptr))
+                            ? A.r.batch
+                            : 0);
+  const bool replay_each_step = FAST || (B > 0 && !episodic);
+  const uint32_t pol_stream = (!FAST && (flags & COBEL_F_TEST_STREAM)) ? COBEL_STREAM_POLICY_TEST
+                                                                       : COBEL_STREAM_POLICY;
+  const uint8_t* const amask =
+      (!FAST && (flags & COBEL_F_MASK_ACTIONS)) ? A.r.action_mask : nullptr;
   const uint64_t seed = A.r.seed;
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   const double alpha = A.r.alpha, gamma = A.r.gamma;
   const float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
 
+  // epsilon-greedy thresholds (cobel_eps_consts::thr), entry e = t * 3 + k in lane e < 48
+  const uint64_t thr_mine = A.eps.thr[(lane % 48) / 3][lane % 3];
+  const uint32_t thr_lo = (uint32_t)thr_mine, thr_hi = (uint32_t)(thr_mine >> 32);
+#if defined(COBEL_STAMPS)
+  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
   // ---- values carried from one step to the next ------------------------------------------
   uint32_t cw0 = 0, cw1 = 0;   // next[0..3] of the current state (uniform)
   uint4 cand = {0, 0, 0, 0};   // !WLDS: lane k < 4 holds the world record of next[state][k]
@@ -211,14 +237,22 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
     const bool on = lane < B;
     const uint32_t sj = idx >> 2;
+#if defined(COBEL_ABLATE) && COBEL_ABLATE == 3
+    return;
+#endif
     // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
     const uint32_t bs = sj & (kHashBuckets - 1), bn = ns & (kHashBuckets - 1);
     if (on) atomicOr(&L.H[bs], 1ull << lane);
     __builtin_amdgcn_wave_barrier();
     unsigned long long cnd = on ? ((L.H[bn] | L.H[bs]) & ((1ull << lane) - 1ull)) : 0ull;
+#if defined(COBEL_ABLATE) && COBEL_ABLATE == 1
+    cnd = 0ull;
+#endif
     __builtin_amdgcn_wave_barrier();
     if (on) L.H[bs] = 0ull;
+    STAMP(2);
     int dep = -1;  // latest earlier lane this lane must wait for
+    // verify candidates, latest first: a hit ends the lane's search
     while (__ballot(cnd != 0ull)) {
       const int e = cnd ? (63 - __clzll((long long)cnd)) : 0;
       const uint32_t se = (uint32_t)__shfl((int)sj, e), ie = (uint32_t)__shfl((int)idx, e);
@@ -230,6 +264,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         cnd &= ~(1ull << e);
       }
     }
+    STAMP(3);
     int first = 0;
     while (first < B) {
       const unsigned long long blocked = __ballot(on && dep >= first);
@@ -257,6 +292,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       __builtin_amdgcn_wave_barrier();
       first = stop;
     }
+    STAMP(4);
   };
   // Dyna-Q batch drawn with x: model entries from LDS, reward estimates from HBM where flagged.
   // (fresh_idx, fresh_r): the entry this step wrote, whose HBM copy may still be in flight.
@@ -289,8 +325,12 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
   int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
   unsigned long long executed = 0;
+#if defined(COBEL_STAMPS)
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
   while (true) {
+    STAMP(5);
     if (!(iflags & 1u)) {
       if (trial >= A.r.trials_target) break;
       state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
@@ -312,33 +352,43 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     const uint32_t mdraw = cobel_word(blk, cm & 3u);   // lanes < B: this step's batch
     cp += 1u;
 
-    // ---- select (policy/greedy.py:40-88) ------------------------------------------------------
+    // ---- one batch of LDS reads serves the whole scalar part of the step ---------------------
+    // Only four successors are possible, so lane k < 4 reads the Q row (and, for small worlds, the
+    // world record) of next[state][k] now; once the action is known the chosen one is a readlane
+    // away and the select -> step -> TD chain pays a single LDS round trip.
     const float4 qrow = Qs[state];
+    const uint32_t succ = next_of(cw0, cw1, lane & 3);
+    const float4 srow = Qs[succ];
+    const float smax = max4(srow);
+    if (WLDS) cand = L.Wl[succ];
+    uint2 m4 = {0u, 0u};   // the four 16-bit model entries of this state
+    if (AGENT == COBEL_AGENT_DYNAQ) m4 = *reinterpret_cast<const uint2*>(&L.M16[state * 4]);
+
+    // ---- select (policy/greedy.py:40-88) ------------------------------------------------------
     int a;
     if (mask_cur == 15u) {
-      a = cobel_eps_greedy_select_thr(qrow.x, qrow.y, qrow.z, qrow.w, cobel_u53(w0, w1), L.thr,
-                                      lane);
+      // integer thresholds of the tie pattern's CDF, held one per lane in thr_lo / thr_hi
+      const float m = max4(qrow);
+      const int t = (int)rfl((uint32_t)((int)(qrow.x == m) | ((int)(qrow.y == m) << 1) |
+                                        ((int)(qrow.z == m) << 2) | ((int)(qrow.w == m) << 3)));
+      const uint64_t K = cobel_u53(w0, w1);
+      a = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const uint64_t T = (uint64_t)rl(thr_lo, t * 3 + k) | ((uint64_t)rl(thr_hi, t * 3 + k) << 32);
+        a += (int)(T <= K);
+      }
     } else {
-      a = cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
-                                       cobel_u01(w0, w1), A.eps, lane);
+      a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
+                                                          cobel_u01(w0, w1), A.eps, lane));
     }
-    a = (int)rfl((uint32_t)a);
+    STAMP(0);
     // ---- env.step (interface/gridworld.py:115-126) ----------------------------------------------
     const int ns = (int)next_of(cw0, cw1, a);
-    uint32_t nw0, nw1, end;
-    float r;
-    if (WLDS) {
-      const uint4 nrec = L.Wl[ns];
-      nw0 = rfl(nrec.x);
-      nw1 = rfl(nrec.y);
-      r = __builtin_bit_cast(float, rfl(nrec.z));
-      end = rfl(nrec.w);
-    } else {
-      nw0 = rl(cand.x, a);
-      nw1 = rl(cand.y, a);
-      r = __builtin_bit_cast(float, rl(cand.z, a));
-      end = rl(cand.w, a);
-    }
+    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
+    const float r = __builtin_bit_cast(float, rl(cand.z, a));
+    const uint32_t end = rl(cand.w, a);
+    const float ns_max = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, smax), a));
     const uint32_t nt = 1u - end;
     const uint32_t sa = (uint32_t)state * 4u + (uint32_t)a;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
@@ -357,7 +407,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (learn) {
       if (AGENT == COBEL_AGENT_DYNAQ) {
         // memory/dyna_q.py:92-96 (float32): rewards[s,a] += lr * (r - rewards[s,a])
-        const uint32_t old = L.M16[sa];
+        const uint32_t pair = (a & 2) ? m4.y : m4.x;
+        const uint32_t old = (a & 1) ? (pair >> 16) : (pair & 0xffffu);
         float R = 0.0f;
         if (old & 0x8000u) R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
         const float d = r - R;
@@ -377,18 +428,17 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
           loglen += 1u;
         }
       }
-      // online TD (agent/dyna_q.py:290-299), float32
-      const float4 nrow = Qs[ns];
-      const float q = Qf[sa];
+      // online TD (agent/dyna_q.py:290-299), float32; Q[ns] and Q[s][a] were read above
+      const float q = (a & 2) ? ((a & 1) ? qrow.w : qrow.z) : ((a & 1) ? qrow.y : qrow.x);
       const float gnt = nt ? gamma_f : 0.0f;
-      float td = r + gnt * max4(nrow);
+      float td = r + gnt * ns_max;
       td = td - q;
       const float qn = q + alpha_f * td;
       if (lane == 0) Qf[sa] = qn;
       td_online = td;
       __builtin_amdgcn_wave_barrier();
     }
-    if (A.r.last_exp && lane == 0) {
+    if (!FAST && A.r.last_exp && lane == 0) {
       int32_t* const e = A.r.last_exp + (size_t)i * 6;
       e[0] = state;
       e[1] = a;
@@ -398,6 +448,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       e[5] = __builtin_bit_cast(int32_t, td_online);
     }
 
+    STAMP(1);
     // ---- bookkeeping --------------------------------------------------------------------------
     trew += (double)r;
     nsteps += 1ull;
@@ -452,6 +503,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     }
   }
 
+#if defined(COBEL_STAMPS)
+  if (A.r.last_exp && lane == 0)
+    for (int k = 0; k < 6; ++k) A.r.last_exp[(size_t)i * 6 + k] = (int32_t)(stamp_sum[k] >> 4);
+#endif
   // ---- write back ---------------------------------------------------------------------------
   __syncthreads();
   for (int s = lane; s < S; s += 64) {
@@ -714,21 +769,30 @@ __global__ __launch_bounds__(256) void k_model_init(uint64_t* __restrict__ model
   model[t] = cobel_model_pack(0.0f, s, 0u);
 }
 
-template <int AGENT, bool OCC, bool WLDS>
+template <int AGENT, bool OCC, bool WLDS, bool FAST>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    COBEL_HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
 template <int AGENT>
-int dispatch_wpi(const tab_args& A, bool occ, bool wlds, size_t lds, hipStream_t st) {
-  if (occ) return wlds ? launch_wpi<AGENT, true, true>(A, lds, st) : launch_wpi<AGENT, true, false>(A, lds, st);
-  return wlds ? launch_wpi<AGENT, false, true>(A, lds, st) : launch_wpi<AGENT, false, false>(A, lds, st);
+int dispatch_wpi(const tab_args& A, bool occ, bool wlds, bool fast, size_t lds, hipStream_t st) {
+  if (AGENT == COBEL_AGENT_DYNAQ && fast) {
+    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true>(A, lds, st)
+                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true>(A, lds, st);
+    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true>(A, lds, st)
+                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true>(A, lds, st);
+  }
+  if (occ) return wlds ? launch_wpi<AGENT, true, true, false>(A, lds, st)
+                       : launch_wpi<AGENT, true, false, false>(A, lds, st);
+  return wlds ? launch_wpi<AGENT, false, true, false>(A, lds, st)
+              : launch_wpi<AGENT, false, false, false>(A, lds, st);
 }
 
 }  // namespace
@@ -834,6 +898,9 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;
   }
-  if (r.agent == COBEL_AGENT_DYNAQ) return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, lds, st);
-  return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, lds, st);
+  const bool fast = r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
+                    !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
+  if (r.agent == COBEL_AGENT_DYNAQ)
+    return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, fast, lds, st);
+  return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, false, lds, st);
 }
