@@ -73,6 +73,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_int32)]),
     'cobel_env_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_uint32, _P]),
     'cobel_env_reset': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_uint32, _P]),
+    'cobel_gather_rows': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'cobel_eps_greedy': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),
     'cobel_tab_query': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),

@@ -1,0 +1,97 @@
+"""Topology-graph builders for the 4-neighbour environments the HIP env kernels serve.
+
+Call surface of the reference's ``cobel.misc.topology_tools`` (misc/topology_tools.py:14-373) for
+``linear_track``, ``grid`` and ``t_maze``: same arguments, same ``(nodes, starting_nodes)`` result
+with ``nodes[id] = {'id', 'pose', 'terminal', 'reward', 'neighbors'}``; ids are ``str(n)`` in
+construction order, neighbours are ordered [left, up, right, down] and point back at the node
+itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` (six neighbours),
+``cross`` and the shapely-based obstacle pruning are outside the accelerated path.
+"""
+from __future__ import annotations
+
+from itertools import product
+from typing import Literal
+
+import numpy as np
+
+
+def _nodes_from_coordinates(coords: np.ndarray, spacing: float) -> dict:
+    """Unit-lattice coordinates -> nodes; neighbours by the reference's distance rule
+    (0 < dx < 1.5 and |dy| < 1 is 'left', ...), evaluated for all pairs at once."""
+    n = len(coords)
+    dx = coords[:, None, 0] - coords[None, :, 0]
+    dy = coords[:, None, 1] - coords[None, :, 1]
+    off = ~np.eye(n, dtype=bool)
+    rules = [(0 < dx) & (dx < 1.5) & (np.abs(dy) < 1),      # left
+             (0 > dy) & (dy > -1.5) & (np.abs(dx) < 1),     # up
+             (0 > dx) & (dx > -1.5) & (np.abs(dy) < 1),     # right
+             (0 < dy) & (dy < 1.5) & (np.abs(dx) < 1)]      # down
+    nodes = {}
+    for i, (x, y) in enumerate(coords):
+        neighbors = []
+        for rule in rules:
+            hit = np.flatnonzero(rule[i] & off[i])
+            neighbors.append(str(hit[-1]) if len(hit) else str(i))   # the last match wins
+        nodes[str(i)] = {'id': str(i), 'pose': (float(x) * spacing, float(y) * spacing, 0.0, 0.0,
+                                                0.0, 0.0),
+                         'terminal': False, 'reward': 0.0, 'neighbors': neighbors}
+    return nodes
+
+
+def linear_track(nb_nodes_track: int, nb_nodes_width: int, spacing: float = 1.0,
+                 reward: float = 1.0, location: Literal['left', 'right'] = 'right'):
+    assert nb_nodes_track > 1, 'Track has to be at least 2 states long!'
+    assert nb_nodes_width > 0, 'Track has to be at least 1 state wide!'
+    assert spacing > 0, 'Node spacing must be positive!'
+    assert location in ['left', 'right'], 'Invalid reward location!'
+    coords = np.array([[i, nb_nodes_width - j - 1] for j in range(nb_nodes_width)
+                       for i in range(nb_nodes_track)], dtype=float)
+    nodes = _nodes_from_coordinates(coords, spacing)
+    starting = []
+    for i in range(nb_nodes_width):
+        goal = str(i * nb_nodes_track + (nb_nodes_track - 1) * (location == 'right'))
+        nodes[goal].update({'terminal': True, 'reward': reward})
+        starting.append(str(i * nb_nodes_track + (nb_nodes_track - 1) * (location == 'left')))
+    return nodes, starting
+
+
+def t_maze(nb_nodes_stem: int, nb_nodes_arm: int, nb_nodes_width: int, spacing: float = 1.0,
+           reward: float = 1.0, location: Literal['left', 'right'] = 'right'):
+    assert nb_nodes_stem > 0 and nb_nodes_arm > 0 and nb_nodes_width > 0
+    assert spacing > 0, 'Node spacing must be positive!'
+    assert location in ['left', 'right'], 'Invalid reward location!'
+    span = nb_nodes_arm * 2 + nb_nodes_width
+    coords = [[j, nb_nodes_stem + nb_nodes_width - 1 - i] for i in range(nb_nodes_width)
+              for j in range(span)]
+    coords += [[nb_nodes_arm + j, nb_nodes_stem - 1 - i] for i in range(nb_nodes_stem)
+               for j in range(nb_nodes_width)]
+    nodes = _nodes_from_coordinates(np.array(coords, dtype=float), spacing)
+    for i in range(nb_nodes_width):
+        nodes[str(span * i + (span - 1) * int(location == 'right'))].update(
+            {'terminal': True, 'reward': reward})
+    return nodes, list(nodes.keys())[-nb_nodes_width:]
+
+
+def grid(nb_nodes, limits=(0.0, 1.0), reward: float = 1.0, location=None):
+    nx = nb_nodes if isinstance(nb_nodes, int) else nb_nodes[0]
+    ny = nb_nodes if isinstance(nb_nodes, int) else nb_nodes[1]
+    assert (nx > 1 and ny >= 1) or (nx >= 1 and ny > 1), 'Invalid environment dimensions!'
+    lim_x = limits if isinstance(limits[0], float) else limits[0]
+    lim_y = limits if isinstance(limits[0], float) else limits[1]
+    assert lim_x[1] > lim_x[0], 'Invalid x coordinate range!'
+    assert lim_y[1] > lim_y[0], 'Invalid y coordinate range!'
+    xs, ys = np.linspace(lim_x[0], lim_x[1], nx), np.linspace(lim_y[0], lim_y[1], ny)
+    nodes = {}
+    for n, (y, x) in enumerate(product(ys, xs)):
+        j, i = divmod(n, nx)
+        nodes[str(n)] = {
+            'id': str(n), 'pose': (float(x), float(lim_y[1] - (y - lim_y[0])), 0.0, 0.0, 0.0, 0.0),
+            'terminal': False, 'reward': 0.0,
+            'neighbors': [str(j * nx + max(i - 1, 0)), str(max(j - 1, 0) * nx + i),
+                          str(j * nx + min(i + 1, nx - 1)), str(min(j + 1, ny - 1) * nx + i)]}
+    if location is None or location not in nodes:
+        location = str(nx - 1)
+    nodes[location].update({'terminal': True, 'reward': reward})
+    starting = list(nodes.keys())
+    starting.remove(location)
+    return nodes, starting

@@ -281,3 +281,28 @@ extern "C" int cobel_rng_bounded(uint32_t* index, uint64_t seed, uint32_t stream
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ table,
+                                                     const int32_t* __restrict__ index,
+                                                     double* __restrict__ out, int n, int width,
+                                                     int rows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * width) return;
+  const int i = t / width, c = t % width;
+  const int r = index[i];
+  out[t] = (r >= 0 && r < rows) ? table[(size_t)r * width + c] : __builtin_nan("");
+}
+
+extern "C" int cobel_gather_rows(const double* table, const int32_t* index, double* out,
+                                 int32_t n, int32_t width, int32_t rows, void* stream) {
+  COBEL_REQUIRE(table && index && out, COBEL_E_ARG, "cobel_gather_rows: NULL argument");
+  COBEL_REQUIRE(n >= 0 && width > 0 && rows > 0, COBEL_E_RANGE, "cobel_gather_rows: bad sizes");
+  const long long total = (long long)n * width;
+  COBEL_REQUIRE(total < (1ll << 31), COBEL_E_RANGE, "cobel_gather_rows: too many elements");
+  if (total == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, table, index, out, n, width, rows);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

@@ -104,6 +104,14 @@ COBEL_API int cobel_env_reset(const cobel_world_t* world, int32_t* state /* [dev
                     uint32_t* env_ctr /* [dev] [N] in/out */, uint64_t seed, int32_t n,
                     uint32_t instance_base, void* stream);
 
+/* Observation lookup: out[i][0..width) = table[index[i]][0..width) (float64 rows).  Replaces
+ * Topology.get_observation for pose observations (interface/topology.py:174-193) and the
+ * coordinate lookup of Gridworld.get_position (interface/gridworld.py:147-156). */
+COBEL_API int cobel_gather_rows(const double* table /* [dev] [rows][width] */,
+                                const int32_t* index /* [dev] [N] */,
+                                double* out /* [dev] [N][width] */, int32_t n, int32_t width,
+                                int32_t rows, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Epsilon-greedy.  Replaces EpsilonGreedy.get_action_probs / select_action
  * (policy/greedy.py:40-88) incl. the Generator.choice draw

@@ -433,8 +433,60 @@ def gen_monitor(worlds):
         occ_bin2=occ2)
 
 
+def gen_topology():
+    """misc/topology_tools.py builders as index tables, unit_tests/test_topology.py:92-109 and a
+    draw-injected random walk through interface/topology.py."""
+    from cobel.interface import Topology
+    from cobel.misc import topology_tools as tt
+    out = {}
+    built = {'linear_10x2': tt.linear_track(10, 2, 1., 20., 'right'),
+             'linear_5x1_left': tt.linear_track(5, 1, 0.5, 2., 'left'),
+             't_maze_4_3_1': tt.t_maze(4, 3, 1), 't_maze_3_2_2_left': tt.t_maze(3, 2, 2, 2.0, 3.0, 'left'),
+             'grid_4x3': tt.grid((4, 3)), 'grid_5': tt.grid(5, (0.0, 2.0), 7.0, '12')}
+    for name, (nodes, starts) in built.items():
+        ids = list(nodes.keys())
+        idx = {k: i for i, k in enumerate(ids)}
+        out[name + '/nbr'] = np.array([[idx[m] for m in nodes[k]['neighbors']] for k in ids])
+        out[name + '/pose'] = np.array([nodes[k]['pose'] for k in ids], dtype=np.float64)
+        out[name + '/reward'] = np.array([nodes[k]['reward'] for k in ids], dtype=np.float64)
+        out[name + '/terminal'] = np.array([bool(nodes[k]['terminal']) for k in ids])
+        out[name + '/starts'] = np.array([idx[k] for k in starts])
+    nodes, starts = built['t_maze_4_3_1']
+    env = Topology(nodes, starts)
+    env.reset()
+    assert env.current_node == '10'
+    actions = [1, 1, 1, 1, 1, 2, 2, 2]
+    st, rw, tm = [], [], []
+    for a in actions:
+        _, r, t, _, _ = env.step(a)
+        st.append(int(env.current_node)), rw.append(r), tm.append(t)
+    assert st == [9, 8, 7, 3, 3, 4, 5, 6] and rw == [0.] * 7 + [1.] and tm == [False] * 7 + [True]
+    out.update(kat_actions=np.array(actions), kat_states=np.array(st), kat_rewards=np.array(rw),
+               kat_terminals=np.array(tm))
+    nodes, starts = built['linear_10x2']
+    env = Topology(nodes, starts, rng=TapeRNG(SEED, 3, STREAM_ENV))
+    rng = np.random.default_rng(11)
+    walk_a, walk_s, walk_obs, walk_r, walk_t = [], [], [], [], []
+    obs, _ = env.reset()
+    first = int(env.current_node)
+    for _ in range(60):
+        a = int(rng.integers(0, 4))
+        obs, r, t, trunc, _ = env.step(a)
+        assert trunc == t
+        walk_a.append(a), walk_s.append(int(env.current_node)), walk_obs.append(obs)
+        walk_r.append(r), walk_t.append(t)
+        if t:
+            env.reset()
+            walk_s[-1] = int(env.current_node) + 1000   # mark: state after the reset
+    out.update(walk_first=np.int64(first), walk_actions=np.array(walk_a), walk_states=np.array(walk_s),
+               walk_obs=np.array(walk_obs), walk_rewards=np.array(walk_r),
+               walk_terminals=np.array(walk_t))
+    np.savez_compressed(os.path.join(HERE, 'topology_kat.npz'), **out)
+
+
 def main():
     worlds = gen_worlds()
+    gen_topology()
     gen_gridworld_kat()
     gen_eps_greedy()
     gen_dynaq(worlds)

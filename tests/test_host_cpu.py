@@ -173,3 +173,25 @@ def test_monitor_allreduce_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+def test_topology_builders_match_reference(golden):
+    """cobel_amd.misc.topology_tools == the reference's linear_track / t_maze / grid as tables."""
+    from cobel_amd.misc import topology_tools as tt
+    k = golden('topology_kat')
+    built = {'linear_10x2': tt.linear_track(10, 2, 1., 20., 'right'),
+             'linear_5x1_left': tt.linear_track(5, 1, 0.5, 2., 'left'),
+             't_maze_4_3_1': tt.t_maze(4, 3, 1),
+             't_maze_3_2_2_left': tt.t_maze(3, 2, 2, 2.0, 3.0, 'left'),
+             'grid_4x3': tt.grid((4, 3)), 'grid_5': tt.grid(5, (0.0, 2.0), 7.0, '12')}
+    for name, (nodes, starts) in built.items():
+        ids = list(nodes.keys())
+        assert ids == [str(i) for i in range(len(ids))]
+        idx = {kk: i for i, kk in enumerate(ids)}
+        nbr = np.array([[idx[m] for m in nodes[kk]['neighbors']] for kk in ids])
+        assert np.array_equal(nbr, k[name + '/nbr']), name
+        assert np.array_equal(np.array([nodes[kk]['pose'] for kk in ids]), k[name + '/pose']), name
+        assert np.array_equal([nodes[kk]['reward'] for kk in ids], k[name + '/reward']), name
+        assert np.array_equal([bool(nodes[kk]['terminal']) for kk in ids], k[name + '/terminal'])
+        assert np.array_equal([idx[kk] for kk in starts], k[name + '/starts']), name
+        assert all(nodes[kk]['id'] == kk for kk in ids)
