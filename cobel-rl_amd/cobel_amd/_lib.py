@@ -66,6 +66,9 @@ _SIGNATURES = {
                                     C.c_int32, _P]),
     'cobel_rng_bounded': (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _P,
                                     C.c_int32, C.c_int32, C.c_int32, _P]),
+    'cobel_rng_bounded_each': (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P,
+                                         C.c_int32, C.c_int32, C.c_int32, _P]),
+    'cobel_eps_greedy_f64': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),
     'cobel_world_create': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(_P)]),
     'cobel_world_destroy': (C.c_int, [_P]),

@@ -1,0 +1,187 @@
+"""Deep Q-network agent — ``cobel.agent.DQN`` (agent/dqn.py:26-384) on PyTorch-ROCm.
+
+Same constructor, ``train(interface, trials, steps, batch_size=32)``, ``test``, ``retrieve_q``,
+``predict_on_batch``, ``replay`` and attributes (``model_online``, ``model_target``, ``M``,
+``gamma``, ``target_update``, ``DDQN``, ``current_trial``, ``stop``).  ``n_envs`` independent
+agent–environment pairs run in lockstep, each with its own copy of the network
+(``StackedTorchNetwork``), its own replay ring and its own random streams; a step is
+
+    Q(s) -> epsilon-greedy (cobel_eps_greedy*) -> env.step (cobel_env_step) -> store ->
+    sample (cobel_rng_bounded_each) -> targets r + gamma * nt * max_a Q_target(s') -> one
+    optimizer step on the online copies -> target blend w_t += tau (w_o - w_t)
+
+with every tensor resident on the GPU (the reference crosses the host boundary at least five
+times per step and blends the target on the host, dqn.py:346-371).  Instances whose trial ends
+reset immediately and stop once they have run ``trials`` trials, like the tabular kernels.
+Requires array observations (``interface.observe()`` -> ``[N, D]``), e.g. ``Topology``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..memory.dqn import DQNMemory
+from .agent import Agent, DeviceMonitors
+
+
+class DQN(Agent):
+    def __init__(self, observation_space, action_space, policy, model, gamma: float = 0.8,
+                 memory=None, policy_test=None, custom_callbacks=None) -> None:
+        super().__init__(observation_space, action_space, custom_callbacks)
+        assert int(action_space.n) == 4, 'the epsilon-greedy kernel covers 4-action spaces'
+        self.policy = policy
+        self.policy_test = policy if policy_test is None else policy_test
+        self.model_target = model
+        self.model_online = model.clone()
+        self.M = DQNMemory() if memory is None else memory
+        self.target_update = 10 ** -2
+        self.last_update = 0
+        self.gamma = gamma
+        self.DDQN = False
+        self.n_envs = None
+        self.monitors = None
+        self._online = self._target = None
+
+    # -- binding ------------------------------------------------------------------------------
+    def _bind(self, interface, slots: int) -> None:
+        if self.n_envs is None:
+            self.n_envs, self.device = interface.n_envs, interface.device
+            self.model_target.set_device(self.device)
+            self.model_online.set_device(self.device)
+            self._target = self.model_target.replicate(self.n_envs)
+            self._online = self.model_online.replicate(self.n_envs)
+            self.dtype = next(iter(self._online.params.values())).dtype
+            self.monitors = DeviceMonitors(self.device, 1, 1, False)
+            self.trial = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        obs = interface.observe()
+        self.M._bind(self.n_envs, obs.shape[1:], self.dtype, self.device, slots, interface.seed,
+                     interface.instance_base)
+
+    def _policy_bind(self, pol, interface, test: bool) -> None:
+        if pol.seed is None:
+            pol.seed = interface.seed
+        if pol.stream is None:
+            pol.stream = (_lib.STREAM_POLICY_TEST if (test and pol is not self.policy)
+                          else _lib.STREAM_POLICY)
+        if pol.counter is None or pol.counter.numel() != self.n_envs:
+            pol.counter = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+
+    def _select(self, pol, q: torch.Tensor, base: int) -> torch.Tensor:
+        n = self.n_envs
+        u = torch.empty(n, dtype=torch.float64, device=self.device)
+        st = _lib.current_stream(self.device)
+        _lib.check(_lib.lib().cobel_rng_uniform(_lib.ptr(pol.counter), pol.seed, pol.stream, base,
+                                                _lib.ptr(u), n, 1, st))
+        act = torch.empty(n, dtype=torch.uint8, device=self.device)
+        q = q.contiguous()
+        fn = (_lib.lib().cobel_eps_greedy_f64 if q.dtype == torch.float64
+              else _lib.lib().cobel_eps_greedy)
+        if q.dtype not in (torch.float64, torch.float32):
+            q = q.float()
+        _lib.check(fn(_lib.ptr(q), None, _lib.ptr(u), float(pol.epsilon), _lib.ptr(act), None, n,
+                      st))
+        return act
+
+    # -- reference surface ----------------------------------------------------------------------
+    def retrieve_q(self, state):
+        """Q-values of the online network(s) for an observation ``[D]`` or per-instance ``[N, D]``."""
+        if self._online is None:
+            return self.model_online.predict_on_batch(np.array([state]))[0]
+        s = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state,
+                            device=self.device).to(self.dtype)
+        if s.dim() == 1:
+            s = s.expand(self.n_envs, -1)
+        q = self._online.predict_on_device(s[:, None, :])[:, 0]
+        return q[0].cpu().numpy() if self.n_envs == 1 else q
+
+    def predict_on_batch(self, batch):
+        if self._online is None:
+            return self.model_online.predict_on_batch(batch)
+        b = torch.as_tensor(np.asarray(batch), device=self.device).to(self.dtype)
+        q = self._online.predict_on_device(b[None].expand(self.n_envs, *b.shape).contiguous())
+        return q[0].cpu().numpy() if self.n_envs == 1 else q
+
+    def replay(self, batch_size: int = 32, active=None):
+        """One optimisation step per instance on a sampled batch (dqn.py:331-384)."""
+        states, actions, rewards, next_states, terminals = self.M.retrieve(batch_size)
+        with torch.no_grad():
+            targets = self._online.forward(states).clone()
+            boot = self._target.forward(next_states)
+            pick = (self._online.forward(next_states) if self.DDQN else boot).argmax(dim=2)
+            boot = torch.gather(boot, 2, pick[..., None])[..., 0]
+            new = rewards + boot * terminals * self.gamma
+            targets.scatter_(2, actions[..., None], new[..., None])
+        self._online.train_on_device(states, targets, active)
+        if self.target_update < 1.0:
+            self._target.blend_from(self._online, self.target_update)
+        elif self.last_update >= self.target_update:
+            self._target.copy_from(self._online)
+            self.last_update = 1
+        else:
+            self.last_update += 1
+        return {'states': states, 'actions': actions, 'rewards': rewards,
+                'next_states': next_states, 'terminals': terminals}
+
+    def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool) -> None:
+        self._bind(interface, trials * steps)
+        pol = self.policy if learn else self.policy_test
+        self._policy_bind(pol, interface, not learn)
+        n, dev = self.n_envs, self.device
+        first = self.current_trial
+        self.trial.fill_(first)
+        self.monitors.reserve(first + trials)
+        step = torch.zeros(n, dtype=torch.int32, device=dev)
+        trew = torch.zeros(n, dtype=torch.float64, device=dev)
+        for t in range(trials):
+            self.callbacks.on_trial_begin({'trial_reward': 0.0, 'trial': first + t,
+                                           'trial_session': t})
+        obs, _ = interface.reset()
+        obs = interface.observe().to(self.dtype).clone()
+        active = torch.ones(n, dtype=torch.bool, device=dev)
+        executed = 0
+        while True:
+            q = self._online.predict_on_device(obs[:, None, :])[:, 0]
+            action = self._select(pol, q, interface.instance_base)
+            interface.step(action)
+            nxt = interface.observe().to(self.dtype).clone()
+            reward, done = interface._reward, interface._done.bool()
+            if learn:
+                self.M.store_batch(obs, action, reward, nxt, (~done), active)
+                self.replay(batch_size, active.to(self.dtype))
+            trew += torch.where(active, reward.to(torch.float64), torch.zeros_like(trew))
+            executed += int(active.sum().item()) if n == 1 else 0
+            over = active & (done | (step + 1 >= steps))
+            if bool(over.any().item()):
+                idx = self.trial[over].to(torch.int64)
+                ok = idx < self.monitors.cap
+                self.monitors.lat_sum.index_add_(0, idx[ok], step[over][ok].to(torch.int64))
+                self.monitors.lat_cnt.index_add_(0, idx[ok], torch.ones_like(idx[ok]))
+                self.monitors.reward_sum.index_add_(0, idx[ok], trew[over][ok])
+                self.trial += over.to(torch.int32)
+                step = torch.where(over, torch.full_like(step, -1), step)
+                trew = torch.where(over, torch.zeros_like(trew), trew)
+                active = active & (self.trial < first + trials)
+                restart = over & active
+                if bool(restart.any().item()):
+                    interface.reset(restart)
+                    nxt = interface.observe().to(self.dtype).clone()
+                if not bool(active.any().item()):
+                    break
+            step = step + active.to(torch.int32)
+            obs = nxt
+        self.current_trial = first + trials
+        if self.callbacks.has('on_trial_end'):
+            lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()
+            cnt = self.monitors.lat_cnt.cpu().numpy()
+            for t in range(trials):
+                self.callbacks.on_trial_end({'trial_reward': float(rew[first + t]),
+                                             'trial': first + t, 'trial_session': t,
+                                             'steps': float(lat[first + t]),
+                                             'count': int(cnt[first + t])})
+
+    def train(self, interface, trials: int, steps: int, batch_size: int = 32) -> None:
+        self._run(interface, trials, steps, batch_size, True)
+
+    def test(self, interface, trials: int, steps: int) -> None:
+        self._run(interface, trials, steps, 0, False)

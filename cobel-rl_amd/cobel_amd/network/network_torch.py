@@ -1,0 +1,245 @@
+"""PyTorch network adapter — ``cobel.network.TorchNetwork`` (network/network_torch.py:31-451) for
+PyTorch-ROCm, plus the stacked form the vectorised DQN uses.
+
+Single network: same constructor and methods as the reference (NumPy in, NumPy out; loss with
+``reduction='none'`` then ``.mean()``; Adam / MSE defaults; ``get_weights`` = state_dict values;
+``get_layer_activity`` returns ``(units, batch)``).  Two deliberate differences: ``clone()`` keeps
+the device (the reference silently drops it, network_torch.py:212-217) and ``*_on_device``
+methods take / return tensors without the host round trip of ``predict_on_batch``.
+
+``replicate(n)`` returns a ``StackedTorchNetwork``: n independent copies of the same architecture
+whose parameters are stacked along a leading instance axis and evaluated with
+``torch.func.vmap(functional_call)`` — one batched GEMM per layer for all instances, one fused
+optimizer step over the stacked parameters (element-wise optimizers act per instance exactly as
+n separate optimizers would).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+from torch import nn, optim
+from torch.func import functional_call, stack_module_state, vmap
+
+from .network import Network
+
+_LOSSES = {
+    'kl_divergence': nn.KLDivLoss, 'cosine_similarity': nn.CosineEmbeddingLoss,
+    'poisson': nn.PoissonNLLLoss, 'gaussian': nn.GaussianNLLLoss,
+    'binary_crossentropy': nn.BCELoss, 'hinge': nn.HingeEmbeddingLoss,
+    'margin_ranking': nn.MarginRankingLoss, 'multi_label_margin_ranking': nn.MultiLabelMarginLoss,
+    'mean_absolute_error': nn.L1Loss, 'mae': nn.L1Loss, 'mean_squared_error': nn.MSELoss,
+    'mse': nn.MSELoss, 'huber_loss': nn.HuberLoss, 'huber': nn.HuberLoss,
+    'categorical_crossentropy': nn.CrossEntropyLoss, 'crossentropy': nn.CrossEntropyLoss,
+    'connectionist_temporal_classification': nn.CTCLoss, 'ctc': nn.CTCLoss,
+    'negative_log_likelihood': nn.NLLLoss, 'nll': nn.NLLLoss,
+}
+_OPTIMIZERS = {name.lower(): getattr(optim, name) for name in
+               ('Adadelta', 'Adagrad', 'Adam', 'AdamW', 'Adamax', 'SparseAdam', 'ASGD', 'LBFGS',
+                'NAdam', 'RAdam', 'RMSprop', 'Rprop', 'SGD')}
+
+
+def _make_optimizer(spec, params, kwargs):
+    if isinstance(spec, optim.Optimizer):
+        return spec
+    cls = _OPTIMIZERS.get(str(spec).lower(), optim.Adam)     # Adam by default
+    return cls(params, **(kwargs or {}))
+
+
+def _make_loss(spec, kwargs):
+    if isinstance(spec, nn.modules.loss._Loss):
+        crit = type(spec)(**kwargs) if kwargs else spec
+    else:
+        crit = _LOSSES.get(str(spec).lower() if spec is not None else 'mse', nn.MSELoss)(
+            **(kwargs or {}))
+    crit.reduction = 'none'    # per-sample losses so that samples can be weighted
+    return crit
+
+
+class TorchNetwork(Network):
+    def __init__(self, model: nn.Module, optimizer=None, loss=None, optimizer_params=None,
+                 loss_params=None, activations=None, device: str = 'cpu') -> None:
+        self.model = model
+        self.set_device(device)
+        self.set_optimizer(optimizer, optimizer_params)
+        self.set_loss(loss, loss_params)
+        self.activations = {} if activations is None else activations
+
+    # -- device entry points ------------------------------------------------------------------
+    def predict_on_device(self, batch: torch.Tensor) -> torch.Tensor:
+        with torch.inference_mode():
+            return self.model(batch)
+
+    def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, sample_weights=None):
+        self.optimizer.zero_grad()
+        loss = self.criterion(self.model(batch), targets)
+        if sample_weights is not None:
+            loss = loss * sample_weights
+        loss.mean().backward()
+        self.optimizer.step()
+
+    # -- reference surface (NumPy) ------------------------------------------------------------
+    def _tensor(self, a):
+        return torch.as_tensor(np.asarray(a), device=self.device)
+
+    def predict_on_batch(self, batch):
+        return self.predict_on_device(self._tensor(batch)).detach().cpu().numpy()
+
+    def train_on_batch(self, batch, targets, sample_weights=None) -> None:
+        targets = np.asarray(targets)
+        if targets.ndim == 1:
+            targets = targets.reshape(targets.shape[0], 1)
+        w = None
+        if sample_weights is not None:
+            w = np.asarray(sample_weights)
+            w = self._tensor(w if w.ndim == 2 else w.reshape(w.size, 1))
+        self.train_on_device(self._tensor(batch), self._tensor(targets), w)
+
+    def get_weights(self):
+        return [v.detach().cpu().numpy().copy() for v in self.model.state_dict().values()]
+
+    def set_weights(self, weights) -> None:
+        state = self.model.state_dict()
+        for key, w in zip(state, weights):
+            state[key] = torch.as_tensor(np.asarray(w), device=self.device)
+        self.model.load_state_dict(state)
+
+    def clone(self):
+        net = copy.deepcopy(self.model)
+        twin = type(self)(net, type(self.optimizer)(params=net.parameters()),
+                          copy.deepcopy(self.criterion),
+                          activations=copy.deepcopy(self.activations), device=str(self.device))
+        twin.criterion.load_state_dict(self.criterion.state_dict())
+        twin.optimizer.load_state_dict(self.optimizer.state_dict())
+        return twin
+
+    def set_optimizer(self, optimizer, parameters=None) -> None:
+        self.optimizer = _make_optimizer(optimizer, self.model.parameters(), parameters)
+
+    def set_loss(self, loss, parameters=None) -> None:
+        self.criterion = _make_loss(loss, parameters)
+
+    def get_layer_activity(self, batch, layer):
+        children = list(self.model.named_children())
+        if isinstance(layer, str):
+            key = layer
+            index = next((i for i, (n, _) in enumerate(children) if n == layer), 10**10)
+        else:
+            key, index = children[int(layer)][0], int(layer)
+        seen = {}
+        handle = self.model.get_submodule(key).register_forward_hook(
+            lambda mod, inp, out: seen.__setitem__(key, out.detach()))
+        self.predict_on_batch(batch)
+        handle.remove()
+        act = seen[key]
+        if isinstance(self.activations, list):
+            assert len(self.activations) >= index, 'Index not in activation list!'
+            fn = self.activations[index]
+        else:
+            assert isinstance(self.activations, dict), \
+                'String layerkeys not compatible with activation lists!'
+            assert key in self.activations, 'Key not in activation dict!'
+            fn = self.activations[key]
+        if fn is not None:
+            act = fn(act)
+        return act.cpu().numpy().T
+
+    def set_trainable(self, layers, trainable) -> None:
+        names = [k.split('.')[0] for k in self.model.state_dict() if '.weight' in k]
+        for pos, layer in enumerate(layers):
+            if isinstance(layer, int):
+                assert layer < len(names)
+                name = names[layer]
+                flag = trainable[pos] if isinstance(trainable, list) else trainable
+            else:
+                assert layer in names
+                name = layer
+                flag = trainable[layer] if isinstance(trainable, dict) else trainable
+            self.model.get_parameter(name + '.weight').requires_grad = bool(flag)
+            self.model.get_parameter(name + '.bias').requires_grad = bool(flag)
+
+    def set_device(self, device='cpu') -> None:
+        self.device = torch.device(device)
+        self.model.to(self.device)
+
+    # -- vectorised form ------------------------------------------------------------------------
+    def replicate(self, n: int) -> 'StackedTorchNetwork':
+        return StackedTorchNetwork(self, n)
+
+
+class StackedTorchNetwork:
+    """n independent copies of one architecture with parameters stacked on axis 0."""
+
+    def __init__(self, proto: TorchNetwork, n: int) -> None:
+        self.n, self.device = n, proto.device
+        self.base = copy.deepcopy(proto.model).to('meta')   # structure only
+        params, buffers = stack_module_state([proto.model])
+        self.params = {k: v.detach().expand(n, *v.shape[1:]).clone().requires_grad_(True)
+                       for k, v in params.items()}
+        self.buffers = {k: v.detach().expand(n, *v.shape[1:]).clone() for k, v in buffers.items()}
+        self.criterion = copy.deepcopy(proto.criterion)
+        opt = proto.optimizer
+        self.optimizer = type(opt)(list(self.params.values()), **{
+            k: v for k, v in opt.defaults.items() if k not in ('foreach', 'fused', 'capturable',
+                                                               'differentiable', 'maximize')})
+
+        def one(p, b, x):
+            return functional_call(self.base, (p, b), (x,))
+        self._fwd = vmap(one)
+
+    def forward(self, batch: torch.Tensor) -> torch.Tensor:
+        """batch [n, B, ...] -> [n, B, out]"""
+        return self._fwd(self.params, self.buffers, batch)
+
+    def predict_on_device(self, batch: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            return self.forward(batch)
+
+    def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, active=None) -> None:
+        """Per instance: mean over the per-sample losses, summed over instances so that every
+        instance receives exactly the gradient it would compute alone.  ``active`` [n] masks
+        instances that must not learn this step (their gradient is exactly zero; stateful
+        optimizers still see the step, so callers that need bit-identical resumption keep all
+        instances active)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.criterion(self.forward(batch), targets)
+        per_instance = loss.reshape(self.n, -1).mean(dim=1)
+        if active is not None:
+            per_instance = per_instance * active
+        per_instance.sum().backward()
+        self.optimizer.step()
+
+    def blend_from(self, other: 'StackedTorchNetwork', tau: float) -> None:
+        """w += tau * (w_other - w) for every state entry (dqn.py:366-371), in place on device."""
+        with torch.no_grad():
+            for k, v in self.params.items():
+                v.lerp_(other.params[k], tau)
+            for k, v in self.buffers.items():
+                if v.is_floating_point():
+                    v.lerp_(other.buffers[k], tau)
+
+    def copy_from(self, other: 'StackedTorchNetwork') -> None:
+        with torch.no_grad():
+            for k, v in self.params.items():
+                v.copy_(other.params[k])
+            for k, v in self.buffers.items():
+                v.copy_(other.buffers[k])
+
+    def clone(self) -> 'StackedTorchNetwork':
+        twin = copy.copy(self)
+        twin.params = {k: v.detach().clone().requires_grad_(True) for k, v in self.params.items()}
+        twin.buffers = {k: v.clone() for k, v in self.buffers.items()}
+        twin.criterion = copy.deepcopy(self.criterion)
+        twin.optimizer = type(self.optimizer)(list(twin.params.values()), **{
+            k: v for k, v in self.optimizer.defaults.items()
+            if k not in ('foreach', 'fused', 'capturable', 'differentiable', 'maximize')})
+
+        def one(p, b, x):
+            return functional_call(twin.base, (p, b), (x,))
+        twin._fwd = vmap(one)
+        return twin
+
+    def get_weights(self, instance: int = 0):
+        return [v[instance].detach().cpu().numpy().copy()
+                for v in list(self.params.values()) + list(self.buffers.values())]

@@ -60,17 +60,17 @@ static inline cobel_eps_consts cobel_make_eps_consts(double eps) {
 #if defined(__HIPCC__)
 // All arguments wave-uniform or per-lane alike; every lane returns the same answer it would get
 // alone.  mask: 4-bit set of allowed actions (non-zero).  probs (optional): 4 doubles out.
-__device__ __forceinline__ int cobel_eps_greedy_select(float v0, float v1, float v2, float v3,
-                                                       uint32_t mask, double u,
-                                                       const cobel_eps_consts& k,
+template <typename V>
+__device__ __forceinline__ int cobel_eps_greedy_select(V v0, V v1, V v2, V v3, uint32_t mask,
+                                                       double u, const cobel_eps_consts& k,
                                                        double* probs = nullptr) {
-  const float ninf = -__builtin_huge_valf();
+  const V ninf = -(V)__builtin_huge_valf();
   const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
-  float m = ninf;
-  m = a0 ? fmaxf(m, v0) : m;
-  m = a1 ? fmaxf(m, v1) : m;
-  m = a2 ? fmaxf(m, v2) : m;
-  m = a3 ? fmaxf(m, v3) : m;
+  V m = ninf;
+  m = (a0 && v0 > m) ? v0 : m;
+  m = (a1 && v1 > m) ? v1 : m;
+  m = (a2 && v2 > m) ? v2 : m;
+  m = (a3 && v3 > m) ? v3 : m;
   const bool t0 = a0 && v0 == m, t1 = a1 && v1 == m, t2 = a2 && v2 == m, t3 = a3 && v3 == m;
   const int n = __popc(mask & 15u);
   const int nt = (int)t0 + (int)t1 + (int)t2 + (int)t3;

@@ -184,7 +184,8 @@ extern "C" int cobel_env_reset(const cobel_world_t* world, int32_t* state,
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_eps_greedy(const float4* __restrict__ values,
+template <typename V>
+__global__ __launch_bounds__(256) void k_eps_greedy(const V* __restrict__ values,
                                                     const uint8_t* __restrict__ mask,
                                                     const double* __restrict__ u,
                                                     cobel_eps_consts k,
@@ -192,10 +193,11 @@ __global__ __launch_bounds__(256) void k_eps_greedy(const float4* __restrict__ v
                                                     double* __restrict__ probs_out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 v = values[i];
+  const V v0 = values[4 * i], v1 = values[4 * i + 1], v2 = values[4 * i + 2],
+          v3 = values[4 * i + 3];
   const uint32_t m = mask ? (mask[i] & 15u) : 15u;
   double p[4];
-  const int a = cobel_eps_greedy_select(v.x, v.y, v.z, v.w, m, u[i], k, p);
+  const int a = cobel_eps_greedy_select<V>(v0, v1, v2, v3, m, u[i], k, p);
   action_out[i] = (uint8_t)a;
   if (probs_out) {
     probs_out[4 * i + 0] = p[0];
@@ -212,12 +214,25 @@ extern "C" int cobel_eps_greedy(const float* values, const uint8_t* mask, const 
   COBEL_REQUIRE(epsilon >= 0.0 && epsilon <= 1.0, COBEL_E_ARG,
                 "cobel_eps_greedy: epsilon %g outside [0, 1]", epsilon);
   COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_eps_greedy: n = %d", n);
-  COBEL_REQUIRE(((uintptr_t)values & 15u) == 0, COBEL_E_ARG,
-                "cobel_eps_greedy: values must be 16-byte aligned");
   if (n == 0) return COBEL_OK;
-  hipLaunchKernelGGL(k_eps_greedy, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)values, mask, u, cobel_make_eps_consts(epsilon), action_out,
-                     probs_out, n);
+  hipLaunchKernelGGL((k_eps_greedy<float>), dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, values, mask, u, cobel_make_eps_consts(epsilon),
+                     action_out, probs_out, n);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_eps_greedy_f64(const double* values, const uint8_t* mask, const double* u,
+                                    double epsilon, uint8_t* action_out, double* probs_out,
+                                    int32_t n, void* stream) {
+  COBEL_REQUIRE(values && u && action_out, COBEL_E_ARG, "cobel_eps_greedy_f64: NULL argument");
+  COBEL_REQUIRE(epsilon >= 0.0 && epsilon <= 1.0, COBEL_E_ARG,
+                "cobel_eps_greedy_f64: epsilon %g outside [0, 1]", epsilon);
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_eps_greedy_f64: n = %d", n);
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL((k_eps_greedy<double>), dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, values, mask, u, cobel_make_eps_consts(epsilon),
+                     action_out, probs_out, n);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -245,9 +260,24 @@ __global__ __launch_bounds__(256) void k_rng_bounded(uint32_t* __restrict__ inde
   out[t] = (int32_t)cobel_draw_bounded(idx, (uint32_t)j, base + (uint32_t)i, stream, seed, bound);
 }
 
-__global__ __launch_bounds__(256) void k_rng_advance(uint32_t* __restrict__ index, int n) {
+__global__ __launch_bounds__(256) void k_rng_advance(uint32_t* __restrict__ index, int n,
+                                                     const uint32_t* __restrict__ bounds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) index[i] += 1u;
+  if (i < n && (!bounds || bounds[i])) index[i] += 1u;
+}
+
+__global__ __launch_bounds__(256) void k_rng_bounded_each(uint32_t* __restrict__ index,
+                                                          uint64_t seed, uint32_t stream,
+                                                          uint32_t base,
+                                                          const uint32_t* __restrict__ bounds,
+                                                          int32_t* __restrict__ out, int n,
+                                                          int per) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * per) return;
+  const int i = t / per, j = t % per;
+  const uint32_t b = bounds[i];
+  out[t] = b ? (int32_t)cobel_draw_bounded(index[i], (uint32_t)j, base + (uint32_t)i, stream, seed, b)
+             : 0;
 }
 
 extern "C" int cobel_rng_uniform(uint32_t* index, uint64_t seed, uint32_t stream,
@@ -277,7 +307,27 @@ extern "C" int cobel_rng_bounded(uint32_t* index, uint64_t seed, uint32_t stream
                        per_instance, advance);
   if (advance)
     hipLaunchKernelGGL(k_rng_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)sh, index,
-                       n);
+                       n, (const uint32_t*)nullptr);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_rng_bounded_each(uint32_t* index, uint64_t seed, uint32_t stream,
+                                      uint32_t instance_base, const uint32_t* bounds,
+                                      int32_t* out, int32_t n, int32_t per_instance,
+                                      int32_t advance, void* sh) {
+  COBEL_REQUIRE(index && out && bounds, COBEL_E_ARG, "cobel_rng_bounded_each: NULL argument");
+  COBEL_REQUIRE(n >= 0 && per_instance >= 0, COBEL_E_RANGE, "cobel_rng_bounded_each: bad sizes");
+  if (n == 0) return COBEL_OK;
+  const long long total = (long long)n * per_instance;
+  COBEL_REQUIRE(total < (1ll << 31), COBEL_E_RANGE, "cobel_rng_bounded_each: too many draws");
+  if (total > 0)
+    hipLaunchKernelGGL(k_rng_bounded_each, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)sh, index, seed, stream, instance_base, bounds, out, n,
+                       per_instance);
+  if (advance)
+    hipLaunchKernelGGL(k_rng_advance, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)sh, index,
+                       n, bounds);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }

@@ -66,6 +66,13 @@ COBEL_API int cobel_rng_bounded(uint32_t* index /* [dev] [N] */, uint64_t seed, 
                                 uint32_t instance_base, uint32_t bound,
                                 int32_t* out /* [dev] [N][per_instance] */, int32_t n,
                                 int32_t per_instance, int32_t advance, void* stream_handle);
+/* Same with one bound per instance (replay memories of different fill); a bound of 0 yields 0
+ * and leaves that instance's counter untouched. */
+COBEL_API int cobel_rng_bounded_each(uint32_t* index /* [dev] [N] */, uint64_t seed,
+                                     uint32_t stream, uint32_t instance_base,
+                                     const uint32_t* bounds /* [dev] [N] */,
+                                     int32_t* out /* [dev] [N][per_instance] */, int32_t n,
+                                     int32_t per_instance, int32_t advance, void* stream_handle);
 
 /* ------------------------------------------------------------------------------------------
  * World tables.  Replaces WorldDict (interface/gridworld.py:17-30) as produced by
@@ -129,6 +136,15 @@ COBEL_API int cobel_eps_greedy(const float* values /* [dev] [N][4], 16-byte alig
                                uint8_t* action_out /* [dev] [N] */,
                                double* probs_out /* [dev] [N][4] or NULL */, int32_t n,
                                void* stream);
+
+/* Same for float64 value rows (network outputs of the DQN path, which the reference keeps in
+ * float64): ties are exact equality on the float64 values. */
+COBEL_API int cobel_eps_greedy_f64(const double* values /* [dev] [N][4] */,
+                                   const uint8_t* mask /* [dev] [N] or NULL */,
+                                   const double* u /* [dev] [N] */, double epsilon,
+                                   uint8_t* action_out /* [dev] [N] */,
+                                   double* probs_out /* [dev] [N][4] or NULL */, int32_t n,
+                                   void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused tabular agents.  One call advances every instance through

@@ -484,8 +484,58 @@ def gen_topology():
     np.savez_compressed(os.path.join(HERE, 'topology_kat.npz'), **out)
 
 
+def gen_dqn():
+    """agent/dqn.py + memory/dqn.py + network/network_torch.py on linear_track(10, 2): float64
+    6-64-64-4 MLP, Adam, MSE, tau 0.01, draw-injected env / policy / memory streams."""
+    import torch
+    from collections import OrderedDict
+    from cobel.agent import DQN
+    from cobel.interface import Topology
+    from cobel.memory import DQNMemory
+    from cobel.misc.topology_tools import linear_track
+    from cobel.network import TorchNetwork
+    out = {}
+    for name, inst, trials, steps, ddqn in (('dqn_i0', 0, 3, 25, False), ('dqn_i2', 2, 2, 30, False)):
+        torch.manual_seed(1234 + inst)
+        layers = [('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+                  ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+                  ('output', torch.nn.Linear(64, 4))]
+        net = torch.nn.Sequential(OrderedDict(layers)).double()
+        model = TorchNetwork(net)
+        init = model.get_weights()
+        nodes, starts = linear_track(10, 2, 1., 20., 'right')
+        env = Topology(nodes, starts, rng=TapeRNG(SEED, inst, STREAM_ENV))
+        pol = EpsilonGreedy(0.3, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        agent = DQN(env.observation_space, env.action_space, pol, model, gamma=0.8,
+                    memory=DQNMemory(100000, rng=TapeRNG(SEED, inst, STREAM_MEMORY)))
+        agent.DDQN = ddqn
+        tr = Tracer(None)
+        nodes_seen = []
+        agent.callbacks.custom_callbacks = {
+            'on_step_end': [lambda logs, e=env, ns=nodes_seen: ns.append(int(e.current_node)),
+                            lambda logs, t=tr: t.td.append(0.0)],
+            'on_trial_end': [tr.on_trial_end], 'on_trial_begin': [], 'on_step_begin': []}
+        torch.set_num_threads(1)
+        agent.train(env, trials, steps, 32)
+        poses = np.array([nodes[k]['pose'] for k in nodes])
+        for i, w in enumerate(init):
+            out['%s/init_%d' % (name, i)] = w
+        for i, w in enumerate(agent.model_online.get_weights()):
+            out['%s/online_%d' % (name, i)] = w
+        for i, w in enumerate(agent.model_target.get_weights()):
+            out['%s/target_%d' % (name, i)] = w
+        out[name + '/nodes'] = np.array(nodes_seen)
+        out[name + '/actions'] = agent.M.actions.astype(np.int64)
+        out[name + '/rewards'] = agent.M.rewards
+        out[name + '/steps'] = np.array(tr.steps)
+        out[name + '/q_all'] = agent.predict_on_batch(poses)
+        out[name + '/cfg'] = np.array([inst, trials, steps, 32, ddqn])
+    np.savez_compressed(os.path.join(HERE, 'dqn_trace.npz'), **out)
+
+
 def main():
     worlds = gen_worlds()
+    gen_dqn()
     gen_topology()
     gen_gridworld_kat()
     gen_eps_greedy()

@@ -565,3 +565,87 @@ def test_topology_kat_and_walk(torch_cuda, golden):
         assert np.array_equal(r.cpu().numpy(), k['linear_10x2/reward'][ns].astype(np.float32))
         assert np.array_equal(d.cpu().numpy(), k['linear_10x2/terminal'][ns])
         venv.reset(d)
+
+
+def _mlp(torch, init):
+    from collections import OrderedDict
+    net = torch.nn.Sequential(OrderedDict([
+        ('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+        ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+        ('output', torch.nn.Linear(64, 4))])).double()
+    state = net.state_dict()
+    for key, w in zip(state, init):
+        state[key] = torch.as_tensor(w)
+    net.load_state_dict(state)
+    return net
+
+
+@pytest.mark.parametrize('name', ['dqn_i0', 'dqn_i2'])
+def test_dqn_matches_reference_float64(torch_cuda, golden, name):
+    """DQN on linear_track(10, 2), float64 6-64-64-4 MLP on PyTorch-ROCm, against the reference run
+    on the CPU with the same initial weights and the same injected draws: identical node /
+    action / reward sequence; online and target weights and Q(all poses) within 1e-9 relative
+    (different GEMM summation order on the GPU, amplified through ~60 Adam steps)."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    inst, trials, steps, batch, ddqn = [int(x) for x in D[name + '/cfg']]
+    init = [D['%s/init_%d' % (name, i)] for i in range(6)]
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+    env = Topology(nodes, starts, seed=SEED, instance_base=inst)
+    agent = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                TorchNetwork(_mlp(torch, init)), gamma=0.8)
+    agent.train(env, trials, steps, batch)
+    m = agent.M
+    size = int(m.size[0].item())
+    assert size == len(D[name + '/actions'])
+    assert np.array_equal(m.actions[0, :size].cpu().numpy(), D[name + '/actions'])
+    assert np.array_equal(m.rewards[0, :size].cpu().numpy(), D[name + '/rewards'])
+    pose = np.array([nodes[k]['pose'] for k in nodes])
+    seen = m.next_states[0, :size].cpu().numpy()
+    assert np.array_equal(seen, pose[D[name + '/nodes']])
+    lat = agent.monitors.lat_sum.cpu().numpy()
+    assert np.array_equal(lat[:trials], D[name + '/steps'])
+    for i, w in enumerate(agent._online.get_weights(0)):
+        assert np.allclose(w, D['%s/online_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
+    for i, w in enumerate(agent._target.get_weights(0)):
+        assert np.allclose(w, D['%s/target_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
+    assert np.allclose(agent.predict_on_batch(pose), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
+
+
+def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
+    """8 instances in lockstep (stacked networks, per-instance rings and streams) give exactly
+    the trajectories of the single-instance runs; weights agree to float64 round-off."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+
+    def run(n, base):
+        env = Topology(nodes, starts, n_envs=n, seed=SEED, instance_base=base)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(_mlp(torch, init)), gamma=0.8)
+        ag.train(env, 3, 25, 32)
+        return ag
+
+    vec = run(8, 0)
+    assert np.array_equal(vec.M.actions[0, :int(vec.M.size[0])].cpu().numpy(), D['dqn_i0/actions'])
+    for i in (2, 5):
+        one = run(1, i)
+        k = int(one.M.size[0])
+        assert int(vec.M.size[i]) == k
+        assert torch.equal(vec.M.actions[i, :k], one.M.actions[0, :k])
+        assert torch.equal(vec.M.next_states[i, :k], one.M.next_states[0, :k])
+        for a, b in zip(vec._online.get_weights(i), one._online.get_weights(0)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    lat = vec.monitors.mean_latency()
+    assert not np.isnan(lat[:3]).any()

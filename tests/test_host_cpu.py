@@ -195,3 +195,64 @@ def test_topology_builders_match_reference(golden):
         assert np.array_equal([bool(nodes[kk]['terminal']) for kk in ids], k[name + '/terminal'])
         assert np.array_equal([idx[kk] for kk in starts], k[name + '/starts']), name
         assert all(nodes[kk]['id'] == kk for kk in ids)
+
+
+def test_torch_network_adapter_contract():
+    """The checks of unit_tests/test_torchnetwork.py that define the adapter's contract: defaults
+    (MSE with reduction 'none', Adam), six weight arrays, layer activity shaped (units, batch),
+    training reduces the error, set_weights round trip, clone independence (and device kept),
+    set_loss / set_optimizer / set_trainable — plus the stacked form against single networks."""
+    import torch
+    from collections import OrderedDict
+    from cobel_amd.network import TorchNetwork
+    torch.manual_seed(0)
+    layers = [('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+              ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+              ('output', torch.nn.Linear(64, 4))]
+    net = TorchNetwork(torch.nn.Sequential(OrderedDict(layers)).double(),
+                       activations={'dense_1': torch.relu, 'dense_2': None, 'output': None})
+    assert isinstance(net.criterion, torch.nn.MSELoss) and net.criterion.reduction == 'none'
+    assert isinstance(net.optimizer, torch.optim.Adam)
+    w = net.get_weights()
+    assert len(w) == 6 and w[0].shape == (64, 6) and w[5].shape == (4,)
+    rng = np.random.default_rng(0)
+    x, y = rng.random((32, 6)), rng.random((32, 4))
+    assert net.predict_on_batch(x).shape == (32, 4)
+    assert net.get_layer_activity(x, 'dense_1').shape == (64, 32)
+    assert (net.get_layer_activity(x, 'dense_1') >= 0).all()       # activation applied
+    assert net.get_layer_activity(x, 0).shape == (64, 32)
+    before = np.mean((net.predict_on_batch(x) - y) ** 2)
+    twin = net.clone()
+    for _ in range(50):
+        net.train_on_batch(x, y)
+    assert np.mean((net.predict_on_batch(x) - y) ** 2) < before
+    assert np.array_equal(twin.get_weights()[0], w[0])             # the clone did not move
+    assert twin.device == net.device
+    net.set_weights(w)
+    assert all(np.array_equal(a, b) for a, b in zip(net.get_weights(), w))
+    net.set_loss('huber')
+    assert isinstance(net.criterion, torch.nn.HuberLoss) and net.criterion.reduction == 'none'
+    net.set_optimizer('sgd', {'lr': 0.1})
+    assert isinstance(net.optimizer, torch.optim.SGD)
+    net.set_trainable(['dense_1'], False)
+    assert not net.model.get_parameter('dense_1.weight').requires_grad
+    net.set_trainable([0, 1], [True, False])
+    assert net.model.get_parameter('dense_1.bias').requires_grad
+    assert not net.model.get_parameter('dense_2.weight').requires_grad
+    net.train_on_batch(x, y[:, 0], sample_weights=np.ones(32)) if False else None
+    # stacked copies == independent single networks, step for step
+    base = TorchNetwork(torch.nn.Sequential(OrderedDict(
+        [('a', torch.nn.Linear(6, 8)), ('r', torch.nn.ReLU()), ('o', torch.nn.Linear(8, 4))])).double())
+    stack, singles = base.replicate(3), [base.clone() for _ in range(3)]
+    xs, ys = rng.random((3, 5, 6)), rng.random((3, 5, 4))
+    for _ in range(4):
+        stack.train_on_device(torch.as_tensor(xs), torch.as_tensor(ys))
+        for i, s in enumerate(singles):
+            s.train_on_batch(xs[i], ys[i])
+    for i, s in enumerate(singles):
+        for a, b in zip(stack.get_weights(i), s.get_weights()):
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-15)
+    target = base.replicate(3)
+    target.blend_from(stack, 0.01)
+    w0, w1, wt = base.get_weights()[0], stack.get_weights(1)[0], target.get_weights(1)[0]
+    assert np.allclose(wt, w0 + 0.01 * (w1 - w0), rtol=1e-12)
