@@ -61,6 +61,42 @@ CONFIGS = {
 SEED = 0xC0BE1
 
 
+def run_c5(device, dtype_name, n=8192, iters=64, warm=4):
+    """C5: 8192 linear_track(10, 2) Topology envs, DQN 6-64-64-4 (gamma .8, eps .3, Adam 1e-3, MSE,
+    tau .01, batch 32, 100 steps/trial) through PyTorch-ROCm with one network per instance."""
+    from collections import OrderedDict
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.memory import DQNMemory
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(OrderedDict([
+        ('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+        ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+        ('output', torch.nn.Linear(64, 4))]))
+    net = net.double() if dtype_name == 'f64' else net.float()
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+    env = Topology(nodes, starts, n_envs=n, seed=SEED, device=device)
+    agent = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                TorchNetwork(net, optimizer_params={'lr': 1e-3}), gamma=0.8,
+                memory=DQNMemory(capacity=256))
+    agent._run(env, 10**6, 100, 32, True, budget=warm)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    agent._run(env, 10**6, 100, 32, True, budget=iters)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
+            'dtype': dtype_name,
+            'config': {'workload': 'C5: %d x linear_track(10,2) Topology, DQN 6-64-64-4 %s, one '
+                                   'network + replay ring per instance, batch 32, via PyTorch-ROCm'
+                                   % (n, dtype_name), 'instances_per_gpu': n,
+                       'lockstep_iterations': iters},
+            'roofline': None}
+
+
 def make_worlds(cfg_name):
     from cobel_amd.misc.gridworld_tools import make_obstacle_maze, make_open_field
     if cfg_name == 'C2':
@@ -252,6 +288,11 @@ def main():
                                 'roofline': r['roofline']}
             except Exception as e:  # e.g. not enough HBM for C4 on a shared device
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        for dt_name in ('f64', 'f32'):
+            try:
+                others['C5_' + dt_name] = run_c5(device, dt_name)
+            except Exception as e:
+                others['C5_' + dt_name] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.config, cfg)

@@ -123,8 +123,10 @@ class DQN(Agent):
         return {'states': states, 'actions': actions, 'rewards': rewards,
                 'next_states': next_states, 'terminals': terminals}
 
-    def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool) -> None:
-        self._bind(interface, trials * steps)
+    def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool,
+             budget: int = 0) -> None:
+        """``budget`` > 0 stops after that many lockstep iterations (benchmarking)."""
+        self._bind(interface, min(trials * steps, budget or trials * steps))
         pol = self.policy if learn else self.policy_test
         self._policy_bind(pol, interface, not learn)
         n, dev = self.n_envs, self.device
@@ -139,7 +141,7 @@ class DQN(Agent):
         obs, _ = interface.reset()
         obs = interface.observe().to(self.dtype).clone()
         active = torch.ones(n, dtype=torch.bool, device=dev)
-        executed = 0
+        iters = 0
         while True:
             q = self._online.predict_on_device(obs[:, None, :])[:, 0]
             action = self._select(pol, q, interface.instance_base)
@@ -150,7 +152,6 @@ class DQN(Agent):
                 self.M.store_batch(obs, action, reward, nxt, (~done), active)
                 self.replay(batch_size, active.to(self.dtype))
             trew += torch.where(active, reward.to(torch.float64), torch.zeros_like(trew))
-            executed += int(active.sum().item()) if n == 1 else 0
             over = active & (done | (step + 1 >= steps))
             if bool(over.any().item()):
                 idx = self.trial[over].to(torch.int64)
@@ -170,6 +171,9 @@ class DQN(Agent):
                     break
             step = step + active.to(torch.int32)
             obs = nxt
+            iters += 1
+            if budget and iters >= budget:
+                break
         self.current_trial = first + trials
         if self.callbacks.has('on_trial_end'):
             lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()
