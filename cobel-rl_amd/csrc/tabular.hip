@@ -23,6 +23,8 @@
 //   memory/dyna_q.py:92-96 (store), :137-155 (retrieve_batch)
 //   agent/q.py:183-228, :305-313, :353-354
 //   monitor/behavior.py:82 (latency = logs['steps'] = index of the last executed step)
+#include <stdlib.h>
+
 #include "cobel_common.h"
 #include "cobel_policy.h"
 
@@ -53,14 +55,14 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
   return (a & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-// LDS carve-up (bytes): Q 16*S | eps thresholds 384 | M16 8*S (Dyna-Q) | H 2048 (replay) |
-//                        world 16*S (WLDS) | occ 4*S
+// LDS carve-up (bytes): Q 16*S | M16 8*S (Dyna-Q) | H 2048 (replay) | world 16*S (WLDS) | occ 4*S
+// (26 KiB at S = 1024 for Dyna-Q: six instances per CU — LDS is allocated in 1 KiB units, so every
+// byte above 26 624 would cost a whole resident wave)
 struct tab_lds {
   float4* Qs;
   float* Qf;
   uint16_t* M16;
   unsigned long long* H;
-  uint64_t* thr;
   uint4* Wl;
   uint32_t* occ;
 };
@@ -69,7 +71,7 @@ constexpr int kHashBuckets = 256;
 
 __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool replay, bool wlds,
                                                          bool occ) {
-  size_t b = (size_t)S * 16 + kThrBytes;
+  size_t b = (size_t)S * 16;
   if (agent == COBEL_AGENT_DYNAQ) b += (size_t)S * 8;
   if (replay) b += kHashBuckets * 8;
   if (wlds) b += (size_t)S * 16;
@@ -105,8 +107,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     L.Qs = reinterpret_cast<float4*>(lds_raw);
     L.Qf = reinterpret_cast<float*>(lds_raw);
     off += (size_t)S * 16;
-    L.thr = reinterpret_cast<uint64_t*>(lds_raw + off);
-    off += kThrBytes;
     L.M16 = reinterpret_cast<uint16_t*>(lds_raw + off);
     if (AGENT == COBEL_AGENT_DYNAQ) off += (size_t)S * 8;
     L.H = reinterpret_cast<unsigned long long*>(lds_raw + off);
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   }
   if (A.use_hash)
     for (int b = lane; b < kHashBuckets; b += 64) L.H[b] = 0ull;
-  if (lane < 48) L.thr[lane] = A.eps.thr[lane / 3][lane % 3];
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -870,7 +869,8 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
   A.use_hash = replay ? 1 : 0;
-  const size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ);
+  size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ);
+  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   hipStream_t st = (hipStream_t)stream;
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
   const bool learn = (r.flags & COBEL_F_LEARN) != 0;

@@ -55,7 +55,7 @@ def test_argument_errors_map_to_reference_exceptions():
         _lib.check(lib.cobel_tab_query(25, 1, 63, None, None))
     lds = C.c_int32()
     _lib.check(lib.cobel_tab_query(1024, 1, 50, C.byref(lds), None))
-    assert lds.value == 1024 * (16 + 8 + 4) + 2048 + 384   # Q, model, visit counters, hash, eps thresholds
+    assert lds.value == 1024 * (16 + 8 + 4) + 2048   # Q, compact model, visit counters, hash
     r, s, t = C.c_float(), C.c_uint16(), C.c_uint8()
     rec = lib.cobel_pack_model(C.c_float(0.75), 321, 1)
     lib.cobel_unpack_model(rec, C.byref(r), C.byref(s), C.byref(t))
