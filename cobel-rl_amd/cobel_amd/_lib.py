@@ -16,6 +16,7 @@ OK, E_ARG, E_RANGE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
 STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST = 0, 1, 2, 3
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
+F_FORCE_LDS_MODEL = 64
 MAX_BATCH = 62
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
  I_REWARD_LO, I_REWARD_HI, I_STEPS_LO, I_STEPS_HI, I_WORDS) = range(13)
@@ -28,7 +29,8 @@ class CobelHipError(RuntimeError):
 class TabRun(C.Structure):
     """``cobel_tab_run_t``."""
     _fields_ = [
-        ('q', C.c_void_p), ('model', C.c_void_p), ('replay_log', C.c_void_p),
+        ('q', C.c_void_p), ('model', C.c_void_p), ('model_index', C.c_void_p),
+        ('replay_log', C.c_void_p),
         ('inst', C.c_void_p), ('action_mask', C.c_void_p),
         ('lat_sum', C.c_void_p), ('lat_cnt', C.c_void_p), ('reward_sum', C.c_void_p),
         ('lat_trace', C.c_void_p), ('occupancy', C.c_void_p), ('steps_done', C.c_void_p),
@@ -85,6 +87,7 @@ _SIGNATURES = {
     'cobel_unpack_model': (None, [C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint16),
                                   C.POINTER(C.c_uint8)]),
     'cobel_model_init': (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    'cobel_model_index_build': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     'cobel_sr_init': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     'cobel_sr_run': (C.c_int, [_P, C.POINTER(SRRun), _P]),
     'cobel_sr_retrieve_q': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),

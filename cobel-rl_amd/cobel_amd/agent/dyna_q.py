@@ -33,6 +33,7 @@ class DynaQ(TabularAgent):
 
     def _extra(self, run) -> None:
         run.model = _lib.ptr(self.M.table)
+        run.model_index = _lib.ptr(self.M.index)
         run.model_lr = float(self.M.learning_rate)
         self.inst[:, _lib.I_CTR_MEMORY] = self.M.counter
 

@@ -23,6 +23,7 @@ class DynaQMemory:
         self.learning_rate = learning_rate
         self.table = None      # torch int64 [N, S, 4] packed records
         self.counter = None    # torch int32 [N] replay-batch counters (COBEL_STREAM_MEMORY)
+        self.index = None      # torch int16 [N, S, 4] digest of `table` for the planning kernel
 
     def _bind(self, n_envs: int, device) -> None:
         if self.table is not None:
@@ -33,6 +34,16 @@ class DynaQMemory:
                                                self.number_of_states,
                                                _lib.current_stream(device)))
         self.counter = torch.zeros(n_envs, dtype=torch.int32, device=device)
+        # 16-bit digest of the table read by the planning kernel (cobel_model_index_build)
+        self.index = torch.empty((n_envs, self.number_of_states, 4), dtype=torch.int16,
+                                 device=device)
+        self.rebuild_index()
+
+    def rebuild_index(self) -> None:
+        """Re-derive the digest after editing ``table`` by hand."""
+        _lib.check(_lib.lib().cobel_model_index_build(
+            _lib.ptr(self.table), _lib.ptr(self.index), self.table.shape[0],
+            self.number_of_states, _lib.current_stream(self.table.device)))
 
     def _decode(self):
         raw = self.table.cpu().numpy()

@@ -39,6 +39,7 @@ struct tab_args {
   cobel_eps_consts eps;
   float alpha_f, gamma_f, model_lr_f;
   int32_t use_hash;  // LDS holds the replay dependency hash table
+  int32_t hash_buckets;
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -68,12 +69,13 @@ struct tab_lds {
 };
 constexpr int kThrBytes = 16 * 3 * 8;
 constexpr int kHashBuckets = 256;
+constexpr int kHashBucketsSmall = 128;   // with MIDX: keeps the footprint at 17 KiB (nine per CU)
 
 __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool replay, bool wlds,
-                                                         bool occ) {
+                                                         bool occ, bool midx = false) {
   size_t b = (size_t)S * 16;
-  if (agent == COBEL_AGENT_DYNAQ) b += (size_t)S * 8;
-  if (replay) b += kHashBuckets * 8;
+  if (agent == COBEL_AGENT_DYNAQ && !midx) b += (size_t)S * 8;
+  if (replay) b += (midx ? kHashBucketsSmall : kHashBuckets) * 8;
   if (wlds) b += (size_t)S * 16;
   if (occ) b += (size_t)S * 4;
   return b;
@@ -97,7 +99,12 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
 // FAST: the run is the plain training case — learning on, planning after every step, no action
 // mask, no per-step host log — so those run-time switches become constants (fewer live scalar
 // registers and branches in the step loop; the generic instantiation spills SGPRs).
-template <int AGENT, bool OCC, bool WLDS, bool FAST>
+// MIDX (with FAST): the 16-bit model entries live in a caller-provided HBM table instead of LDS
+// (run.model_index, 8 B per state, L2 resident for the instances in flight).  The memory stream is
+// counter based, so the entries a step will sample are gathered one step ahead and patched in
+// registers with the one entry that step itself writes.  LDS shrinks to Q + hash = 17 KiB and
+// nine instances fit on a CU instead of six.
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -108,9 +115,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     L.Qf = reinterpret_cast<float*>(lds_raw);
     off += (size_t)S * 16;
     L.M16 = reinterpret_cast<uint16_t*>(lds_raw + off);
-    if (AGENT == COBEL_AGENT_DYNAQ) off += (size_t)S * 8;
+    if (AGENT == COBEL_AGENT_DYNAQ && !MIDX) off += (size_t)S * 8;
     L.H = reinterpret_cast<unsigned long long*>(lds_raw + off);
-    if (A.use_hash) off += kHashBuckets * 8;
+    if (A.use_hash) off += (size_t)A.hash_buckets * 8;
     L.Wl = reinterpret_cast<uint4*>(lds_raw + off);
     if (WLDS) off += (size_t)S * 16;
     L.occ = reinterpret_cast<uint32_t*>(lds_raw + off);
@@ -130,6 +137,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       (AGENT == COBEL_AGENT_Q && A.r.replay_log) ? A.r.replay_log + (size_t)i * A.r.log_cap
                                                  : nullptr;
   const uint32_t SA = (uint32_t)S * 4u;
+  uint16_t* const Mg = MIDX ? A.r.model_index + (size_t)i * SA : nullptr;
+  const uint32_t hmask = (uint32_t)A.hash_buckets - 1u;
 
   // ---- stage the instance: Q, compact model, world records --------------------------------
   for (int s = lane; s < S; s += 64) {
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (WLDS) L.Wl[s] = W4[s];
     if (OCC) L.occ[s] = 0u;
   }
-  if (AGENT == COBEL_AGENT_DYNAQ) {
+  if (AGENT == COBEL_AGENT_DYNAQ && !MIDX) {
     // 16-bit model entry: next state | nonterminal << 14 | (reward estimate != +0.0f) << 15.
     // The float32 reward estimates stay in HBM and are fetched only for flagged entries.
     for (uint32_t e = (uint32_t)lane; e < SA; e += 64u) {
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     }
   }
   if (A.use_hash)
-    for (int b = lane; b < kHashBuckets; b += 64) L.H[b] = 0ull;
+    for (int b = lane; b < A.hash_buckets; b += 64) L.H[b] = 0ull;
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -195,6 +204,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // and 63 hold policy blocks pb_idx and pb_idx + 1 (four consecutive action draws).
   cobel_u4 blk = {0, 0, 0, 0};
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
+  uint2 m4 = {0u, 0u};         // MIDX: the four model entries of the current state
+  uint32_t idx_cur = 0;        // MIDX, lane j < B: pair sampled by this step's replay j ...
+  uint32_t mg_cur = 0;         // ... and its model entry, gathered one step ahead
   uint32_t qx = 0;             // QAgent replay: memory draw of the upcoming batch
   uint64_t qrec = 0;           // ... and the logged experience it selects, gathered ahead
 
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   };
   const bool cached_mem = AGENT == COBEL_AGENT_DYNAQ && B > 0;
   auto refresh_draws = [&]() {   // one Philox evaluation refills both caches
-    const uint32_t pi = cp >> 1, mi = cm >> 2;
+    const uint32_t pi = cp >> 1, mi = (MIDX ? cm + 1u : cm) >> 2;   // MIDX draws one batch ahead
     const bool hit = (pi - pb_idx) <= 1u && (!cached_mem || mi == mb_idx);
     if (hit) return;
     const bool p0 = lane == 62, p1 = lane == 63;
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
     if (!WLDS && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    if (MIDX) m4 = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)s * 4u]);
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
   };
 
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     return;
 #endif
     // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
-    const uint32_t bs = sj & (kHashBuckets - 1), bn = ns & (kHashBuckets - 1);
+    const uint32_t bs = sj & hmask, bn = ns & hmask;
     if (on) atomicOr(&L.H[bs], 1ull << lane);
     __builtin_amdgcn_wave_barrier();
     unsigned long long cnd = on ? ((L.H[bn] | L.H[bs]) & ((1ull << lane) - 1ull)) : 0ull;
@@ -316,6 +329,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
   // ---- prologue -----------------------------------------------------------------------------
   if (iflags & 1u) enter_state(state);
+  if (MIDX) {
+    idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
+    mg_cur = lane < B ? (uint32_t)Mg[idx_cur] : 0u;
+  }
   if (AGENT == COBEL_AGENT_Q && replay_each_step) {
     qx = draw_m(cm);
     const uint32_t room = loglen < (uint32_t)A.r.log_cap ? 1u : 0u;
@@ -360,8 +377,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     const float4 srow = Qs[succ];
     const float smax = max4(srow);
     if (WLDS) cand = L.Wl[succ];
-    uint2 m4 = {0u, 0u};   // the four 16-bit model entries of this state
-    if (AGENT == COBEL_AGENT_DYNAQ) m4 = *reinterpret_cast<const uint2*>(&L.M16[state * 4]);
+    if (AGENT == COBEL_AGENT_DYNAQ && !MIDX)   // the four 16-bit model entries of this state
+      m4 = *reinterpret_cast<const uint2*>(&L.M16[state * 4]);
 
     // ---- select (policy/greedy.py:40-88) ------------------------------------------------------
     int a;
@@ -394,12 +411,15 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // Successor records for the next step: issued before this step's stores (a wave's memory
     // operations retire in order, so a load issued behind a store would also wait for the
     // store's acknowledgement) and consumed one step later, behind the planning.
+    uint2 m4_next = {0u, 0u};
     if (!trial_over) {
       if (!WLDS && lane < 4) cand = W4[next_of(nw0, nw1, lane)];
+      if (MIDX) m4_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
       mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
     }
 
     uint32_t fresh_idx = ~0u;   // model / log entry written by this step
+    uint32_t fresh_m = 0u;
     float fresh_r = 0.0f;
     uint64_t fresh_rec = 0;
     float td_online = 0.0f;
@@ -415,9 +435,17 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         const uint32_t rbits = __builtin_bit_cast(uint32_t, Rn);
         fresh_idx = sa;
         fresh_r = Rn;
+        fresh_m = (uint32_t)ns | (nt << 14) | (rbits ? 0x8000u : 0u);
         if (lane == 0) {
           model[sa] = cobel_model_pack(Rn, (uint32_t)ns, nt);
-          L.M16[sa] = (uint16_t)((uint32_t)ns | (nt << 14) | (rbits ? 0x8000u : 0u));
+          if (MIDX) Mg[sa] = (uint16_t)fresh_m;
+          else L.M16[sa] = (uint16_t)fresh_m;
+          if (!MIDX && A.r.model_index) A.r.model_index[(size_t)i * SA + sa] = (uint16_t)fresh_m;
+        }
+        if (MIDX && ns == state) {   // the prefetched entries of the next state predate this store
+          const uint32_t sh = (a & 1) ? 16u : 0u;
+          uint32_t& w = (a & 2) ? m4_next.y : m4_next.x;
+          w = (w & ~(0xffffu << sh)) | (fresh_m << sh);
         }
       } else if (rlog) {
         if (loglen < (uint32_t)A.r.log_cap) {
@@ -459,7 +487,23 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
     // ---- planning / replay ----------------------------------------------------------------------
     if (replay_each_step) {
-      if (AGENT == COBEL_AGENT_DYNAQ) {
+      if (AGENT == COBEL_AGENT_DYNAQ && MIDX) {
+        // next step's batch: draw, start the gather; then run this step's batch
+        const uint32_t idx_next = lane < B ? cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA) : 0u;
+        uint32_t mg_next = lane < B ? (uint32_t)Mg[idx_next] : 0u;
+        const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
+        float r = 0.0f;
+        if (lane < B) {
+          if (m & 0x8000u) r = __builtin_bit_cast(float, model32[2u * idx_cur]);
+          if (idx_cur == fresh_idx) r = fresh_r;
+        }
+        run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r);
+        if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
+        idx_cur = idx_next;
+        mg_cur = mg_next;
+        m4 = m4_next;
+        cm += 1u;
+      } else if (AGENT == COBEL_AGENT_DYNAQ) {
         plan_dynaq(mdraw, fresh_idx, fresh_r);
         cm += 1u;
       } else {
@@ -768,30 +812,47 @@ __global__ __launch_bounds__(256) void k_model_init(uint64_t* __restrict__ model
   model[t] = cobel_model_pack(0.0f, s, 0u);
 }
 
-template <int AGENT, bool OCC, bool WLDS, bool FAST>
+// 16-bit index entries from packed model records (see k_tab_wpi: next | nt << 14 | (R != 0) << 15)
+__global__ __launch_bounds__(256) void k_model_index(const uint64_t* __restrict__ model,
+                                                     uint16_t* __restrict__ index, size_t total) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint64_t rec = model[t];
+  const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+  index[t] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
+}
+
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     COBEL_HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST>),
+        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
 template <int AGENT>
-int dispatch_wpi(const tab_args& A, bool occ, bool wlds, bool fast, size_t lds, hipStream_t st) {
-  if (AGENT == COBEL_AGENT_DYNAQ && fast) {
-    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true>(A, lds, st)
-                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true>(A, lds, st);
-    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true>(A, lds, st)
-                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true>(A, lds, st);
+int dispatch_wpi(const tab_args& A, bool occ, bool wlds, bool fast, bool midx, size_t lds,
+                 hipStream_t st) {
+  if (AGENT == COBEL_AGENT_DYNAQ && fast && midx) {
+    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true, true>(A, lds, st)
+                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true, true>(A, lds, st);
+    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true, true>(A, lds, st)
+                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true, true>(A, lds, st);
   }
-  if (occ) return wlds ? launch_wpi<AGENT, true, true, false>(A, lds, st)
-                       : launch_wpi<AGENT, true, false, false>(A, lds, st);
-  return wlds ? launch_wpi<AGENT, false, true, false>(A, lds, st)
-              : launch_wpi<AGENT, false, false, false>(A, lds, st);
+  if (AGENT == COBEL_AGENT_DYNAQ && fast) {
+    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true, false>(A, lds, st)
+                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true, false>(A, lds, st);
+    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true, false>(A, lds, st)
+                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true, false>(A, lds, st);
+  }
+  if (occ) return wlds ? launch_wpi<AGENT, true, true, false, false>(A, lds, st)
+                       : launch_wpi<AGENT, true, false, false, false>(A, lds, st);
+  return wlds ? launch_wpi<AGENT, false, true, false, false>(A, lds, st)
+              : launch_wpi<AGENT, false, false, false, false>(A, lds, st);
 }
 
 }  // namespace
@@ -822,6 +883,19 @@ extern "C" int cobel_model_init(uint64_t* model, int32_t n, int32_t n_states, vo
   if (total == 0) return COBEL_OK;
   hipLaunchKernelGGL(k_model_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, model, total, n_states * 4);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_model_index_build(const uint64_t* model, uint16_t* index, int32_t n,
+                                       int32_t n_states, void* stream) {
+  COBEL_REQUIRE(model && index, COBEL_E_ARG, "cobel_model_index_build: NULL argument");
+  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 16384, COBEL_E_RANGE,
+                "cobel_model_index_build: bad sizes");
+  const size_t total = (size_t)n * n_states * 4;
+  if (total == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_model_index, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, model, index, total);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -869,7 +943,11 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
   A.use_hash = replay ? 1 : 0;
-  size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ);
+  const bool fast = r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
+                    !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
+  const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
+  A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
+  size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
   if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   hipStream_t st = (hipStream_t)stream;
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
@@ -898,9 +976,7 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;
   }
-  const bool fast = r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
-                    !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   if (r.agent == COBEL_AGENT_DYNAQ)
-    return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, fast, lds, st);
-  return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, false, lds, st);
+    return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, fast, midx, lds, st);
+  return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, false, false, lds, st);
 }

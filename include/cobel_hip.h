@@ -188,11 +188,17 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
 #define COBEL_F_MASK_ACTIONS 8u   /* agent.mask_actions                                      */
 #define COBEL_F_TEST_STREAM 16u   /* draw u from COBEL_STREAM_POLICY_TEST (separate policy)  */
 #define COBEL_F_FORCE_WAVE 32u    /* always use the wave-per-instance kernel (testing)       */
+#define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 
 typedef struct {
   /* tables, all caller-owned device memory */
   float* q;              /* [N][S][4] float32 Q                                              */
   uint64_t* model;       /* DYNAQ: [N][S][4] packed {f32 R; u16 NS; u8 nonterminal; u8 0}    */
+  uint16_t* model_index; /* DYNAQ, optional: [N][S][4] 16-bit digest of `model`
+                            (next | nonterminal << 14 | (R != +0) << 15, cobel_model_index_build),
+                            kept in sync by the kernel.  When present the planning kernel reads
+                            it from HBM/L2 instead of holding a copy in LDS: nine instances per
+                            CU instead of six.                                                 */
   uint64_t* replay_log;  /* Q with batch > 0: [N][log_cap] packed experiences (q.py:213), or NULL:
                             lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30 */
   int32_t* inst;         /* [N][COBEL_I_WORDS]                                               */
@@ -236,6 +242,11 @@ COBEL_API void cobel_unpack_model(uint64_t rec, float* reward, uint16_t* next_st
  * R = 0, NS[s][a] = s, nonterminal = 0. */
 COBEL_API int cobel_model_init(uint64_t* model /* [dev] [N][S][4] */, int32_t n, int32_t n_states,
                      void* stream);
+/* (Re)build the 16-bit digest of a model table — after cobel_model_init or whenever the caller
+ * has edited `model` by hand. */
+COBEL_API int cobel_model_index_build(const uint64_t* model /* [dev] [N][S][4] */,
+                                      uint16_t* index /* [dev] [N][S][4] */, int32_t n,
+                                      int32_t n_states, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Successor-representation agent.  Replaces SR.train / SR.update / SR.retrieve_q

@@ -649,3 +649,33 @@ def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
     lat = vec.monitors.mean_latency()
     assert not np.isnan(lat[:3]).any()
+
+
+def test_model_index_variants_agree(torch_cuda, golden_worlds):
+    """The planning kernel with the model digest in HBM (gathered one step ahead) and with the
+    digest in LDS produce identical tables, counters and digests — on a maze with several reward
+    sites (flagged reward estimates) and bumping moves (ns == s patches)."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    world = as_world(golden_worlds('walls_8x8'))
+
+    def run(extra):
+        env = Gridworld(world, n_envs=96, seed=31337)
+        ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.2))
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | extra | ag._policy_in(ag.policy, env, False)
+        ag.monitors.reserve(16, 96, True)
+        for _ in range(5):
+            ag._launch(env, ag.policy, flags, 16, 25, 33, 40)
+        return ag
+
+    a, b = run(0), run(_lib.F_FORCE_LDS_MODEL)
+    assert torch.equal(a._q, b._q) and torch.equal(a.M.table, b.M.table)
+    assert torch.equal(a.M.index, b.M.index) and torch.equal(a.inst, b.inst)
+    fresh = torch.empty_like(a.M.index)
+    _lib.check(_lib.lib().cobel_model_index_build(_lib.ptr(a.M.table), _lib.ptr(fresh), 96, 64, None))
+    assert torch.equal(fresh, a.M.index)
