@@ -36,8 +36,11 @@ COBEL_HD cobel_u4 cobel_philox(uint32_t index, uint32_t sub, uint32_t instance, 
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = cobel_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = cobel_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32), not a mul_hi / mul_lo pair
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;

@@ -192,9 +192,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
   // epsilon-greedy thresholds (cobel_eps_consts::thr), entry e = t * 3 + k in lane e < 48
   const uint64_t thr_mine = A.eps.thr[(lane % 48) / 3][lane % 3];
-  const uint32_t thr_lo = (uint32_t)thr_mine, thr_hi = (uint32_t)(thr_mine >> 32);
 #if defined(COBEL_STAMPS)
-  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = 0;
+  unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
 #endif
   // ---- values carried from one step to the next ------------------------------------------
   uint32_t cw0 = 0, cw1 = 0;   // next[0..3] of the current state (uniform)
@@ -205,6 +204,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   cobel_u4 blk = {0, 0, 0, 0};
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
   uint2 m4 = {0u, 0u};         // MIDX: the four model entries of the current state
+  int m4_fix = -1;             // MIDX: entry of m4 overwritten by the previous step's store, or -1
+  uint32_t m4_fix_val = 0u;
   uint32_t idx_cur = 0;        // MIDX, lane j < B: pair sampled by this step's replay j ...
   uint32_t mg_cur = 0;         // ... and its model entry, gathered one step ahead
   uint32_t qx = 0;             // QAgent replay: memory draw of the upcoming batch
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       step = 0;
       trew = 0.0;
       iflags |= 1u;
+      m4_fix = -1;
       enter_state(state);
     }
     if (budget == 0) break;
@@ -362,6 +364,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
     // ---- draws of this step (cached blocks; one Philox evaluation per ~4 steps) ---------------
     refresh_draws();
+#if defined(COBEL_STAMPS_FINE)
+    STAMP(6);
+#endif
     const int src_lane = 62 + (int)((cp >> 1) - pb_idx);
     const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
     const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
@@ -379,7 +384,19 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (WLDS) cand = L.Wl[succ];
     if (AGENT == COBEL_AGENT_DYNAQ && !MIDX)   // the four 16-bit model entries of this state
       m4 = *reinterpret_cast<const uint2*>(&L.M16[state * 4]);
+    if (MIDX && m4_fix >= 0) {   // (plain selects: a reference into m4 would send it to scratch)
+      const uint32_t sh = (m4_fix & 1) ? 16u : 0u;
+      const uint32_t keep = ~(0xffffu << sh), put = m4_fix_val << sh;
+      const uint32_t x = (m4_fix & 2) ? m4.x : ((m4.x & keep) | put);
+      const uint32_t y = (m4_fix & 2) ? ((m4.y & keep) | put) : m4.y;
+      m4.x = x;
+      m4.y = y;
+      m4_fix = -1;
+    }
 
+#if defined(COBEL_STAMPS_FINE)
+    STAMP(7);
+#endif
     // ---- select (policy/greedy.py:40-88) ------------------------------------------------------
     int a;
     if (mask_cur == 15u) {
@@ -387,13 +404,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       const float m = max4(qrow);
       const int t = (int)rfl((uint32_t)((int)(qrow.x == m) | ((int)(qrow.y == m) << 1) |
                                         ((int)(qrow.z == m) << 2) | ((int)(qrow.w == m) << 3)));
+      // every lane e < 48 compares its own threshold (entry e = t * 3 + k) with the draw; the
+      // three bits of this tie pattern in the ballot count the thresholds passed
       const uint64_t K = cobel_u53(w0, w1);
-      a = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const uint64_t T = (uint64_t)rl(thr_lo, t * 3 + k) | ((uint64_t)rl(thr_hi, t * 3 + k) << 32);
-        a += (int)(T <= K);
-      }
+      const unsigned long long passed = __ballot(thr_mine <= K);
+      a = __popcll((passed >> (t * 3)) & 7ull);
     } else {
       a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
                                                           cobel_u01(w0, w1), A.eps, lane));
@@ -408,6 +423,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     const uint32_t nt = 1u - end;
     const uint32_t sa = (uint32_t)state * 4u + (uint32_t)a;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+#if defined(COBEL_STAMPS_FINE)
+    STAMP(8);
+#endif
     // Successor records for the next step: issued before this step's stores (a wave's memory
     // operations retire in order, so a load issued behind a store would also wait for the
     // store's acknowledgement) and consumed one step later, behind the planning.
@@ -418,6 +436,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
     }
 
+#if defined(COBEL_STAMPS_FINE)
+    STAMP(9);
+#endif
     uint32_t fresh_idx = ~0u;   // model / log entry written by this step
     uint32_t fresh_m = 0u;
     float fresh_r = 0.0f;
@@ -442,11 +463,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
           else L.M16[sa] = (uint16_t)fresh_m;
           if (!MIDX && A.r.model_index) A.r.model_index[(size_t)i * SA + sa] = (uint16_t)fresh_m;
         }
-        if (MIDX && ns == state) {   // the prefetched entries of the next state predate this store
-          const uint32_t sh = (a & 1) ? 16u : 0u;
-          uint32_t& w = (a & 2) ? m4_next.y : m4_next.x;
-          w = (w & ~(0xffffu << sh)) | (fresh_m << sh);
-        }
+        // (if ns == state the entries prefetched for the next step predate this store; they are
+        //  patched when they are consumed, not here — touching them now would wait for the load)
+        m4_fix = (MIDX && ns == state) ? a : -1;
+        m4_fix_val = fresh_m;
       } else if (rlog) {
         if (loglen < (uint32_t)A.r.log_cap) {
           fresh_rec = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
@@ -549,6 +569,14 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 #if defined(COBEL_STAMPS)
   if (A.r.last_exp && lane == 0)
     for (int k = 0; k < 6; ++k) A.r.last_exp[(size_t)i * 6 + k] = (int32_t)(stamp_sum[k] >> 4);
+#if defined(COBEL_STAMPS_FINE)
+  if (A.r.last_exp && lane == 0) {
+    A.r.last_exp[(size_t)i * 6 + 2] = (int32_t)(stamp_sum[6] >> 4);
+    A.r.last_exp[(size_t)i * 6 + 3] = (int32_t)(stamp_sum[7] >> 4);
+    A.r.last_exp[(size_t)i * 6 + 4] = (int32_t)(stamp_sum[8] >> 4);
+    A.r.last_exp[(size_t)i * 6 + 5] = (int32_t)(stamp_sum[9] >> 4);
+  }
+#endif
 #endif
   // ---- write back ---------------------------------------------------------------------------
   __syncthreads();

@@ -7,7 +7,7 @@ from cobel_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, 'cobel-rl_amd', 'lib', 'libcobel_hip_stamps.so')
 import bench
 dev = torch.device('cuda', 0)
-for n, B in [(65536, 50), (65536, 0)]:
+for n, B in [(65536, 50)]:
     cfg = dict(bench.CONFIGS['C3'], instances=n, env_steps_per_launch=256, batch=B)
     env, agent = bench.build_agent('C3', cfg, n, 0, dev)
     r = bench.Runner(cfg, env, agent)
@@ -15,7 +15,7 @@ for n, B in [(65536, 50), (65536, 0)]:
     def patched(interface, pol, flags, tt, steps, budget, batch):
         mon = agent.monitors
         run = _lib.TabRun()
-        run.q = _lib.ptr(agent._q); run.inst = _lib.ptr(agent.inst); run.model = _lib.ptr(agent.M.table)
+        run.q = _lib.ptr(agent._q); run.inst = _lib.ptr(agent.inst); run.model = _lib.ptr(agent.M.table); run.model_index = _lib.ptr(agent.M.index)
         run.lat_sum, run.lat_cnt, run.reward_sum = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt), _lib.ptr(mon.reward_sum)
         run.steps_done = _lib.ptr(mon.steps_done); run.last_exp = _lib.ptr(agent._last_exp)
         run.n, run.trial_cap, run.instance_base = agent.n_envs, mon.cap, interface.instance_base
@@ -26,7 +26,7 @@ for n, B in [(65536, 50), (65536, 0)]:
     agent._launch = patched
     r.launch(); torch.cuda.synchronize()
     st = agent._last_exp.cpu().numpy().astype(np.float64) * 16 / 256   # s_memtime ticks per step
-    names = ['draws+select', 'env+store+TD', 'plan: M16+hash', 'plan: candidates', 'plan: rounds', 'bookkeeping+prefetch+loop']
+    names = ['select after LDS batch', 'store+TD (after prefetch issue)', 'refresh_draws', 'readlane draws + LDS batch reads', 'env readlanes', 'prefetch issue'] if os.environ.get('FINE') else ['draws+select', 'env+store+TD', 'plan: M16+hash', 'plan: candidates', 'plan: rounds', 'bookkeeping+prefetch+loop']
     tot = st.sum(axis=1).mean()
     print('n=%d B=%d: %.0f ticks per step per wave' % (n, B, tot))
     for k in range(6):
