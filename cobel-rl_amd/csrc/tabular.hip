@@ -168,8 +168,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
   uint32_t loglen = (uint32_t)inst[COBEL_I_LOG_LEN];
   uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
-  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
-  unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
+  // trial reward: a per-lane (vector) register on purpose — it is only ever accumulated, and as a
+  // wave-uniform value it would occupy scalar registers the step loop is short of
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO + (lane & 0));
+  asm volatile("" : "+v"(trew));
 
   const uint32_t flags = A.r.flags;
   const bool learn = FAST || (flags & COBEL_F_LEARN);
@@ -184,11 +186,15 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
                                                                        : COBEL_STREAM_POLICY;
   const uint8_t* const amask =
       (!FAST && (flags & COBEL_F_MASK_ACTIONS)) ? A.r.action_mask : nullptr;
-  const uint64_t seed = A.r.seed;
+  uint64_t seed = A.r.seed;
+  asm volatile("" : "+v"(seed));
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
-  const double alpha = A.r.alpha, gamma = A.r.gamma;
-  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  // Loop constants that only ever feed vector instructions are pinned to vector registers: the
+  // step loop is short of scalar registers (spills cost instructions), not of vector ones.
+  double alpha = A.r.alpha, gamma = A.r.gamma;
+  float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
 
   // epsilon-greedy thresholds (cobel_eps_consts::thr), entry e = t * 3 + k in lane e < 48
   const uint64_t thr_mine = A.eps.thr[(lane % 48) / 3][lane % 3];
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   auto refresh_draws = [&]() {   // one Philox evaluation refills both caches
     const uint32_t pi = cp >> 1, mi = (MIDX ? cm + 1u : cm) >> 2;   // MIDX draws one batch ahead
     const bool hit = (pi - pb_idx) <= 1u && (!cached_mem || mi == mb_idx);
-    if (hit) return;
+    if (__builtin_expect(hit, 1)) return;
     const bool p0 = lane == 62, p1 = lane == 63;
     blk = cobel_philox(p1 ? pi + 1u : (p0 ? pi : mi), (p0 || p1) ? 0u : (uint32_t)lane, g,
                        (p0 || p1) ? pol_stream : COBEL_STREAM_MEMORY, seed);
@@ -340,21 +346,22 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     qrec = log_gather(qx, loglen + room, loglen);
   }
 
-  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
-  unsigned long long executed = 0;
+  const int budget0 = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  int budget = budget0;   // steps executed by this call = budget0 - budget
 #if defined(COBEL_STAMPS)
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
 
   while (true) {
     STAMP(5);
-    if (!(iflags & 1u)) {
+    if (__builtin_expect(!(iflags & 1u), 0)) {
       if (trial >= A.r.trials_target) break;
       state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
                                                                start_cnt)];
       ce += 1u;
       step = 0;
       trew = 0.0;
+      asm volatile("" : "+v"(trew));
       iflags |= 1u;
       m4_fix = -1;
       enter_state(state);
@@ -450,7 +457,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         const uint32_t pair = (a & 2) ? m4.y : m4.x;
         const uint32_t old = (a & 1) ? (pair >> 16) : (pair & 0xffffu);
         float R = 0.0f;
-        if (old & 0x8000u) R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
+        if (__builtin_expect((old & 0x8000u) != 0u, 0))
+          R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
         const float d = r - R;
         const float Rn = R + mlr_f * d;
         const uint32_t rbits = __builtin_bit_cast(uint32_t, Rn);
@@ -498,8 +506,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     STAMP(1);
     // ---- bookkeeping --------------------------------------------------------------------------
     trew += (double)r;
-    nsteps += 1ull;
-    executed += 1ull;
     if (OCC && lane == 0) L.occ[ns] += 1u;
     state = ns;
     cw0 = nw0;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       }
     }
 
-    if (trial_over) {
+    if (__builtin_expect(trial_over, 0)) {
       // agent/dyna_q.py:207-212: current_trial += 1; logs['steps'] = step (0-based)
       if (lane == 0 && trial >= 0 && trial < A.r.trial_cap) {
         if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
@@ -596,8 +602,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     inst[COBEL_I_CTR_MEMORY] = (int32_t)cm;
     inst[COBEL_I_LOG_LEN] = (int32_t)loglen;
     inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    const unsigned long long executed = (unsigned long long)(budget0 - budget);
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
-    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
     if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
   }
 }
