@@ -262,6 +262,7 @@ def main():
     ap.add_argument('--instances', type=int, default=0)
     ap.add_argument('--env-steps', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-c5', action='store_true', help='skip the PyTorch DQN leg (profiling runs)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -288,7 +289,7 @@ def main():
                                 'roofline': r['roofline']}
             except Exception as e:  # e.g. not enough HBM for C4 on a shared device
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
-        for dt_name in ('f64', 'f32'):
+        for dt_name in (() if args.no_c5 else ('f64', 'f32')):
             try:
                 others['C5_' + dt_name] = run_c5(device, dt_name)
             except Exception as e:
