@@ -158,3 +158,54 @@ def make_obstacle_maze(height: int, width: int, seed: int, density: float = 0.20
     return make_gridworld(height, width, terminals=[goal_state],
                           rewards=np.array([[goal_state, reward]]), goals=[goal_state],
                           invalid_states=walls, starting_states=starts)
+
+
+def corridor_gridworld(height: int, width: int, corridor, terminals, rewards, goals,
+                       starting_states) -> World:
+    """Gridworld whose walls are given by a boolean ``corridor[h, w]`` mask: every move between a
+    corridor cell and a non-corridor cell is an invalid transition (both directions).  Cells
+    outside the corridor remain ordinary, unreachable states — the structure the reference's
+    maze templates build by listing border-crossing transitions explicitly."""
+    inside = np.asarray(corridor, dtype=bool).reshape(height, width)
+    s = np.arange(height * width).reshape(height, width)
+    pairs = []
+    for a, b, ia, ib in ((s[:, :-1], s[:, 1:], inside[:, :-1], inside[:, 1:]),
+                         (s[:-1, :], s[1:, :], inside[:-1, :], inside[1:, :])):
+        cross = ia != ib
+        pairs += list(zip(a[cross].tolist(), b[cross].tolist()))
+        pairs += list(zip(b[cross].tolist(), a[cross].tolist()))
+    return make_gridworld(height, width, terminals, rewards, goals, starting_states,
+                          invalid_transitions=pairs)
+
+
+def make_t_maze(stem_length: int, arm_length: int, goal_arm: Literal['left', 'right'] = 'right',
+                reward: float = 1) -> World:
+    """T-maze (gridworld_tools.py:237-298): arms along the top row, stem below their centre; the
+    agent starts at the foot of the stem, the end of the chosen arm is the terminal goal."""
+    assert stem_length > 0 and arm_length > 0, 'Stem and arm length must be greater than zero!'
+    height, width = stem_length + 1, arm_length * 2 + 1
+    goal = 0 if goal_arm == 'left' else width - 1
+    inside = np.zeros((height, width), dtype=bool)
+    inside[0, :] = True
+    inside[:, arm_length] = True
+    return corridor_gridworld(height, width, inside, [goal], np.array([[goal, reward]]), [goal],
+                              [height * width - arm_length - 1])
+
+
+def load_world(path: str) -> World:
+    """Load a WorldDict pickled by the reference's gridworld editor
+    (``pickle.dump(self.world, ...)``, misc/gridworld_gui.py:225) or by user code, and derive the
+    compact tables the kernels use.  The dense ``sas`` tensor is dropped after ``next`` has been
+    taken from it (it is re-created on demand)."""
+    import pickle
+    with open(path, 'rb') as fh:
+        raw = pickle.load(fh)
+    assert raw.get('deterministic', True), 'only deterministic worlds are supported'
+    world = World()
+    for key, value in raw.items():
+        if key != 'sas':
+            world[key] = value
+    world['next'] = (np.asarray(raw['next'], dtype=np.uint16) if 'next' in raw
+                     else np.argmax(raw['sas'], axis=2).astype(np.uint16))
+    world.setdefault('deterministic', True)
+    return world

@@ -49,7 +49,7 @@ _lib = None
 def lib(path: str | None = None):
     global _lib
     if _lib is None or path is not None:
-        target = path or LIB
+        target = path or os.environ.get('COBEL_ORACLE_LIB') or LIB   # e.g. the `make asan` build
         if path is None and (not os.path.exists(LIB) or os.path.getmtime(LIB) <
                              os.path.getmtime(os.path.join(HERE, 'cobel_oracle.c'))):
             subprocess.check_call(['make', '-C', HERE], stdout=subprocess.DEVNULL)

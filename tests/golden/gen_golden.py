@@ -160,6 +160,8 @@ def gen_worlds():
         'windy_5x6_down': gt.make_windy_gridworld(
             5, 6, np.array([0, 1, 2, 1, 0, 3]), 3, 1.0, 'down'),
         'open_32x32': gt.make_open_field(32, 32, 0, 1),
+        't_maze_3_2_right': gt.make_t_maze(3, 2, 'right', 1.0),
+        't_maze_2_4_left': gt.make_t_maze(2, 4, 'left', 2.0),
     }
     for seed in (1234, 1235):
         walls = maze_cells(seed)
@@ -170,6 +172,13 @@ def gen_worlds():
     for name, w in worlds.items():
         for k, v in compact(w).items():
             out['%s/%s' % (name, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'worlds.npz'), **out)
+    # a WorldDict as the reference's gridworld editor pickles it (misc/gridworld_gui.py:225)
+    import pickle
+    with open(os.path.join(HERE, 'double_t_maze_2_1.pkl'), 'wb') as fh:
+        pickle.dump(dict(gt.make_double_t_maze(2, 1)), fh, protocol=4)
+    for k, v in compact(gt.make_double_t_maze(2, 1)).items():
+        out['double_t_maze_2_1/%s' % k] = v
     np.savez_compressed(os.path.join(HERE, 'worlds.npz'), **out)
     return worlds
 

@@ -81,6 +81,10 @@ def test_world_builders_match_reference_tables(golden_worlds):
         'open_32x32': gt.make_open_field(32, 32, 0, 1),
         'maze_32x32_1234': gt.make_obstacle_maze(32, 32, 1234),
         'maze_32x32_1235': gt.make_obstacle_maze(32, 32, 1235),
+        't_maze_3_2_right': gt.make_t_maze(3, 2, 'right', 1.0),
+        't_maze_2_4_left': gt.make_t_maze(2, 4, 'left', 2.0),
+        'double_t_maze_2_1': gt.load_world(os.path.join(ROOT, 'tests', 'golden',
+                                                        'double_t_maze_2_1.pkl')),
     }
     for name, w in built.items():
         g = golden_worlds(name)
