@@ -224,24 +224,20 @@ class RefSR:
         self.current_trial = 0
 
     def retrieve_q(self, state):
-        # sr.py:302-306: V = sum(SR * rewards, axis=1); q[a] = mean(V[transitions[s][a] == 1])
-        rows = self.T[state]
-        v = np.sum(self.SR[rows] * self.rewards, axis=1)
-        return np.array([np.mean(v[a:a + 1]) for a in range(self.A)])
+        # sr.py:302-306: V = sum(SR * rewards, axis=1) over ALL rows (the reference's S^2 cost
+        # pattern is kept so that this loop is a faithful CPU baseline); q[a] = V[T[s, a]]
+        v = np.sum(self.SR * self.rewards, axis=1)
+        return np.array([np.mean(v[self.T[state, a]:self.T[state, a] + 1]) for a in range(self.A)])
 
     def update(self, s, a, r, ns, nt):
         d = r - self.rewards[ns]
         self.rewards[ns] += d * self.learning_rate
         self.T[s, a] = ns
-        unit = np.zeros(self.S)
-        unit[s] = 1.0
-        td = unit
+        td = np.eye(self.S)[s]                       # float64 whatever the table dtype
         if nt > 0:
             td += self.gamma * np.copy(self.SR[ns])
         else:
-            nxt = np.zeros(self.S)
-            nxt[ns] = 1.0
-            td += self.gamma * nxt
+            td += self.gamma * np.eye(self.S)[ns]
         td -= np.copy(self.SR[s])
         self.SR[s] += self.learning_rate * td
 

@@ -1,0 +1,53 @@
+"""Calibration of the cpu_baseline 'port' (oracle/ref_loop.py) against the REAL reference, run in
+the build container where both exist.  Prints env-steps/s of both on the C1, C3
+and C4 analogues, single process, one core."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import numpy as np
+import gen_golden as G   # loads the reference through the import shim
+from cobel.agent import DynaQ
+from cobel.agent.sr import SR
+from cobel.interface import Gridworld
+from cobel.policy import EpsilonGreedy
+from cobel.misc import gridworld_tools as gt
+from oracle import ref_loop
+from oracle.philox import TapeRNG, STREAM_ENV, STREAM_POLICY, STREAM_MEMORY
+
+def time_it(fn, count, budget=8.0):
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < budget:
+        fn(); n = count()
+    return n / (time.perf_counter() - t0)
+
+rows = []
+for name, world, kind, B, steps in (('C1 5x5 Dyna-Q B=32', gt.make_open_field(5, 5, 0, 1), 'dynaq', 32, 50),
+                                    ('C3-analogue 32x32 Dyna-Q B=50', gt.make_open_field(32, 32, 0, 1), 'dynaq', 50, 200),
+                                    ('C4-analogue 32x32 SR', gt.make_open_field(32, 32, 0, 1), 'sr', 0, 200)):
+    S = world['states']
+    # real reference, its own numpy Generators
+    env = Gridworld(world, rng=np.random.default_rng(0))
+    pol = EpsilonGreedy(0.1, rng=np.random.default_rng(1))
+    cnt = [0]
+    cb = {'on_step_end': [lambda logs: cnt.__setitem__(0, cnt[0] + 1)]}
+    if kind == 'dynaq':
+        ag = DynaQ(env.observation_space, env.action_space, pol, custom_callbacks=cb)
+        ag.M.rng = np.random.default_rng(2)
+        ref = time_it(lambda: ag.train(env, 1, steps, B), lambda: cnt[0])
+    else:
+        ag = SR(env.observation_space, env.action_space, pol, custom_callbacks=cb)
+        ref = time_it(lambda: ag.train(env, 1, steps), lambda: cnt[0])
+    tabs = dict(next=np.argmax(world['sas'], axis=2), reward=world['rewards'], terminal=world['terminals'],
+                starts=world['starting_states'])
+    renv = ref_loop.RefGridworld(tabs, np.random.default_rng(0))
+    rpol = ref_loop.RefEpsilonGreedy(0.1, np.random.default_rng(1))
+    tr = ref_loop.new_trace()
+    if kind == 'dynaq':
+        rag = ref_loop.RefDynaQ(S, 4, rpol, np.random.default_rng(2))
+        port = time_it(lambda: rag.train(renv, 1, steps, B, trace=tr), lambda: len(tr['sarsn']))
+    else:
+        rag = ref_loop.RefSR(S, 4, rpol)
+        port = time_it(lambda: rag.train(renv, 1, steps, trace=tr), lambda: len(tr['sarsn']))
+    rows.append((name, ref, port, port / ref))
+    print('%-32s reference %8.0f  port %8.0f  ratio %.2f' % rows[-1])
