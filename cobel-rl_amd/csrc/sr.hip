@@ -47,6 +47,7 @@ struct sr_plan {
   uint8_t leaf_len[kMaxLeaves];
   uint8_t op_dst[kMaxLeaves], op_src[kMaxLeaves];
   int n_leaves, n_ops;
+  int balanced;  // 1: n_leaves in {1, 2, 4, 8}, all leaves 128 long -> butterfly combine
 };
 
 // NumPy pairwise_sum recursion (n <= 128: leaf; else split at n/2 rounded down to a multiple
@@ -95,6 +96,7 @@ __device__ void build_plan(sr_plan* p, int S, int* stack /* 64 ints of LDS scrat
   }
   p->n_leaves = nl;
   p->n_ops = no;
+  p->balanced = (nl == 1 || nl == 2 || nl == 4 || nl == 8) && S == 128 * nl;
 }
 
 // V = pairwise_sum_k(row[k] * rw[k]) by one wave; row and rw are in padded LDS layout.
@@ -138,6 +140,13 @@ __device__ __forceinline__ float wave_pairwise_dot(const float* row, const float
   }
   __builtin_amdgcn_wave_barrier();
   float v = 0.0f;
+  if (plan->balanced) {
+    // 2^k equal leaves (S = 128 * 2^k, k <= 3): the halving tree is a butterfly over the leaf
+    // index, ((L0+L1)+(L2+L3))+((L4+L5)+(L6+L7)), and every leaf sum is already in a register
+    v = leafsum[lane >> 3 < nl ? lane >> 3 : 0];
+    for (int o = 8; o < 8 * nl; o <<= 1) v = v + __shfl_xor(v, o);
+    return __shfl(v, 0);
+  }
   if (lane == 0) {
     for (int o = 0; o < plan->n_ops; ++o)
       leafsum[plan->op_dst[o]] = leafsum[plan->op_dst[o]] + leafsum[plan->op_src[o]];
