@@ -16,7 +16,7 @@ OK, E_ARG, E_RANGE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
 STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST = 0, 1, 2, 3
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
-F_FORCE_LDS_MODEL = 64
+F_FORCE_LDS_MODEL, F_NO_PREFETCH = 64, 128
 MAX_BATCH = 62
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
  I_REWARD_LO, I_REWARD_HI, I_STEPS_LO, I_STEPS_HI, I_WORDS) = range(13)

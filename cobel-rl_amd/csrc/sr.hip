@@ -155,6 +155,13 @@ __device__ __forceinline__ float wave_pairwise_dot(const float* row, const float
   return __shfl(v, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), which would wait for the row prefetch that is meant to stay in
+// flight across the update phase.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <bool VEC>
 __device__ __forceinline__ void load_row(float* dst, const float* __restrict__ src, int S, int t,
                                          int nthreads) {
@@ -213,7 +220,11 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
   return (a & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-template <bool VEC, bool OCC>
+// PRE (VEC and S <= 1024): as soon as the action is known, wave a starts loading the value row it
+// will need in the NEXT step (row T[ns][a]) into registers, so the HBM latency of the four value
+// rows overlaps the row update of this step.  The one row that cannot be prefetched — SR[s], which
+// this step rewrites — is taken from the LDS copy the update leaves behind.
+template <bool VEC, bool OCC, bool PRE>
 __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -273,6 +284,11 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
 
   int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
   unsigned long long executed = 0;
+  // PRE: this wave's value row of the coming step, elements lane*4 + 256*j in pre_j (named
+  // registers on purpose: an array carried around the loop is demoted to scratch memory)
+  float4 pre0 = {0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
+  int pre_mode = 0;     // 0 load at the top of the step, 1 in `pre`, 2 in the LDS spare row 4
+  float* const spare = L.rows + (size_t)4 * L.PS;
 
   while (true) {
     if (!(iflags & 1u)) {
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
       step = 0;
       trew = 0.0;
       iflags |= 1u;
+      pre_mode = 0;
       enter_state(state);
     }
     if (budget == 0) break;
@@ -291,11 +308,27 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     // ---- retrieve_q (sr.py:302-306): wave a evaluates V[T[s][a]] ----------------------------
     const int my_row = (int)L.T[state * 4 + wave];
     float* const my_buf = L.rows + (size_t)wave * L.PS;
-    load_row<VEC>(my_buf, SRg + (size_t)my_row * S, S, lane, 64);
+    const int e0 = lane * 4;
+    if (PRE && pre_mode == 1) {
+      if (e0 < S) *reinterpret_cast<float4*>(my_buf + phys(e0)) = pre0;
+      if (e0 + 256 < S) *reinterpret_cast<float4*>(my_buf + phys(e0 + 256)) = pre1;
+      if (e0 + 512 < S) *reinterpret_cast<float4*>(my_buf + phys(e0 + 512)) = pre2;
+      if (e0 + 768 < S) *reinterpret_cast<float4*>(my_buf + phys(e0 + 768)) = pre3;
+    } else if (PRE && pre_mode == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + 256 * j;
+        if (e < S)
+          *reinterpret_cast<float4*>(my_buf + phys(e)) =
+              *reinterpret_cast<const float4*>(spare + phys(e));
+      }
+    } else {
+      load_row<VEC>(my_buf, SRg + (size_t)my_row * S, S, lane, 64);
+    }
     __builtin_amdgcn_wave_barrier();
     const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * kMaxLeaves, lane);
     if (lane == 0) L.V[wave] = v;
-    __syncthreads();
+    lds_barrier();
     const float4 q = *reinterpret_cast<const float4*>(L.V);
 
     // ---- select + env.step -------------------------------------------------------------------
@@ -312,6 +345,25 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     const float r = __builtin_bit_cast(float, rl(cand.z, a));
     const uint32_t end = rl(cand.w, a);
     const uint32_t nt = 1u - end;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    if (PRE) {
+      pre_mode = 0;
+      if (!trial_over) {
+        // T[state][a] becomes ns in this step; every other entry of T[ns][.] is already final
+        const int nrow = (learn && ns == state && wave == a) ? ns : (int)L.T[ns * 4 + wave];
+        if (learn && nrow == state) {
+          pre_mode = 2;
+        } else {
+          const float4* const src4 =
+              reinterpret_cast<const float4*>(SRg + (size_t)nrow * S) + lane;
+          if (e0 < S) pre0 = src4[0];
+          if (e0 + 256 < S) pre1 = src4[64];
+          if (e0 + 512 < S) pre2 = src4[128];
+          if (e0 + 768 < S) pre3 = src4[192];
+          pre_mode = 1;
+        }
+      }
+    }
 
     if (learn) {
       // rows already in LDS? (T[s][.] as it was when the value rows were loaded)
@@ -324,7 +376,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
       }
       if (ns == state && src_ns < 0) src_ns = 4;  // shares the spare row with SR[s]
       const bool need_ns = nt != 0u;
-      __syncthreads();  // every wave has read T[s][.] before it changes
+      lds_barrier();  // every wave has read T[s][.] before it changes
       if (src_s < 0) {
         load_row<VEC>(L.rows + (size_t)4 * L.PS, SRg + (size_t)state * S, S, t, 256);
         src_s = 4;
@@ -343,7 +395,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
         L.T[state * 4 + a] = (uint16_t)ns;
         Tg[state * 4 + a] = (uint16_t)ns;
       }
-      __syncthreads();
+      lds_barrier();
       // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
       const float* const row_s = L.rows + (size_t)src_s * L.PS;
       const float* const row_n = L.rows + (size_t)(need_ns ? src_ns : src_s) * L.PS;
@@ -369,6 +421,9 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
           o.z = upd1(e + 2, cs.z, cn.z);
           o.w = upd1(e + 3, cs.w, cn.w);
           reinterpret_cast<float4*>(out)[e >> 2] = o;
+          // keep the new row in LDS for the waves whose next value row it is (the thread that
+          // read elements e..e+3 is the only one that writes them, also when spare is a source)
+          if (PRE) *reinterpret_cast<float4*>(spare + phys(e)) = o;
         }
       } else {
         for (int e = t; e < S; e += 256) out[e] = upd1(e, row_s[phys(e)], row_n[phys(e)]);
@@ -388,7 +443,6 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     nsteps += 1ull;
     executed += 1ull;
     if (OCC && t == 0) occ[ns] += 1u;
-    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     state = ns;
     cw0 = nw0;
     cw1 = nw1;
@@ -406,9 +460,11 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
       trial += 1;
       iflags &= ~1u;
     }
-    // the row just stored must be visible to the loads of the next step, and the LDS rows it
-    // was computed from must not be overwritten before every thread is done with them
-    __syncthreads();
+    // The LDS rows this step computed from must not be overwritten before every thread is done
+    // with them.  Without the prefetch (and at trial ends) the row just stored must also be
+    // visible to the global loads of the next step: full barrier.
+    if (PRE && !trial_over) lds_barrier();
+    else __syncthreads();
   }
 
   if (OCC) {
@@ -469,13 +525,13 @@ __global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
   }
 }
 
-template <bool VEC, bool OCC>
+template <bool VEC, bool OCC, bool PRE>
 int launch_sr(const sr_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC>),
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr<VEC, OCC>), dim3(A.r.n), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE>), dim3(A.r.n), dim3(256), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -529,8 +585,10 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   A.gamma_f = (float)r.gamma;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (S % 4) == 0;
-  if (vec) return occ ? launch_sr<true, true>(A, lds, st) : launch_sr<true, false>(A, lds, st);
-  return occ ? launch_sr<false, true>(A, lds, st) : launch_sr<false, false>(A, lds, st);
+  const bool pre = vec && S <= 1024 && !(r.flags & COBEL_F_NO_PREFETCH);
+  if (pre) return occ ? launch_sr<true, true, true>(A, lds, st) : launch_sr<true, false, true>(A, lds, st);
+  if (vec) return occ ? launch_sr<true, true, false>(A, lds, st) : launch_sr<true, false, false>(A, lds, st);
+  return occ ? launch_sr<false, true, false>(A, lds, st) : launch_sr<false, false, false>(A, lds, st);
 }
 
 extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const float* rewards,

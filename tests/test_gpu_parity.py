@@ -679,3 +679,32 @@ def test_model_index_variants_agree(torch_cuda, golden_worlds):
     fresh = torch.empty_like(a.M.index)
     _lib.check(_lib.lib().cobel_model_index_build(_lib.ptr(a.M.table), _lib.ptr(fresh), 96, 64, None))
     assert torch.equal(fresh, a.M.index)
+
+
+def test_sr_prefetch_variants_agree(torch_cuda):
+    """k_sr with the next step's value rows prefetched into registers (default) and with rows
+    loaded at the top of every step give identical SR matrices, transition tables and counters
+    (32x32 open field, long enough for revisits, bumps into walls and trial ends)."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    world = make_open_field(32, 32, 0, 1)
+
+    def run(extra):
+        env = Gridworld(world, n_envs=12, seed=2718)
+        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.3))
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | extra | ag._policy_in(ag.policy, env, False)
+        ag.monitors.reserve(64, 12, True)
+        for _ in range(3):
+            ag._launch(env, ag.policy, flags, 0x7fffffff, 60, 170, 0)
+        return ag
+
+    a, b = run(0), run(_lib.F_NO_PREFETCH)
+    assert torch.equal(a._sr, b._sr) and torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
+    assert torch.equal(a.inst, b.inst)
+    assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
