@@ -67,7 +67,7 @@ class DQN(Agent):
         if pol.counter is None or pol.counter.numel() != self.n_envs:
             pol.counter = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
 
-    def _select(self, pol, q: torch.Tensor, base: int) -> torch.Tensor:
+    def _select(self, pol, q: torch.Tensor, base: int, idle=None) -> torch.Tensor:
         n = self.n_envs
         u = torch.empty(n, dtype=torch.float64, device=self.device)
         st = _lib.current_stream(self.device)
@@ -81,6 +81,8 @@ class DQN(Agent):
             q = q.float()
         _lib.check(fn(_lib.ptr(q), None, _lib.ptr(u), float(pol.epsilon), _lib.ptr(act), None, n,
                       st))
+        if idle is not None:        # instances that are done do not consume their streams
+            pol.counter -= idle.to(torch.int32)
         return act
 
     # -- reference surface ----------------------------------------------------------------------
@@ -105,6 +107,8 @@ class DQN(Agent):
     def replay(self, batch_size: int = 32, active=None):
         """One optimisation step per instance on a sampled batch (dqn.py:331-384)."""
         states, actions, rewards, next_states, terminals = self.M.retrieve(batch_size)
+        if active is not None:      # instances that are done do not consume their streams
+            self.M.counter -= (~active & (self.M.size > 0)).to(torch.int32)
         with torch.no_grad():
             targets = self._online.forward(states).clone()
             boot = self._target.forward(next_states)
@@ -114,9 +118,9 @@ class DQN(Agent):
             targets.scatter_(2, actions[..., None], new[..., None])
         self._online.train_on_device(states, targets, active)
         if self.target_update < 1.0:
-            self._target.blend_from(self._online, self.target_update)
+            self._target.blend_from(self._online, self.target_update, active)
         elif self.last_update >= self.target_update:
-            self._target.copy_from(self._online)
+            self._target.copy_from(self._online, active)
             self.last_update = 1
         else:
             self.last_update += 1
@@ -142,38 +146,43 @@ class DQN(Agent):
         obs = interface.observe().to(self.dtype).clone()
         active = torch.ones(n, dtype=torch.bool, device=dev)
         iters = 0
+        all_active = True     # host-side knowledge; exact because it is refreshed every step
+        zero64 = torch.zeros(n, dtype=torch.int64, device=dev)
+        cap = self.monitors.cap
         while True:
             q = self._online.predict_on_device(obs[:, None, :])[:, 0]
-            action = self._select(pol, q, interface.instance_base)
+            idle = None if all_active else ~active
+            action = self._select(pol, q, interface.instance_base, idle)
             interface.step(action)
             nxt = interface.observe().to(self.dtype).clone()
             reward, done = interface._reward, interface._done.bool()
             if learn:
-                self.M.store_batch(obs, action, reward, nxt, (~done), active)
-                self.replay(batch_size, active.to(self.dtype))
+                self.M.store_batch(obs, action, reward, nxt, (~done), None if all_active else active)
+                self.replay(batch_size, None if all_active else active)
             trew += torch.where(active, reward.to(torch.float64), torch.zeros_like(trew))
+            # trial ends, entirely masked (no host round trip per step)
             over = active & (done | (step + 1 >= steps))
-            if bool(over.any().item()):
-                idx = self.trial[over].to(torch.int64)
-                ok = idx < self.monitors.cap
-                self.monitors.lat_sum.index_add_(0, idx[ok], step[over][ok].to(torch.int64))
-                self.monitors.lat_cnt.index_add_(0, idx[ok], torch.ones_like(idx[ok]))
-                self.monitors.reward_sum.index_add_(0, idx[ok], trew[over][ok])
-                self.trial += over.to(torch.int32)
-                step = torch.where(over, torch.full_like(step, -1), step)
-                trew = torch.where(over, torch.zeros_like(trew), trew)
-                active = active & (self.trial < first + trials)
-                restart = over & active
-                if bool(restart.any().item()):
-                    interface.reset(restart)
-                    nxt = interface.observe().to(self.dtype).clone()
-                if not bool(active.any().item()):
-                    break
-            step = step + active.to(torch.int32)
+            idx = torch.where(over, self.trial.to(torch.int64), zero64).clamp_(0, cap - 1)
+            ok = over & (self.trial < cap)
+            self.monitors.lat_sum.index_add_(0, idx, torch.where(ok, step.to(torch.int64), zero64))
+            self.monitors.lat_cnt.index_add_(0, idx, ok.to(torch.int64))
+            self.monitors.reward_sum.index_add_(0, idx, torch.where(ok, trew, torch.zeros_like(trew)))
+            self.trial += over.to(torch.int32)
+            trew = torch.where(over, torch.zeros_like(trew), trew)
+            active = active & (self.trial < first + trials)
+            restart = over & active
+            interface.reset(restart)
+            nxt = torch.where(restart[:, None], interface.observe().to(self.dtype), nxt)
+            step = torch.where(over, torch.zeros_like(step), step + active.to(torch.int32))
             obs = nxt
             iters += 1
             if budget and iters >= budget:
                 break
+            if not budget:   # train(): one look at the device per step keeps idle instances frozen
+                left = int(active.sum().item())      # exactly; the fixed-budget (bench) mode never
+                if left == 0:                        # has idle instances and never synchronises
+                    break
+                all_active = left == n
         self.current_trial = first + trials
         if self.callbacks.has('on_trial_end'):
             lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()

@@ -198,36 +198,87 @@ class StackedTorchNetwork:
 
     def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, active=None) -> None:
         """Per instance: mean over the per-sample losses, summed over instances so that every
-        instance receives exactly the gradient it would compute alone.  ``active`` [n] masks
-        instances that must not learn this step (their gradient is exactly zero; stateful
-        optimizers still see the step, so callers that need bit-identical resumption keep all
-        instances active)."""
+        instance receives exactly the gradient it would compute alone.  ``active`` ([n] bool)
+        freezes the other instances completely — parameters AND optimizer state — as if their
+        own single-instance run had simply not executed this step (Adam / AdamW-free path;
+        other optimizers only get their parameters restored)."""
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.criterion(self.forward(batch), targets)
-        per_instance = loss.reshape(self.n, -1).mean(dim=1)
-        if active is not None:
-            per_instance = per_instance * active
-        per_instance.sum().backward()
-        self.optimizer.step()
+        loss.reshape(self.n, -1).mean(dim=1).sum().backward()
+        if active is None and getattr(self, '_diverged', False):
+            # per-instance step counts exist: torch's optimizer (one shared count) no longer fits
+            active = torch.ones(self.n, dtype=torch.bool, device=self.device)
+        if active is None:
+            self.optimizer.step()
+        elif type(self.optimizer) is optim.Adam and not self.optimizer.defaults.get('amsgrad'):
+            self._adam_masked(active)
+        else:
+            keep = [p.detach().clone() for p in self.params.values()]
+            self.optimizer.step()
+            with torch.no_grad():
+                for p, old in zip(self.params.values(), keep):
+                    mask = active.view(self.n, *([1] * (p.dim() - 1)))
+                    p.copy_(torch.where(mask, p, old))
 
-    def blend_from(self, other: 'StackedTorchNetwork', tau: float) -> None:
-        """w += tau * (w_other - w) for every state entry (dqn.py:366-371), in place on device."""
-        with torch.no_grad():
-            for k, v in self.params.items():
-                v.lerp_(other.params[k], tau)
-            for k, v in self.buffers.items():
-                if v.is_floating_point():
-                    v.lerp_(other.buffers[k], tau)
+    @torch.no_grad()
+    def _adam_masked(self, active: torch.Tensor) -> None:
+        """torch.optim.Adam's update (same operation order) applied to the active instances only;
+        step counts are kept per instance so bias corrections match each instance's own history."""
+        self._diverged = True
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+        for p in self.params.values():
+            st = opt.state[p]
+            if 'exp_avg' not in st:
+                st['exp_avg'] = torch.zeros_like(p)
+                st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+            if 'steps' not in st:   # per-instance step counts (seeded from torch's scalar count)
+                st['steps'] = torch.full((self.n,), float(st['step']), dtype=torch.float64,
+                                         device=p.device)
+            shape = (self.n,) + (1,) * (p.dim() - 1)
+            mask = active.view(shape)
+            g = p.grad if wd == 0 else p.grad.add(p, alpha=wd)
+            st['steps'] += active.to(torch.float64)
+            t = st['steps'].clamp(min=1.0).view(shape)
+            m_new = st['exp_avg'].lerp(g, 1 - b1)
+            v_new = (st['exp_avg_sq'] * b2).addcmul_(g, g, value=1 - b2)
+            st['exp_avg'].copy_(torch.where(mask, m_new, st['exp_avg']))
+            st['exp_avg_sq'].copy_(torch.where(mask, v_new, st['exp_avg_sq']))
+            bc1 = 1 - b1 ** t
+            bc2_sqrt = (1 - b2 ** t).sqrt()
+            denom = (st['exp_avg_sq'].sqrt() / bc2_sqrt.to(p.dtype)).add_(eps)
+            upd = p - (lr / bc1).to(p.dtype) * (st['exp_avg'] / denom)
+            p.copy_(torch.where(mask, upd, p))
+            st['step'] += 1   # keeps torch's own bookkeeping monotone (used only if all step)
 
-    def copy_from(self, other: 'StackedTorchNetwork') -> None:
+    def blend_from(self, other: 'StackedTorchNetwork', tau: float, active=None) -> None:
+        """w += tau * (w_other - w) for every state entry (dqn.py:366-371), in place on device;
+        instances outside ``active`` keep their weights."""
         with torch.no_grad():
-            for k, v in self.params.items():
-                v.copy_(other.params[k])
-            for k, v in self.buffers.items():
-                v.copy_(other.buffers[k])
+            for k, v in list(self.params.items()) + list(self.buffers.items()):
+                if not v.is_floating_point():
+                    continue
+                src = other.params[k] if k in other.params else other.buffers[k]
+                if active is None:
+                    v.lerp_(src, tau)
+                else:
+                    w = active.view(self.n, *([1] * (v.dim() - 1))).to(v.dtype) * tau
+                    v.lerp_(src, w)
+
+    def copy_from(self, other: 'StackedTorchNetwork', active=None) -> None:
+        with torch.no_grad():
+            for k, v in list(self.params.items()) + list(self.buffers.items()):
+                src = other.params[k] if k in other.params else other.buffers[k]
+                if active is None:
+                    v.copy_(src)
+                else:
+                    v.copy_(torch.where(active.view(self.n, *([1] * (v.dim() - 1))), src, v))
 
     def clone(self) -> 'StackedTorchNetwork':
         twin = copy.copy(self)
+        twin._diverged = False
         twin.params = {k: v.detach().clone().requires_grad_(True) for k, v in self.params.items()}
         twin.buffers = {k: v.clone() for k, v in self.buffers.items()}
         twin.criterion = copy.deepcopy(self.criterion)

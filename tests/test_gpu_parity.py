@@ -708,3 +708,160 @@ def test_sr_prefetch_variants_agree(torch_cuda):
     assert torch.equal(a._sr, b._sr) and torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
     assert torch.equal(a.inst, b.inst)
     assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
+
+
+# ---------------------------------------------------------------------------------------------
+# Edge cases: empty batches of instances, extreme batch sizes, one-step trials, zero trials,
+# large state spaces (LDS near its limit), replay-log overflow.
+def test_edge_empty_and_zero_work(torch_cuda):
+    torch = torch_cuda
+    import ctypes as C
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    lib = _lib.lib()
+    env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=3, seed=1)
+    # n = 0 is a no-op for every entry point
+    z32 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    _lib.check(lib.cobel_env_step(env.handle.ptr, _lib.ptr(z32), _lib.ptr(z32), None, None, 0, 0, None))
+    _lib.check(lib.cobel_env_reset(env.handle.ptr, _lib.ptr(z32), None, _lib.ptr(z32), 1, 0, 0, None))
+    run = _lib.TabRun()
+    run.q, run.inst, run.model = _lib.ptr(z32), _lib.ptr(z32), _lib.ptr(z32)
+    run.n, run.agent, run.steps_per_trial, run.epsilon = 0, 1, 5, 0.1
+    _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
+    # zero trials: nothing moves, nothing is drawn
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    before = env.state.clone()
+    agent.train(env, 0, 10, 8)
+    assert torch.equal(env.state, before) and agent.env_steps() == 0 and agent.current_trial == 0
+    assert float(agent.Q.abs().sum()) == 0.0
+    # bad arguments are refused before any launch
+    run.n, run.steps_per_trial = 3, 0
+    with pytest.raises(IndexError):
+        _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
+    run.steps_per_trial, run.batch = 5, 63
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
+    with pytest.raises(IndexError):   # next state out of range
+        bad = make_open_field(3, 3, 0, 1)
+        bad['next'] = bad['next'].copy()
+        bad['next'][4, 2] = 9
+        Gridworld(bad)
+
+
+@pytest.mark.parametrize('batch,steps', [(1, 1), (62, 7), (33, 200)])
+def test_edge_batch_sizes_and_one_step_trials(torch_cuda, golden_worlds, batch, steps):
+    """Planning batches of 1 and of the maximum 62, trials of a single step (every step ends a
+    trial), against the C oracle."""
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    world = as_world(golden_worlds('walls_8x8'))
+    n, trials = 70, 9
+    env = Gridworld(world, n_envs=n, seed=555)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.25))
+    agent.track_instances = True
+    agent.train(env, trials, steps, batch)
+    o = c_oracle.TabOracle(_oracle_world([world]), n, c_oracle.AG_DYNAQ, 555, True, epsilon=0.25,
+                           trial_cap=trials)
+    o.run(trials, steps, batch)
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(agent.monitors.lat_trace.cpu().numpy(), o.lat_trace)
+    assert np.array_equal(agent.M.states, o.MS)
+
+
+def test_edge_large_state_space(torch_cuda):
+    """64x64 = 4096 states: Q alone is 64 KiB of LDS per instance (dynamic LDS above the 64 KiB
+    default), model digest in HBM or in LDS (96 KiB)."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    world = make_obstacle_maze(64, 64, 7, density=0.15)
+    n = 20
+
+    def run(extra):
+        env = Gridworld(world, n_envs=n, seed=4096)
+        ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | extra | ag._policy_in(ag.policy, env, False)
+        ag.monitors.reserve(8, n, True)
+        ag._launch(env, ag.policy, flags, 0x7fffffff, 300, 400, 50)
+        torch.cuda.synchronize()
+        return ag
+
+    a, b = run(0), run(_lib.F_FORCE_LDS_MODEL)
+    assert torch.equal(a._q, b._q) and torch.equal(a.M.table, b.M.table)
+    o = c_oracle.TabOracle(_oracle_world([world]), n, c_oracle.AG_DYNAQ, 4096, True, trial_cap=8)
+    o.run(0x7fffffff, 300, 50, step_budget=400)
+    assert np.array_equal(a._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(a.M.states, o.MS)
+
+
+def test_edge_replay_log_overflow(torch_cuda, golden_worlds):
+    """QAgent whose experience log is smaller than the run: logging stops at capacity, replay keeps
+    sampling the truncated log (oracle has the same rule)."""
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    world = as_world(golden_worlds('walls_8x8'))
+    n = 40
+    env = Gridworld(world, n_envs=n, seed=808)
+    agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.3))
+    agent._bind(env)
+    agent.reserve_replay(37)
+    agent._session(env, 5, 20, 10, True)
+    o = c_oracle.TabOracle(_oracle_world([world]), n, c_oracle.AG_Q, 808, True, alpha=0.9, gamma=0.8,
+                           epsilon=0.3, trial_cap=5, log_cap=37)
+    o.run(5, 20, 10)
+    assert int(agent.inst[:, 6].max().item()) == 37
+    assert np.array_equal(agent.inst[:, 6].cpu().numpy(), o.inst['log_len'].astype(np.int32))
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+
+
+def test_dqn_idle_instances_are_frozen(torch_cuda, golden):
+    """Instances finish their trials at different times (short track, trials end early); an
+    instance that is done must stay exactly as its own single-instance run left it — weights,
+    optimizer history, replay ring, stream counters — while the others keep training."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(4, 1, 1., 1., 'right')
+
+    def run(n, base):
+        env = Topology(nodes, starts, n_envs=n, seed=777, instance_base=base)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.5),
+                 TorchNetwork(_mlp(torch, init)), gamma=0.8)
+        ag.train(env, 4, 30, 16)
+        ag.train(env, 2, 30, 16)        # a second call continues every instance's own history
+        return ag, env
+
+    vec, venv = run(6, 0)
+    sizes = vec.M.size.cpu().numpy()
+    assert len(set(sizes.tolist())) > 1, 'the scenario needs instances of different length'
+    for i in (0, 3, 5):
+        one, oenv = run(1, i)
+        k = int(one.M.size[0])
+        assert int(sizes[i]) == k
+        assert torch.equal(vec.M.actions[i, :k], one.M.actions[0, :k])
+        assert torch.equal(vec.M.next_states[i, :k], one.M.next_states[0, :k])
+        assert int(vec.policy.counter[i]) == int(one.policy.counter[0])
+        assert int(vec.M.counter[i]) == int(one.M.counter[0])
+        assert int(venv.env_ctr[i]) == int(oenv.env_ctr[0])
+        for a, b in zip(vec._online.get_weights(i), one._online.get_weights(0)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), np.abs(a - b).max()
+        for a, b in zip(vec._target.get_weights(i), one._target.get_weights(0)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), np.abs(a - b).max()
