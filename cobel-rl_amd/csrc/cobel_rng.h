@@ -53,7 +53,10 @@ COBEL_HD cobel_u4 cobel_philox(uint32_t index, uint32_t sub, uint32_t instance, 
 }
 
 COBEL_HD uint32_t cobel_word(const cobel_u4& b, uint32_t k) {
-  return k == 0u ? b.x : (k == 1u ? b.y : (k == 2u ? b.z : b.w));
+  // two-level select (no comparisons against constants: with a wave-uniform k the compiler
+  // otherwise builds a chain of scalar branches)
+  const uint32_t lo = (k & 1u) ? b.y : b.x, hi = (k & 1u) ? b.w : b.z;
+  return (k & 2u) ? hi : lo;
 }
 
 // k in [0, n): Lemire multiply-shift without rejection (bias <= n / 2^32).

@@ -465,12 +465,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         fresh_idx = sa;
         fresh_r = Rn;
         fresh_m = (uint32_t)ns | (nt << 14) | (rbits ? 0x8000u : 0u);
-        if (lane == 0) {
-          model[sa] = cobel_model_pack(Rn, (uint32_t)ns, nt);
-          if (MIDX) Mg[sa] = (uint16_t)fresh_m;
-          else L.M16[sa] = (uint16_t)fresh_m;
-          if (!MIDX && A.r.model_index) A.r.model_index[(size_t)i * SA + sa] = (uint16_t)fresh_m;
-        }
         // (if ns == state the entries prefetched for the next step predate this store; they are
         //  patched when they are consumed, not here — touching them now would wait for the load)
         m4_fix = (MIDX && ns == state) ? a : -1;
@@ -479,8 +473,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         if (loglen < (uint32_t)A.r.log_cap) {
           fresh_rec = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
           fresh_idx = loglen;
-          if (lane == 0) rlog[loglen] = fresh_rec;
-          loglen += 1u;
         }
       }
       // online TD (agent/dyna_q.py:290-299), float32; Q[ns] and Q[s][a] were read above
@@ -489,7 +481,18 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       float td = r + gnt * ns_max;
       td = td - q;
       const float qn = q + alpha_f * td;
-      if (lane == 0) Qf[sa] = qn;
+      if (lane == 0) {   // all of this step's stores in one predicated block
+        Qf[sa] = qn;
+        if (AGENT == COBEL_AGENT_DYNAQ) {
+          model[sa] = cobel_model_pack(fresh_r, (uint32_t)ns, nt);
+          if (MIDX) Mg[sa] = (uint16_t)fresh_m;
+          else L.M16[sa] = (uint16_t)fresh_m;
+          if (!MIDX && A.r.model_index) A.r.model_index[(size_t)i * SA + sa] = (uint16_t)fresh_m;
+        } else if (rlog && fresh_idx != ~0u) {
+          rlog[fresh_idx] = fresh_rec;
+        }
+      }
+      if (AGENT == COBEL_AGENT_Q && rlog && fresh_idx != ~0u) loglen += 1u;
       td_online = td;
       __builtin_amdgcn_wave_barrier();
     }
@@ -515,12 +518,14 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (replay_each_step) {
       if (AGENT == COBEL_AGENT_DYNAQ && MIDX) {
         // next step's batch: draw, start the gather; then run this step's batch
-        const uint32_t idx_next = lane < B ? cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA) : 0u;
-        uint32_t mg_next = lane < B ? (uint32_t)Mg[idx_next] : 0u;
+        uint32_t idx_next = 0u, mg_next = 0u;
         const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
         float r = 0.0f;
-        if (lane < B) {
-          if (m & 0x8000u) r = __builtin_bit_cast(float, model32[2u * idx_cur]);
+        if (lane < B) {   // one predicated block for everything the replay lanes do here
+          idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
+          mg_next = (uint32_t)Mg[idx_next];
+          if (__builtin_expect((m & 0x8000u) != 0u, 0))
+            r = __builtin_bit_cast(float, model32[2u * idx_cur]);
           if (idx_cur == fresh_idx) r = fresh_r;
         }
         run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r);
