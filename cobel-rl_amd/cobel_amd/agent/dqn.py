@@ -54,6 +54,9 @@ class DQN(Agent):
             self.dtype = next(iter(self._online.params.values())).dtype
             self.monitors = DeviceMonitors(self.device, 1, 1, False)
             self.trial = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        self._bind_memory(interface, slots)
+
+    def _bind_memory(self, interface, slots: int) -> None:
         obs = interface.observe()
         self.M._bind(self.n_envs, obs.shape[1:], self.dtype, self.device, slots, interface.seed,
                      interface.instance_base)
@@ -158,7 +161,8 @@ class DQN(Agent):
             reward, done = interface._reward, interface._done.bool()
             if learn:
                 self.M.store_batch(obs, action, reward, nxt, (~done), None if all_active else active)
-                self.replay(batch_size, None if all_active else active)
+                if not getattr(self, '_no_replay', False):
+                    self.replay(batch_size, None if all_active else active)
             trew += torch.where(active, reward.to(torch.float64), torch.zeros_like(trew))
             # trial ends, entirely masked (no host round trip per step)
             over = active & (done | (step + 1 >= steps))

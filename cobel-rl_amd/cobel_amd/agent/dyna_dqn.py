@@ -1,0 +1,159 @@
+"""Dyna-DQN — ``cobel.agent.dyna_q.DynaDQN`` (agent/dyna_q.py:333-708) on PyTorch-ROCm.
+
+The agent of ``cobel_amd.agent.DQN`` with the replay memory replaced by the tabular world model of
+Dyna-Q: every step stores ``(s, a) -> (reward estimate, s', nonterminal)`` in the model
+(``DynaQMemory.store``, memory/dyna_q.py:92-96, float64 as in the reference) and the replay batch
+is ``batch_size`` pairs drawn uniformly from ALL ``S x A`` pairs (``retrieve_batch``, :137-155 —
+never-visited pairs are self-loops with reward 0), mapped to network inputs through
+``observations[state]`` (one-hot by default, dyna_q.py:472-476).
+
+Vectorised like ``DQN``: ``n_envs`` independent agent–model–network triples in lockstep, every
+tensor on the GPU; action selection and pair sampling use the library's streams
+(``cobel_eps_greedy_f64`` / ``cobel_rng_uniform`` / ``cobel_rng_bounded``).  Needs an environment
+with integer states (``Gridworld``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..spaces import Discrete
+from .dqn import DQN
+
+
+class _ModelMemory:
+    """Device tables of DynaQMemory for N instances, float64 rewards (reference dtype)."""
+
+    def __init__(self, states: int, actions: int, learning_rate: float = 0.9) -> None:
+        self.S, self.A, self.learning_rate = states, actions, learning_rate
+        self.n = None
+
+    def bind(self, n: int, device, seed: int, base: int) -> None:
+        if self.n is not None:
+            return
+        self.n, self.device, self.seed, self.base = n, device, seed, base
+        S, A = self.S, self.A
+        self.rewards = torch.zeros((n, S * A), dtype=torch.float64, device=device)
+        self.states = torch.arange(S, device=device).repeat_interleave(A)[None].repeat(n, 1)
+        self.terminals = torch.zeros((n, S * A), dtype=torch.float64, device=device)
+        self.counter = torch.zeros(n, dtype=torch.int32, device=device)
+        self._rows = torch.arange(n, device=device)
+
+    def store(self, s, a, r, ns, nt, active=None) -> None:
+        rows = self._rows if active is None else self._rows[active]
+        sel = (lambda x: x) if active is None else (lambda x: x[active])
+        idx = sel(s).to(torch.int64) * self.A + sel(a).to(torch.int64)
+        old = self.rewards[rows, idx]
+        self.rewards[rows, idx] = old + self.learning_rate * (sel(r).to(torch.float64) - old)
+        self.states[rows, idx] = sel(ns).to(torch.int64)
+        self.terminals[rows, idx] = sel(nt).to(torch.float64)
+
+    def store_batch(self, obs, action, reward, nxt, nonterminal, active=None) -> None:
+        """DQN._run's storage hook: the model is indexed by the integer states, which the
+        environment view records around each step."""
+        self.store(self.view.prev_state, action, reward, self.view.env.state, nonterminal, active)
+
+    def sample(self, batch: int, active=None):
+        idx = torch.empty((self.n, batch), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().cobel_rng_bounded(
+            _lib.ptr(self.counter), self.seed, _lib.STREAM_MEMORY, self.base, self.S * self.A,
+            _lib.ptr(idx), self.n, batch, 1, _lib.current_stream(self.device)))
+        if active is not None:
+            self.counter -= (~active).to(torch.int32)
+        idx = idx.to(torch.int64)
+        rows = self._rows[:, None]
+        return (idx // self.A, idx % self.A, self.rewards[rows, idx], self.states[rows, idx],
+                self.terminals[rows, idx])
+
+
+class DynaDQN(DQN):
+    def __init__(self, observation_space, action_space, policy, model, observations=None,
+                 policy_test=None, gamma: float = 0.99, memory=None,
+                 custom_callbacks=None) -> None:
+        assert type(observation_space) is Discrete, 'DynaDQN requires a discrete observation space!'
+        assert type(action_space) is Discrete, 'DynaDQN requires a discrete action space!'
+        super().__init__(observation_space, action_space, policy, model, gamma, None, policy_test,
+                         custom_callbacks)
+        n_states = int(observation_space.n)
+        self.observations = np.eye(n_states) if observations is None else np.asarray(observations)
+        lr = 0.9 if memory is None else memory.learning_rate
+        self.M = _ModelMemory(n_states, int(action_space.n), lr)
+        self.action_mask = np.ones((n_states, int(action_space.n)), dtype=bool)
+        self.mask_actions = False
+        self.episodic_replay = False
+        self._no_replay = False
+
+    # DQN._run talks to the environment through observe(); wrap integer states as table rows
+    class _ObsView:
+        def __init__(self, env, table):
+            self.env, self.table = env, table
+            self.n_envs, self.device, self.seed = env.n_envs, env.device, env.seed
+            self.instance_base = env.instance_base
+
+        def observe(self):
+            return self.table[self.env.state.to(torch.int64)]
+
+        def step(self, action):
+            self.prev_state = self.env.state.clone()
+            return self.env.step(action)
+
+        def reset(self, mask=None):
+            return self.env.reset(mask)
+
+        @property
+        def _reward(self):
+            return self.env._reward
+
+        @property
+        def _done(self):
+            return self.env._done
+
+    def _bind_memory(self, interface, slots: int) -> None:
+        self.M.bind(self.n_envs, self.device, interface.seed, interface.instance_base)
+
+    def _view(self, interface):
+        table = torch.as_tensor(self.observations, device=interface.device)
+        view = DynaDQN._ObsView(interface, table)
+        self.M.view = view
+        return view
+
+    def replay(self, batch_size: int = 32, active=None):
+        s, a, r, ns, nt = self.M.sample(batch_size, active)
+        table = self._table.to(self.dtype)
+        states, next_states = table[s], table[ns]
+        with torch.no_grad():
+            targets = self._online.forward(states).clone()
+            boot = self._target.forward(next_states)
+            pick = (self._online.forward(next_states) if self.DDQN else boot).argmax(dim=2)
+            boot = torch.gather(boot, 2, pick[..., None])[..., 0]
+            new = r.to(self.dtype) + boot * nt.to(self.dtype) * self.gamma
+            targets.scatter_(2, a[..., None], new[..., None])
+        self._online.train_on_device(states, targets, active)
+        self.last_update += 1
+        if self.target_update < 1.0:
+            self._target.blend_from(self._online, self.target_update, active)
+        elif self.last_update == self.target_update:
+            self._target.copy_from(self._online, active)
+            self.last_update = 0
+
+    def _run(self, interface, trials, steps, batch_size, learn, budget: int = 0) -> None:
+        view = self._view(interface)
+        self._table = view.table
+        self._env = interface
+        super()._run(view, trials, steps, batch_size, learn, budget)
+
+    def train(self, interface, trials: int, steps: int = 32, batch_size: int = 32,
+              no_replay: bool = False) -> None:
+        assert not self.mask_actions and not self.episodic_replay, \
+            'action masks / episodic replay are not part of the accelerated DynaDQN path'
+        self._no_replay = no_replay
+        self._run(interface, trials, steps, batch_size, True)
+
+    def retrieve_q(self, state):
+        if self._online is None:
+            return self.model_online.predict_on_batch(np.array([self.observations[state]]))[0]
+        return super().retrieve_q(self.observations[int(state)])
+
+    def predict_on_batch(self, batch):
+        return super().predict_on_batch(self.observations[np.array(batch).astype(int)])

@@ -542,8 +542,53 @@ def gen_dqn():
     np.savez_compressed(os.path.join(HERE, 'dqn_trace.npz'), **out)
 
 
+def gen_dyna_dqn():
+    """agent/dyna_q.py:333-708 (DynaDQN) on a 4x4 open field: one-hot observations, float64
+    16-32-4 MLP, draw-injected streams."""
+    import torch
+    from collections import OrderedDict
+    from cobel.agent.dyna_q import DynaDQN
+    from cobel.network import TorchNetwork
+    out = {}
+    for name, inst, trials, steps, B in (('ddqn_i0', 0, 3, 20, 16), ('ddqn_i1', 1, 2, 25, 8)):
+        torch.manual_seed(99 + inst)
+        net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(32, 4))])).double()
+        model = TorchNetwork(net)
+        init = model.get_weights()
+        world = gt.make_open_field(4, 4, 0, 1)
+        env = Gridworld(world, rng=TapeRNG(SEED, inst, STREAM_ENV))
+        pol = EpsilonGreedy(0.2, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        agent = DynaDQN(env.observation_space, env.action_space, pol, model, gamma=0.9)
+        agent.M.rng = TapeRNG(SEED, inst, STREAM_MEMORY)
+        tr = Tracer(None)
+        agent.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            agent.callbacks.custom_callbacks.setdefault(k, [])
+        tr.on_step_end = None
+        torch.set_num_threads(1)
+        agent.train(env, trials, steps, B)
+        d = tr.pack()
+        for i, w in enumerate(init):
+            out['%s/init_%d' % (name, i)] = w
+        for i, w in enumerate(agent.model_online.get_weights()):
+            out['%s/online_%d' % (name, i)] = w
+        for i, w in enumerate(agent.model_target.get_weights()):
+            out['%s/target_%d' % (name, i)] = w
+        out[name + '/state'], out[name + '/action'] = d['state'], d['action']
+        out[name + '/steps'] = d['steps']
+        out[name + '/M_rewards'] = agent.M.rewards
+        out[name + '/M_states'] = agent.M.states
+        out[name + '/M_terminals'] = agent.M.terminals
+        out[name + '/q_all'] = agent.predict_on_batch(np.arange(16))
+        out[name + '/cfg'] = np.array([inst, trials, steps, B])
+    np.savez_compressed(os.path.join(HERE, 'dyna_dqn_trace.npz'), **out)
+
+
 def main():
     worlds = gen_worlds()
+    gen_dyna_dqn()
     gen_dqn()
     gen_topology()
     gen_gridworld_kat()

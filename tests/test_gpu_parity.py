@@ -865,3 +865,41 @@ def test_dqn_idle_instances_are_frozen(torch_cuda, golden):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12), np.abs(a - b).max()
         for a, b in zip(vec._target.get_weights(i), one._target.get_weights(0)):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize('name', ['ddqn_i0', 'ddqn_i1'])
+def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
+    """DynaDQN (DQN fed by the tabular Dyna-Q model) on a 4x4 open field, float64, against the
+    reference with the same initial weights and injected draws: identical state / action
+    sequence and model tables; networks within 1e-9."""
+    torch = torch_cuda
+    from collections import OrderedDict
+    from cobel_amd.agent import DynaDQN
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dyna_dqn_trace')
+    inst, trials, steps, B = [int(x) for x in D[name + '/cfg']]
+    net = torch.nn.Sequential(OrderedDict([
+        ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
+        ('output', torch.nn.Linear(32, 4))])).double()
+    state = net.state_dict()
+    for i, key in enumerate(state):
+        state[key] = torch.as_tensor(D['%s/init_%d' % (name, i)])
+    net.load_state_dict(state)
+    env = Gridworld(make_open_field(4, 4, 0, 1), n_envs=3, seed=SEED, instance_base=inst)
+    agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.2), TorchNetwork(net),
+                    gamma=0.9)
+    agent.train(env, trials, steps, B)
+    m = agent.M
+    assert np.array_equal(m.states[0].cpu().numpy().reshape(16, 4), D[name + '/M_states'])
+    assert np.array_equal(m.terminals[0].cpu().numpy().reshape(16, 4), D[name + '/M_terminals'])
+    assert np.array_equal(m.rewards[0].cpu().numpy().reshape(16, 4), D[name + '/M_rewards'])
+    for i, w in enumerate(agent._online.get_weights(0)):
+        assert np.allclose(w, D['%s/online_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
+    for i, w in enumerate(agent._target.get_weights(0)):
+        assert np.allclose(w, D['%s/target_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
+    q = agent._online.predict_on_device(
+        torch.eye(16, dtype=torch.float64, device='cuda')[None].expand(3, 16, 16).contiguous())
+    assert np.allclose(q[0].cpu().numpy(), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
