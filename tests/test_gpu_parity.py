@@ -903,3 +903,68 @@ def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     q = agent._online.predict_on_device(
         torch.eye(16, dtype=torch.float64, device='cuda')[None].expand(3, 16, 16).contiguous())
     assert np.allclose(q[0].cpu().numpy(), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: a scattered sample of instances against the oracle plus
+# size-independent properties (conservation of steps / trials / visits) over all instances.
+def _sample_vs_oracle(agent, env, cfg, agent_kind, ids, launches, budget, **okw):
+    from oracle import c_oracle
+    w = _oracle_world(env.worlds)
+    q = agent._q[ids].cpu().numpy().astype(np.float64)
+    inst = agent.inst[ids].cpu().numpy()
+    for k, g in enumerate(ids):
+        o = c_oracle.TabOracle(w, 1, agent_kind, env.seed, True, instance_base=int(g), **okw)
+        for _ in range(launches):
+            o.run(0x7fffffff, cfg['steps_per_trial'], cfg['batch'], step_budget=budget)
+        assert np.array_equal(q[k], o.Q[0]), g
+        assert inst[k, 0] == o.inst['state'][0] and inst[k, 2] == o.inst['trial'][0], g
+        assert inst[k, 3] == int(o.inst['ctr_env'][0]) and inst[k, 4] == int(o.inst['ctr_policy'][0])
+
+
+def test_full_size_c3_sample_and_conservation(torch_cuda):
+    """C3 at 65 536 instances x 64 mazes, Dyna-Q with 50 planning updates per step: 192 instances
+    spread over the whole range bit-exact against the oracle; every instance executed exactly
+    the budgeted steps; trial / visit totals are conserved."""
+    from oracle import c_oracle
+    n, launches, budget = 65536, 2, 48
+    cfg, env, agent = _bench_like(torch_cuda, 'C3', n, launches, budget)
+    ids = np.unique(np.concatenate([np.arange(0, n, 911), [1, 63, 64, n - 1]]))[:192]
+    _sample_vs_oracle(agent, env, cfg, c_oracle.AG_DYNAQ, ids, launches, budget)
+    inst = agent.inst.cpu().numpy()
+    steps = inst[:, 10].astype(np.int64)
+    assert (steps == launches * budget).all() and agent.env_steps() == n * launches * budget
+    mon = agent.monitors
+    assert int(mon.lat_cnt.sum().item()) == int(inst[:, 2].astype(np.int64).sum())
+    assert int(mon.occupancy.sum().item()) == n * launches * budget
+    # steps of finished trials + steps of the running trials == all steps
+    finished = int(mon.lat_sum.sum().item()) + int(mon.lat_cnt.sum().item())
+    running = int((inst[:, 1].astype(np.int64) * (inst[:, 7] & 1)).sum())
+    assert finished + running == n * launches * budget
+
+
+def test_full_size_c2_sample_and_conservation(torch_cuda):
+    """C2 at 65 536 x 5x5 (lane-per-instance kernel): 1 024 instances bit-exact against the oracle,
+    conservation of steps and trials over all of them."""
+    torch = torch_cuda
+    import bench
+    from oracle import c_oracle
+    n, launches, budget = 65536, 2, 200
+    cfg = dict(bench.CONFIGS['C2'], instances=n, env_steps_per_launch=budget)
+    env, agent = bench.build_agent('C2', cfg, n, 0, torch.device('cuda', 0))
+    runner = bench.Runner(cfg, env, agent)
+    for _ in range(launches):
+        runner.launch()
+    torch.cuda.synchronize()
+    ids = np.arange(0, n, 64)[:1024] + (np.arange(1024) % 64)
+    o = c_oracle.TabOracle(_oracle_world(env.worlds), n, c_oracle.AG_Q, env.seed, True, alpha=0.9,
+                           gamma=0.8, trial_cap=4096)
+    for _ in range(launches):
+        o.run(0x7fffffff, cfg['steps_per_trial'], 0, step_budget=budget)
+    assert np.array_equal(agent._q[ids].cpu().numpy().astype(np.float64), o.Q[ids])
+    inst = agent.inst.cpu().numpy()
+    assert np.array_equal(inst[:, 0], o.inst['state']) and np.array_equal(inst[:, 2], o.inst['trial'])
+    mon = agent.monitors
+    assert np.array_equal(mon.lat_sum.cpu().numpy(), o.lat_sum.astype(np.int64))
+    assert np.array_equal(mon.lat_cnt.cpu().numpy(), o.lat_cnt.astype(np.int64))
+    assert agent.env_steps() == n * launches * budget == int(inst[:, 10].astype(np.int64).sum())
