@@ -209,3 +209,130 @@ def load_world(path: str) -> World:
                      else np.argmax(raw['sas'], axis=2).astype(np.uint16))
     world.setdefault('deterministic', True)
     return world
+
+
+def make_double_t_maze(stem_length: int, arm_length: int,
+                       goal_arm: Literal['left-left', 'left-right', 'right-left',
+                                         'right-right'] = 'right-right',
+                       reward: float = 1) -> World:
+    """Double T-maze (gridworld_tools.py:301-432): a main stem leads up to a cross arm whose two
+    ends carry a small T each; the four arm ends of the small Ts are the candidate goals."""
+    assert stem_length > 0 and arm_length > 0, 'Stem and arm length must be greater than zero!'
+    a = arm_length
+    height, width = stem_length * 2 + 2, a * 4 + 3
+    goal = {'left-left': 0, 'left-right': a * 2, 'right-left': a * 2 + 2,
+            'right-right': a * 4 + 2}[goal_arm]
+    inside = np.zeros((height, width), dtype=bool)
+    inside[0, :2 * a + 1] = True                    # arms of the left small T
+    inside[0, 2 * a + 2:] = True                    # arms of the right small T
+    inside[1:stem_length + 1, a] = True             # stems of the small Ts
+    inside[1:stem_length + 1, 3 * a + 2] = True
+    inside[stem_length + 1, a:3 * a + 3] = True     # cross arm
+    inside[stem_length + 1:, 2 * a + 1] = True      # main stem
+    return corridor_gridworld(height, width, inside, [goal], np.array([[goal, reward]]), [goal],
+                              [height * width - a * 2 - 2])
+
+
+def make_8_maze(center_height: int, lap_width: int,
+                goal_location: Literal['left', 'right'] = 'right', reward: float = 1) -> World:
+    """Figure-8 maze (gridworld_tools.py:669-735): two laps sharing the centre corridor; the goal
+    sits halfway down the outer side of one lap, the agent starts right of the centre on top."""
+    assert center_height > 0 and lap_width > 0, \
+        'Center height and lap width must be greater than zero!'
+    height, width = center_height + 2, lap_width * 2 + 3
+    goal = int((center_height + 2) / 2) * width + (width - 1 if goal_location == 'right' else 0)
+    inside = np.zeros((height, width), dtype=bool)
+    inside[[0, height - 1], :] = True
+    inside[:, [0, lap_width + 1, width - 1]] = True
+    return corridor_gridworld(height, width, inside, [goal], np.array([[goal, reward]]), [goal],
+                              [lap_width + 2])
+
+
+def make_cross_maze(arm_length: int, arm_width: int,
+                    goal_arm: Literal['left', 'top', 'right', 'bottom'] = 'top',
+                    reward: float = 1.0) -> World:
+    """Cross maze (gridworld_tools.py:898-974): four arms of width ``arm_width`` around a square
+    centre; every cell at the end of the goal arm is a rewarded terminal, the agent starts
+    anywhere in the centre.  As in the reference (:963) the goal cells pay 1 whatever ``reward``
+    says."""
+    assert arm_length > 0 and arm_width > 0
+    assert goal_arm in ('left', 'top', 'right', 'bottom'), 'Invalid goal arm!'
+    size = arm_length * 2 + arm_width
+    band = np.arange(size)
+    mid = (band >= arm_length) & (band < arm_length + arm_width)
+    inside = mid[:, None] | mid[None, :]
+    k = np.arange(arm_width)
+    terminals = {'top': k + arm_length, 'left': k * size + arm_length * size,
+                 'right': k * size + arm_length * size + (size - 1),
+                 'bottom': k + arm_length + size * (size - 1)}[goal_arm].tolist()
+    rewards = np.stack([np.array(terminals, dtype=float), np.ones(arm_width)], 1)
+    starts = [arm_length * size + arm_length + i * size + j for i in range(arm_width)
+              for j in range(arm_width)]
+    return corridor_gridworld(size, size, inside, terminals, rewards, terminals, starts)
+
+
+def make_two_sided_t_maze(stem_length: int, arm_length: int,
+                          goal_arm: Literal['left-left', 'left-right', 'right-left',
+                                            'right-right'] = 'right-right',
+                          reward: float = 1) -> World:
+    """Two-sided T-maze (gridworld_tools.py:435-506): a horizontal stem with a vertical arm pair
+    at either end (an "H" lying on its side); the agent starts in the middle of the stem."""
+    assert stem_length > 0 and arm_length > 0, 'Stem and arm length must be greater than zero!'
+    height, width = arm_length * 2 + 1, stem_length + 2
+    goal = {'left-right': 0, 'right-left': width - 1, 'left-left': width * (height - 1),
+            'right-right': width * height - 1}.get(goal_arm, 0)
+    inside = np.zeros((height, width), dtype=bool)
+    inside[:, [0, width - 1]] = True
+    inside[arm_length, :] = True
+    return corridor_gridworld(height, width, inside, [goal], np.array([[goal, reward]]), [goal],
+                              [arm_length * width + int(stem_length / 2)])
+
+
+def make_two_choice_t_maze(center_height: int, lap_width: int, arm_length: int,
+                           chirality: Literal['left', 'right'] = 'right',
+                           goal_location: Literal['left', 'right'] = 'right',
+                           reward: float = 1) -> World:
+    """Two-choice T-maze (gridworld_tools.py:509-666): a figure-8 frame whose centre corridor
+    stops halfway down at the bar of an inner T shifted to one side (``chirality``); the T's stem
+    continues to the bottom corridor.  As in the reference (:554) the goal pays 1 whatever
+    ``reward`` says, and the start column does not depend on the chirality (:551)."""
+    assert arm_length > 0, '!'
+    assert center_height > 2, '!'
+    assert lap_width >= arm_length * 2 + 1, '!'
+    assert chirality in ['left', 'right'], 'Invalid chirality!'
+    height, width = center_height + 2, lap_width * 2 + 3
+    goal = int(height / 2) * width + (width - 1 if goal_location == 'right' else 0)
+    bar_row, centre = int((center_height - 1) / 2) + 1, lap_width + 1
+    side = 1 if chirality == 'right' else -1
+    inside = np.zeros((height, width), dtype=bool)
+    inside[[0, height - 1], :] = True
+    inside[:, [0, width - 1]] = True
+    inside[:bar_row + 1, centre] = True
+    lo, hi = sorted((centre, centre + side * 2 * arm_length))
+    inside[bar_row, lo:hi + 1] = True
+    inside[bar_row:, centre + side * arm_length] = True
+    return corridor_gridworld(height, width, inside, [goal], np.array([[goal, 1.0]]), [goal],
+                              [width * (height - 1) + lap_width + arm_length])
+
+
+def make_detour_maze(width_small: int, height_small: int, width_large: int, height_large: int,
+                     reward: float = 1) -> World:
+    """Detour maze (gridworld_tools.py:738-895): a straight corridor from the start (bottom) to
+    the goal (top) with a small loop hanging off its lower left and a large loop off its upper
+    right, both joining it at the same crossing."""
+    assert width_small > 0 and height_small > 0, \
+        'Width and height of the small side piece must be greater than zero!'
+    assert width_large > width_small and height_large > height_small, \
+        'Width and height of the large side piece must be greater than those of the small side piece!'
+    width, height = width_small + width_large + 3, height_small + height_large + 5
+    spine, crossing = width_small + 1, height_large + 2
+    low = crossing + height_small + 1
+    inside = np.zeros((height, width), dtype=bool)
+    inside[:, spine] = True
+    inside[crossing, :] = True
+    inside[1, spine:] = True                        # large loop: out along row 1, down the right edge
+    inside[1:crossing + 1, width - 1] = True
+    inside[crossing:low + 1, 0] = True              # small loop: down the left edge, back along `low`
+    inside[low, :spine + 1] = True
+    return corridor_gridworld(height, width, inside, [spine], np.array([[spine, reward]]), [spine],
+                              [spine + width * (height - 1)])

@@ -162,6 +162,15 @@ def gen_worlds():
         'open_32x32': gt.make_open_field(32, 32, 0, 1),
         't_maze_3_2_right': gt.make_t_maze(3, 2, 'right', 1.0),
         't_maze_2_4_left': gt.make_t_maze(2, 4, 'left', 2.0),
+        'double_t_maze_3_2_lr': gt.make_double_t_maze(3, 2, 'left-right', 1.5),
+        'two_sided_t_maze_4_3_ll': gt.make_two_sided_t_maze(4, 3, 'left-left', 2.0),
+        'two_choice_t_maze_5_7_3_ll': gt.make_two_choice_t_maze(5, 7, 3, 'left', 'left'),
+        'two_choice_t_maze_4_5_2_rr': gt.make_two_choice_t_maze(4, 5, 2, 'right', 'right'),
+        '8_maze_3_2_right': gt.make_8_maze(3, 2, 'right', 1.0),
+        '8_maze_4_3_left': gt.make_8_maze(4, 3, 'left', 0.5),
+        'detour_maze_2_2_4_3': gt.make_detour_maze(2, 2, 4, 3, 1.0),
+        'cross_maze_2_2_left': gt.make_cross_maze(2, 2, 'left'),
+        'cross_maze_3_1_bottom': gt.make_cross_maze(3, 1, 'bottom', 4.0),
     }
     for seed in (1234, 1235):
         walls = maze_cells(seed)

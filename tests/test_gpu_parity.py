@@ -445,6 +445,52 @@ def test_qagent_replay_vs_oracle(torch_cuda, golden_worlds):
     assert len(agent.M) == int(o.inst['log_len'][0])
 
 
+MAZE_TEMPLATES = {
+    't_maze': lambda gt: gt.make_t_maze(3, 2, 'right', 1.0),
+    'double_t_maze': lambda gt: gt.make_double_t_maze(3, 2, 'left-right', 1.5),
+    'two_sided_t_maze': lambda gt: gt.make_two_sided_t_maze(4, 3, 'left-left', 2.0),
+    'two_choice_t_maze': lambda gt: gt.make_two_choice_t_maze(5, 7, 3, 'left', 'left'),
+    '8_maze': lambda gt: gt.make_8_maze(4, 3, 'left', 0.5),
+    'detour_maze': lambda gt: gt.make_detour_maze(2, 2, 4, 3, 1.0),
+    'cross_maze': lambda gt: gt.make_cross_maze(2, 2, 'left'),
+}
+
+
+@pytest.mark.parametrize('template', sorted(MAZE_TEMPLATES))
+def test_maze_templates_dynaq_and_sr_vs_oracle(torch_cuda, template):
+    """Dyna-Q (20 planning updates per step) and SR on every maze template of gridworld_tools
+    (the tables themselves are pinned to the reference in test_host_cpu), 192 instances each,
+    against the C oracle: Q / SR tables, world models and per-trial latencies."""
+    from cobel_amd.agent import SR, DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc import gridworld_tools as gt
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    world = MAZE_TEMPLATES[template](gt)
+    n = 192
+    env = Gridworld(world, n_envs=n, seed=2024)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.15))
+    agent.track_instances = True
+    agent.train(env, 12, 60, 20)
+    o = c_oracle.TabOracle(_oracle_world([world]), n, c_oracle.AG_DYNAQ, 2024, True,
+                           epsilon=0.15, trial_cap=12)
+    o.run(12, 60, 20)
+    assert np.array_equal(agent._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(agent.M.states, o.MS) and np.array_equal(agent.M.terminals, o.MT)
+    assert np.array_equal(agent.monitors.lat_trace.cpu().numpy(), o.lat_trace)
+    assert (o.lat_trace[:, -1] < 59).any()          # some instances do reach the goal
+
+    env = Gridworld(world, n_envs=n, seed=2025)
+    sr = SR(env.observation_space, env.action_space, EpsilonGreedy(0.15))
+    sr.track_instances = True
+    sr.train(env, 8, 60)
+    so = c_oracle.SROracle(_oracle_world([world]), n, 2025, True, epsilon=0.15, trial_cap=8)
+    so.run(8, 60)
+    assert np.array_equal(sr._sr.cpu().numpy().astype(np.float64), so.SR)
+    assert np.array_equal(sr._T.cpu().numpy().astype(np.int64), so.T)
+    assert np.array_equal(sr.monitors.lat_trace.cpu().numpy(), so.lat_trace)
+
+
 @pytest.mark.parametrize('n,worlds', [(4100, 1), (200, 3)])
 def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds):
     """Runs without planning take the lane-per-instance kernel (64 instances per wave): Q-learning
