@@ -40,6 +40,7 @@ struct tab_args {
   float alpha_f, gamma_f, model_lr_f;
   int32_t use_hash;  // LDS holds the replay dependency hash table
   int32_t hash_buckets;
+  int32_t hash_exact;  // S * 4 <= 4096: the two-table exact dependency lookup applies
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -259,6 +260,41 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 #if defined(COBEL_ABLATE) && COBEL_ABLATE == 3
     return;
 #endif
+    int dep = -1;  // latest earlier lane this lane must wait for
+    if (A.hash_exact) {
+      // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
+      // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
+      // that write into row ns are those in one of the four H1 buckets of (ns & 15) and in the
+      // H2 bucket of ns >> 4.  No false candidates, nothing to verify.
+      unsigned long long* const H1 = L.H;
+      unsigned long long* const H2 = L.H + 64;
+      const uint32_t h1 = idx & 63u, h2 = idx >> 6;
+      const unsigned long long bit = 1ull << lane;
+      if (on) {
+        atomicOr(&H1[h1], bit);
+        atomicOr(&H2[h2], bit);
+      }
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long cnd = 0ull;
+      if (on) {
+        const ulonglong2* const r4 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 15u) * 4u]);
+        const ulonglong2 ra = r4[0], rb = r4[1];
+        const unsigned long long cell = H1[h1] & H2[h2];
+        const unsigned long long row = ((ra.x | ra.y) | (rb.x | rb.y)) & H2[ns >> 4];
+        cnd = (cell | row) & (bit - 1ull);
+      }
+#if defined(COBEL_ABLATE) && COBEL_ABLATE == 1
+      cnd = 0ull;
+#endif
+      __builtin_amdgcn_wave_barrier();
+      if (on) {
+        H1[h1] = 0ull;
+        H2[h2] = 0ull;
+      }
+      STAMP(2);
+      if (cnd) dep = 63 - __clzll((long long)cnd);
+      STAMP(3);
+    } else {
     // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
     const uint32_t bs = sj & hmask, bn = ns & hmask;
     if (on) atomicOr(&L.H[bs], 1ull << lane);
@@ -270,7 +306,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     __builtin_amdgcn_wave_barrier();
     if (on) L.H[bs] = 0ull;
     STAMP(2);
-    int dep = -1;  // latest earlier lane this lane must wait for
     // verify candidates, latest first: a hit ends the lane's search
     while (__ballot(cnd != 0ull)) {
       const int e = cnd ? (63 - __clzll((long long)cnd)) : 0;
@@ -284,6 +319,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       }
     }
     STAMP(3);
+    }
     int first = 0;
     while (first < B) {
       const unsigned long long blocked = __ballot(on && dep >= first);
@@ -987,6 +1023,7 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
+  A.hash_exact = (world->n_states * 4 <= 4096 && !getenv("COBEL_DEBUG_NO_EXACT_HASH")) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
   if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   hipStream_t st = (hipStream_t)stream;

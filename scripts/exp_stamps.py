@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch, numpy as np
 from cobel_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'cobel-rl_amd', 'lib', 'libcobel_hip_stamps.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'cobel-rl_amd', 'lib', os.environ.get('COBEL_LIB', 'libcobel_hip_stamps.so'))
 import bench
 dev = torch.device('cuda', 0)
 for n, B in [(65536, 50)]:
