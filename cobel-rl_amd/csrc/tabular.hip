@@ -49,8 +49,13 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
 __device__ __forceinline__ uint32_t rfl(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+// max of a Q row in two instructions (fmaxf() costs two more: it first quiets each operand)
 __device__ __forceinline__ float max4(const float4 v) {
-  return fmaxf(fmaxf(fmaxf(v.x, v.y), v.z), v.w);
+  float m;
+  asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"
+      : "=&v"(m)
+      : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  return m;
 }
 __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
   const uint32_t w = (a & 2) ? w1 : w0;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   uint4 cand = {0, 0, 0, 0};   // !WLDS: lane k < 4 holds the world record of next[state][k]
   uint32_t mask_cur = 15u;
   // Cached Philox output: lanes < B hold memory block mb_idx (four consecutive batches), lanes 62
-  // and 63 hold policy blocks pb_idx and pb_idx + 1 (four consecutive action draws).
+  // and 63 hold policy blocks 2 pb_idx and 2 pb_idx + 1 (action draws 4 pb_idx .. 4 pb_idx + 3).
   cobel_u4 blk = {0, 0, 0, 0};
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
   uint2 m4 = {0u, 0u};         // MIDX: the four model entries of the current state
@@ -223,14 +228,19 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     return cobel_word(b, counter & 3u);
   };
   const bool cached_mem = AGENT == COBEL_AGENT_DYNAQ && B > 0;
-  auto refresh_draws = [&]() {   // one Philox evaluation refills both caches
-    const uint32_t pi = cp >> 1, mi = (MIDX ? cm + 1u : cm) >> 2;   // MIDX draws one batch ahead
-    const bool hit = (pi - pb_idx) <= 1u && (!cached_mem || mi == mb_idx);
+  // One Philox evaluation refills both caches.  The policy lanes hold the aligned block pair
+  // {2 pq, 2 pq + 1} = action draws 4 pq .. 4 pq + 3.  With MIDX the memory block is needed one
+  // batch ahead, so there the policy pair is also fetched one draw ahead (after this step's draw
+  // has been taken from the old pair): both caches then run dry in the same step whenever the two
+  // counters advance together, and one evaluation serves four steps.
+  auto refresh_draws = [&](uint32_t pq) {
+    const uint32_t mi = (MIDX ? cm + 1u : cm) >> 2;
+    const bool hit = pq == pb_idx && (!cached_mem || mi == mb_idx);
     if (__builtin_expect(hit, 1)) return;
     const bool p0 = lane == 62, p1 = lane == 63;
-    blk = cobel_philox(p1 ? pi + 1u : (p0 ? pi : mi), (p0 || p1) ? 0u : (uint32_t)lane, g,
-                       (p0 || p1) ? pol_stream : COBEL_STREAM_MEMORY, seed);
-    pb_idx = pi;
+    blk = cobel_philox(p1 ? 2u * pq + 1u : (p0 ? 2u * pq : mi), (p0 || p1) ? 0u : (uint32_t)lane,
+                       g, (p0 || p1) ? pol_stream : COBEL_STREAM_MEMORY, seed);
+    pb_idx = pq;
     mb_idx = mi;
   };
   auto log_gather = [&](uint32_t x, uint32_t bound, uint32_t have) -> uint64_t {
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // ---- prologue -----------------------------------------------------------------------------
   if (iflags & 1u) enter_state(state);
   if (MIDX) {
+    refresh_draws(cp >> 2);   // the pair this call's first action draw comes from
     idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
     mg_cur = lane < B ? (uint32_t)Mg[idx_cur] : 0u;
   }
@@ -406,13 +417,14 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     budget -= 1;
 
     // ---- draws of this step (cached blocks; one Philox evaluation per ~4 steps) ---------------
-    refresh_draws();
+    if (!MIDX) refresh_draws(cp >> 2);
 #if defined(COBEL_STAMPS_FINE)
     STAMP(6);
 #endif
-    const int src_lane = 62 + (int)((cp >> 1) - pb_idx);
+    const int src_lane = 62 + (int)((cp >> 1) & 1u);
     const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
     const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
+    if (MIDX) refresh_draws((cp + 1u) >> 2);
     const uint32_t mdraw = cobel_word(blk, cm & 3u);   // lanes < B: this step's batch
     cp += 1u;
 
@@ -445,8 +457,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (mask_cur == 15u) {
       // integer thresholds of the tie pattern's CDF, held one per lane in thr_lo / thr_hi
       const float m = max4(qrow);
-      const int t = (int)rfl((uint32_t)((int)(qrow.x == m) | ((int)(qrow.y == m) << 1) |
-                                        ((int)(qrow.z == m) << 2) | ((int)(qrow.w == m) << 3)));
+      // (the row is wave-uniform: each compare yields an all-or-nothing lane mask, and the tie
+      //  pattern is assembled from bit k of mask k on the scalar unit)
+      const int t = (int)(((uint32_t)__ballot(qrow.x == m) & 1u) | ((uint32_t)__ballot(qrow.y == m) & 2u) |
+                          ((uint32_t)__ballot(qrow.z == m) & 4u) | ((uint32_t)__ballot(qrow.w == m) & 8u));
       // every lane e < 48 compares its own threshold (entry e = t * 3 + k) with the draw; the
       // three bits of this tie pattern in the ballot count the thresholds passed
       const uint64_t K = cobel_u53(w0, w1);
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       trial += 1;
       iflags &= ~1u;
       if (episodic && B > 0) {
-        refresh_draws();
+        refresh_draws(cp >> 2);
         plan_dynaq(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
         cm += 1u;
       }
