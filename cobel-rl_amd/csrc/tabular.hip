@@ -264,8 +264,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // Lane j < B holds replay j = (idx -> (s, a), r, ns, nt).  The reference applies them in order
   // (agent/dyna_q.py:329-330); j may run once every earlier lane that writes a cell j reads —
   // s_i == ns_j (row of the max) or idx_i == idx_j (the cell itself) — has written.
-  auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
-    const bool on = lane < B;
+  // (inside == true: the caller already runs under `lane < B`; one predicated region instead of
+  //  one per table access)
+  auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r, bool inside = false) {
+    const bool on = inside || lane < B;
     const uint32_t sj = idx >> 2;
 #if defined(COBEL_ABLATE) && COBEL_ABLATE == 3
     return;
@@ -570,16 +572,16 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         // next step's batch: draw, start the gather; then run this step's batch
         uint32_t idx_next = 0u, mg_next = 0u;
         const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
-        float r = 0.0f;
-        if (lane < B) {   // one predicated block for everything the replay lanes do here
+        if (lane < B) {   // one predicated region for everything the replay lanes do
+          float r = 0.0f;
           idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
           mg_next = (uint32_t)Mg[idx_next];
           if (__builtin_expect((m & 0x8000u) != 0u, 0))
             r = __builtin_bit_cast(float, model32[2u * idx_cur]);
           if (idx_cur == fresh_idx) r = fresh_r;
+          run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r, true);
+          if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
         }
-        run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r);
-        if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
         idx_cur = idx_next;
         mg_cur = mg_next;
         m4 = m4_next;
