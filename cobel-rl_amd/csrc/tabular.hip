@@ -382,8 +382,28 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
               __builtin_bit_cast(float, lo));
   };
 
+  // interface/gridworld.py:142 — draw the start state of the next trial (false: all trials done)
+  auto begin_trial = [&]() -> bool {
+    if (trial >= A.r.trials_target) return false;
+    state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                             start_cnt)];
+    ce += 1u;
+    step = 0;
+    trew = 0.0;
+    asm volatile("" : "+v"(trew));
+    iflags |= 1u;
+    m4_fix = -1;
+    enter_state(state);
+    return true;
+  };
+
   // ---- prologue -----------------------------------------------------------------------------
+  // (a trial is begun where the previous one ends — also when the step budget is used up, as the
+  //  start draw belongs to the trial count, not to the budget — so the loop itself never has to
+  //  ask whether it is inside a trial)
+  bool live = true;
   if (iflags & 1u) enter_state(state);
+  else live = begin_trial();
   if (MIDX) {
     refresh_draws(cp >> 2);   // the pair this call's first action draw comes from
     idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
@@ -401,20 +421,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
 
-  while (true) {
+  while (live) {
     STAMP(5);
-    if (__builtin_expect(!(iflags & 1u), 0)) {
-      if (trial >= A.r.trials_target) break;
-      state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
-                                                               start_cnt)];
-      ce += 1u;
-      step = 0;
-      trew = 0.0;
-      asm volatile("" : "+v"(trew));
-      iflags |= 1u;
-      m4_fix = -1;
-      enter_state(state);
-    }
     if (budget == 0) break;
     budget -= 1;
 
@@ -624,6 +632,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         plan_dynaq(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
         cm += 1u;
       }
+      if (!begin_trial()) break;
     } else {
       step += 1;
     }
