@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // and 63 hold policy blocks 2 pb_idx and 2 pb_idx + 1 (action draws 4 pb_idx .. 4 pb_idx + 3).
   cobel_u4 blk = {0, 0, 0, 0};
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
+  int refresh_in = 0;          // MIDX: steps left before the cached draws must be renewed
   uint2 m4 = {0u, 0u};         // MIDX: the four model entries of the current state
   int m4_fix = -1;             // MIDX: entry of m4 overwritten by the previous step's store, or -1
   uint32_t m4_fix_val = 0u;
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // batch ahead, so there the policy pair is also fetched one draw ahead (after this step's draw
   // has been taken from the old pair): both caches then run dry in the same step whenever the two
   // counters advance together, and one evaluation serves four steps.
-  auto refresh_draws = [&](uint32_t pq) {
+  auto refresh_draws = [&](uint32_t pq, bool force = false) {
     const uint32_t mi = (MIDX ? cm + 1u : cm) >> 2;
-    const bool hit = pq == pb_idx && (!cached_mem || mi == mb_idx);
+    const bool hit = !force && pq == pb_idx && (!cached_mem || mi == mb_idx);
     if (__builtin_expect(hit, 1)) return;
     const bool p0 = lane == 62, p1 = lane == 63;
     blk = cobel_philox(p1 ? 2u * pq + 1u : (p0 ? 2u * pq : mi), (p0 || p1) ? 0u : (uint32_t)lane,
@@ -406,6 +407,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   else live = begin_trial();
   if (MIDX) {
     refresh_draws(cp >> 2);   // the pair this call's first action draw comes from
+    {
+      const int jp = 3 - (int)(cp & 3u), jm = 4 - (int)((cm + 1u) & 3u);
+      refresh_in = jp < jm ? jp : jm;   // steps until one of the two caches runs dry
+    }
     idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
     mg_cur = lane < B ? (uint32_t)Mg[idx_cur] : 0u;
   }
@@ -434,7 +439,16 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     const int src_lane = 62 + (int)((cp >> 1) & 1u);
     const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
     const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
-    if (MIDX) refresh_draws((cp + 1u) >> 2);
+    if (MIDX) {
+      // both counters advance by one per step here, so the step at which a cache runs dry is
+      // known in advance: a countdown instead of two index comparisons per step
+      if (refresh_in == 0) {
+        refresh_draws((cp + 1u) >> 2, true);
+        const int jp = 4 - (int)((cp + 1u) & 3u), jm = 4 - (int)((cm + 1u) & 3u);
+        refresh_in = jp < jm ? jp : jm;
+      }
+      refresh_in -= 1;
+    }
     const uint32_t mdraw = cobel_word(blk, cm & 3u);   // lanes < B: this step's batch
     cp += 1u;
 
