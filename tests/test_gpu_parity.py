@@ -697,10 +697,13 @@ def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
     assert not np.isnan(lat[:3]).any()
 
 
-def test_model_index_variants_agree(torch_cuda, golden_worlds):
+@pytest.mark.parametrize('offset', [0, 1, 2, 3])
+def test_model_index_variants_agree(torch_cuda, golden_worlds, offset):
     """The planning kernel with the model digest in HBM (gathered one step ahead) and with the
     digest in LDS produce identical tables, counters and digests — on a maze with several reward
-    sites (flagged reward estimates) and bumping moves (ns == s patches)."""
+    sites (flagged reward estimates) and bumping moves (ns == s patches).  `offset` steps without
+    planning come first, so that the policy and memory stream counters take every relative
+    phase (the cached-draw refresh schedule of the digest-in-HBM kernel depends on it)."""
     torch = torch_cuda
     from cobel_amd import _lib
     from cobel_amd.agent import DynaQ
@@ -715,6 +718,8 @@ def test_model_index_variants_agree(torch_cuda, golden_worlds):
         ag._env_in(env)
         flags = _lib.F_LEARN | extra | ag._policy_in(ag.policy, env, False)
         ag.monitors.reserve(16, 96, True)
+        if offset:
+            ag._launch(env, ag.policy, flags | _lib.F_NO_REPLAY, 16, 25, offset, 40)
         for _ in range(5):
             ag._launch(env, ag.policy, flags, 16, 25, 33, 40)
         return ag
