@@ -216,9 +216,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   cobel_u4 blk = {0, 0, 0, 0};
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
   int refresh_in = 0;          // MIDX: steps left before the cached draws must be renewed
-  uint2 m4 = {0u, 0u};         // MIDX: the four model entries of the current state
-  int m4_fix = -1;             // MIDX: entry of m4 overwritten by the previous step's store, or -1
-  uint32_t m4_fix_val = 0u;
+  uint2 m4 = {0u, 0u};         // !MIDX: the four 16-bit model entries of the current state
+  uint2 mrec = {0u, 0u};       // MIDX, lane k < 4: model record (state, k), gathered one step ahead
+  uint32_t fix_sa = ~0u;       // MIDX: the pair whose record the previous step rewrote (possibly
+  float fix_r = 0.0f;          //       after that gather had been issued), and its new reward
   uint32_t idx_cur = 0;        // MIDX, lane j < B: pair sampled by this step's replay j ...
   uint32_t mg_cur = 0;         // ... and its model entry, gathered one step ahead
   uint32_t qx = 0;             // QAgent replay: memory draw of the upcoming batch
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
     if (!WLDS && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
-    if (MIDX) m4 = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)s * 4u]);
+    if (MIDX && lane < 4)
+      mrec = *reinterpret_cast<const uint2*>(&model[(uint32_t)s * 4u + (uint32_t)lane]);
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
   };
 
@@ -393,7 +395,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     trew = 0.0;
     asm volatile("" : "+v"(trew));
     iflags |= 1u;
-    m4_fix = -1;
     enter_state(state);
     return true;
   };
@@ -463,15 +464,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (WLDS) cand = L.Wl[succ];
     if (AGENT == COBEL_AGENT_DYNAQ && !MIDX)   // the four 16-bit model entries of this state
       m4 = *reinterpret_cast<const uint2*>(&L.M16[state * 4]);
-    if (MIDX && m4_fix >= 0) {   // (plain selects: a reference into m4 would send it to scratch)
-      const uint32_t sh = (m4_fix & 1) ? 16u : 0u;
-      const uint32_t keep = ~(0xffffu << sh), put = m4_fix_val << sh;
-      const uint32_t x = (m4_fix & 2) ? m4.x : ((m4.x & keep) | put);
-      const uint32_t y = (m4_fix & 2) ? ((m4.y & keep) | put) : m4.y;
-      m4.x = x;
-      m4.y = y;
-      m4_fix = -1;
-    }
 
 #if defined(COBEL_STAMPS_FINE)
     STAMP(7);
@@ -510,10 +502,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // Successor records for the next step: issued before this step's stores (a wave's memory
     // operations retire in order, so a load issued behind a store would also wait for the
     // store's acknowledgement) and consumed one step later, behind the planning.
-    uint2 m4_next = {0u, 0u};
+    uint2 mrec_next = {0u, 0u};
     if (!trial_over) {
       if (!WLDS && lane < 4) cand = W4[next_of(nw0, nw1, lane)];
-      if (MIDX) m4_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
+      if (MIDX && lane < 4)
+        mrec_next = *reinterpret_cast<const uint2*>(&model[(uint32_t)ns * 4u + (uint32_t)lane]);
       mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
     }
 
@@ -528,21 +521,29 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (learn) {
       if (AGENT == COBEL_AGENT_DYNAQ) {
         // memory/dyna_q.py:92-96 (float32): rewards[s,a] += lr * (r - rewards[s,a])
-        const uint32_t pair = (a & 2) ? m4.y : m4.x;
-        const uint32_t old = (a & 1) ? (pair >> 16) : (pair & 0xffffu);
         float R = 0.0f;
-        if (__builtin_expect((old & 0x8000u) != 0u, 0))
-          R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
+        if (MIDX) {
+          // the record of (state, a) came in with the successor records, one step ahead; if the
+          // previous step rewrote it after that gather was issued, its value is still at hand
+          R = __builtin_bit_cast(float, rl(mrec.x, a));
+          if (sa == fix_sa) R = fix_r;
+        } else {
+          const uint32_t pair = (a & 2) ? m4.y : m4.x;
+          const uint32_t old = (a & 1) ? (pair >> 16) : (pair & 0xffffu);
+          if (__builtin_expect((old & 0x8000u) != 0u, 0))
+            R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
+        }
         const float d = r - R;
         const float Rn = R + mlr_f * d;
         const uint32_t rbits = __builtin_bit_cast(uint32_t, Rn);
         fresh_idx = sa;
         fresh_r = Rn;
         fresh_m = (uint32_t)ns | (nt << 14) | (rbits ? 0x8000u : 0u);
-        // (if ns == state the entries prefetched for the next step predate this store; they are
-        //  patched when they are consumed, not here — touching them now would wait for the load)
-        m4_fix = (MIDX && ns == state) ? a : -1;
-        m4_fix_val = fresh_m;
+        // (if the next step is in this state again — a bumping move, or a trial that starts
+        //  here — the records gathered for it may predate this store; the one entry concerned
+        //  is replaced when it is consumed)
+        fix_sa = sa;
+        fix_r = Rn;
       } else if (rlog) {
         if (loglen < (uint32_t)A.r.log_cap) {
           fresh_rec = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         }
         idx_cur = idx_next;
         mg_cur = mg_next;
-        m4 = m4_next;
+        mrec = mrec_next;
         cm += 1u;
       } else if (AGENT == COBEL_AGENT_DYNAQ) {
         plan_dynaq(mdraw, fresh_idx, fresh_r);
