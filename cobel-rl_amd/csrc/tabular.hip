@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     return;
 #endif
     int dep = -1;  // latest earlier lane this lane must wait for
-    if (A.hash_exact) {
+    if (__builtin_expect(A.hash_exact != 0, 1)) {
       // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
       // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
       // that write into row ns are those in one of the four H1 buckets of (ns & 15) and in the
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     STAMP(3);
     }
     int first = 0;
-    while (first < B) {
+    do {   // (B >= 1 here; most batches need one or two rounds)
       const unsigned long long blocked = __ballot(on && dep >= first);
       const int stop = blocked ? (__ffsll((long long)blocked) - 1) : B;
       if (lane >= first && lane < stop) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       }
       __builtin_amdgcn_wave_barrier();
       first = stop;
-    }
+    } while (first < B);
     STAMP(4);
   };
   // Dyna-Q batch drawn with x: model entries from LDS, reward estimates from HBM where flagged.
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (MIDX) {
       // both counters advance by one per step here, so the step at which a cache runs dry is
       // known in advance: a countdown instead of two index comparisons per step
-      if (refresh_in == 0) {
+      if (__builtin_expect(refresh_in == 0, 0)) {
         refresh_draws((cp + 1u) >> 2, true);
         const int jp = 4 - (int)((cp + 1u) & 3u), jm = 4 - (int)((cm + 1u) & 3u);
         refresh_in = jp < jm ? jp : jm;
@@ -504,9 +504,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // store's acknowledgement) and consumed one step later, behind the planning.
     uint2 mrec_next = {0u, 0u};
     if (!trial_over) {
-      if (!WLDS && lane < 4) cand = W4[next_of(nw0, nw1, lane)];
-      if (MIDX && lane < 4)
-        mrec_next = *reinterpret_cast<const uint2*>(&model[(uint32_t)ns * 4u + (uint32_t)lane]);
+      if (lane < 4) {
+        if (!WLDS) cand = W4[next_of(nw0, nw1, lane)];
+        if (MIDX)
+          mrec_next = *reinterpret_cast<const uint2*>(&model[(uint32_t)ns * 4u + (uint32_t)lane]);
+      }
       mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
     }
 
