@@ -26,6 +26,18 @@ class CobelHipError(RuntimeError):
     """HIP runtime failure or unsupported configuration reported by the library."""
 
 
+class ParamSet(C.Structure):
+    """``cobel_param_set_t`` (512 bytes; fill with ``cobel_param_set_fill``)."""
+    _fields_ = [
+        ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
+        ('model_lr', C.c_double),
+        ('alpha_f', C.c_float), ('gamma_f', C.c_float), ('model_lr_f', C.c_float),
+        ('reserved_', C.c_float),
+        ('eps_base', C.c_double * 5), ('eps_bonus', C.c_double * 5),
+        ('eps_thr', (C.c_uint64 * 3) * 16),
+    ]
+
+
 class TabRun(C.Structure):
     """``cobel_tab_run_t``."""
     _fields_ = [
@@ -41,6 +53,8 @@ class TabRun(C.Structure):
         ('steps_per_trial', C.c_int32), ('step_budget', C.c_int32), ('batch', C.c_int32),
         ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
         ('model_lr', C.c_double), ('seed', C.c_uint64),
+        ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
+        ('reserved_', C.c_int32),
     ]
 
 
@@ -57,6 +71,8 @@ class SRRun(C.Structure):
         ('step_budget', C.c_int32),
         ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
         ('seed', C.c_uint64),
+        ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
+        ('reserved_', C.c_int32),
     ]
 
 
@@ -80,6 +96,8 @@ _SIGNATURES = {
     'cobel_env_reset': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_uint32, _P]),
     'cobel_gather_rows': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'cobel_eps_greedy': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),
+    'cobel_param_set_fill': (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.POINTER(ParamSet)]),
     'cobel_tab_query': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),
     'cobel_tab_run': (C.c_int, [_P, C.POINTER(TabRun), _P]),

@@ -154,6 +154,49 @@ class FusedAgent(Agent):
         self.inst = None
         self.monitors = None
         self._last_exp = None
+        self._pset_key = self._pset_dev = self._pidx_dev = None
+        self._pset_n = 0
+
+    # -- hyper-parameters -----------------------------------------------------------------------
+    def _hyper(self, run, alpha, gamma, epsilon, model_lr=None) -> None:
+        """Hand the hyper-parameters to a run struct.  Scalars go in as they are.  If any of them
+        is array-valued (one entry per instance) the distinct combinations become parameter sets
+        and every instance gets the index of its set — the reference's grid search
+        (optimizer/grid_search.py:173-262, one simulation per combination) folded onto the
+        instance axis of one launch."""
+        import ctypes as C
+        names = ('alpha', 'gamma', 'epsilon') + (('model_lr',) if model_lr is not None else ())
+        vals = [np.asarray(v, dtype=np.float64)
+                for v in (alpha, gamma, epsilon) + ((model_lr,) if model_lr is not None else ())]
+        if all(v.ndim == 0 for v in vals):
+            for name, v in zip(names, vals):
+                setattr(run, name, float(v))
+            return
+        n = self.n_envs
+        for v in vals:
+            assert v.ndim == 0 or v.shape == (n,), \
+                'per-instance hyper-parameters need one entry per environment instance'
+        cols = np.stack([np.broadcast_to(v, (n,)) for v in vals], axis=1)
+        if model_lr is None:
+            cols = np.concatenate([cols, np.full((n, 1), 0.9)], axis=1)
+        key = cols.tobytes()
+        if key != self._pset_key:
+            uniq, inv = np.unique(cols, axis=0, return_inverse=True)
+            assert len(uniq) <= 65535, 'at most 65535 distinct parameter combinations per launch'
+            sets = (_lib.ParamSet * len(uniq))()
+            for k, (a, g, e, m) in enumerate(uniq):
+                _lib.check(_lib.lib().cobel_param_set_fill(float(a), float(g), float(e), float(m),
+                                                           C.byref(sets[k])))
+            raw = np.frombuffer(sets, dtype=np.uint8).copy()
+            self._pset_dev = torch.as_tensor(raw, device=self.device)
+            self._pidx_dev = torch.as_tensor(
+                np.ascontiguousarray(inv.reshape(-1).astype(np.uint16)).view(np.int16),
+                device=self.device)
+            self._pset_key, self._pset_n = key, len(uniq)
+        for name, v in zip(names, cols[0]):      # placeholders; the kernel reads the sets
+            setattr(run, name, float(v))
+        run.param_sets, run.param_index = _lib.ptr(self._pset_dev), _lib.ptr(self._pidx_dev)
+        run.n_param_sets = self._pset_n
 
     # -- device state -------------------------------------------------------------------------
     def _bind(self, interface) -> None:

@@ -34,8 +34,10 @@ class DynaQ(TabularAgent):
     def _extra(self, run) -> None:
         run.model = _lib.ptr(self.M.table)
         run.model_index = _lib.ptr(self.M.index)
-        run.model_lr = float(self.M.learning_rate)
         self.inst[:, _lib.I_CTR_MEMORY] = self.M.counter
+
+    def _model_lr(self):
+        return self.M.learning_rate
 
     def _launch(self, *args) -> None:
         super()._launch(*args)

@@ -77,8 +77,8 @@ class SR(FusedAgent):
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base, run.flags = interface.instance_base, flags
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
-        run.alpha, run.gamma = float(self.learning_rate), float(self.gamma)
-        run.epsilon, run.seed = float(pol.epsilon), interface.seed
+        run.seed = interface.seed
+        self._hyper(run, self.learning_rate, self.gamma, pol.epsilon)
         _lib.check(_lib.lib().cobel_sr_run(interface.handle.ptr, C.byref(run),
                                            _lib.current_stream(self.device)))
 

@@ -62,6 +62,9 @@ class TabularAgent(FusedAgent):
     def _extra(self, run: _lib.TabRun) -> None:
         pass
 
+    def _model_lr(self):
+        return 0.9
+
     def _launch(self, interface, pol, flags, trials_target, steps, budget, batch) -> None:
         mon = self.monitors
         run = _lib.TabRun()
@@ -80,10 +83,8 @@ class TabularAgent(FusedAgent):
         run.agent, run.flags = self.agent_kind, flags
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
         run.batch = batch
-        run.alpha, run.gamma = float(self.learning_rate), float(self.gamma)
-        run.epsilon = float(pol.epsilon)
-        run.model_lr = 0.9
         run.seed = interface.seed
+        self._hyper(run, self.learning_rate, self.gamma, pol.epsilon, self._model_lr())
         self._extra(run)
         _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
                                             _lib.current_stream(self.device)))

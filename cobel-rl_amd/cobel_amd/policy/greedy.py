@@ -27,7 +27,7 @@ def _mask_bits(mask, n: int, device):
 class EpsilonGreedy(Policy):
     def __init__(self, epsilon: float = 0.1, rng=None) -> None:
         super().__init__(rng)
-        assert epsilon >= 0.0 and epsilon <= 1.0
+        assert np.all(np.asarray(epsilon) >= 0.0) and np.all(np.asarray(epsilon) <= 1.0)
         self.epsilon = epsilon
 
     # -- helpers ----------------------------------------------------------------------------

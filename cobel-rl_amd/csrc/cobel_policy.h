@@ -22,6 +22,13 @@ struct cobel_eps_consts {
   uint64_t thr[16][3];
 };
 
+// The two tables the float64 (masked) selection needs, for kernels that take them from a
+// per-instance parameter set instead of the launch-wide constants.
+struct cobel_eps_bb {
+  double base[5];
+  double bonus[5];
+};
+
 // Constant lookup written as selects: a runtime index into a by-value kernel argument would send
 // the struct to scratch memory.
 #if defined(__HIPCC__)
@@ -60,9 +67,9 @@ static inline cobel_eps_consts cobel_make_eps_consts(double eps) {
 #if defined(__HIPCC__)
 // All arguments wave-uniform or per-lane alike; every lane returns the same answer it would get
 // alone.  mask: 4-bit set of allowed actions (non-zero).  probs (optional): 4 doubles out.
-template <typename V>
+template <typename V, typename K>
 __device__ __forceinline__ int cobel_eps_greedy_select(V v0, V v1, V v2, V v3, uint32_t mask,
-                                                       double u, const cobel_eps_consts& k,
+                                                       double u, const K& k,
                                                        double* probs = nullptr) {
   const V ninf = -(V)__builtin_huge_valf();
   const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
@@ -92,10 +99,10 @@ __device__ __forceinline__ int cobel_eps_greedy_select(V v0, V v1, V v2, V v3, u
 
 // Same selection when the whole wave holds identical arguments: lanes 0..2 each take one of the
 // three float64 divisions, a ballot counts the thresholds passed.  Returns a wave-uniform value.
+template <typename K>
 __device__ __forceinline__ int cobel_eps_greedy_select_wave(float v0, float v1, float v2,
                                                             float v3, uint32_t mask, double u,
-                                                            const cobel_eps_consts& k,
-                                                            int lane) {
+                                                            const K& k, int lane) {
   const float ninf = -__builtin_huge_valf();
   const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
   float m = ninf;

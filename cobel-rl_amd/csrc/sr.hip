@@ -224,7 +224,8 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
 // will need in the NEXT step (row T[ns][a]) into registers, so the HBM latency of the four value
 // rows overlaps the row update of this step.  The one row that cannot be prefetched — SR[s], which
 // this step rewrites — is taken from the LDS copy the update leaves behind.
-template <bool VEC, bool OCC, bool PRE>
+// PSETS: hyper-parameters from per-instance parameter sets (run.param_index).
+template <bool VEC, bool OCC, bool PRE, bool PSETS>
 __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -265,8 +266,20 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   const uint64_t seed = A.r.seed;
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
-  const double alpha = A.r.alpha, gamma = A.r.gamma;
-  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f;
+  const cobel_param_set_t* P = nullptr;   // this instance's parameter set, if any
+  if (PSETS) {
+    const int k = (int)A.r.param_index[i];
+    P = A.r.param_sets + (k < A.r.n_param_sets ? k : A.r.n_param_sets - 1);
+  }
+  const double alpha = PSETS ? P->alpha : A.r.alpha, gamma = PSETS ? P->gamma : A.r.gamma;
+  const float alpha_f = PSETS ? P->alpha_f : A.alpha_f, gamma_f = PSETS ? P->gamma_f : A.gamma_f;
+  cobel_eps_bb ebb;
+  ebb.base[0] = ebb.bonus[0] = 0.0;
+#pragma unroll
+  for (int n = 1; n <= 4; ++n) {
+    ebb.base[n] = PSETS ? P->eps_base[n] : A.eps.base[n];
+    ebb.bonus[n] = PSETS ? P->eps_bonus[n] : A.eps.bonus[n];
+  }
 
   uint32_t cw0 = 0, cw1 = 0;
   uint4 cand = {0, 0, 0, 0};
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
     cp += 1u;
     const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
-                                                                  A.eps, lane));
+                                                                  ebb, lane));
     const int ns = (int)next_of(cw0, cw1, a);
     const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
     const float r = __builtin_bit_cast(float, rl(cand.z, a));
@@ -525,13 +538,13 @@ __global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
   }
 }
 
-template <bool VEC, bool OCC, bool PRE>
+template <bool VEC, bool OCC, bool PRE, bool PSETS>
 int launch_sr(const sr_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE>),
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE, PSETS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE>), dim3(A.r.n), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE, PSETS>), dim3(A.r.n), dim3(256), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -564,6 +577,8 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
                 r.steps_per_trial);
   COBEL_REQUIRE(r.epsilon >= 0.0 && r.epsilon <= 1.0, COBEL_E_ARG,
                 "cobel_sr_run: epsilon %g outside [0, 1]", r.epsilon);
+  COBEL_REQUIRE(!r.param_index || (r.param_sets && r.n_param_sets > 0), COBEL_E_ARG,
+                "cobel_sr_run: param_index given without parameter sets");
   COBEL_REQUIRE(!(r.flags & COBEL_F_MASK_ACTIONS) || r.action_mask, COBEL_E_ARG,
                 "cobel_sr_run: mask_actions set without an action mask");
   const int S = world->n_states;
@@ -586,9 +601,18 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (S % 4) == 0;
   const bool pre = vec && S <= 1024 && !(r.flags & COBEL_F_NO_PREFETCH);
-  if (pre) return occ ? launch_sr<true, true, true>(A, lds, st) : launch_sr<true, false, true>(A, lds, st);
-  if (vec) return occ ? launch_sr<true, true, false>(A, lds, st) : launch_sr<true, false, false>(A, lds, st);
-  return occ ? launch_sr<false, true, false>(A, lds, st) : launch_sr<false, false, false>(A, lds, st);
+#define COBEL_SR(V, PF)                                                                   \
+  do {                                                                                    \
+    if (r.param_index)                                                                    \
+      return occ ? launch_sr<V, true, PF, true>(A, lds, st)                               \
+                 : launch_sr<V, false, PF, true>(A, lds, st);                             \
+    return occ ? launch_sr<V, true, PF, false>(A, lds, st)                                \
+               : launch_sr<V, false, PF, false>(A, lds, st);                              \
+  } while (0)
+  if (pre) COBEL_SR(true, true);
+  if (vec) COBEL_SR(true, false);
+  COBEL_SR(false, false);
+#undef COBEL_SR
 }
 
 extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const float* rewards,

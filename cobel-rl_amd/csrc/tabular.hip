@@ -110,7 +110,10 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
 // counter based, so the entries a step will sample are gathered one step ahead and patched in
 // registers with the one entry that step itself writes.  LDS shrinks to Q + hash = 17 KiB and
 // nine instances fit on a CU instead of six.
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX>
+// PSETS: hyper-parameters come from per-instance parameter sets (run.param_index).  A template
+// switch rather than a run-time one: the mere possibility of taking the loop constants from
+// memory changes the register allocation of the whole step loop.
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -198,12 +201,27 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   // Loop constants that only ever feed vector instructions are pinned to vector registers: the
   // step loop is short of scalar registers (spills cost instructions), not of vector ones.
-  double alpha = A.r.alpha, gamma = A.r.gamma;
-  float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  // hyper-parameters: launch-wide, or this instance's parameter set (grid-search fan-out)
+  const cobel_param_set_t* P = nullptr;
+  if (PSETS) {
+    const int k = (int)A.r.param_index[i];
+    P = A.r.param_sets + (k < A.r.n_param_sets ? k : A.r.n_param_sets - 1);
+  }
+  double alpha = PSETS ? P->alpha : A.r.alpha, gamma = PSETS ? P->gamma : A.r.gamma;
+  float alpha_f = PSETS ? P->alpha_f : A.alpha_f, gamma_f = PSETS ? P->gamma_f : A.gamma_f,
+        mlr_f = PSETS ? P->model_lr_f : A.model_lr_f;
+  cobel_eps_bb ebb;
+  ebb.base[0] = ebb.bonus[0] = 0.0;
+#pragma unroll
+  for (int n = 1; n <= 4; ++n) {
+    ebb.base[n] = PSETS ? P->eps_base[n] : A.eps.base[n];
+    ebb.bonus[n] = PSETS ? P->eps_bonus[n] : A.eps.bonus[n];
+  }
   asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
 
   // epsilon-greedy thresholds (cobel_eps_consts::thr), entry e = t * 3 + k in lane e < 48
-  const uint64_t thr_mine = A.eps.thr[(lane % 48) / 3][lane % 3];
+  const uint64_t thr_mine = PSETS ? P->eps_thr[(lane % 48) / 3][lane % 3]
+                              : A.eps.thr[(lane % 48) / 3][lane % 3];
 #if defined(COBEL_STAMPS)
   unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
 #endif
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       a = __popcll((passed >> (t * 3)) & 7ull);
     } else {
       a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
-                                                          cobel_u01(w0, w1), A.eps, lane));
+                                                          cobel_u01(w0, w1), ebb, lane));
     }
     STAMP(0);
     // ---- env.step (interface/gridworld.py:115-126) ----------------------------------------------
@@ -940,37 +958,41 @@ __global__ __launch_bounds__(256) void k_model_index(const uint64_t* __restrict_
   index[t] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
 }
 
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX>
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     COBEL_HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX>),
+        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS>), dim3(A.r.n), dim3(64), lds,
+                     st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
+template <int AGENT, bool FAST, bool MIDX, bool PSETS>
+int dispatch_wpi2(const tab_args& A, bool occ, bool wlds, size_t lds, hipStream_t st) {
+  if (occ) return wlds ? launch_wpi<AGENT, true, true, FAST, MIDX, PSETS>(A, lds, st)
+                       : launch_wpi<AGENT, true, false, FAST, MIDX, PSETS>(A, lds, st);
+  return wlds ? launch_wpi<AGENT, false, true, FAST, MIDX, PSETS>(A, lds, st)
+              : launch_wpi<AGENT, false, false, FAST, MIDX, PSETS>(A, lds, st);
+}
+
+// The plain-training kernels exist with and without parameter sets; the generic ones (masks,
+// episodic replay, test runs, QAgent replay) always read them through the same code.
 template <int AGENT>
 int dispatch_wpi(const tab_args& A, bool occ, bool wlds, bool fast, bool midx, size_t lds,
                  hipStream_t st) {
-  if (AGENT == COBEL_AGENT_DYNAQ && fast && midx) {
-    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true, true>(A, lds, st)
-                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true, true>(A, lds, st);
-    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true, true>(A, lds, st)
-                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true, true>(A, lds, st);
-  }
-  if (AGENT == COBEL_AGENT_DYNAQ && fast) {
-    if (occ) return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, true, true, true, false>(A, lds, st)
-                         : launch_wpi<COBEL_AGENT_DYNAQ, true, false, true, false>(A, lds, st);
-    return wlds ? launch_wpi<COBEL_AGENT_DYNAQ, false, true, true, false>(A, lds, st)
-                : launch_wpi<COBEL_AGENT_DYNAQ, false, false, true, false>(A, lds, st);
-  }
-  if (occ) return wlds ? launch_wpi<AGENT, true, true, false, false>(A, lds, st)
-                       : launch_wpi<AGENT, true, false, false, false>(A, lds, st);
-  return wlds ? launch_wpi<AGENT, false, true, false, false>(A, lds, st)
-              : launch_wpi<AGENT, false, false, false, false>(A, lds, st);
+  const bool psets = A.r.param_index != nullptr;
+  if (AGENT == COBEL_AGENT_DYNAQ && fast && midx)
+    return psets ? dispatch_wpi2<COBEL_AGENT_DYNAQ, true, true, true>(A, occ, wlds, lds, st)
+                 : dispatch_wpi2<COBEL_AGENT_DYNAQ, true, true, false>(A, occ, wlds, lds, st);
+  if (AGENT == COBEL_AGENT_DYNAQ && fast)
+    return psets ? dispatch_wpi2<COBEL_AGENT_DYNAQ, true, false, true>(A, occ, wlds, lds, st)
+                 : dispatch_wpi2<COBEL_AGENT_DYNAQ, true, false, false>(A, occ, wlds, lds, st);
+  return psets ? dispatch_wpi2<AGENT, false, false, true>(A, occ, wlds, lds, st)
+               : dispatch_wpi2<AGENT, false, false, false>(A, occ, wlds, lds, st);
 }
 
 }  // namespace
@@ -1039,6 +1061,8 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   COBEL_REQUIRE(!(r.flags & COBEL_F_MASK_ACTIONS) || r.action_mask, COBEL_E_ARG,
                 "cobel_tab_run: mask_actions set without an action mask");
   COBEL_REQUIRE(r.trial_cap >= 0 && r.log_cap >= 0, COBEL_E_RANGE, "cobel_tab_run: negative cap");
+  COBEL_REQUIRE(!r.param_index || (r.param_sets && r.n_param_sets > 0), COBEL_E_ARG,
+                "cobel_tab_run: param_index given without parameter sets");
   COBEL_REQUIRE(r.agent != COBEL_AGENT_Q || world->n_states <= 16384, COBEL_E_UNSUPPORTED,
                 "cobel_tab_run: replay records address at most 16384 states");
   int32_t lds_max = 0;
@@ -1072,7 +1096,8 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
   const bool learn = (r.flags & COBEL_F_LEARN) != 0;
   const size_t lds_lpi = (size_t)world->n_states * 1024 + kThrBytes + (size_t)world->n_states * 16;
-  if (!replay && !occ && (!learn || r.agent == COBEL_AGENT_Q) &&
+  // (per-instance parameter sets: the lane-per-instance kernel keeps ONE threshold table per wave)
+  if (!replay && !occ && !r.param_index && (!learn || r.agent == COBEL_AGENT_Q) &&
       lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
       r.n >= 64 && !(r.flags & COBEL_F_FORCE_WAVE)) {
     const bool one = world->n_worlds == 1;

@@ -23,7 +23,31 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1000; }
+extern "C" int cobel_abi_version(void) { return 1001; }
+
+extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
+                                    cobel_param_set_t* out) {
+  COBEL_REQUIRE(out, COBEL_E_ARG, "cobel_param_set_fill: NULL out");
+  COBEL_REQUIRE(epsilon >= 0.0 && epsilon <= 1.0, COBEL_E_ARG,
+                "cobel_param_set_fill: epsilon %g outside [0, 1]", epsilon);
+  static_assert(sizeof(cobel_param_set_t) == 512, "cobel_param_set_t layout");
+  const cobel_eps_consts c = cobel_make_eps_consts(epsilon);
+  out->alpha = alpha;
+  out->gamma = gamma;
+  out->epsilon = epsilon;
+  out->model_lr = model_lr;
+  out->alpha_f = (float)alpha;
+  out->gamma_f = (float)gamma;
+  out->model_lr_f = (float)model_lr;
+  out->reserved_ = 0.0f;
+  for (int n = 0; n < 5; ++n) {
+    out->eps_base[n] = c.base[n];
+    out->eps_bonus[n] = c.bonus[n];
+  }
+  for (int t = 0; t < 16; ++t)
+    for (int k = 0; k < 3; ++k) out->eps_thr[t][k] = c.thr[t][k];
+  return COBEL_OK;
+}
 
 extern "C" uint64_t cobel_pack_model(float reward, uint16_t next_state, uint8_t nonterminal) {
   return cobel_model_pack(reward, next_state, nonterminal ? 1u : 0u);

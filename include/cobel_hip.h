@@ -191,6 +191,24 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
 #define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 #define COBEL_F_NO_PREFETCH 128u   /* SR: load value rows at the top of each step (testing)        */
 
+/* Per-instance hyper-parameters.  The reference explores hyper-parameters by running one
+ * simulation per combination (optimizer/grid_search.py:173-262: `simulation(task, parameters)`
+ * for every entry of `parameter_combinations`, nb_runs times); here the combinations ride on the
+ * instance axis of ONE launch: instance i uses param_sets[param_index[i]].  A set carries the
+ * agent's learning rate and discount (agent/dyna_q.py:112-113, q.py:121-122, sr.py:115-116), the
+ * policy's epsilon (policy/greedy.py:35) and the world model's learning rate
+ * (memory/dyna_q.py:66), plus the constants derived from them on the host in float64 — fill it
+ * with cobel_param_set_fill, never by hand.  512 bytes. */
+typedef struct {
+  double alpha, gamma, epsilon, model_lr;
+  float alpha_f, gamma_f, model_lr_f, reserved_;
+  double eps_base[5];      /* eps / n,        n = 1..4 (index 0 unused)                       */
+  double eps_bonus[5];     /* (1 - eps) / t,  t = 1..4                                        */
+  uint64_t eps_thr[16][3]; /* per tie pattern: ceil(cdf_k * 2^53) of the unmasked CDF         */
+} cobel_param_set_t;
+COBEL_API int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
+                                   cobel_param_set_t* out /* [host] */);
+
 typedef struct {
   /* tables, all caller-owned device memory */
   float* q;              /* [N][S][4] float32 Q                                              */
@@ -227,6 +245,12 @@ typedef struct {
   int32_t batch;         /* B: planning / replay updates per step (0..COBEL_MAX_BATCH)       */
   double alpha, gamma, epsilon, model_lr;
   uint64_t seed;
+  /* optional per-instance hyper-parameters: with param_index != NULL instance i uses
+     param_sets[param_index[i]] (index < n_param_sets) and the four scalars above are ignored */
+  const cobel_param_set_t* param_sets; /* [dev] [n_param_sets]                               */
+  const uint16_t* param_index;         /* [dev] [N]                                          */
+  int32_t n_param_sets;
+  int32_t reserved_;
 } cobel_tab_run_t;
 
 #define COBEL_MAX_BATCH 62
@@ -275,6 +299,10 @@ typedef struct {
   int32_t trials_target, steps_per_trial, step_budget;
   double alpha, gamma, epsilon;
   uint64_t seed;
+  const cobel_param_set_t* param_sets; /* as in cobel_tab_run_t (model_lr unused)            */
+  const uint16_t* param_index;
+  int32_t n_param_sets;
+  int32_t reserved_;
 } cobel_sr_run_t;
 
 COBEL_API int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n, int32_t n_states,

@@ -595,8 +595,44 @@ def gen_dyna_dqn():
     np.savez_compressed(os.path.join(HERE, 'dyna_dqn_trace.npz'), **out)
 
 
+def _opt_sim(task, params):
+    return task['bias'] + params['x_1'] + params['x_2'] ** 2 + params['x_3'] ** 3
+
+
+def _opt_loss(data_sim, data_exp):
+    error = 0.
+    for t in data_sim:
+        error += (np.mean(data_sim[t]) - data_exp[t]) ** 2
+    return error / len(data_sim)
+
+
+def gen_optimizer():
+    """GridSearchOptimizer: enumeration orders (grid_search.py:112-171) and a fit of the
+    docstring example (:68-88) on two tasks."""
+    import tempfile
+    from cobel.optimizer import GridSearchOptimizer
+    params = {'x_1': [0, 1, 2, 3, 4], 'x_2': np.array([0.4, 0.1, 0.2, 0.3, 0.0]),
+              'x_3': [0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1]}
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for order in ('nested', 'systematic'):
+            opt = GridSearchOptimizer(tmp + '/', params, order=order)
+            out['keys_' + order] = np.array(list(opt.parameter_combinations), dtype=np.float64)
+        small = {'x_1': [0, 2, 4], 'x_2': np.array([0.3, 0.1]), 'x_3': [0.5, 0.9]}
+        tasks = {'task_1': {'bias': 0.0}, 'task_2': {'bias': 1.5}}
+        data = {'task_1': _opt_sim(tasks['task_1'], {'x_1': 2, 'x_2': 0.1, 'x_3': 0.9}),
+                'task_2': _opt_sim(tasks['task_2'], {'x_1': 2, 'x_2': 0.1, 'x_3': 0.9})}
+        opt = GridSearchOptimizer(tmp + '/', small, nb_runs=2)
+        fit = opt.fit(_opt_sim, tasks, data, _opt_loss, store_simulation_data=True)
+        out['fit_keys'] = np.array(list(fit), dtype=np.float64)
+        out['fit_values'] = np.array([fit[k] for k in fit], dtype=np.float64)
+        out['fit_files'] = np.array(sorted(os.listdir(tmp)))
+    np.savez_compressed(os.path.join(HERE, 'optimizer_kat.npz'), **out)
+
+
 def main():
     worlds = gen_worlds()
+    gen_optimizer()
     gen_dyna_dqn()
     gen_dqn()
     gen_topology()

@@ -491,6 +491,155 @@ def test_maze_templates_dynaq_and_sr_vs_oracle(torch_cuda, template):
     assert np.array_equal(sr.monitors.lat_trace.cpu().numpy(), so.lat_trace)
 
 
+# ---------------------------------------------------------------------------------------------
+# Per-instance hyper-parameters (parameter sets): the reference runs one simulation per
+# combination (optimizer/grid_search.py:173-262); here combinations ride on the instance axis.
+# Streams are keyed by the global instance id, so instance i of a mixed launch must equal
+# instance i of a launch in which EVERY instance uses i's combination — and those uniform
+# launches are the ones pinned to the reference / the C oracle above.
+PSET_COMBOS = [(0.99, 0.99, 0.1, 0.9), (0.5, 0.9, 0.3, 0.9), (0.99, 0.8, 0.0, 0.5),
+               (0.1, 0.99, 1.0, 0.9), (0.5, 0.9, 0.3, 0.25)]
+
+
+def _pset_arrays(n):
+    which = (np.arange(n) * 7 + 3) % len(PSET_COMBOS)
+    cols = np.array(PSET_COMBOS)[which]
+    return which, cols[:, 0].copy(), cols[:, 1].copy(), cols[:, 2].copy(), cols[:, 3].copy()
+
+
+@pytest.mark.parametrize('variant', ['dynaq_fast', 'dynaq_masked', 'dynaq_lds_model', 'qagent_replay',
+                                     'qagent_online'])
+def test_param_sets_tabular_equal_uniform_runs(torch_cuda, golden_worlds, variant):
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ, QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.memory import DynaQMemory
+    from cobel_amd.policy import EpsilonGreedy
+    world = as_world(golden_worlds('walls_8x8'))
+    n = 160
+    which, alpha, gamma, eps, mlr = _pset_arrays(n)
+
+    def run(a, g, e, m):
+        env = Gridworld(world, n_envs=n, seed=777, instance_base=40)
+        if variant.startswith('dynaq'):
+            ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(e), learning_rate=a,
+                       gamma=g, memory=DynaQMemory(64, 4, m))
+            if variant == 'dynaq_masked':
+                ag.mask_actions = True
+                ag.action_mask[:, 2] = False
+                ag.action_mask[5] = True
+        else:
+            ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(e), learning_rate=a,
+                        gamma=g)
+        ag.track_instances = True
+        if variant == 'dynaq_lds_model':
+            ag._bind(env)
+            ag._env_in(env)
+            flags = _lib.F_LEARN | _lib.F_FORCE_LDS_MODEL | ag._policy_in(ag.policy, env, False)
+            ag.monitors.reserve(8, n, True)
+            ag._launch(env, ag.policy, flags, 8, 30, 0, 24)
+        elif variant == 'qagent_online':
+            ag.train(env, 8, 30, 0)
+        else:
+            ag.train(env, 8, 30, 24)
+        torch.cuda.synchronize()
+        return ag
+
+    mixed = run(alpha, gamma, eps, mlr)
+    for k, (a, g, e, m) in enumerate(PSET_COMBOS):
+        uni = run(a, g, e, m)
+        sel = torch.as_tensor(np.flatnonzero(which == k), device='cuda')
+        assert len(sel) > 0
+        assert torch.equal(mixed._q[sel], uni._q[sel]), (variant, k)
+        assert torch.equal(mixed.inst[sel], uni.inst[sel]), (variant, k)
+        assert torch.equal(mixed.monitors.lat_trace[sel], uni.monitors.lat_trace[sel])
+        if variant.startswith('dynaq'):
+            assert torch.equal(mixed.M.table[sel], uni.M.table[sel]), (variant, k)
+            assert torch.equal(mixed.M.index[sel], uni.M.index[sel]), (variant, k)
+    # the combinations do differ from one another (the test is not vacuous)
+    a0 = torch.as_tensor(np.flatnonzero(which == 0)[:1], device='cuda')
+    a1 = torch.as_tensor(np.flatnonzero(which == 1)[:1], device='cuda')
+    assert not torch.equal(mixed._q[a0], mixed._q[a1])
+
+
+def test_param_sets_sr_equal_uniform_runs(torch_cuda, golden_worlds):
+    torch = torch_cuda
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    world = as_world(golden_worlds('walls_8x8'))
+    n = 96
+    which, alpha, gamma, eps, _ = _pset_arrays(n)
+
+    def run(a, g, e):
+        env = Gridworld(world, n_envs=n, seed=4711, instance_base=3)
+        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(e), learning_rate=a, gamma=g)
+        ag.track_instances = True
+        ag.train(env, 6, 30)
+        torch.cuda.synchronize()
+        return ag
+
+    mixed = run(alpha, gamma, eps)
+    for k, (a, g, e, _) in enumerate(PSET_COMBOS):
+        uni = run(a, g, e)
+        sel = torch.as_tensor(np.flatnonzero(which == k), device='cuda')
+        assert torch.equal(mixed._sr[sel], uni._sr[sel]), k
+        assert torch.equal(mixed._T[sel], uni._T[sel]) and torch.equal(mixed._rw[sel], uni._rw[sel])
+        assert torch.equal(mixed.inst[sel], uni.inst[sel]), k
+
+
+def test_grid_search_vectorised_equals_sequential(torch_cuda, golden_worlds, tmp_path):
+    """GridSearchOptimizer.fit_vectorised: every (combination, run) is one instance of a single
+    Dyna-Q launch with per-instance learning rate / epsilon; the fit equals the reference-style
+    sequential fit() in which each combination is simulated on its own (same instance ids)."""
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.optimizer import GridSearchOptimizer, spread_over_instances
+    from cobel_amd.policy import EpsilonGreedy
+    world = as_world(golden_worlds('open_5x5'))
+    grid = {'learning_rate': [0.2, 0.6, 0.99], 'epsilon': np.array([0.3, 0.05])}
+    tasks = {'short': {'trials': 12, 'steps': 20}, 'long': {'trials': 6, 'steps': 40}}
+    data = {'short': 6.0, 'long': 8.0}
+    runs, launches = 4, []
+
+    def simulate(task, lr, eps, n, base):
+        env = Gridworld(world, n_envs=n, seed=99, instance_base=base)
+        agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(eps),
+                      learning_rate=lr)
+        agent.track_instances = True
+        agent.train(env, task['trials'], task['steps'], 16)
+        launches.append(n)
+        return agent.monitors.lat_trace[:, -3:].double().mean(dim=1).cpu().numpy()
+
+    def batched(task, combos, nb_runs):
+        arrays, which = spread_over_instances(combos, nb_runs)
+        lat = simulate(task, arrays['learning_rate'], arrays['epsilon'], len(which), 0)
+        return [list(lat[which == c]) for c in range(len(combos))]
+
+    def loss(sim, exp):
+        return float(np.mean([(np.mean(sim[t]) - exp[t]) ** 2 for t in sim]))
+
+    d1, d2 = tmp_path / 'vec', tmp_path / 'seq'
+    d1.mkdir()
+    d2.mkdir()
+    vec = GridSearchOptimizer(str(d1) + '/', grid, nb_runs=runs)
+    fit_v = vec.fit_vectorised(batched, tasks, data, loss)
+    assert launches == [24, 24] and len(fit_v) == 6
+
+    seq = GridSearchOptimizer(str(d2) + '/', grid, nb_runs=1)
+    order = {key: c for c, key in enumerate(seq.parameter_combinations)}
+
+    def one(task, params):   # all runs of one combination, at the instance ids they had above
+        c = order[(params['learning_rate'], params['epsilon'])]
+        return simulate(task, params['learning_rate'], params['epsilon'], runs, c * runs)
+
+    fit_s = seq.fit(one, tasks, data, lambda sim, exp: loss({t: sim[t][0] for t in sim}, exp))
+    assert list(fit_s) == list(fit_v)
+    assert [fit_s[k] for k in fit_s] == [fit_v[k] for k in fit_v]
+    assert len(set(fit_v.values())) > 1
+
+
 @pytest.mark.parametrize('n,worlds', [(4100, 1), (200, 3)])
 def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds):
     """Runs without planning take the lane-per-instance kernel (64 instances per wave): Q-learning

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1000
+    assert lib.cobel_abi_version() == 1001
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -32,13 +32,43 @@ def test_struct_layouts_match_the_header():
     """ctypes mirrors of the run structs have the size the C compiler gives them."""
     from cobel_amd import _lib
     src = ('#include "cobel_hip.h"\n#include <stdio.h>\n'
-           'int main(){printf("%zu %zu\\n", sizeof(cobel_tab_run_t), sizeof(cobel_sr_run_t));}')
+           'int main(){printf("%zu %zu %zu\\n", sizeof(cobel_tab_run_t), sizeof(cobel_sr_run_t), '
+           'sizeof(cobel_param_set_t));}')
     exe = '/tmp/cobel_sizeof_%d' % os.getpid()
     subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe],
                    input=src.encode(), check=True)
-    a, b = subprocess.check_output([exe]).split()
+    a, b, c = subprocess.check_output([exe]).split()
     os.remove(exe)
     assert int(a) == C.sizeof(_lib.TabRun) and int(b) == C.sizeof(_lib.SRRun)
+    assert int(c) == C.sizeof(_lib.ParamSet) == 512
+
+
+@pytest.mark.parametrize('eps', [0.0, 0.1, 0.3, 1.0])
+def test_param_set_constants_follow_the_reference_policy(eps):
+    """cobel_param_set_fill (host code, no GPU): the epsilon-greedy constants of a parameter set
+    are the reference's own float64 expressions (policy/greedy.py:83-86) — eps / n,
+    (1 - eps) / n_ties, and per tie pattern the integer thresholds ceil(cdf * 2^53) of the
+    normalised CDF that oracle/ref_loop.RefEpsilonGreedy (pinned to the reference's KAT) forms."""
+    import math
+    from cobel_amd import _lib
+    from oracle.ref_loop import RefEpsilonGreedy
+    ps = _lib.ParamSet()
+    _lib.check(_lib.lib().cobel_param_set_fill(0.7, 0.95, eps, 0.8, C.byref(ps)))
+    assert (ps.alpha, ps.gamma, ps.epsilon, ps.model_lr) == (0.7, 0.95, eps, 0.8)
+    assert ps.alpha_f == np.float32(0.7) and ps.gamma_f == np.float32(0.95)
+    assert ps.model_lr_f == np.float32(0.8)
+    for n in range(1, 5):
+        assert ps.eps_base[n] == eps / n and ps.eps_bonus[n] == ((1.0 - eps) * 1.0) / n
+    pol = RefEpsilonGreedy(eps, None)
+    for t in range(1, 16):
+        v = np.array([1.0 if (t >> a) & 1 else 0.0 for a in range(4)], dtype=np.float32)
+        cdf = np.cumsum(pol.get_action_probs(v))
+        cdf /= cdf[-1]
+        for k in range(3):
+            want = math.ceil(math.ldexp(float(cdf[k]), 53))
+            assert ps.eps_thr[t][k] == min(want, 2 ** 64 - 1), (t, k)
+    with pytest.raises(AssertionError):
+        _lib.check(_lib.lib().cobel_param_set_fill(0.5, 0.5, 1.5, 0.9, C.byref(ps)))
 
 
 def test_argument_errors_map_to_reference_exceptions():
@@ -269,3 +299,69 @@ def test_torch_network_adapter_contract():
     target.blend_from(stack, 0.01)
     w0, w1, wt = base.get_weights()[0], stack.get_weights(1)[0], target.get_weights(1)[0]
     assert np.allclose(wt, w0 + 0.01 * (w1 - w0), rtol=1e-12)
+
+
+def _opt_sim(task, params):
+    return task['bias'] + params['x_1'] + params['x_2'] ** 2 + params['x_3'] ** 3
+
+
+def _opt_loss(data_sim, data_exp):
+    error = 0.
+    for t in data_sim:
+        error += (np.mean(data_sim[t]) - data_exp[t]) ** 2
+    return error / len(data_sim)
+
+
+def test_grid_search_matches_reference(golden, tmp_path):
+    """GridSearchOptimizer: 'nested' and 'systematic' enumerate the combinations in the
+    reference's order (grid_search.py:112-171); fit() leaves the same files and fitness values;
+    fit_vectorised() over a batched simulation gives the same fit; recompute_fit() reads the
+    stored simulation data back."""
+    import pickle
+    from cobel_amd.optimizer import GridSearchOptimizer, spread_over_instances
+    D = golden('optimizer_kat')
+    params = {'x_1': [0, 1, 2, 3, 4], 'x_2': np.array([0.4, 0.1, 0.2, 0.3, 0.0]),
+              'x_3': [0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.1]}
+    for order in ('nested', 'systematic'):
+        opt = GridSearchOptimizer(str(tmp_path) + '/', params, order=order)
+        keys = np.array(list(opt.parameter_combinations), dtype=np.float64)
+        assert np.array_equal(keys, D['keys_' + order]), order
+        k0 = next(iter(opt.parameter_combinations))
+        assert opt.parameter_combinations[k0] == dict(zip(params, k0))
+    shuffled = GridSearchOptimizer(str(tmp_path) + '/', params, order='shuffled',
+                                   rng=np.random.default_rng(5))
+    assert sorted(shuffled.parameter_combinations) == sorted(opt.parameter_combinations)
+
+    small = {'x_1': [0, 2, 4], 'x_2': np.array([0.3, 0.1]), 'x_3': [0.5, 0.9]}
+    tasks = {'task_1': {'bias': 0.0}, 'task_2': {'bias': 1.5}}
+    data = {t: _opt_sim(tasks[t], {'x_1': 2, 'x_2': 0.1, 'x_3': 0.9}) for t in tasks}
+    d1 = tmp_path / 'seq'
+    d1.mkdir()
+    opt = GridSearchOptimizer(str(d1) + '/', small, nb_runs=2)
+    fit = opt.fit(_opt_sim, tasks, data, _opt_loss, store_simulation_data=True)
+    assert np.array_equal(np.array(list(fit), dtype=np.float64), D['fit_keys'])
+    assert np.array_equal(np.array([fit[k] for k in fit]), D['fit_values'])
+    assert sorted(os.listdir(d1)) == list(D['fit_files'])
+    with open(d1 / 'fit.pkl', 'rb') as fh:
+        assert pickle.load(fh) == fit
+
+    calls = []
+
+    def batched(task, combos, nb_runs):
+        calls.append(len(combos))
+        arrays, which = spread_over_instances(combos, nb_runs)
+        assert len(which) == len(combos) * nb_runs and set(arrays) == set(small)
+        vals = task['bias'] + arrays['x_1'] + arrays['x_2'] ** 2 + arrays['x_3'] ** 3
+        return [list(vals[which == c]) for c in range(len(combos))]
+
+    d2 = tmp_path / 'vec'
+    d2.mkdir()
+    vec = GridSearchOptimizer(str(d2) + '/', small, nb_runs=2)
+    fit_v = vec.fit_vectorised(batched, tasks, data, _opt_loss, store_simulation_data=True)
+    assert calls == [12, 12]                       # one call per task, all combinations at once
+    assert list(fit_v) == list(fit) and np.allclose([fit_v[k] for k in fit_v],
+                                                    [fit[k] for k in fit], rtol=0, atol=1e-15)
+    assert sorted(os.listdir(d2)) == list(D['fit_files'])
+    again = GridSearchOptimizer(str(d2) + '/', small, nb_runs=2)
+    assert again.recompute_fit(data, lambda sim, exp: 7.0) == {k: 7.0 for k in fit}
+    assert again.fit_vectorised(batched, tasks, data, _opt_loss) == fit_v and calls == [12, 12]
