@@ -45,6 +45,7 @@ class TabRun(C.Structure):
         ('replay_log', C.c_void_p),
         ('inst', C.c_void_p), ('action_mask', C.c_void_p),
         ('lat_sum', C.c_void_p), ('lat_cnt', C.c_void_p), ('reward_sum', C.c_void_p),
+        ('resp_cnt', C.c_void_p),
         ('lat_trace', C.c_void_p), ('occupancy', C.c_void_p), ('steps_done', C.c_void_p),
         ('last_exp', C.c_void_p),
         ('n', C.c_int32), ('log_cap', C.c_int32), ('trial_cap', C.c_int32),
@@ -64,6 +65,7 @@ class SRRun(C.Structure):
         ('sr', C.c_void_p), ('trans', C.c_void_p), ('rewards', C.c_void_p), ('inst', C.c_void_p),
         ('action_mask', C.c_void_p),
         ('lat_sum', C.c_void_p), ('lat_cnt', C.c_void_p), ('reward_sum', C.c_void_p),
+        ('resp_cnt', C.c_void_p),
         ('lat_trace', C.c_void_p), ('occupancy', C.c_void_p), ('steps_done', C.c_void_p),
         ('last_exp', C.c_void_p),
         ('n', C.c_int32), ('trial_cap', C.c_int32), ('instance_base', C.c_uint32),

@@ -79,10 +79,12 @@ class DeviceMonitors:
     """Per-trial reductions written by the kernels: escape latency (``logs['steps']``,
     monitor/behavior.py:82), trial reward, and per-state visit counts."""
 
-    def __init__(self, device, n_worlds: int, n_states: int, occupancy: bool = False) -> None:
+    def __init__(self, device, n_worlds: int, n_states: int, occupancy: bool = False,
+                 responses: bool = False) -> None:
         self.device = device
         self.cap = 0
-        self.lat_sum = self.lat_cnt = self.reward_sum = None
+        self.lat_sum = self.lat_cnt = self.reward_sum = self.resp_cnt = None
+        self.responses = responses    # count rewarded trials (ResponseMonitor) — opt-in
         self.occupancy = (torch.zeros((n_worlds, n_states), dtype=torch.int64, device=device)
                           if occupancy else None)
         self.steps_done = torch.zeros(1, dtype=torch.int64, device=device)
@@ -98,6 +100,8 @@ class DeviceMonitors:
             self.lat_sum = grow(self.lat_sum, torch.int64)
             self.lat_cnt = grow(self.lat_cnt, torch.int64)
             self.reward_sum = grow(self.reward_sum, torch.float64)
+            if self.responses:
+                self.resp_cnt = grow(self.resp_cnt, torch.int64)
             if per_instance or self.lat_trace is not None:
                 new = torch.full((n_envs, trials), -1, dtype=torch.int32, device=self.device)
                 if self.lat_trace is not None:
@@ -113,7 +117,8 @@ class DeviceMonitors:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        bufs = [b for b in (self.lat_sum, self.lat_cnt, self.occupancy, self.steps_done)
+        bufs = [b for b in (self.lat_sum, self.lat_cnt, self.resp_cnt, self.occupancy,
+                            self.steps_done)
                 if b is not None]
         flat = torch.cat([b.reshape(-1) for b in bufs])
         dist.all_reduce(flat)
@@ -126,6 +131,14 @@ class DeviceMonitors:
 
     def mean_latency(self) -> np.ndarray:
         s, c = self.lat_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return np.where(c > 0, s / np.maximum(c, 1), np.nan)
+
+    def mean_response(self) -> np.ndarray:
+        """Fraction of instances rewarded in each trial (ResponseMonitor's default response,
+        monitor/behavior.py:286-289, averaged over instances)."""
+        assert self.resp_cnt is not None, 'set agent.track_responses = True before training'
+        s, c = self.resp_cnt.cpu().numpy(), self.lat_cnt.cpu().numpy()
         with np.errstate(invalid='ignore', divide='ignore'):
             return np.where(c > 0, s / np.maximum(c, 1), np.nan)
 
@@ -148,6 +161,7 @@ class FusedAgent(Agent):
         self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
         self.mask_actions = False
         self.track_occupancy = False
+        self.track_responses = False   # per-trial count of rewarded instances (ResponseMonitor)
         self.track_instances = False   # keep per-instance latency traces [N, trials]
         self.device = None
         self.n_envs = None
@@ -209,7 +223,7 @@ class FusedAgent(Agent):
         assert int(interface.observation_space.n) == self.n_states
         self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)
         self.monitors = DeviceMonitors(self.device, interface.handle.n_worlds, self.n_states,
-                                       self.track_occupancy)
+                                       self.track_occupancy, self.track_responses)
         self._last_exp = torch.zeros((self.n_envs, 6), dtype=torch.int32, device=self.device)
         self._alloc_tables()
 

@@ -73,7 +73,7 @@ class TabularAgent(FusedAgent):
         self._mask_dev = self._mask_bits() if (flags & _lib.F_MASK_ACTIONS) else None
         run.action_mask = _lib.ptr(self._mask_dev)
         run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
-        run.reward_sum = _lib.ptr(mon.reward_sum)
+        run.reward_sum, run.resp_cnt = _lib.ptr(mon.reward_sum), _lib.ptr(mon.resp_cnt)
         run.lat_trace = _lib.ptr(mon.lat_trace)
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done = _lib.ptr(mon.steps_done)

@@ -1,1 +1,2 @@
-from .behavior import EscapeLatencyMonitor, Monitor, RewardMonitor  # noqa: F401
+from .behavior import (EscapeLatencyMonitor, Monitor, QMonitor, ResponseMonitor,  # noqa: F401
+                       RewardMonitor, TrajectoryMonitor)

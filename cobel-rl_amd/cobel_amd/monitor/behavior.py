@@ -1,5 +1,5 @@
-"""Behavioural monitors — ``EscapeLatencyMonitor`` and ``RewardMonitor`` of the reference
-(monitor/behavior.py:14-209) without the plotting.
+"""Behavioural monitors of the reference (monitor/behavior.py:16-464: ``EscapeLatencyMonitor``,
+``RewardMonitor``, ``ResponseMonitor``, ``TrajectoryMonitor``, ``QMonitor``) without the plotting.
 
 ``update(logs)`` has the reference's semantics (``latency_trace[trial] = logs['steps']`` and the
 11-trial running nan-mean, behavior.py:82-85), so it can be registered under ``on_trial_end``
@@ -72,3 +72,70 @@ class RewardMonitor(Monitor):
 
     def get_trace(self):
         return self.reward_trace
+
+
+class ResponseMonitor(Monitor):
+    """Per-trial responses and their cumulative curve (behavior.py:212-301).  A response is what
+    the user's callback put into ``logs['response']``; without one it is whether the trial was
+    rewarded."""
+
+    def __init__(self, trials: int, widget=None) -> None:
+        super().__init__(widget)
+        self.responses = np.full(trials, float('nan'), dtype='float')
+        self.CRC = np.copy(self.responses)
+
+    def update(self, logs: dict) -> None:
+        trial = logs['trial']
+        if 'response' in logs:
+            self.responses[trial] = logs['response']
+        else:
+            self.responses[trial] = int(logs['trial_reward'] > 0)
+        self.CRC[trial] = np.sum(self.responses[: (trial + 1)])
+
+    def update_from_device(self, monitors, reduce: bool = True) -> None:
+        """Vectorised runs: the response of a trial is the FRACTION of instances rewarded in it
+        (mean of the per-instance default responses)."""
+        if reduce:
+            monitors.all_reduce()
+        rate = monitors.mean_response()
+        for trial in range(min(len(rate), len(self.responses))):
+            if not np.isnan(rate[trial]):
+                self.update({'trial': trial, 'response': rate[trial]})
+
+    def get_trace(self):
+        return self.responses
+
+
+class TrajectoryMonitor(Monitor):
+    """Positions visited, one list per trial (behavior.py:304-385); register under
+    ``on_step_end``."""
+
+    def __init__(self, trials: int, env, widget=None) -> None:
+        super().__init__(widget)
+        self.env = env
+        self.trajectory_trace: list = []
+        self.current_trial = None
+
+    def update(self, logs: dict) -> None:
+        if self.current_trial != logs['trial_session']:
+            self.current_trial = logs['trial_session']
+            self.trajectory_trace.append([])
+        self.trajectory_trace[-1].append(self.env.get_position())
+
+    def get_trace(self):
+        return self.trajectory_trace
+
+
+class QMonitor(Monitor):
+    """Q-function of a fixed set of observations after every update (behavior.py:388-464)."""
+
+    def __init__(self, trials: int, observations, widget=None) -> None:
+        super().__init__(widget)
+        self.observations = observations
+        self.q_trace: list = []
+
+    def update(self, logs: dict) -> None:
+        self.q_trace.append(logs['agent'].predict_on_batch(self.observations))
+
+    def get_trace(self):
+        return self.q_trace

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
         if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
         if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
         if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
+        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + trial, 1ull);
         if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
       }
       trial += 1;

@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
         if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
         if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
+        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + trial, 1ull);
         if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
       }
       trial += 1;
@@ -767,11 +768,14 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   // write one cached accumulator back to the global monitors
   auto evict = [&](int k) {
     const int t = wtag[k];
-    const uint32_t c = wcnt[k];
+    // (low half: instances that finished the trial; high half: those with a positive reward —
+    //  a slot serves one trial index of one wave, so neither exceeds 64)
+    const uint32_t c = wcnt[k] & 0xffffu, rc = wcnt[k] >> 16;
     if (c && t >= 0 && t < A.r.trial_cap) {
       if (A.r.lat_sum) atomicAdd(A.r.lat_sum + t, (unsigned long long)wsum[k]);
       if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + t, (unsigned long long)c);
       if (A.r.reward_sum) atomicAdd(A.r.reward_sum + t, wrew[k]);
+      if (A.r.resp_cnt && rc) atomicAdd(A.r.resp_cnt + t, (unsigned long long)rc);
     }
     wrew[k] = 0.0;
     wsum[k] = 0u;
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
         while (__any(pending)) {
           if (pending && wtag[slot] == trial) {
             atomicAdd(&wsum[slot], (uint32_t)step);
-            atomicAdd(&wcnt[slot], 1u);
+            atomicAdd(&wcnt[slot], trew > 0.0 ? 0x10001u : 1u);
             atomicAdd(&wrew[slot], trew);
             pending = false;
           }
@@ -1101,7 +1105,7 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
       lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
       r.n >= 64 && !(r.flags & COBEL_F_FORCE_WAVE)) {
     const bool one = world->n_worlds == 1;
-    const bool mon = r.lat_sum || r.lat_cnt || r.reward_sum;
+    const bool mon = r.lat_sum || r.lat_cnt || r.reward_sum || r.resp_cnt;
     const size_t bytes = lds_lpi + (mon ? (size_t)kMonBytes : 0);
     const dim3 grid((unsigned)((r.n + 63) / 64));
 #define COBEL_LPI(ONE, MON)                                                                    \

@@ -226,6 +226,8 @@ typedef struct {
   unsigned long long* lat_sum;  /* [trial_cap] sum over instances of logs['steps']           */
   unsigned long long* lat_cnt;  /* [trial_cap] instances that finished that trial            */
   double* reward_sum;           /* [trial_cap] sum of trial rewards                          */
+  unsigned long long* resp_cnt; /* [trial_cap] instances whose trial reward was > 0: the default
+                                   response of ResponseMonitor (monitor/behavior.py:286-289)    */
   int32_t* lat_trace;           /* [N][trial_cap] per-instance logs['steps'], or NULL        */
   unsigned long long* occupancy;/* [n_worlds][S] visits of next_state                        */
   unsigned long long* steps_done; /* [1] env steps executed by this call (added)             */
@@ -289,6 +291,7 @@ typedef struct {
   unsigned long long* lat_sum;
   unsigned long long* lat_cnt;
   double* reward_sum;
+  unsigned long long* resp_cnt;
   int32_t* lat_trace;
   unsigned long long* occupancy;
   unsigned long long* steps_done;

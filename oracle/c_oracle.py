@@ -122,6 +122,7 @@ class TabOracle:
         self.lat_sum = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.lat_cnt = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.reward_sum = np.zeros(max(trial_cap, 1))
+        self.resp_cnt = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.occupancy = np.zeros((world.W, S), dtype=np.uint64) if occupancy else None
 
     def run(self, trials_target: int, steps_per_trial: int, batch: int = 0, flags: int = F_LEARN,
@@ -138,7 +139,7 @@ class TabOracle:
             C.byref(self.world.c), C.byref(c), _p(self.inst), _p(self.Q), _p(self.MR),
             _p(self.MS), _p(self.MT), _p(lg[0]), _p(lg[1]), _p(lg[2]), _p(lg[3]), _p(lg[4]),
             _p(self.mask), _p(self.lat_trace), _p(self.lat_sum), _p(self.lat_cnt),
-            _p(self.reward_sum), _p(self.occupancy), C.c_int32(trace_inst),
+            _p(self.reward_sum), _p(self.resp_cnt), _p(self.occupancy), C.c_int32(trace_inst),
             _p(trace) if trace_cap else None, C.c_int64(trace_cap), C.byref(tlen))
         assert rc == 0
         return trace[: tlen.value]
@@ -166,6 +167,7 @@ class SROracle:
         self.lat_sum = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.lat_cnt = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.reward_sum = np.zeros(max(trial_cap, 1))
+        self.resp_cnt = np.zeros(max(trial_cap, 1), dtype=np.uint64)
         self.occupancy = np.zeros((world.W, S), dtype=np.uint64) if occupancy else None
 
     def run(self, trials_target: int, steps_per_trial: int, flags: int = F_LEARN,
@@ -179,7 +181,7 @@ class SROracle:
         rc = lib().orc_sr_run(
             C.byref(self.world.c), C.byref(c), _p(self.inst), _p(self.SR), _p(self.T),
             _p(self.RW), _p(self.mask), _p(self.lat_trace), _p(self.lat_sum), _p(self.lat_cnt),
-            _p(self.reward_sum), _p(self.occupancy), C.c_int32(trace_inst),
+            _p(self.reward_sum), _p(self.resp_cnt), _p(self.occupancy), C.c_int32(trace_inst),
             _p(trace) if trace_cap else None, _p(qtrace) if trace_cap else None,
             C.c_int64(trace_cap), C.byref(tlen))
         assert rc == 0

@@ -154,7 +154,8 @@ static void td_planning(double* Q, int s, int a, double r, int ns, int nt, doubl
 int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q, double* MR,
                 int32_t* MS, int32_t* MT, int32_t* LS, int32_t* LA, double* LR, int32_t* LNS,
                 int32_t* LNT, const uint8_t* action_mask, int32_t* lat_trace,
-                uint64_t* lat_sum, uint64_t* lat_cnt, double* reward_sum, uint64_t* occupancy,
+                uint64_t* lat_sum, uint64_t* lat_cnt, double* reward_sum, uint64_t* resp_cnt,
+                uint64_t* occupancy,
                 int32_t trace_inst, double* trace, int64_t trace_cap, int64_t* trace_len) {
   const int S = w->n_states, f32 = c->f32;
   const int learn = (c->flags & F_LEARN) != 0;
@@ -240,6 +241,8 @@ int orc_tab_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* Q,
           if (lat_sum) lat_sum[t] += (uint64_t)in->step;
           if (lat_cnt) lat_cnt[t] += 1;
           if (reward_sum) reward_sum[t] += in->trial_reward;
+          /* ResponseMonitor's default response: int(trial_reward > 0) (monitor/behavior.py:289) */
+          if (resp_cnt && in->trial_reward > 0.0) resp_cnt[t] += 1;
           if (lat_trace) lat_trace[(size_t)i * c->trial_cap + t] = in->step;
         }
         in->trial += 1;
@@ -293,7 +296,8 @@ double orc_pairwise_dot(const double* a, const double* b, int n, int f32) {
  * instance trace_inst. */
 int orc_sr_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* SR, int32_t* T,
                double* RW, const uint8_t* action_mask, int32_t* lat_trace, uint64_t* lat_sum,
-               uint64_t* lat_cnt, double* reward_sum, uint64_t* occupancy, int32_t trace_inst,
+               uint64_t* lat_cnt, double* reward_sum, uint64_t* resp_cnt, uint64_t* occupancy,
+               int32_t trace_inst,
                double* trace, double* qtrace, int64_t trace_cap, int64_t* trace_len) {
   const int S = w->n_states, f32 = c->f32;
   const int learn = (c->flags & F_LEARN) != 0;
@@ -366,6 +370,8 @@ int orc_sr_run(const orc_world* w, const orc_cfg* c, orc_inst* inst, double* SR,
           if (lat_sum) lat_sum[t] += (uint64_t)in->step;
           if (lat_cnt) lat_cnt[t] += 1;
           if (reward_sum) reward_sum[t] += in->trial_reward;
+          /* ResponseMonitor's default response: int(trial_reward > 0) (monitor/behavior.py:289) */
+          if (resp_cnt && in->trial_reward > 0.0) resp_cnt[t] += 1;
           if (lat_trace) lat_trace[(size_t)i * c->trial_cap + t] = in->step;
         }
         in->trial += 1;

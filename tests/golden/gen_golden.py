@@ -443,8 +443,21 @@ def gen_monitor(worlds):
     trajs = [world['coordinates'][s] for s in traj_states]
     occ = {m: get_occupancy_map(trajs, 8, 8, 1.0, m) for m in ('expand', 'include', 'ignore')}
     occ2 = get_occupancy_map(trajs, 8, 8, 2.0, 'expand')
+    # RewardMonitor / ResponseMonitor (behavior.py:174-199, :269-290) on the same trial order
+    from cobel.monitor import ResponseMonitor, RewardMonitor
+    rewards = np.round(rng.random(trials) * 2.0 - 0.5, 3)
+    responses = rng.integers(0, 2, trials)
+    rew_mon, resp_a, resp_b = RewardMonitor(trials, (-0.5, 1.5)), ResponseMonitor(trials), \
+        ResponseMonitor(trials)
+    for t in order:
+        rew_mon.update({'trial': t, 'trial_reward': float(rewards[t])})
+        resp_a.update({'trial': t, 'trial_reward': float(rewards[t])})
+        resp_b.update({'trial': t, 'trial_reward': float(rewards[t]), 'response': int(responses[t])})
     np.savez_compressed(
         os.path.join(HERE, 'monitor_kat.npz'), steps=steps, order=np.array(order),
+        rewards=rewards, responses=responses, reward_trace=rew_mon.reward_trace,
+        reward_avg=rew_mon.reward_trace_avg, resp_default=resp_a.responses, crc_default=resp_a.CRC,
+        resp_given=resp_b.responses, crc_given=resp_b.CRC,
         latency=mon.latency_trace, latency_avg=mon.latency_trace_avg, max_steps=np.int64(max_steps),
         traj_states=np.concatenate(traj_states), traj_len=np.array([30, 1, 77]),
         occ_expand=occ['expand'], occ_include=occ['include'], occ_ignore=occ['ignore'],

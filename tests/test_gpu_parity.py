@@ -314,6 +314,7 @@ def _bench_like(torch, cfg_name, n, launches, budget, base=0):
     env.env_ctr.zero_()
     env.reset()
     agent.track_occupancy = True
+    agent.track_responses = True
     runner = bench.Runner(cfg, env, agent)
     for _ in range(launches):
         runner.launch()
@@ -362,6 +363,7 @@ def test_c3_dynaq_mazes_vs_oracle(torch_cuda):
     _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'ctr_memory', 'flags'])
     assert np.array_equal(agent.monitors.lat_sum.cpu().numpy()[:64], o.lat_sum.astype(np.int64))
     assert np.array_equal(agent.monitors.lat_cnt.cpu().numpy()[:64], o.lat_cnt.astype(np.int64))
+    assert np.array_equal(agent.monitors.resp_cnt.cpu().numpy()[:64], o.resp_cnt.astype(np.int64))
     assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
     assert agent.env_steps() == n * launches * budget == int(o.inst['steps'].sum())
 
@@ -379,6 +381,14 @@ def test_c2_qlearning_vs_oracle(torch_cuda):
     _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'flags'])
     assert np.array_equal(agent.monitors.lat_sum.cpu().numpy(), o.lat_sum.astype(np.int64))
     assert np.array_equal(agent.monitors.lat_cnt.cpu().numpy(), o.lat_cnt.astype(np.int64))
+    assert np.array_equal(agent.monitors.resp_cnt.cpu().numpy(), o.resp_cnt.astype(np.int64))
+    assert o.resp_cnt.sum() > 0 and (o.resp_cnt <= o.lat_cnt).all()
+    from cobel_amd.monitor import ResponseMonitor
+    rm = ResponseMonitor(4096)
+    rm.update_from_device(agent.monitors, reduce=False)
+    done = o.lat_cnt > 0
+    assert np.array_equal(rm.responses[done], o.resp_cnt[done] / o.lat_cnt[done])
+    assert np.isnan(rm.responses[~done]).all()
     assert np.allclose(agent.monitors.reward_sum.cpu().numpy(), o.reward_sum, rtol=0, atol=1e-9)
     assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
 
@@ -397,6 +407,8 @@ def test_c4_sr_32x32_vs_oracle(torch_cuda):
     assert np.array_equal(agent._sr.cpu().numpy().astype(np.float64), o.SR)
     _cmp_inst(agent, o, ['state', 'step', 'trial', 'ctr_env', 'ctr_policy', 'flags'])
     assert np.array_equal(agent.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
+    assert np.array_equal(agent.monitors.resp_cnt.cpu().numpy()[:16], o.resp_cnt.astype(np.int64))
+    assert np.array_equal(agent.monitors.lat_cnt.cpu().numpy()[:16], o.lat_cnt.astype(np.int64))
 
 
 def test_sr_retrieve_q_matches_numpy_sum(torch_cuda):

@@ -149,6 +149,41 @@ def test_monitors_match_reference(golden):
     assert np.array_equal(mon.latency_trace, k['latency'], equal_nan=True)
     assert np.array_equal(mon.latency_trace_avg, k['latency_avg'], equal_nan=True)
     assert mon.get_trace() is mon.latency_trace
+    # RewardMonitor / ResponseMonitor (monitor/behavior.py:174-199, :269-290)
+    from cobel_amd.monitor import QMonitor, ResponseMonitor, RewardMonitor, TrajectoryMonitor
+    n = len(k['steps'])
+    rew, ra, rb = RewardMonitor(n, (-0.5, 1.5)), ResponseMonitor(n), ResponseMonitor(n)
+    for t in k['order']:
+        t = int(t)
+        rew.update({'trial': t, 'trial_reward': float(k['rewards'][t])})
+        ra.update({'trial': t, 'trial_reward': float(k['rewards'][t])})
+        rb.update({'trial': t, 'trial_reward': float(k['rewards'][t]),
+                   'response': int(k['responses'][t])})
+    assert np.array_equal(rew.reward_trace, k['reward_trace'], equal_nan=True)
+    assert np.array_equal(rew.reward_trace_avg, k['reward_avg'], equal_nan=True)
+    assert np.array_equal(ra.responses, k['resp_default'], equal_nan=True)
+    assert np.array_equal(ra.CRC, k['crc_default'], equal_nan=True)
+    assert np.array_equal(rb.responses, k['resp_given'], equal_nan=True)
+    assert np.array_equal(rb.CRC, k['crc_given'], equal_nan=True)
+
+    class Env:           # behavior.py:359-372: a new list whenever logs['trial_session'] changes
+        pos = 0
+
+        def get_position(self):
+            self.pos += 1
+            return np.array([self.pos, 0.0])
+    tm = TrajectoryMonitor(5, Env())
+    for session in (0, 0, 0, 1, 1, 0):
+        tm.update({'trial_session': session})
+    assert [len(t) for t in tm.get_trace()] == [3, 2, 1] and tm.get_trace()[1][0][0] == 4
+
+    class Agent:         # behavior.py:441-451
+        def predict_on_batch(self, obs):
+            return np.asarray(obs)[:, None] * np.ones(4)
+    qm = QMonitor(5, np.arange(3))
+    qm.update({'agent': Agent()})
+    qm.update({'agent': Agent()})
+    assert len(qm.get_trace()) == 2 and qm.get_trace()[0].shape == (3, 4)
 
 
 def test_occupancy_map_matches_reference(golden, golden_worlds):
