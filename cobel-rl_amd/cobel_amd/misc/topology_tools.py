@@ -1,11 +1,11 @@
 """Topology-graph builders for the 4-neighbour environments the HIP env kernels serve.
 
 Call surface of the reference's ``cobel.misc.topology_tools`` (misc/topology_tools.py:14-373) for
-``linear_track``, ``grid`` and ``t_maze``: same arguments, same ``(nodes, starting_nodes)`` result
+``linear_track``, ``grid``, ``t_maze`` and ``cross``: same arguments, same ``(nodes, starting_nodes)`` result
 with ``nodes[id] = {'id', 'pose', 'terminal', 'reward', 'neighbors'}``; ids are ``str(n)`` in
 construction order, neighbours are ordered [left, up, right, down] and point back at the node
-itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` (six neighbours),
-``cross`` and the shapely-based obstacle pruning are outside the accelerated path.
+itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` (six neighbours, i.e.
+six actions) and the shapely-based obstacle pruning are outside the accelerated path.
 """
 from __future__ import annotations
 
@@ -95,3 +95,41 @@ def grid(nb_nodes, limits=(0.0, 1.0), reward: float = 1.0, location=None):
     starting = list(nodes.keys())
     starting.remove(location)
     return nodes, starting
+
+
+def cross(nb_nodes_arm: int, nb_nodes_width: int, spacing: float = 1.0, rotation: float = 0.0):
+    """Cross arena (topology_tools.py:376-469): four arms of ``nb_nodes_arm`` x ``nb_nodes_width``
+    nodes around a square centre, no terminal node, every node a starting node; node ids run
+    through the upper arm (top row first), the horizontal bar, then the lower arm.  Poses are laid
+    out on the unit square, scaled to ``spacing``, centred and rotated by ``rotation`` degrees."""
+    assert nb_nodes_arm > 0, 'The arm must be at least 1 node long!'
+    assert nb_nodes_width > 0, 'The corridors must be at least 1 node wide!'
+    assert spacing > 0, 'Node spacing must be positive!'
+    a, w = nb_nodes_arm, nb_nodes_width
+    d = 2 * a + w
+    ticks = np.linspace(0, 1.0, d)
+    unit = [(ticks[a + j], ticks[-(1 + i)]) for i in range(a) for j in range(w)]
+    unit += [(ticks[i], ticks[-(a + 1 + j)]) for j in range(w) for i in range(d)]
+    unit += [(ticks[a + j], ticks[-(i + 1 + a + w)]) for i in range(a) for j in range(w)]
+    unit = np.array(unit)
+    n = len(unit)
+    dx = unit[:, None, 0] - unit[None, :, 0]
+    dy = unit[:, None, 1] - unit[None, :, 1]
+    t = 1.1 / (d - 1.0)
+    off = ~np.eye(n, dtype=bool)
+    rules = [(0 < dx) & (dx < t) & (np.abs(dy) < t / 2), (0 > dy) & (dy > -t) & (np.abs(dx) < t / 2),
+             (0 > dx) & (dx > -t) & (np.abs(dy) < t / 2), (0 < dy) & (dy < t) & (np.abs(dx) < t / 2)]
+    extent = (d - 1) * spacing
+    offset = spacing * (d - 1) / 2
+    theta = np.deg2rad(rotation)
+    rot = np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]])
+    nodes = {}
+    for i in range(n):
+        neighbors = []
+        for rule in rules:
+            hit = np.flatnonzero(rule[i] & off[i])
+            neighbors.append(str(hit[-1]) if len(hit) else str(i))
+        x, y = rot @ (np.array((unit[i, 0], unit[i, 1])) * extent - offset)
+        nodes[str(i)] = {'id': str(i), 'pose': (float(x), float(y), 0.0, 0.0, 0.0, 0.0),
+                         'terminal': False, 'reward': 0.0, 'neighbors': neighbors}
+    return nodes, list(nodes.keys())

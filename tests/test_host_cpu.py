@@ -254,14 +254,16 @@ def test_monitor_allreduce_two_ranks_gloo(tmp_path):
 
 
 def test_topology_builders_match_reference(golden):
-    """cobel_amd.misc.topology_tools == the reference's linear_track / t_maze / grid as tables."""
+    """cobel_amd.misc.topology_tools == the reference's linear_track / t_maze / grid / cross as
+    tables."""
     from cobel_amd.misc import topology_tools as tt
     k = golden('topology_kat')
     built = {'linear_10x2': tt.linear_track(10, 2, 1., 20., 'right'),
              'linear_5x1_left': tt.linear_track(5, 1, 0.5, 2., 'left'),
              't_maze_4_3_1': tt.t_maze(4, 3, 1),
              't_maze_3_2_2_left': tt.t_maze(3, 2, 2, 2.0, 3.0, 'left'),
-             'grid_4x3': tt.grid((4, 3)), 'grid_5': tt.grid(5, (0.0, 2.0), 7.0, '12')}
+             'grid_4x3': tt.grid((4, 3)), 'grid_5': tt.grid(5, (0.0, 2.0), 7.0, '12'),
+             'cross_2_1_rot30': tt.cross(2, 1, 0.5, 30.0), 'cross_3_2': tt.cross(3, 2, 2.0)}
     for name, (nodes, starts) in built.items():
         ids = list(nodes.keys())
         assert ids == [str(i) for i in range(len(ids))]
