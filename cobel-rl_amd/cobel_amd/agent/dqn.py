@@ -88,6 +88,10 @@ class DQN(Agent):
             pol.counter -= idle.to(torch.int32)
         return act
 
+    def _q_values(self, obs: torch.Tensor) -> torch.Tensor:
+        """Q-values ``[N, A]`` of the per-instance online networks for observations ``[N, D]``."""
+        return self._online.predict_on_device(obs[:, None, :])[:, 0]
+
     # -- reference surface ----------------------------------------------------------------------
     def retrieve_q(self, state):
         """Q-values of the online network(s) for an observation ``[D]`` or per-instance ``[N, D]``."""
@@ -153,7 +157,7 @@ class DQN(Agent):
         zero64 = torch.zeros(n, dtype=torch.int64, device=dev)
         cap = self.monitors.cap
         while True:
-            q = self._online.predict_on_device(obs[:, None, :])[:, 0]
+            q = self._q_values(obs)
             idle = None if all_active else ~active
             action = self._select(pol, q, interface.instance_base, idle)
             interface.step(action)

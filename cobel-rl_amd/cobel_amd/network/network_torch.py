@@ -196,15 +196,25 @@ class StackedTorchNetwork:
         with torch.no_grad():
             return self.forward(batch)
 
-    def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, active=None) -> None:
+    def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, active=None,
+                        sample_mask=None) -> None:
         """Per instance: mean over the per-sample losses, summed over instances so that every
         instance receives exactly the gradient it would compute alone.  ``active`` ([n] bool)
         freezes the other instances completely — parameters AND optimizer state — as if their
         own single-instance run had simply not executed this step (Adam / AdamW-free path;
-        other optimizers only get their parameters restored)."""
+        other optimizers only get their parameters restored).  ``sample_mask`` ([n, B] bool):
+        instance i trains on the samples it marks only, exactly as if it had been handed that
+        sub-batch (mean over its elements); instances that mark none must be outside ``active``."""
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.criterion(self.forward(batch), targets)
-        loss.reshape(self.n, -1).mean(dim=1).sum().backward()
+        if sample_mask is None:
+            loss.reshape(self.n, -1).mean(dim=1).sum().backward()
+        else:
+            per_sample = loss.reshape(self.n, loss.shape[1], -1)
+            width = per_sample.shape[2]
+            kept = per_sample * sample_mask[..., None].to(per_sample.dtype)
+            count = sample_mask.sum(dim=1).clamp(min=1).to(per_sample.dtype)
+            (kept.sum(dim=(1, 2)) / (count * width)).sum().backward()
         if active is None and getattr(self, '_diverged', False):
             # per-instance step counts exist: torch's optimizer (one shared count) no longer fits
             active = torch.ones(self.n, dtype=torch.bool, device=self.device)

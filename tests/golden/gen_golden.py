@@ -609,6 +609,62 @@ def gen_dyna_dqn():
     np.savez_compressed(os.path.join(HERE, 'dyna_dqn_trace.npz'), **out)
 
 
+def gen_dyna_dsr():
+    """agent/dyna_q.py:711-1150 (DynaDSR) on a 4x4 open field: one-hot observations, float64
+    16-24-16 successor networks (one per action), 16-12-1 reward network, draw-injected streams;
+    one run with the default switches, one with use_DR / use_follow_up_state / terminality
+    respected / periodic target copies."""
+    import torch
+    from collections import OrderedDict
+    from cobel.agent.dyna_q import DynaDSR
+    from cobel.network import TorchNetwork
+    out = {}
+    runs = (('ddsr_default', 0, 3, 15, 12, dict()),
+            ('ddsr_switches', 1, 2, 18, 10, dict(use_DR=True, use_follow_up_state=True,
+                                                 ignore_terminality=False, target_update=3)))
+    for name, inst, trials, steps, B, switches in runs:
+        torch.manual_seed(7 + inst)
+        sr_net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(16, 24)), ('relu_1', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(24, 16))])).double()
+        rw_net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(16, 12)), ('relu_1', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(12, 1))])).double()
+        model_sr, model_rw = TorchNetwork(sr_net), TorchNetwork(rw_net)
+        init_sr, init_rw = model_sr.get_weights(), model_rw.get_weights()
+        world = gt.make_open_field(4, 4, 0, 1)
+        env = Gridworld(world, rng=TapeRNG(SEED, inst, STREAM_ENV))
+        pol = EpsilonGreedy(0.25, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        agent = DynaDSR(env.observation_space, env.action_space, pol, model_sr, model_rw, gamma=0.9)
+        for k, v in switches.items():
+            setattr(agent, k, v)
+        agent.M.rng = TapeRNG(SEED, inst, STREAM_MEMORY)
+        tr = Tracer(None)
+        agent.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            agent.callbacks.custom_callbacks.setdefault(k, [])
+        tr.on_step_end = None
+        torch.set_num_threads(1)
+        agent.train(env, trials, steps, B)
+        d = tr.pack()
+        for i, w in enumerate(init_sr):
+            out['%s/init_sr_%d' % (name, i)] = w
+        for i, w in enumerate(init_rw):
+            out['%s/init_rw_%d' % (name, i)] = w
+        for a in range(4):
+            for i, w in enumerate(agent.models_online[a].get_weights()):
+                out['%s/online_%d_%d' % (name, a, i)] = w
+            for i, w in enumerate(agent.models_target[a].get_weights()):
+                out['%s/target_%d_%d' % (name, a, i)] = w
+        for i, w in enumerate(agent.model_reward.get_weights()):
+            out['%s/reward_%d' % (name, i)] = w
+        out[name + '/state'], out[name + '/action'] = d['state'], d['action']
+        out[name + '/steps'] = d['steps']
+        out[name + '/q_all'] = agent.predict_on_batch(np.arange(16))
+        out[name + '/cfg'] = np.array([inst, trials, steps, B])
+    np.savez_compressed(os.path.join(HERE, 'dyna_dsr_trace.npz'), **out)
+
+
 def _opt_sim(task, params):
     return task['bias'] + params['x_1'] + params['x_2'] ** 2 + params['x_3'] ** 3
 
@@ -647,6 +703,7 @@ def gen_optimizer():
 def main():
     worlds = gen_worlds()
     gen_optimizer()
+    gen_dyna_dsr()
     gen_dyna_dqn()
     gen_dqn()
     gen_topology()

@@ -1117,6 +1117,58 @@ def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     assert np.allclose(q[0].cpu().numpy(), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize('name', ['ddsr_default', 'ddsr_switches'])
+def test_dyna_dsr_matches_reference(torch_cuda, golden, name):
+    """DynaDSR (deep successor representation fed by the tabular Dyna-Q model) on a 4x4 open
+    field, float64, against the reference with the same initial weights and injected draws:
+    identical state / action sequence; the four online and four target successor networks, the
+    reward network and the resulting Q-values within 1e-9.  Instance 0 of three (the others run
+    different streams), so the per-network masked training and step counts are exercised."""
+    torch = torch_cuda
+    from collections import OrderedDict
+    from cobel_amd.agent import DynaDSR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dyna_dsr_trace')
+    inst, trials, steps, B = [int(x) for x in D[name + '/cfg']]
+
+    def net(sizes, tag):
+        m = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(sizes[0], sizes[1])), ('relu_1', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(sizes[1], sizes[2]))])).double()
+        state = m.state_dict()
+        for i, key in enumerate(state):
+            state[key] = torch.as_tensor(D['%s/init_%s_%d' % (name, tag, i)])
+        m.load_state_dict(state)
+        return TorchNetwork(m)
+
+    env = Gridworld(make_open_field(4, 4, 0, 1), n_envs=3, seed=SEED, instance_base=inst)
+    agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.25),
+                    net((16, 24, 16), 'sr'), net((16, 12, 1), 'rw'), gamma=0.9)
+    if name == 'ddsr_switches':
+        agent.use_DR, agent.use_follow_up_state = True, True
+        agent.ignore_terminality, agent.target_update = False, 3
+    seen = []
+    agent.callbacks.custom_callbacks = {'on_trial_end': [lambda logs: seen.append(logs['steps'])]}
+    agent.track_instances = True
+    agent.train(env, trials, steps, B)
+    for a in range(4):
+        for i, w in enumerate(agent.get_weights(a)):
+            assert np.allclose(w, D['%s/online_%d_%d' % (name, a, i)], rtol=1e-9, atol=1e-12), (a, i)
+        for i, w in enumerate(agent.get_weights(a, target=True)):
+            assert np.allclose(w, D['%s/target_%d_%d' % (name, a, i)], rtol=1e-9, atol=1e-12), (a, i)
+    for i, w in enumerate(agent.get_reward_weights()):
+        assert np.allclose(w, D['%s/reward_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
+    q = agent.predict_on_batch(np.arange(16))
+    assert np.allclose(q[0].cpu().numpy(), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
+    assert np.allclose(agent.retrieve_q(5)[0].cpu().numpy(), D[name + '/q_all'][5], rtol=1e-9,
+                       atol=1e-12)
+    # the other two instances ran their own streams and ended up elsewhere
+    assert not np.allclose(q[1].cpu().numpy(), q[0].cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: a scattered sample of instances against the oracle plus
 # size-independent properties (conservation of steps / trials / visits) over all instances.
