@@ -1232,3 +1232,33 @@ def test_full_size_c2_sample_and_conservation(torch_cuda):
     assert np.array_equal(mon.lat_sum.cpu().numpy(), o.lat_sum.astype(np.int64))
     assert np.array_equal(mon.lat_cnt.cpu().numpy(), o.lat_cnt.astype(np.int64))
     assert agent.env_steps() == n * launches * budget == int(inst[:, 10].astype(np.int64).sum())
+
+
+def test_full_size_c4_sample_and_conservation(torch_cuda):
+    """C4 at 16 384 instances x 32x32 (64 GiB of successor matrices): 12 instances spread over
+    the range bit-exact against the oracle (SR rows, transition table, reward estimate); every
+    instance executed the budgeted steps; no instance has more changed SR rows than steps."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip('needs 64 GiB of HBM for the successor matrices')
+    n, launches, budget = 16384, 2, 40
+    cfg, env, agent = _bench_like(torch, 'C4', n, launches, budget)
+    ids = [0, 1, 63, 64, 4097, 8191, 8192, 12345, 16000, 16382, 16383, 777]
+    w = _oracle_world(env.worlds)
+    for g in ids:
+        o = c_oracle.SROracle(w, 1, env.seed, True, instance_base=g)
+        for _ in range(launches):
+            o.run(0x7fffffff, cfg['steps_per_trial'], step_budget=budget)
+        assert np.array_equal(agent._sr[g].cpu().numpy().astype(np.float64), o.SR[0]), g
+        assert np.array_equal(agent._T[g].cpu().numpy().astype(np.int64), o.T[0]), g
+        assert np.array_equal(agent._rw[g].cpu().numpy().astype(np.float64), o.RW[0]), g
+    inst = agent.inst.cpu().numpy()
+    assert (inst[:, 10].astype(np.int64) == launches * budget).all()
+    assert agent.env_steps() == n * launches * budget
+    assert int(agent.monitors.occupancy.sum().item()) == n * launches * budget
+    # a walk of 80 steps changes at most 80 rows: all others are still rows of the identity
+    sr = agent._sr[:128]
+    changed = (sr != torch.eye(1024, device='cuda')[None]).any(dim=2).sum(dim=1)
+    assert int(changed.max().item()) <= launches * budget and int(changed.min().item()) > 0

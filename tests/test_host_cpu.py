@@ -402,3 +402,11 @@ def test_grid_search_matches_reference(golden, tmp_path):
     again = GridSearchOptimizer(str(d2) + '/', small, nb_runs=2)
     assert again.recompute_fit(data, lambda sim, exp: 7.0) == {k: 7.0 for k in fit}
     assert again.fit_vectorised(batched, tasks, data, _opt_loss) == fit_v and calls == [12, 12]
+
+
+def test_graft_entry_build_runs_on_a_gpu_less_host():
+    """__graft_entry__.build(): both Makefiles, the import and the ABI check (what the driver runs
+    here every round)."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.build()
