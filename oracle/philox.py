@@ -23,6 +23,12 @@ Stream layout (shared with ``cobel-rl_amd/csrc/cobel_rng.h`` — keep in sync):
     STREAM_ENV    = 0  c = number of resets so far
     STREAM_POLICY = 1  c = number of select_action()s
     STREAM_MEMORY = 2  c = number of replay batches, sub = position in the batch
+    STREAM_AGENT  = 4  c = draws of the agent's own generator (SFMA dynamic mode, sfma.py:312)
+
+A generator that mixes integer and double draws (SFMAMemory.rng: ``integers`` at the start of a
+replay, ``choice(p=...)`` per reactivation, memory/sfma.py:258-333) takes its doubles from
+``sub = double_sub + j`` (j = position in a vector draw) with ``double_sub = 1``: an integer draw
+and a double draw then never share a Philox block, whatever their counters.
 
 Bounded integers are ``(word * n) >> 32`` (Lemire multiply-shift without the
 rejection step; bias <= n / 2**32).  Uniform doubles follow NumPy's recipe
@@ -32,7 +38,7 @@ from __future__ import annotations
 
 import numpy as np
 
-STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_AUX = 0, 1, 2, 3
+STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_AUX, STREAM_AGENT = 0, 1, 2, 3, 4
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)
@@ -107,15 +113,24 @@ class TapeRNG:
     tests/test_oracle_rng.py against a recording Generator).
     """
 
-    def __init__(self, seed: int, instance: int, stream: int, start: int = 0) -> None:
+    def __init__(self, seed: int, instance: int, stream: int, start: int = 0,
+                 double_sub: int = 0) -> None:
         self.seed, self.instance, self.stream = int(seed), int(instance), int(stream)
         self.index = int(start)
+        self.double_sub = int(double_sub)
         self.log: list = []  # every value handed out, in order (for fixtures)
 
-    def random(self) -> float:
-        u = float(draw_double(self.seed, self.instance, self.index, 0, self.stream))
+    def random(self, size=None):
+        if size is None:
+            u = float(draw_double(self.seed, self.instance, self.index, self.double_sub,
+                                  self.stream))
+            self.index += 1
+            self.log.append(u)
+            return u
+        u = draw_double(self.seed, self.instance, self.index,
+                        self.double_sub + np.arange(int(size)), self.stream)
         self.index += 1
-        self.log.append(u)
+        self.log.append(u.copy())
         return u
 
     def integers(self, low, high=None, size=None):
@@ -140,7 +155,6 @@ class TapeRNG:
         a = np.arange(a) if np.isscalar(a) else np.asarray(a)
         if p is None:
             return a[self.integers(0, len(a), size)]
-        assert size is None
         cdf = np.cumsum(p)
         cdf /= cdf[-1]
-        return a[cdf.searchsorted(self.random(), side='right')]
+        return a[cdf.searchsorted(self.random(size), side='right')]

@@ -429,6 +429,167 @@ def gen_sr(worlds):
     np.savez_compressed(os.path.join(HERE, 'sr_traces.npz'), **out)
 
 
+MODES = ['default', 'reverse', 'forward', 'blend_forward', 'blend_reverse', 'interpolate',
+         'sweeping']
+
+
+def sfma_world_5x5():
+    """The world of unit_tests/test_sfma.py:44-60 and demo/gridworld/demo_sfma.py:36-55."""
+    inv = [(3, 4), (4, 3), (8, 9), (9, 8), (13, 14), (14, 13)]
+    w = gt.make_gridworld(5, 5, terminals=[4], rewards=np.array([[4, 10]]), goals=[4],
+                          invalid_transitions=inv)
+    w['starting_states'] = np.array([12])
+    return w
+
+
+def sfma_world_6x7():
+    """Walls, two rewards of different sign, several starts; short trials time out (replay then
+    starts from an experience drawn by strength, memory/sfma.py:262-270)."""
+    inv_t = [(8, 9), (9, 8), (15, 16), (16, 15), (22, 23), (23, 22), (30, 37), (37, 30)]
+    return gt.make_gridworld(6, 7, terminals=[6, 35], rewards=np.array([[6, 1.0], [35, -0.5], [17, 0.25]]),
+                             goals=[6], invalid_states=[10, 24, 25], invalid_transitions=inv_t,
+                             starting_states=[41, 21, 3, 29])
+
+
+def gen_sfma():
+    """agent/sfma.py:233-458 + memory/sfma.py:195-416 + memory/utils/metrics.py, driven by the
+    build's streams: env / policy as everywhere, SFMAMemory.rng = memory stream with doubles on
+    sub 1, SFMA.rng = agent stream."""
+    from cobel.agent import SFMA
+    from cobel.memory import SFMAMemory
+    from cobel.memory.utils import DR, SR as SRMetric, Euclidean
+    from oracle.philox import STREAM_AGENT
+    worlds = {'sfma_5x5': sfma_world_5x5(), 'sfma_6x7': sfma_world_6x7()}
+    out = {}
+    for wname, w in worlds.items():
+        for k, v in compact(w).items():
+            out['world/%s/%s' % (wname, k)] = v
+        out['world/%s/invalid_transitions' % wname] = np.array(
+            w['invalid_transitions'], dtype=np.int64).reshape(-1, 2)
+        out['metric/%s/DR' % wname] = DR(w['width'], w['height'], w['sas'], 0.9,
+                                         w['invalid_transitions']).D
+        out['metric/%s/SR' % wname] = SRMetric(w['sas'], 0.9).D
+        out['metric/%s/Euclidean' % wname] = Euclidean(w['width'], w['height']).D
+    # name: (world, instance, f32, metric, mode, trials, steps, B, options)
+    cases = {
+        'dr_default_f64': ('sfma_5x5', 0, False, 'DR', 'default', 30, 50, 32, {}),
+        'dr_default_f32': ('sfma_5x5', 0, True, 'DR', 'default', 30, 50, 32, {}),
+        'dr_reverse_f32': ('sfma_5x5', 1, True, 'DR', 'reverse', 10, 50, 32, {'mask': True}),
+        'sr_forward_f32': ('sfma_5x5', 2, True, 'SR', 'forward', 8, 50, 32, {}),
+        'eu_sweeping_f32': ('sfma_5x5', 3, True, 'Euclidean', 'sweeping', 8, 50, 32, {}),
+        'dr_dynamic_f32': ('sfma_5x5', 4, True, 'DR', 'default', 30, 50, 32, {'dynamic': True}),
+        'dr_dynamic_f64': ('sfma_5x5', 4, False, 'DR', 'default', 30, 50, 32, {'dynamic': True}),
+        'sr_random_mask_f32': ('sfma_5x5', 5, True, 'SR', 'default', 20, 50, 32,
+                               {'random': True, 'mask': True}),
+        'dr_random_f32': ('sfma_5x5', 6, True, 'DR', 'default', 24, 50, 20, {'random': True}),
+        'dr_traintest_f32': ('sfma_5x5', 7, True, 'DR', 'reverse', 14, 50, 32,
+                             {'mask': True, 'noreplay_trials': 5, 'test_trials': 5}),
+        'w67_dr_reverse_f32': ('sfma_6x7', 8, True, 'DR', 'reverse', 12, 14, 24, {}),
+        'w67_dr_reverse_f64': ('sfma_6x7', 8, False, 'DR', 'reverse', 12, 14, 24, {}),
+        'w67_sr_blendf_f32': ('sfma_6x7', 9, True, 'SR', 'blend_forward', 20, 14, 16, {}),
+        'w67_sr_blendr_f32': ('sfma_6x7', 10, True, 'SR', 'blend_reverse', 10, 14, 16,
+                              {'mask': True}),
+        'w67_eu_interp_f32': ('sfma_6x7', 11, True, 'Euclidean', 'interpolate', 10, 14, 16, {}),
+        'w67_dr_recency_f32': ('sfma_6x7', 12, True, 'DR', 'default', 20, 14, 16,
+                               {'recency': True, 'C_normalize': True, 'D_normalize': True}),
+        'w67_dr_determ_f32': ('sfma_6x7', 13, True, 'DR', 'reverse', 10, 14, 16,
+                              {'deterministic': True, 'R_normalize': False}),
+        'w67_dr_start_f32': ('sfma_6x7', 14, True, 'DR', 'default', 8, 14, 12,
+                             {'start_replay': True, 'nb_replays': 2}),
+        'w67_sr_mods_f32': ('sfma_6x7', 15, True, 'SR', 'forward', 10, 14, 16,
+                            {'reward_mod_local': True, 'reward_mod': True, 'state_mod': True,
+                             'decay_strength': 0.95, 'decay_inhibition': 0.8,
+                             'reward_modulation': 0.5}),
+        'w67_dr_dynamic_f32': ('sfma_6x7', 16, True, 'DR', 'default', 12, 14, 16,
+                               {'dynamic': True, 'beta': 5.0}),
+    }
+    for name, (wname, inst, f32, mname, mode, trials, steps, B, kw) in cases.items():
+        w = worlds[wname]
+        env = _env(w, inst)
+        if mname == 'DR':
+            metric = DR(w['width'], w['height'], w['sas'], 0.9, w['invalid_transitions'])
+        elif mname == 'SR':
+            metric = SRMetric(w['sas'], 0.9)
+        else:
+            metric = Euclidean(w['width'], w['height'])
+        mem = SFMAMemory(metric, w['states'], 4, rng=TapeRNG(SEED, inst, STREAM_MEMORY, double_sub=1))
+        if 'decay_inhibition' in kw:
+            mem.decay_inhibition = kw['decay_inhibition']
+        if 'decay_strength' in kw:
+            mem.decay_strength = kw['decay_strength']
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        pol_test = EpsilonGreedy(0.0, rng=TapeRNG(SEED, inst, 3)) if kw.get('test_trials') else None
+        ag = SFMA(env.observation_space, env.action_space, pol, mem, pol_test,
+                  rng=TapeRNG(SEED, inst, STREAM_AGENT))
+        ag.M.mode = mode
+        for k in ('recency', 'C_normalize', 'D_normalize', 'R_normalize', 'deterministic',
+                  'reward_mod_local', 'reward_mod', 'state_mod', 'reward_modulation', 'beta'):
+            if k in kw:
+                setattr(ag.M, k, kw[k])
+        for k in ('dynamic', 'random', 'start_replay', 'nb_replays'):
+            if k in kw:
+                setattr(ag, k, kw[k])
+        if f32:
+            ag.Q = ag.Q.astype(np.float32)
+            ag.M.rewards = ag.M.rewards.astype(np.float32)
+        if kw.get('mask'):
+            ag.mask_actions = True
+            ag.action_mask = bump_mask(w)
+        tr = Tracer(ag)
+        rp, modes, td_acc, started = [], [], [], []
+
+        def on_replay_begin(logs, started=started):
+            started.append(('steps' not in logs))   # start-of-trial replays come before 'steps'
+
+        def on_replay_end(logs, rp=rp, ag=ag, started=started):
+            kind = 1 if started[-1] else 0
+            for e in logs['replay']:
+                rp.append((ag.current_trial - (0 if kind else 1), kind, e['state'], e['action'],
+                           float(e['reward']), e['next_state'], e['terminal'],
+                           float(e.get('td', np.nan))))
+
+        def on_trial_end(logs, modes=modes, td_acc=td_acc, ag=ag):
+            modes.append(MODES.index(logs['replay_mode']))
+            td_acc.append(float(ag.td))
+
+        cbs = {k: list(v) for k, v in tr.callbacks().items()}
+        cbs['on_trial_end'].append(on_trial_end)
+        cbs['on_replay_begin'] = [on_replay_begin]
+        cbs['on_replay_end'] = [on_replay_end]
+        for k in ('on_trial_begin', 'on_step_begin'):
+            cbs.setdefault(k, [])
+        ag.callbacks.custom_callbacks = cbs
+        ag.train(env, trials, steps, B)
+        n_train = len(tr.sarsn)
+        if kw.get('noreplay_trials'):
+            ag.train(env, kw['noreplay_trials'], steps, B, True)
+        n_train2 = len(tr.sarsn)
+        if kw.get('test_trials'):
+            ag.test(env, kw['test_trials'], steps)
+        d = tr.pack()
+        rpa = np.array(rp, dtype=np.float64).reshape(-1, 8)
+        d.update(
+            Q=np.array(ag.Q, dtype=np.float64), M_rewards=np.array(ag.M.rewards, dtype=np.float64),
+            M_states=ag.M.states.astype(np.int16), M_terminals=ag.M.terminals.astype(np.int8),
+            C=ag.M.C.copy(), T=ag.M.T.copy(), I=ag.M.I.copy(),
+            rp_trial=rpa[:, 0].astype(np.int32), rp_kind=rpa[:, 1].astype(np.int8),
+            rp_state=rpa[:, 2].astype(np.int16), rp_action=rpa[:, 3].astype(np.int8),
+            rp_reward=rpa[:, 4], rp_next=rpa[:, 5].astype(np.int16),
+            rp_nonterminal=rpa[:, 6].astype(np.int8), rp_td=rpa[:, 7],
+            replay_mode=np.array(modes, dtype=np.int8), td_acc=np.array(td_acc),
+            final_mode=np.int64(MODES.index(ag.M.mode)),
+            n_train_steps=np.array([n_train, n_train2], dtype=np.int64),
+            cfg=np.array([inst, f32, trials, steps, B], dtype=np.int64),
+            alpha=np.float64(ag.learning_rate), gamma=np.float64(ag.gamma), eps=np.float64(0.1),
+            ctr=np.array([env.rng.index, pol.rng.index, mem.rng.index, ag.rng.index], dtype=np.int64),
+            opts=np.array(repr(dict(kw, metric=mname, mode=mode, world=wname))))
+        if kw.get('mask'):
+            d['action_mask'] = ag.action_mask
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'sfma_traces.npz'), **out)
+
+
 def gen_monitor(worlds):
     """monitor/behavior.py:73-97 and analysis/behavior_spatial.py:9-73."""
     rng = np.random.default_rng(7)
@@ -713,10 +874,15 @@ def main():
     gen_qagent(worlds)
     gen_sr(worlds)
     gen_monitor(worlds)
+    gen_sfma()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-24s %8d B' % (f, os.path.getsize(os.path.join(HERE, f))))
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1:      # regenerate selected fixtures only: gen_golden.py gen_sfma ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+    else:
+        main()
