@@ -5,8 +5,8 @@ The package mirrors the reference's module layout for the accelerated path only:
     cobel_amd.misc.gridworld_tools   make_gridworld, make_open_field, ...
     cobel_amd.interface              Gridworld, Topology (vectorised: n_envs instances)
     cobel_amd.policy                 EpsilonGreedy
-    cobel_amd.memory                 DynaQMemory
-    cobel_amd.agent                  DynaQ, QAgent, SR
+    cobel_amd.memory                 DynaQMemory, DQNMemory, SFMAMemory (+ memory.utils metrics)
+    cobel_amd.agent                  DynaQ, QAgent, SR, SFMA, DQN, DynaDQN, DynaDSR
     cobel_amd.monitor                EscapeLatencyMonitor, RewardMonitor
     cobel_amd.analysis               get_occupancy_map
 
@@ -28,6 +28,7 @@ def install_as_cobel() -> None:
 
     me = sys.modules[__name__]
     sys.modules.setdefault('cobel', me)
-    for sub in ('misc', 'misc.gridworld_tools', 'interface', 'policy', 'memory', 'agent',
+    for sub in ('misc', 'misc.gridworld_tools', 'interface', 'policy', 'memory', 'memory.utils',
+                'memory.utils.metrics', 'memory.sfma', 'agent',
                 'monitor', 'analysis', 'spaces'):
         sys.modules.setdefault('cobel.' + sub, importlib.import_module(__name__ + '.' + sub))

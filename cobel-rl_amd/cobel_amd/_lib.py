@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcobel_hip.so')
 
 OK, E_ARG, E_RANGE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
-STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST = 0, 1, 2, 3
+STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST, STREAM_AGENT = 0, 1, 2, 3, 4
+SUB_DOUBLE = 1
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
 F_FORCE_LDS_MODEL, F_NO_PREFETCH = 64, 128
@@ -56,6 +57,42 @@ class TabRun(C.Structure):
         ('model_lr', C.c_double), ('seed', C.c_uint64),
         ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
         ('reserved_', C.c_int32),
+    ]
+
+
+SFMA_MODES = ('default', 'reverse', 'forward', 'blend_forward', 'blend_reverse', 'interpolate',
+              'sweeping')
+(SF_RANDOM, SF_DYNAMIC, SF_START_REPLAY, SF_DETERMINISTIC, SF_RECENCY, SF_C_NORMALIZE,
+ SF_D_NORMALIZE, SF_R_NORMALIZE, SF_REWARD_MOD_LOCAL, SF_REWARD_MOD, SF_STATE_MOD) = (
+    1 << k for k in range(11))
+(SI_CLOCK, SI_EPOCH, SI_MODE, SI_FLAGS, SI_TD_LO, SI_TD_HI, SI_CTR_AGENT, SI_RESERVED,
+ SI_WORDS) = range(9)
+SFMA_EVENT_BYTES = 24
+
+
+class SFMARun(C.Structure):
+    """``cobel_sfma_run_t``."""
+    _fields_ = [
+        ('q', C.c_void_p), ('model', C.c_void_p), ('strength', C.c_void_p), ('stamp', C.c_void_p),
+        ('inst', C.c_void_p), ('sfma_inst', C.c_void_p), ('metric', C.c_void_p),
+        ('recency_tab', C.c_void_p), ('random_cdf', C.c_void_p), ('action_mask', C.c_void_p),
+        ('lat_sum', C.c_void_p), ('lat_cnt', C.c_void_p), ('reward_sum', C.c_void_p),
+        ('resp_cnt', C.c_void_p), ('lat_trace', C.c_void_p), ('occupancy', C.c_void_p),
+        ('steps_done', C.c_void_p), ('replays_done', C.c_void_p), ('last_exp', C.c_void_p),
+        ('replay_trace', C.c_void_p), ('trace_len', C.c_void_p),
+        ('n', C.c_int32), ('trial_cap', C.c_int32), ('trace_cap', C.c_int32),
+        ('recency_len', C.c_int32), ('instance_base', C.c_uint32),
+        ('flags', C.c_uint32), ('sfma_flags', C.c_uint32),
+        ('trials_target', C.c_int32), ('steps_per_trial', C.c_int32), ('step_budget', C.c_int32),
+        ('batch', C.c_int32), ('nb_replays', C.c_int32), ('reserved_', C.c_int32),
+        ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
+        ('model_lr', C.c_double),
+        ('decay_inhibition', C.c_double), ('decay_strength', C.c_double),
+        ('c_step', C.c_double), ('i_step', C.c_double), ('r_threshold', C.c_double),
+        ('beta', C.c_double),
+        ('reward_modulation', C.c_double), ('blend', C.c_double), ('interp_fwd', C.c_double),
+        ('interp_rev', C.c_double),
+        ('seed', C.c_uint64),
     ]
 
 
@@ -111,6 +148,8 @@ _SIGNATURES = {
     'cobel_sr_init': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     'cobel_sr_run': (C.c_int, [_P, C.POINTER(SRRun), _P]),
     'cobel_sr_retrieve_q': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    'cobel_sfma_query': (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
+    'cobel_sfma_run': (C.c_int, [_P, C.POINTER(SFMARun), _P]),
 }
 EXPORTS = tuple(sorted(_SIGNATURES))
 

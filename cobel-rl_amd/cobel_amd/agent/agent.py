@@ -279,10 +279,19 @@ class FusedAgent(Agent):
         return int(self.monitors.steps_done.item()) if self.monitors is not None else 0
 
     # -- the shared trial driver ----------------------------------------------------------------
+    def _trial_logs(self, logs: dict) -> dict:
+        """Agent-specific keys of the logs a trial starts with."""
+        return logs
+
+    def _after_trial(self, logs: dict) -> dict:
+        """Called after the launch(es) of one trial in per-trial mode, before on_trial_end."""
+        return logs
+
     def _session(self, interface, trials: int, steps: int, batch: int, learn: bool,
-                 extra_flags: int = 0) -> None:
+                 extra_flags: int = 0, pol=None) -> None:
         self._bind(interface)
-        pol = self.policy if learn else self.policy_test
+        if pol is None:
+            pol = self.policy if learn else self.policy_test
         flags = extra_flags | (_lib.F_LEARN if learn else 0)
         if self.mask_actions:
             flags |= _lib.F_MASK_ACTIONS
@@ -309,9 +318,8 @@ class FusedAgent(Agent):
                         'count': int(cnt[first + t])})
         else:
             for t in range(trials):
-                logs = self.callbacks.on_trial_begin({'trial_reward': 0.0,
-                                                      'trial': self.current_trial,
-                                                      'trial_session': t})
+                logs = self.callbacks.on_trial_begin(self._trial_logs(
+                    {'trial_reward': 0.0, 'trial': self.current_trial, 'trial_session': t}))
                 target = self.current_trial + 1
                 if per_step:
                     step = 0
@@ -336,6 +344,7 @@ class FusedAgent(Agent):
                     logs['trial_reward'] = float(
                         self.monitors.reward_sum[self.current_trial].item())
                 self.current_trial += 1
+                logs = self._after_trial(logs)
                 logs = self.callbacks.on_trial_end(logs)
                 if self.stop:
                     break

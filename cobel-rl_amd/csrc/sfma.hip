@@ -1,0 +1,640 @@
+// SFMA agent — one wavefront per agent–env instance (gfx950).
+//
+// SFMA is Dyna-Q whose replay picks experiences by priority R = C * D * (1 - I) [* T]: strength x
+// similarity to the experience replayed last x (1 - inhibition) [x recency].  The reference
+// evaluates R over all 4S experiences with NumPy for every single reactivation and draws one
+// from softmax(R); that O(4S) scan + draw is the hot part (32 per trial by default).
+//
+// Here an instance's tables live in LDS for the whole call: Q (float32 [S][4]), strengths C
+// (float64 [4S]), inhibition I (float64 [S]), the model's successor table NS (u16 [4S], experience
+// order j = a * S + s) and one scratch vector of 4S priorities.  Lane l owns the experiences
+// [l * chunk, (l + 1) * chunk), so the cumulative sum behind the draw is one wave scan of lane
+// totals plus a short in-lane running sum — element order as in the reference's cumsum.  The rows
+// D[cur], D[next] of the similarity matrix (shared by all instances of a world, L2 resident) are
+// staged in LDS once per reactivation.  The model's reward estimates stay in HBM (written through,
+// read once per reactivated experience); recency T is kept as a store stamp per experience and a
+// table of decay powers instead of a vector that is rescaled on every store.
+//
+// Reference behaviour restated (paths relative to /root/reference/src/cobel):
+//   agent/sfma.py:233-334 (train), :336-396 (test), :398-458 (replay, update_q)
+//   memory/sfma.py:195-236 (store), :238-347 (replay), :349-372 (softmax), :374-416 (random batch)
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+namespace {
+
+struct sfma_args {
+  const cobel_wrec* rec;
+  const uint16_t* starts;
+  const int32_t* start_off;
+  int32_t S, n_worlds;
+  int32_t chunk;  // experiences per lane: ceil(4S / 64)
+  cobel_sfma_run_t r;
+  cobel_eps_bb eps;
+  float alpha_f, gamma_f, model_lr_f;
+};
+
+struct sfma_lds {
+  float4* Q;     // [S]
+  double* C;     // [4S] strengths
+  double* P;     // [4S] priorities / draw weights of the current reactivation
+  double* I;     // [S]  inhibition
+  double* Dc;    // [S]  similarity row of the current state
+  double* Dn;    // [S]  similarity row of the next state
+  uint16_t* NS;  // [4S] model successor of experience j
+};
+
+__host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
+  return ((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 8) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
+  sfma_lds L;
+  size_t off = 0;
+  L.Q = reinterpret_cast<float4*>(base + off);
+  off += (size_t)S * 16;
+  L.C = reinterpret_cast<double*>(base + off);
+  off += (size_t)S * 32;
+  L.P = reinterpret_cast<double*>(base + off);
+  off += (size_t)S * 32;
+  L.I = reinterpret_cast<double*>(base + off);
+  off += (size_t)S * 8;
+  L.Dc = reinterpret_cast<double*>(base + off);
+  off += (size_t)S * 8;
+  L.Dn = reinterpret_cast<double*>(base + off);
+  off += (size_t)S * 8;
+  L.NS = reinterpret_cast<uint16_t*>(base + off);
+  return L;
+}
+
+// Orders this wave's LDS traffic across lanes (one wave per workgroup: no s_barrier needed).
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
+  const uint32_t w = (a & 2) ? w1 : w0;
+  return (a & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_scan_f64(double v, int lane) {  // inclusive
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double t = __shfl_up(v, o);
+    if (lane >= o) v = v + t;
+  }
+  return v;
+}
+__device__ __forceinline__ float max4_masked(const float4 q, uint32_t mask) {
+  float m = -__builtin_huge_valf();
+  if (mask & 1u) m = fmaxf(m, q.x);
+  if (mask & 2u) m = fmaxf(m, q.y);
+  if (mask & 4u) m = fmaxf(m, q.z);
+  if (mask & 8u) m = fmaxf(m, q.w);
+  return m;
+}
+
+// First experience whose weight equals vmax (np.argmax), wave-uniform.
+__device__ __forceinline__ int wave_first_equal(const double* P, int n4, int chunk, int lane,
+                                                double vmax) {
+  const int j0 = lane * chunk;
+  int first = 0x7fffffff;
+  for (int k = chunk - 1; k >= 0; --k) {
+    const int j = j0 + k;
+    if (j < n4 && P[j] == vmax) first = j;
+  }
+  return wave_min_i32(first);
+}
+
+// Generator.choice(arange(n4), p = w / sum(w)) for the weights w >= 0 in P, driven by the uniform
+// u: the number of experiences whose normalised cumulative weight is <= u.  Wave-uniform result.
+__device__ __forceinline__ int wave_choice(const double* P, int n4, int chunk, int lane, double u,
+                                           double wmax) {
+  const int j0 = lane * chunk;
+  double loc = 0.0;
+  for (int k = 0; k < chunk; ++k)
+    if (j0 + k < n4) loc = loc + P[j0 + k];
+  const double incl = wave_scan_f64(loc, lane);
+  double excl = __shfl_up(incl, 1);
+  if (lane == 0) excl = 0.0;
+  // the cumulative weight at the last experience; lanes behind it hold nothing
+  const double total = __shfl(excl + loc, (n4 - 1) / chunk);
+  int cnt = 0;
+  double run = 0.0;
+  for (int k = 0; k < chunk; ++k)
+    if (j0 + k < n4) {
+      run = run + P[j0 + k];
+      cnt += ((excl + run) / total <= u) ? 1 : 0;
+    }
+  int idx = wave_sum_i32(cnt);
+  idx = idx < n4 ? idx : n4 - 1;
+  // an experience of weight zero has probability zero; rounding at a lane boundary of the scan
+  // is the only way to land on one
+  if (!(P[idx] > 0.0)) idx = wave_first_equal(P, n4, chunk, lane, wmax);
+  return idx;
+}
+
+__global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int S = A.S, n4 = 4 * A.S, chunk = A.chunk;
+  const sfma_lds L = carve(lds_raw, S);
+  const int lane = (int)threadIdx.x;
+  const int i = (int)blockIdx.x;
+  const uint32_t g = A.r.instance_base + (uint32_t)i;
+  const int world = (int)(g % (uint32_t)A.n_worlds);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
+  const double* const Dm = A.r.metric + (size_t)world * S * S;
+  float* const Qg = A.r.q + (size_t)i * n4;
+  uint64_t* const Mg = A.r.model + (size_t)i * n4;
+  double* const Cg = A.r.strength + (size_t)i * n4;
+  uint32_t* const stamp = A.r.stamp + (size_t)i * n4;
+
+  for (int e = lane; e < S; e += 64) {
+    L.Q[e] = reinterpret_cast<const float4*>(Qg)[e];
+    L.I[e] = 0.0;
+  }
+  for (int e = lane; e < n4; e += 64) {
+    L.C[e] = Cg[e];
+    L.NS[(e & 3) * S + (e >> 2)] = (uint16_t)((Mg[e] >> 32) & 0xffffu);
+  }
+  wsync();
+
+  int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
+  int32_t* const sinst = A.r.sfma_inst + (size_t)i * COBEL_SI_WORDS;
+  int state = inst[COBEL_I_STATE];
+  int step = inst[COBEL_I_STEP];
+  int trial = inst[COBEL_I_TRIAL];
+  uint32_t ce = (uint32_t)inst[COBEL_I_CTR_ENV];
+  uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
+  uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
+  uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
+  unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
+  uint32_t clock = (uint32_t)sinst[COBEL_SI_CLOCK];
+  uint32_t epoch = (uint32_t)sinst[COBEL_SI_EPOCH];
+  int mode = sinst[COBEL_SI_MODE];
+  uint32_t sflags = (uint32_t)sinst[COBEL_SI_FLAGS];
+  double td_acc = *reinterpret_cast<const double*>(sinst + COBEL_SI_TD_LO);
+  uint32_t ca = (uint32_t)sinst[COBEL_SI_CTR_AGENT];
+  int tpos = A.r.trace_len ? A.r.trace_len[i] : 0;
+
+  const uint32_t flags = A.r.flags, sf = A.r.sfma_flags;
+  const bool learn = flags & COBEL_F_LEARN;
+  const uint32_t pol_stream =
+      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
+  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const uint64_t seed = A.r.seed;
+  const int start_lo = A.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
+  const double alpha = A.r.alpha, gamma = A.r.gamma;
+  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+
+  cobel_u4 pblk = {0, 0, 0, 0};
+  uint32_t pb_idx = ~0u;
+  unsigned long long executed = 0, replayed = 0;
+  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+
+  // agent.update_q for a replayed experience (agent/sfma.py:437-455 with M.rewards float32 and
+  // M.terminals int64: float64 arithmetic, one rounding into the float32 table)
+  auto replay_td = [&](int s, int a, int ns, float R, uint32_t nt) -> double {
+    const float4 nrow = L.Q[ns];
+    const float m = max4_masked(nrow, amask ? (uint32_t)amask[ns] & 15u : 15u);
+    const float q = reinterpret_cast<const float*>(L.Q)[s * 4 + a];
+    const double gnt = gamma * (double)nt;
+    double td = (double)R + gnt * (double)m;
+    td = td - (double)q;
+    wsync();
+    if (lane == 0) reinterpret_cast<float*>(L.Q)[s * 4 + a] = (float)((double)q + alpha * td);
+    wsync();
+    td_acc = ((sflags & 1u) ? (double)(float)td_acc : td_acc) + fabs(td);
+    sflags &= ~1u;
+    return td;
+  };
+  auto record = [&](int s, int a, int ns, float R, uint32_t nt, int kind, int tr, double td) {
+    if (A.r.replay_trace && lane == 0 && tpos < A.r.trace_cap) {
+      cobel_sfma_event_t ev;
+      ev.sa = (uint32_t)s | ((uint32_t)a << 16) | (nt << 24) | ((uint32_t)kind << 25);
+      ev.next = (uint32_t)ns;
+      ev.reward = R;
+      ev.trial = tr;
+      ev.td = td;
+      A.r.replay_trace[(size_t)i * A.r.trace_cap + tpos] = ev;
+    }
+    tpos += 1;
+  };
+
+  // SFMAMemory.replay (memory/sfma.py:238-347) [+ the TD updates of SFMA.replay when `update`]
+  auto sfma_replay = [&](int start_state, bool update, int kind, int tr) {
+    int action = (int)cobel_draw_bounded(cm, 0u, g, COBEL_STREAM_MEMORY, seed, 4u);
+    cm += 1u;
+    int cur = start_state;
+    const int j0 = lane * chunk;
+    if (cur < 0) {
+      // no terminal state was reached: start from an experience drawn by strength (:262-270)
+      double wmax = 0.0;
+      for (int k = 0; k < chunk; ++k)
+        if (j0 + k < n4) {
+          const double c = L.C[j0 + k];
+          const double w = c < 0.0 ? 0.0 : c;
+          L.P[j0 + k] = w;
+          wmax = fmax(wmax, w);
+        }
+      wmax = wave_max_f64(wmax);
+      wsync();
+      const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE, g, COBEL_STREAM_MEMORY, seed);
+      cm += 1u;
+      const int pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
+      action = pick / S;
+      cur = pick - action * S;
+      wsync();
+    }
+    int nxt = (int)L.NS[action * S + cur];
+    for (int e = lane; e < S; e += 64) L.I[e] = 0.0;
+    double cmax = 1.0;
+    if (sf & COBEL_SF_C_NORMALIZE) {
+      double m = -__builtin_huge_val();
+      for (int e = lane; e < n4; e += 64) m = fmax(m, L.C[e]);
+      cmax = wave_max_f64(m);
+    }
+    wsync();
+    const bool need_next = mode == COBEL_SFMA_FORWARD || mode == COBEL_SFMA_BLEND_FORWARD ||
+                           mode == COBEL_SFMA_INTERPOLATE || mode == COBEL_SFMA_SWEEPING;
+    for (int it = 0; it < A.r.batch; ++it) {
+      // similarity rows (:284-287); D_normalize divides the row of the current state only
+      {
+        const double* const rc = Dm + (size_t)cur * S;
+        const double* const rn = Dm + (size_t)nxt * S;
+        double dmax = 1.0;
+        if (sf & COBEL_SF_D_NORMALIZE) {
+          double m = -__builtin_huge_val();
+          for (int e = lane; e < S; e += 64) m = fmax(m, rc[e]);
+          dmax = wave_max_f64(m);
+        }
+        for (int e = lane; e < S; e += 64) {
+          const double d = rc[e];
+          L.Dc[e] = (sf & COBEL_SF_D_NORMALIZE) ? d / dmax : d;
+          if (need_next) L.Dn[e] = rn[e];
+        }
+      }
+      wsync();
+      // priority ratings (:288-316)
+      double rmax = 0.0;
+      {
+        int s = j0 % S;
+        for (int k = 0; k < chunk; ++k) {
+          const int j = j0 + k;
+          if (j < n4) {
+            double c = L.C[j];
+            if (sf & COBEL_SF_C_NORMALIZE) c = c / cmax;
+            double d;
+            if (mode == COBEL_SFMA_DEFAULT) d = L.Dc[s];
+            else if (mode == COBEL_SFMA_FORWARD) d = L.Dn[s];
+            else if (mode == COBEL_SFMA_REVERSE) d = L.Dc[L.NS[j]];
+            else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + A.r.blend * L.Dn[s];
+            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + A.r.blend * L.Dc[L.NS[j]];
+            else if (mode == COBEL_SFMA_INTERPOLATE)
+              d = A.r.interp_fwd * L.Dn[s] + A.r.interp_rev * L.Dc[L.NS[j]];
+            else d = L.Dn[L.NS[j]];
+            double R = c * d;
+            R = R * (1.0 - L.I[s]);
+            if (sf & COBEL_SF_RECENCY) {
+              const uint32_t st = stamp[j];
+              double t = 0.0;
+              if (st > epoch) {
+                const uint32_t age = clock - st;
+                t = A.r.recency_tab[age < (uint32_t)A.r.recency_len ? age
+                                                                      : (uint32_t)A.r.recency_len - 1u];
+              }
+              R = R * t;
+            }
+            if (R < A.r.r_threshold) R = 0.0;
+            L.P[j] = R;
+            rmax = fmax(rmax, R);
+          }
+          s += 1;
+          if (s == S) s = 0;
+        }
+      }
+      rmax = wave_max_f64(rmax);
+      if (!(rmax > 0.0)) break;  // np.sum(R) == 0: nothing left to reactivate (:317-318)
+      wsync();
+      int pick;
+      if (sf & COBEL_SF_DETERMINISTIC) {
+        pick = wave_first_equal(L.P, n4, chunk, lane, rmax);
+      } else {
+        // softmax(R, offset -1, beta) = exp(beta R) - 1 (:349-372), then the draw
+        double wmax = 0.0;
+        for (int k = 0; k < chunk; ++k)
+          if (j0 + k < n4) {
+            double R = L.P[j0 + k];
+            if (sf & COBEL_SF_R_NORMALIZE) R = R / rmax;
+            const double w = exp(R * A.r.beta) + -1.0;
+            L.P[j0 + k] = w;
+            wmax = fmax(wmax, w);
+          }
+        wmax = wave_max_f64(wmax);
+        if (!(wmax > 0.0)) {  // np.sum(exp) == 0 -> exp.fill(1)
+          for (int k = 0; k < chunk; ++k)
+            if (j0 + k < n4) L.P[j0 + k] = 1.0;
+          wmax = 1.0;
+        }
+        wsync();
+        const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE, g, COBEL_STREAM_MEMORY, seed);
+        cm += 1u;
+        pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
+      }
+      action = pick / S;
+      cur = pick - action * S;
+      nxt = (int)L.NS[pick];
+      wsync();
+      // inhibition (:336-337)
+      for (int e = lane; e < S; e += 64) L.I[e] = L.I[e] * A.r.decay_inhibition;
+      wsync();
+      if (lane == 0) L.I[cur] = fmin(L.I[cur] + A.r.i_step, 1.0);
+      // the reactivated experience
+      const uint64_t rec = Mg[cur * 4 + action];
+      const float R = __builtin_bit_cast(float, (uint32_t)rec);
+      const uint32_t nt = (uint32_t)(rec >> 48) & 1u;
+      double td = __builtin_nan("");
+      if (update) td = replay_td(cur, action, nxt, R, nt);
+      record(cur, action, nxt, R, nt, kind, tr, td);
+      replayed += 1ull;
+      wsync();
+    }
+  };
+
+  // SFMAMemory.retrieve_random_batch (:374-416) + the TD updates
+  auto random_replay = [&](int tr) {
+    const int j0 = lane * chunk;
+    for (int b = 0; b < A.r.batch; ++b) {
+      const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE + (uint32_t)b, g, COBEL_STREAM_MEMORY,
+                                      seed);
+      int cnt = 0;
+      for (int k = 0; k < chunk; ++k)
+        if (j0 + k < n4) cnt += (A.r.random_cdf[j0 + k] <= u) ? 1 : 0;
+      int idx = wave_sum_i32(cnt);
+      idx = idx < n4 ? idx : n4 - 1;
+      const int a = idx / S, s = idx - a * S;   // unravel_index(order='F')
+      const int ns = (int)L.NS[idx];
+      const uint64_t rec = Mg[s * 4 + a];
+      const float R = __builtin_bit_cast(float, (uint32_t)rec);
+      const uint32_t nt = (uint32_t)(rec >> 48) & 1u;
+      const double td = replay_td(s, a, ns, R, nt);
+      record(s, a, ns, R, nt, 0, tr, td);
+      replayed += 1ull;
+    }
+    cm += 1u;   // one vector draw per batch
+  };
+
+  while (true) {
+    if (!(iflags & 1u)) {
+      if (trial >= A.r.trials_target) break;
+      if (budget == 0) break;
+      state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                               start_cnt)];
+      ce += 1u;
+      step = 0;
+      trew = 0.0;
+      iflags |= 1u;
+      if (learn && (sf & COBEL_SF_START_REPLAY)) sfma_replay(state, false, 1, trial);
+    }
+    if (budget == 0) break;
+    budget -= 1;
+
+    // ---- select + env.step ---------------------------------------------------------------------
+    const float4 q = L.Q[state];
+    const uint32_t mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
+    if ((cp >> 1) != pb_idx) {
+      pb_idx = cp >> 1;
+      pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
+    }
+    const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
+    cp += 1u;
+    const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
+                                                                  A.eps, lane));
+    const uint4 wc = W4[state];
+    const int ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
+    const uint4 wn = W4[ns];
+    const float r = __builtin_bit_cast(float, rfl(wn.z));
+    const uint32_t end = rfl(wn.w);
+    const uint32_t nt = 1u - end;
+    float td_online = 0.0f;
+
+    if (learn) {
+      const int sa = state * 4 + a, j = a * S + state;
+      // M.store (memory/sfma.py:204-236)
+      const float Rold = __builtin_bit_cast(float, (uint32_t)Mg[sa]);
+      const float d = r - Rold;
+      const float Rnew = Rold + mlr_f * d;
+      if (lane == 0) {
+        Mg[sa] = cobel_model_pack(Rnew, (uint32_t)ns, nt);
+        L.NS[j] = (uint16_t)ns;
+      }
+      if (A.r.decay_strength != 1.0) {
+        for (int e = lane; e < n4; e += 64) L.C[e] = L.C[e] * A.r.decay_strength;
+        wsync();
+      }
+      clock += 1u;
+      if (lane == 0) {
+        double c = L.C[j] + A.r.c_step;
+        if (sf & COBEL_SF_REWARD_MOD_LOCAL) c = c + (double)r * A.r.reward_modulation;
+        L.C[j] = c;
+        stamp[j] = clock;
+      }
+      if (sf & COBEL_SF_REWARD_MOD) {
+        wsync();
+        const double* const row = Dm + (size_t)state * S;
+        for (int e = lane; e < n4; e += 64) {
+          const int s2 = e % S;
+          L.C[e] = L.C[e] + ((double)r * row[s2]) * A.r.reward_modulation;
+        }
+      }
+      if (sf & COBEL_SF_STATE_MOD) {
+        wsync();
+        if (lane < 4) L.C[lane * S + state] = L.C[lane * S + state] + 1.0;
+      }
+      // agent.update_q online (agent/sfma.py:437-455), float32
+      const float4 nrow = L.Q[ns];
+      const float m = max4_masked(nrow, amask ? (uint32_t)amask[ns] & 15u : 15u);
+      const float qsa = (a & 2) ? ((a & 1) ? q.w : q.z) : ((a & 1) ? q.y : q.x);
+      const float gnt = nt ? gamma_f : 0.0f;
+      float td = r + gnt * m;
+      td = td - qsa;
+      wsync();
+      if (lane == 0) reinterpret_cast<float*>(L.Q)[sa] = qsa + alpha_f * td;
+      wsync();
+      td_online = td;
+      if (sflags & 1u) td_acc = (double)((float)td_acc + fabsf(td));
+      else td_acc = td_acc + (double)fabsf(td);
+    }
+
+    if (A.r.last_exp && lane == 0) {
+      int32_t* const e = A.r.last_exp + (size_t)i * 6;
+      e[0] = state;
+      e[1] = a;
+      e[2] = ns;
+      e[3] = (int32_t)nt;
+      e[4] = __builtin_bit_cast(int32_t, r);
+      e[5] = __builtin_bit_cast(int32_t, td_online);
+    }
+    trew += (double)r;
+    nsteps += 1ull;
+    executed += 1ull;
+    if (A.r.occupancy && lane == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
+    state = ns;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    if (!trial_over) {
+      step += 1;
+    } else {
+      if (lane == 0 && trial >= 0 && trial < A.r.trial_cap) {
+        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
+        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
+        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
+        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + trial, 1ull);
+        if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
+      }
+      const int tr = trial;
+      trial += 1;
+      iflags &= ~1u;
+      if (learn && !(flags & COBEL_F_NO_REPLAY)) {
+        if (sf & COBEL_SF_DYNAMIC) {
+          // agent/sfma.py:308-316: p(reverse) = 1 / (1 + exp(-(5 td - 2))), in the type the
+          // |TD| sum has at this point
+          double p0, p1;
+          if (sflags & 1u) {
+            const float x = (float)td_acc * 5.0f - 2.0f;
+            const float p = 1.0f / (1.0f + expf(-x));
+            p0 = (double)p;
+            p1 = (double)(1.0f - p);
+          } else {
+            const double x = td_acc * 5.0 - 2.0;
+            p0 = 1.0 / (1.0 + exp(-x));
+            p1 = 1.0 - p0;
+          }
+          const double uu = cobel_draw_u01(ca, 0u, g, COBEL_STREAM_AGENT, seed);
+          ca += 1u;
+          const double c1 = p0 + p1;
+          mode = (p0 / c1 <= uu) ? COBEL_SFMA_DEFAULT : COBEL_SFMA_REVERSE;
+          td_acc = 0.0;
+          sflags |= 1u;
+        }
+        for (int rep = 0; rep < A.r.nb_replays; ++rep) {
+          if (sf & COBEL_SF_RANDOM) random_replay(tr);
+          else sfma_replay(end ? ns : -1, true, 0, tr);
+        }
+        epoch = clock;  // M.T.fill(0)
+      }
+    }
+  }
+
+  wsync();
+  for (int e = lane; e < S; e += 64) reinterpret_cast<float4*>(Qg)[e] = L.Q[e];
+  for (int e = lane; e < n4; e += 64) Cg[e] = L.C[e];
+  if (lane == 0) {
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_CTR_MEMORY] = (int32_t)cm;
+    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
+    sinst[COBEL_SI_CLOCK] = (int32_t)clock;
+    sinst[COBEL_SI_EPOCH] = (int32_t)epoch;
+    sinst[COBEL_SI_MODE] = mode;
+    sinst[COBEL_SI_FLAGS] = (int32_t)sflags;
+    *reinterpret_cast<double*>(sinst + COBEL_SI_TD_LO) = td_acc;
+    sinst[COBEL_SI_CTR_AGENT] = (int32_t)ca;
+    if (A.r.trace_len) A.r.trace_len[i] = tpos;
+    if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
+    if (A.r.replays_done && replayed) atomicAdd(A.r.replays_done, replayed);
+  }
+}
+
+}  // namespace
+
+static const size_t kSfmaLdsLimit = 160 * 1024;
+
+extern "C" int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes) {
+  COBEL_REQUIRE(n_states > 0, COBEL_E_RANGE, "cobel_sfma_query: %d states", n_states);
+  const size_t lds = sfma_lds_bytes(n_states);
+  if (lds_bytes) *lds_bytes = (int32_t)lds;
+  COBEL_REQUIRE(lds <= kSfmaLdsLimit && n_states <= 16383, COBEL_E_UNSUPPORTED,
+                "cobel_sfma_query: %d states need %zu B of LDS per instance (limit %zu)", n_states,
+                lds, kSfmaLdsLimit);
+  return COBEL_OK;
+}
+
+extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run,
+                              void* stream) {
+  COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sfma_run: NULL world/run");
+  const cobel_sfma_run_t& r = *run;
+  COBEL_REQUIRE(r.q && r.model && r.strength && r.stamp && r.inst && r.sfma_inst && r.metric,
+                COBEL_E_ARG,
+                "cobel_sfma_run: q, model, strength, stamp, inst, sfma_inst and metric are required");
+  COBEL_REQUIRE(((uintptr_t)r.q & 15u) == 0 && ((uintptr_t)r.inst & 7u) == 0 &&
+                    ((uintptr_t)r.sfma_inst & 7u) == 0 && ((uintptr_t)r.replay_trace & 7u) == 0,
+                COBEL_E_ARG, "cobel_sfma_run: q must be 16-byte, inst / sfma_inst / trace 8-byte aligned");
+  COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_sfma_run: n = %d", r.n);
+  COBEL_REQUIRE(r.steps_per_trial > 0, COBEL_E_RANGE, "cobel_sfma_run: steps_per_trial = %d",
+                r.steps_per_trial);
+  COBEL_REQUIRE(r.batch >= 0 && r.nb_replays >= 0, COBEL_E_RANGE,
+                "cobel_sfma_run: batch = %d, nb_replays = %d", r.batch, r.nb_replays);
+  COBEL_REQUIRE(r.epsilon >= 0.0 && r.epsilon <= 1.0, COBEL_E_ARG,
+                "cobel_sfma_run: epsilon %g outside [0, 1]", r.epsilon);
+  COBEL_REQUIRE(!(r.flags & COBEL_F_MASK_ACTIONS) || r.action_mask, COBEL_E_ARG,
+                "cobel_sfma_run: mask_actions set without an action mask");
+  COBEL_REQUIRE(!(r.sfma_flags & COBEL_SF_RANDOM) || r.random_cdf, COBEL_E_ARG,
+                "cobel_sfma_run: random replay needs random_cdf");
+  COBEL_REQUIRE(!(r.sfma_flags & COBEL_SF_RECENCY) || (r.recency_tab && r.recency_len > 0),
+                COBEL_E_ARG, "cobel_sfma_run: recency needs recency_tab");
+  COBEL_REQUIRE(!r.replay_trace || (r.trace_len && r.trace_cap > 0), COBEL_E_ARG,
+                "cobel_sfma_run: replay_trace needs trace_len and trace_cap");
+  const int S = world->n_states;
+  int32_t lds = 0;
+  const int rc = cobel_sfma_query(S, &lds);
+  if (rc != COBEL_OK) return rc;
+  if (r.n == 0) return COBEL_OK;
+  sfma_args A;
+  A.rec = world->rec;
+  A.starts = world->starts;
+  A.start_off = world->start_off;
+  A.S = S;
+  A.n_worlds = world->n_worlds;
+  A.chunk = (4 * S + 63) / 64;
+  A.r = r;
+  const cobel_eps_consts ec = cobel_make_eps_consts(r.epsilon);
+  for (int k = 0; k < 5; ++k) {
+    A.eps.base[k] = ec.base[k];
+    A.eps.bonus[k] = ec.bonus[k];
+  }
+  A.alpha_f = (float)r.alpha;
+  A.gamma_f = (float)r.gamma;
+  A.model_lr_f = (float)r.model_lr;
+  if ((size_t)lds > 64 * 1024)
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sfma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sfma, dim3(r.n), dim3(64), (size_t)lds, (hipStream_t)stream, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

@@ -47,6 +47,10 @@ extern "C" {
 #define COBEL_STREAM_POLICY 1u /* c = select_action calls          (greedy.py:58)         */
 #define COBEL_STREAM_MEMORY 2u /* c = replay batches, sub = j      (memory/dyna_q.py:137) */
 #define COBEL_STREAM_POLICY_TEST 3u
+#define COBEL_STREAM_AGENT 4u  /* c = draws of the agent's own generator (agent/sfma.py:312) */
+/* A generator that mixes integer and double draws (SFMAMemory.rng) takes its doubles from
+ * sub = 1 + j (j = position in a vector draw): integer and double draws never share a block. */
+#define COBEL_SUB_DOUBLE 1u
 
 COBEL_API const char* cobel_last_error(void);
 /* ABI version of this header: major * 1000 + minor. */
@@ -315,6 +319,115 @@ COBEL_API int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* run
 COBEL_API int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const float* rewards,
                         const int32_t* states /* [dev] [N] */, float* q_out /* [dev] [N][4] */,
                         int32_t n, int32_t n_states, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SFMA agent: Dyna-Q whose replay is driven by Spatial structure and Frequency-weighted Memory
+ * Access.  Replaces SFMA.train / test / replay / update_q (agent/sfma.py:233-458) and
+ * SFMAMemory.store / replay / softmax / retrieve_random_batch (memory/sfma.py:195-416) for N
+ * instances; the similarity metric (memory/utils/metrics.py) comes in as a matrix.
+ *
+ * Per trial: online steps (select -> env.step -> store -> TD), then — unless NO_REPLAY —
+ * nb_replays replays of `batch` reactivations.  One reactivation ranks all 4S experiences
+ * j = a * S + s by R = C * D * (1 - I) [* T] (strength x similarity x (1 - inhibition) [x
+ * recency]), thresholds, normalises, and draws one from softmax(R) = exp(beta R) - 1
+ * (memory/sfma.py:280-333); the drawn experience is applied with a TD update at once (the batch
+ * the reference builds first does not depend on Q, so the order of effects is the same).
+ *
+ * Numerics: Q and the model's reward estimates are float32 and follow the reference run with
+ * float32 tables (online TD float32, replayed TD float64 rounded once on store, |TD| sum float32
+ * until the first replayed TD after a reset); strengths, inhibition, recency, similarities and
+ * priorities are float64 as in the reference.  The drawn index is
+ * #{k : cumsum(w)_k / cumsum(w)_last <= u}: the reference normalises w three times before the same
+ * count and sums sequentially, here the sum is a wave scan and exp() is the device's — equal up
+ * to a few ulp of the CDF, so a draw differs from the reference's only if u falls within ~1e-14
+ * of a CDF edge.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  COBEL_SFMA_DEFAULT = 0, COBEL_SFMA_REVERSE = 1, COBEL_SFMA_FORWARD = 2,
+  COBEL_SFMA_BLEND_FORWARD = 3, COBEL_SFMA_BLEND_REVERSE = 4, COBEL_SFMA_INTERPOLATE = 5,
+  COBEL_SFMA_SWEEPING = 6, COBEL_SFMA_MODES = 7
+};
+
+#define COBEL_SF_RANDOM 1u            /* agent.random: uniform batches (memory/sfma.py:374-416) */
+#define COBEL_SF_DYNAMIC 2u           /* agent.dynamic: reverse/default drawn from the |TD| sum  */
+#define COBEL_SF_START_REPLAY 4u      /* agent.start_replay: a replay (without TD) at trial start */
+#define COBEL_SF_DETERMINISTIC 8u     /* M.deterministic: argmax instead of the softmax draw      */
+#define COBEL_SF_RECENCY 16u          /* M.recency                                                */
+#define COBEL_SF_C_NORMALIZE 32u      /* M.C_normalize                                            */
+#define COBEL_SF_D_NORMALIZE 64u      /* M.D_normalize                                            */
+#define COBEL_SF_R_NORMALIZE 128u     /* M.R_normalize (default on)                               */
+#define COBEL_SF_REWARD_MOD_LOCAL 256u/* M.reward_mod_local                                       */
+#define COBEL_SF_REWARD_MOD 512u      /* M.reward_mod                                             */
+#define COBEL_SF_STATE_MOD 1024u      /* M.state_mod                                              */
+
+/* Per-instance SFMA state: 8 x 32-bit words, caller-owned [dev] [N][8]. */
+enum {
+  COBEL_SI_CLOCK = 0,     /* uint32 experiences stored so far (the recency clock)              */
+  COBEL_SI_EPOCH = 1,     /* uint32 clock at the last T.fill(0) (agent/sfma.py:325)            */
+  COBEL_SI_MODE = 2,      /* int32  M.mode (COBEL_SFMA_*); rewritten in dynamic mode           */
+  COBEL_SI_FLAGS = 3,     /* bit 0: the |TD| sum currently has float32 type                    */
+  COBEL_SI_TD_LO = 4,     /* float64 agent.td, the |TD| sum (2 words)                          */
+  COBEL_SI_TD_HI = 5,
+  COBEL_SI_CTR_AGENT = 6, /* uint32 next index on COBEL_STREAM_AGENT                           */
+  COBEL_SI_RESERVED = 7,
+  COBEL_SI_WORDS = 8
+};
+
+/* One replayed experience (logs['replay'], agent/sfma.py:273,322), 24 bytes. */
+typedef struct {
+  uint32_t sa;     /* state | action << 16 | nonterminal << 24 | kind << 25 (1 = trial start)  */
+  uint32_t next;   /* next state                                                               */
+  float reward;    /* M.rewards[s][a] at replay time                                           */
+  int32_t trial;   /* agent.current_trial of the trial the replay belongs to                   */
+  double td;       /* TD error of the update (NaN for start-of-trial replays)                  */
+} cobel_sfma_event_t;
+
+typedef struct {
+  /* tables, caller-owned device memory */
+  float* q;               /* [N][S][4] float32 Q                                              */
+  uint64_t* model;        /* [N][S][4] packed records as in cobel_tab_run_t (cobel_model_init) */
+  double* strength;       /* [N][4S]  M.C, index a * S + s                                    */
+  uint32_t* stamp;        /* [N][4S]  clock value at which (s, a) was last stored; M.T[j] =
+                             recency_tab[clock - stamp[j]] if stamp[j] > epoch else 0         */
+  int32_t* inst;          /* [N][COBEL_I_WORDS]                                               */
+  int32_t* sfma_inst;     /* [N][COBEL_SI_WORDS]                                              */
+  const double* metric;   /* [n_worlds][S][S] similarity matrix metric.D of each world        */
+  const double* recency_tab; /* [recency_len] 1, d, fl(d*d), ... by repeated multiplication
+                             (M.T *= decay_recency per store); ages beyond the end use the last */
+  const double* random_cdf;  /* [4S] RANDOM: cumsum(p) / cumsum(p)[-1] of the masked uniform p */
+  const uint8_t* action_mask; /* [S] 4-bit masks or NULL                                       */
+  /* monitors (any may be NULL), as in cobel_tab_run_t */
+  unsigned long long* lat_sum;
+  unsigned long long* lat_cnt;
+  double* reward_sum;
+  unsigned long long* resp_cnt;
+  int32_t* lat_trace;
+  unsigned long long* occupancy;
+  unsigned long long* steps_done;
+  unsigned long long* replays_done; /* [1] experiences reactivated by this call (added)       */
+  int32_t* last_exp;      /* [N][6] as in cobel_tab_run_t                                     */
+  cobel_sfma_event_t* replay_trace; /* [N][trace_cap] or NULL                                 */
+  int32_t* trace_len;     /* [N] in/out: events appended so far (counts past trace_cap too)   */
+  /* sizes */
+  int32_t n, trial_cap, trace_cap, recency_len;
+  uint32_t instance_base;
+  /* run parameters */
+  uint32_t flags;         /* COBEL_F_LEARN | NO_REPLAY | MASK_ACTIONS | TEST_STREAM           */
+  uint32_t sfma_flags;    /* COBEL_SF_*                                                       */
+  int32_t trials_target, steps_per_trial, step_budget;
+  int32_t batch;          /* replay length                                                    */
+  int32_t nb_replays;     /* agent.nb_replays                                                 */
+  int32_t reserved_;
+  double alpha, gamma, epsilon, model_lr;        /* agent lr, discount, policy eps, M.learning_rate */
+  double decay_inhibition, decay_strength;       /* M.decay_inhibition, M.decay_strength      */
+  double c_step, i_step, r_threshold, beta;      /* M.C_step, M.I_step, M.R_threshold, M.beta */
+  double reward_modulation, blend, interp_fwd, interp_rev;
+  uint64_t seed;
+} cobel_sfma_run_t;
+
+/* 0 = supported; fills *lds_bytes with the LDS one instance needs. */
+COBEL_API int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes);
+COBEL_API int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run, void* stream);
 
 #ifdef __cplusplus
 }

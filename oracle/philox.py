@@ -155,6 +155,7 @@ class TapeRNG:
         a = np.arange(a) if np.isscalar(a) else np.asarray(a)
         if p is None:
             return a[self.integers(0, len(a), size)]
-        cdf = np.cumsum(p)
+        # Generator.choice converts p to float64 before the cumulative sum
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
         cdf /= cdf[-1]
         return a[cdf.searchsorted(self.random(size), side='right')]

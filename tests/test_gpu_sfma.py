@@ -1,0 +1,292 @@
+"""GPU parity tests of the SFMA path (cobel_sfma_run through the host classes) against the golden
+runs captured from the real reference (tests/golden/sfma_traces.npz) and against the NumPy
+restatement (oracle/sfma_loop.py) on seeded inputs.
+
+Bar: trajectories, step counts, replayed experiences (state, action, successor, flag), replay modes
+and stream counters bit-exact; float32 Q / model rewards and the float64 strengths, recency values,
+replayed TD errors and |TD| sums bit-exact against the reference run with float32 tables; Q within
+1e-6 of the float64 reference while the runs coincide."""
+import numpy as np
+import pytest
+
+from conftest import SEED, as_world
+from sfma_common import sfma_case, sfma_cases
+
+pytestmark = pytest.mark.gpu
+
+MEM_KEYS = ('recency', 'C_normalize', 'D_normalize', 'R_normalize', 'deterministic',
+            'reward_mod_local', 'reward_mod', 'state_mod', 'reward_modulation', 'beta',
+            'decay_inhibition', 'decay_strength')
+AGENT_KEYS = ('dynamic', 'random', 'start_replay', 'nb_replays')
+
+
+@pytest.fixture(scope='module')
+def Z(golden):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return golden('sfma_traces')
+
+
+def build(world, D, opts, n_envs, base, callbacks=None, eps=0.1):
+    from cobel_amd.agent import SFMA
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.memory import SFMAMemory
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld(as_world(world), n_envs=n_envs, seed=SEED, instance_base=base)
+    mem = SFMAMemory(D, env.observation_space.n, 4)
+    for k in MEM_KEYS:
+        if k in opts:
+            setattr(mem, k, opts[k])
+    pol_test = EpsilonGreedy(0.0) if opts.get('test_trials') else None
+    agent = SFMA(env.observation_space, env.action_space, EpsilonGreedy(eps), mem, pol_test,
+                 custom_callbacks=callbacks)
+    agent.M.mode = opts['mode']
+    for k in AGENT_KEYS:
+        if k in opts:
+            setattr(agent, k, opts[k])
+    if opts.get('mask') is not None and opts.get('mask') is not False:
+        agent.mask_actions = True
+        agent.action_mask = np.asarray(opts['mask'], dtype=bool)
+    agent.track_instances = True
+    agent.keep_replay_trace = True
+    return env, agent
+
+
+def run_schedule(env, agent, opts, trials, steps, B):
+    agent.train(env, trials, steps, B)
+    if opts.get('noreplay_trials'):
+        agent.train(env, opts['noreplay_trials'], steps, B, True)
+    if opts.get('test_trials'):
+        agent.test(env, opts['test_trials'], steps)
+
+
+def events_of(agent, i):
+    evs = [ev for k, ev in agent.replay_events if k == i]
+    from cobel_amd.agent.sfma import EVENT
+    return np.concatenate(evs) if evs else np.zeros(0, dtype=EVENT)
+
+
+def check_events(ev, rp):
+    """Trace records of one instance against rows (trial, kind, s, a, r, ns, nt, td)."""
+    sa = ev['sa'].astype(np.int64)
+    assert len(ev) == len(rp)
+    assert np.array_equal(ev['trial'], rp[:, 0])
+    assert np.array_equal((sa >> 25) & 1, rp[:, 1])
+    assert np.array_equal(sa & 0xFFFF, rp[:, 2])
+    assert np.array_equal((sa >> 16) & 0xFF, rp[:, 3])
+    assert np.array_equal(ev['reward'].astype(np.float64), rp[:, 4])
+    assert np.array_equal(ev['next'], rp[:, 5])
+    assert np.array_equal((sa >> 24) & 1, rp[:, 6])
+    assert np.array_equal(ev['td'], rp[:, 7], equal_nan=True)
+
+
+F32_CASES = ['dr_default_f32', 'dr_reverse_f32', 'sr_forward_f32', 'eu_sweeping_f32',
+             'dr_dynamic_f32', 'sr_random_mask_f32', 'dr_random_f32', 'dr_traintest_f32',
+             'w67_dr_reverse_f32', 'w67_sr_blendf_f32', 'w67_sr_blendr_f32', 'w67_eu_interp_f32',
+             'w67_dr_recency_f32', 'w67_dr_determ_f32', 'w67_dr_start_f32', 'w67_sr_mods_f32',
+             'w67_dr_dynamic_f32']
+
+
+def test_fixture_list_is_complete(Z):
+    assert sorted(F32_CASES) == [n for n in sfma_cases(Z) if n.endswith('_f32')]
+
+
+@pytest.mark.parametrize('name', F32_CASES)
+def test_sfma_golden_vectorised(Z, name):
+    """Three instances in one launch per call; the one the fixture was recorded for reproduces the
+    reference's float32 run: steps, replays, Q, model, strengths, recency, |TD| sum, counters."""
+    from cobel_amd import _lib
+    g, world, D, opts = sfma_case(Z, name)
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    env, agent = build(world, D, opts, 3, inst - 1 if inst else 0)
+    i = 1 if inst else 0
+    run_schedule(env, agent, opts, trials, steps, B)
+    n_trials = len(g('steps'))
+    assert np.array_equal(agent.monitors.lat_trace[i].cpu().numpy()[:n_trials], g('steps'))
+    rp = np.stack([g(k).astype(np.float64) for k in
+                   ('rp_trial', 'rp_kind', 'rp_state', 'rp_action', 'rp_reward', 'rp_next',
+                    'rp_nonterminal', 'rp_td')], axis=1)
+    check_events(events_of(agent, i), rp)
+    assert np.array_equal(agent.Q[i].cpu().numpy().astype(np.float64), g('Q'))
+    assert np.array_equal(agent.M.rewards[i].astype(np.float64), g('M_rewards'))
+    assert np.array_equal(agent.M.states[i], g('M_states'))
+    assert np.array_equal(agent.M.terminals[i], g('M_terminals'))
+    assert np.array_equal(agent.M.C[i], g('C'))
+    assert np.array_equal(agent.M.T[i], g('T'))
+    assert agent.td[i] == g('td_acc')[-1]
+    assert agent.M.modes[i] == _lib.SFMA_MODES[int(g('final_mode'))]
+    ctr = [int(env.env_ctr[i]), int(agent.policy.counter[i]), int(agent.M.counter[i]),
+           int(agent.M.state[i, _lib.SI_CTR_AGENT])]
+    assert ctr == list(g('ctr'))
+
+
+class Spy:
+    def __init__(self):
+        self.sarsn, self.td, self.steps, self.reward, self.q = [], [], [], [], []
+        self.modes, self.replays, self.begun = [], [], 0
+
+    def step_end(self, logs):
+        self.sarsn.append((logs['state'], logs['action'], logs['reward'], logs['next_state'],
+                           logs['terminal']))
+        self.td.append(logs.get('td', 0.0))
+
+    def trial_end(self, logs):
+        self.steps.append(logs['steps'])
+        self.reward.append(logs['trial_reward'])
+        self.q.append(np.array(logs['agent'].Q, dtype=np.float64))
+        self.modes.append(logs['replay_mode'])
+
+    def replay_begin(self, logs):
+        self.begun += 1
+
+    def replay_end(self, logs):
+        self.replays.append([(e['state'], e['action'], float(e['reward']), e['next_state'],
+                              e['terminal'], e.get('td', np.nan)) for e in logs['replay']])
+
+
+@pytest.mark.parametrize('name', ['dr_reverse_f32', 'dr_traintest_f32', 'w67_dr_start_f32',
+                                  'w67_dr_dynamic_f32'])
+def test_sfma_golden_per_step_callbacks(Z, name):
+    """n_envs = 1 with the reference's callbacks (on_replay_* included): the per-step experience
+    stream, per-trial Q tables, replay modes and the replay batches handed to on_replay_end."""
+    from cobel_amd import _lib
+    g, world, D, opts = sfma_case(Z, name)
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    spy = Spy()
+    cbs = {'on_step_end': [spy.step_end], 'on_trial_end': [spy.trial_end],
+           'on_replay_begin': [spy.replay_begin], 'on_replay_end': [spy.replay_end]}
+    env, agent = build(world, D, opts, 1, inst, cbs)
+    run_schedule(env, agent, opts, trials, steps, B)
+    a = np.array(spy.sarsn, dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(a[:, col], g(key)), key
+    n_train = int(g('n_train_steps')[1])
+    assert np.array_equal(np.array(spy.td, dtype=np.float64)[:n_train], g('td')[:n_train])
+    assert np.array_equal(spy.steps, g('steps'))
+    assert np.array_equal(spy.reward, g('trial_reward'))
+    assert np.array_equal(np.array(spy.q), g('Q_trial'))
+    assert [_lib.SFMA_MODES.index(m) for m in spy.modes] == list(g('replay_mode'))
+    flat = np.array([e for batch in spy.replays for e in batch], dtype=np.float64).reshape(-1, 6)
+    ref = np.stack([g(k).astype(np.float64) for k in ('rp_state', 'rp_action', 'rp_reward',
+                                                      'rp_next', 'rp_nonterminal', 'rp_td')], 1)
+    assert np.array_equal(flat, ref, equal_nan=True)
+    assert spy.begun == len(spy.replays)
+
+
+@pytest.mark.parametrize('pair', [('dr_default_f32', 'dr_default_f64'),
+                                  ('dr_dynamic_f32', 'dr_dynamic_f64'),
+                                  ('w67_dr_reverse_f32', 'w67_dr_reverse_f64')])
+def test_sfma_float32_vs_float64_reference(Z, pair):
+    """Against the float64 reference as shipped: same trajectory and replays on these fixtures,
+    Q after every trial within 1e-6 relative to max(1, |Q|)."""
+    f32, f64 = pair
+    g, world, D, opts = sfma_case(Z, f32)
+    inst, _, trials, steps, B = [int(x) for x in g('cfg')]
+    spy = Spy()
+    env, agent = build(world, D, opts, 1, inst, {'on_trial_end': [spy.trial_end]})
+    run_schedule(env, agent, opts, trials, steps, B)
+    assert np.array_equal(spy.steps, Z[f64 + '/steps'])
+    ref = Z[f64 + '/Q_trial']
+    for t in range(len(ref)):
+        assert np.max(np.abs(spy.q[t] - ref[t]) / np.maximum(1.0, np.abs(ref[t]))) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# against the restatement on worlds the fixtures do not cover (more experiences per lane)
+# ---------------------------------------------------------------------------------------------
+def _field(h, w, goal, reward, walls=()):
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    return make_gridworld(h, w, terminals=[goal], rewards=np.array([[goal, reward]]),
+                          goals=[goal], invalid_transitions=list(walls))
+
+
+def _oracle_world(world):
+    c = world.compact()
+    return dict(next=c['next'], reward=c['reward'].astype(np.float64), terminal=c['terminal'],
+                starts=c['starts'])
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(h=7, w=7, metric='DR', mode='reverse', steps=40, B=24, opts={}),
+    dict(h=10, w=10, metric='SR', mode='default', steps=60, B=32, opts={'recency': True}),
+    dict(h=10, w=10, metric='Euclidean', mode='sweeping', steps=30, B=16,
+         opts={'dynamic': True, 'start_replay': True}),
+    dict(h=9, w=13, metric='DR', mode='interpolate', steps=50, B=20,
+         opts={'decay_strength': 0.97, 'reward_mod': True, 'C_normalize': True}),
+    dict(h=16, w=16, metric='SR', mode='blend_reverse', steps=80, B=12, opts={'random': False}),
+    dict(h=10, w=10, metric='DR', mode='default', steps=40, B=40, opts={'random': True}),
+])
+def test_sfma_vs_oracle_larger_worlds(Z, cfg):
+    """48 instances in one launch, 6 of them re-run by the NumPy restatement: trajectories,
+    replays, tables."""
+    from cobel_amd.memory.utils import DR, SR, Euclidean
+    from oracle import sfma_loop
+    h, w = cfg['h'], cfg['w']
+    walls = [(w + 1, w + 2), (w + 2, w + 1), (2 * w + 1, 2 * w + 2), (2 * w + 2, 2 * w + 1)]
+    world = _field(h, w, w - 1, 1.0, walls)
+    if cfg['metric'] == 'DR':
+        D = DR(w, h, world['next'], 0.9, world['invalid_transitions']).D
+    elif cfg['metric'] == 'SR':
+        D = SR(world['next'], 0.9).D
+    else:
+        D = Euclidean(w, h).D
+    opts = dict(cfg['opts'], mode=cfg['mode'])
+    trials = 6
+    tab = dict(world.compact(), height=h, width=w, coordinates=world['coordinates'])
+    env, agent = build(tab, D, opts, 48, 1000)
+    run_schedule(env, agent, opts, trials, cfg['steps'], cfg['B'])
+    ow = _oracle_world(world)
+    for i in (0, 5, 17, 23, 40, 47):
+        ag, oenv = sfma_loop.run_case(ow, D, SEED, 1000 + i, True, cfg['mode'], opts, trials,
+                                      cfg['steps'], cfg['B'])
+        assert np.array_equal(agent.monitors.lat_trace[i].cpu().numpy()[:trials], ag.steps), i
+        rp = np.array(ag.replayed, dtype=np.float64).reshape(-1, 8)
+        check_events(events_of(agent, i), rp)
+        assert np.array_equal(agent.Q[i].cpu().numpy(), ag.Q), i
+        assert np.array_equal(agent.M.rewards[i], ag.M.rewards), i
+        assert np.array_equal(agent.M.states[i], ag.M.states), i
+        assert np.array_equal(agent.M.C[i], ag.M.C), i
+        assert np.array_equal(agent.M.T[i], ag.M.T), i
+        assert agent.td[i] == float(ag.td), i
+
+
+def test_sfma_chunking_and_sharding_invariance(Z):
+    """The same 16 instances as one launch, as 5-step launches (callbacks force per-trial/-step
+    driving only for n_envs = 1, so chunk by train() calls) and as two shards: identical tables."""
+    g, world, D, opts = sfma_case(Z, 'w67_dr_reverse_f32')
+    env, ref = build(world, D, opts, 16, 50)
+    ref.train(env, 9, 14, 24)
+    env2, a2 = build(world, D, opts, 16, 50)
+    for _ in range(3):
+        a2.train(env2, 3, 14, 24)
+    assert np.array_equal(ref.Q.cpu().numpy(), a2.Q.cpu().numpy())
+    assert np.array_equal(ref.M.C, a2.M.C)
+    parts = []
+    for base, n in ((50, 6), (56, 10)):
+        e, a = build(world, D, opts, n, base)
+        a.train(e, 9, 14, 24)
+        parts.append(a)
+    assert np.array_equal(ref.Q.cpu().numpy(),
+                          np.concatenate([p.Q.cpu().numpy() for p in parts]))
+    assert np.array_equal(ref.M.C, np.concatenate([p.M.C for p in parts]))
+    assert np.array_equal(ref.M.table.cpu().numpy(),
+                          np.concatenate([p.M.table.cpu().numpy() for p in parts]))
+
+
+def test_sfma_edges(Z):
+    """batch 0 (replay draws its start action and stops), one-step trials, error modulation."""
+    g, world, D, opts = sfma_case(Z, 'dr_default_f32')
+    from oracle import sfma_loop
+    ow = dict(next=world['next'], reward=world['reward'], terminal=world['terminal'],
+              starts=world['starts'])
+    for steps, B in ((1, 4), (50, 0), (3, 1)):
+        env, agent = build(world, D, opts, 2, 7)
+        agent.train(env, 5, steps, B)
+        ag, _ = sfma_loop.run_case(ow, D, SEED, 8, True, 'default', opts, 5, steps, B)
+        assert np.array_equal(agent.Q[1].cpu().numpy(), ag.Q)
+        assert np.array_equal(agent.M.C[1], ag.M.C)
+        assert int(agent.M.counter[1]) == ag.M.rng.index
+    env, agent = build(world, D, opts, 1, 0)
+    agent.M.error_mod = True
+    with pytest.raises(KeyError):
+        agent.train(env, 1, 5, 4)
