@@ -19,6 +19,8 @@ Workloads, all synthetic, tables zero-initialised as the refere
      updates per step, 200 steps per trial.
   C2: 65 536 x 5x5 open field, Q-learning alpha .9 gamma .8 eps .1, no replay, 50 steps/trial.
   C4: 16 384 x 32x32 open field, SR alpha .1 gamma .99 eps .1, 200 steps/trial (64 GiB of SR).
+  C6: 65 536 x the 5x5 walled world of demo/gridworld/demo_sfma.py, SFMA with the DR metric in
+      reverse mode, 32 reactivations per trial (reported beside the headline).
 
 `roofline.achieved` = algorithmic bytes per env step (C2 67 B, C3 1 628 B,
 C4 32 817 B) x env steps per launch / mean launch duration, the latter measured with HIP events
@@ -57,6 +59,12 @@ CONFIGS = {
                bytes_per_step=32817, agent='sr',
                desc='16384 x 32x32 open gridworld, successor representation (alpha .1, gamma .99, '
                     'eps .1), 200 steps/trial'),
+    # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's SFMA demo, vectorised
+    'C6': dict(instances=65536, env_steps_per_launch=200, steps_per_trial=50, batch=32,
+               bytes_per_step=98, bytes_per_reactivation=20 * 100 + 16 * 25 + 32, agent='sfma',
+               desc='65536 x 5x5 walled gridworld of demo/gridworld/demo_sfma.py, SFMA (alpha .99, '
+                    'gamma .99, eps .1, DR metric gamma .9, reverse mode, action mask on), 32 '
+                    'reactivations per trial, 50 steps/trial'),
 }
 SEED = 0xC0BE1
 
@@ -103,6 +111,13 @@ def make_worlds(cfg_name):
         return [make_open_field(5, 5, 0, 1)]
     if cfg_name == 'C3':
         return [make_obstacle_maze(32, 32, 1234 + k) for k in range(64)]
+    if cfg_name == 'C6':
+        from cobel_amd.misc.gridworld_tools import make_gridworld
+        walls = [(3, 4), (4, 3), (8, 9), (9, 8), (13, 14), (14, 13), (18, 19), (19, 18)]
+        w = make_gridworld(5, 5, terminals=[4], rewards=np.array([[4, 10]]), goals=[4],
+                           invalid_transitions=walls)
+        w['starting_states'] = np.array([12])
+        return [w]
     return [make_open_field(32, 32, 0, 1)]
 
 
@@ -113,6 +128,17 @@ def build_agent(cfg_name, cfg, n, rank, device):
     env = Gridworld(make_worlds(cfg_name), n_envs=n, seed=SEED, device=device,
                     instance_base=rank * n)
     pol = EpsilonGreedy(0.1)
+    if cfg['agent'] == 'sfma':
+        from cobel_amd.agent import SFMA
+        from cobel_amd.memory import SFMAMemory
+        from cobel_amd.memory.utils import DR
+        w = env.world
+        metric = DR(w['width'], w['height'], w['next'], 0.9, w['invalid_transitions'])
+        agent = SFMA(env.observation_space, env.action_space, pol,
+                     SFMAMemory(metric, env.observation_space.n, 4))
+        agent.M.mode = 'reverse'
+        agent.mask_actions = True
+        return env, agent
     if cfg['agent'] == 'q':
         agent = QAgent(env.observation_space, env.action_space, pol)
     elif cfg['agent'] == 'dynaq':
@@ -145,6 +171,23 @@ def cpu_baseline(cfg_name, cfg, seconds=12.0):
     world = make_worlds(cfg_name)[0]
     tabs = world.compact()
     S = int(world['states'])
+    if cfg['agent'] == 'sfma':
+        from oracle import sfma_loop
+        D = sfma_loop.metric_dr(world['width'], world['height'], tabs['next'].astype(np.int64),
+                                0.9, world['invalid_transitions'])
+        ag, env = sfma_loop.run_case(tabs, D, SEED, 0, True, 'reverse',
+                                     {'mask': np.ones((S, 4), dtype=bool)}, 0,
+                                     cfg['steps_per_trial'], cfg['batch'])
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            ag.train(env, 1, cfg['steps_per_trial'], cfg['batch'])
+        dt = time.perf_counter() - t0
+        return {'value': len(ag.sarsn) / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+                'reactivations_per_s': len(ag.replayed) / dt,
+                'sample': 'oracle/sfma_loop.py (NumPy restatement of the reference SFMA loop, '
+                          'float32 tables), instance 0 of the same workload, %d env steps + %d '
+                          'reactivations in %.1f s on 1 of %d host cores'
+                          % (len(ag.sarsn), len(ag.replayed), dt, os.cpu_count() or 1)}
     env = ref_loop.RefGridworld(tabs, philox.TapeRNG(SEED, 0, philox.STREAM_ENV))
     pol = ref_loop.RefEpsilonGreedy(0.1, philox.TapeRNG(SEED, 0, philox.STREAM_POLICY))
     mem = philox.TapeRNG(SEED, 0, philox.STREAM_MEMORY)
@@ -198,6 +241,8 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
         runner.launch()
     torch.cuda.synchronize(device)
     before = agent.env_steps()
+    sfma = cfg['agent'] == 'sfma'
+    replays_before = int(agent.replays_done.item()) if sfma else 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
@@ -227,6 +272,9 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
     assert total_steps == expect, 'kernel executed %d env steps, expected %d' % (total_steps, expect)
     mean_launch_s = float(np.mean(launch_ms)) * 1e-3
     alg_bytes_per_launch = cfg['bytes_per_step'] * n * cfg['env_steps_per_launch']
+    if sfma:   # reactivations per launch depend on the trial lengths: count them (this rank)
+        replays = int(agent.replays_done.item()) - replays_before
+        alg_bytes_per_launch += cfg['bytes_per_reactivation'] * replays // args.steps
     achieved = alg_bytes_per_launch / mean_launch_s / 1e9
     res = {
         'metric': 'gridworld env-steps/sec (whole job)',
@@ -244,11 +292,14 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
                      'algorithmic_bytes_per_launch': alg_bytes_per_launch,
                      'kernel': {'q': 'k_tab_lpi', 'dynaq': 'k_tab_wpi<DYNAQ>',
-                                'sr': 'k_sr'}[cfg['agent']],
+                                'sr': 'k_sr', 'sfma': 'k_sfma'}[cfg['agent']],
                      'algorithmic_bytes_per_env_step': cfg['bytes_per_step'],
                      'launch_ms_mean': mean_launch_s * 1e3,
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
+    if sfma:
+        res['reactivations_per_s'] = replays * world_size / elapsed
+        res['roofline']['algorithmic_bytes_per_reactivation'] = cfg['bytes_per_reactivation']
     return res, cfg
 
 
@@ -258,7 +309,7 @@ def main():
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=sorted(CONFIGS))
-    ap.add_argument('--also', default='C2,C4', help='extra configs reported under "other_configs"')
+    ap.add_argument('--also', default='C2,C4,C6', help='extra configs reported under "other_configs"')
     ap.add_argument('--instances', type=int, default=0)
     ap.add_argument('--env-steps', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -287,6 +338,10 @@ def main():
                 others[name] = {'value': r['value'], 'unit': r['unit'],
                                 'ms_per_step': r['ms_per_step'], 'config': r['config'],
                                 'roofline': r['roofline']}
+                if 'reactivations_per_s' in r:
+                    others[name]['reactivations_per_s'] = r['reactivations_per_s']
+                    if rank == 0 and not args.no_cpu_baseline:
+                        others[name]['cpu_baseline'] = cpu_baseline(name, CONFIGS[name], 8.0)
             except Exception as e:  # e.g. not enough HBM for C4 on a shared device
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         for dt_name in (() if args.no_c5 else ('f64', 'f32')):

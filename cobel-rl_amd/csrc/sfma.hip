@@ -7,12 +7,13 @@
 //
 // Here an instance's tables live in LDS for the whole call: Q (float32 [S][4]), strengths C
 // (float64 [4S]), inhibition I (float64 [S]), the model's successor table NS (u16 [4S], experience
-// order j = a * S + s) and one scratch vector of 4S priorities.  Lane l owns the experiences
+// order j = a * S + s, flag bit 15), its reward estimates R (float32 [4S]) and one scratch vector
+// of 4S priorities.  Lane l owns the experiences
 // [l * chunk, (l + 1) * chunk), so the cumulative sum behind the draw is one wave scan of lane
 // totals plus a short in-lane running sum — element order as in the reference's cumsum.  The rows
 // D[cur], D[next] of the similarity matrix (shared by all instances of a world, L2 resident) are
-// staged in LDS once per reactivation.  The model's reward estimates stay in HBM (written through,
-// read once per reactivated experience); recency T is kept as a store stamp per experience and a
+// staged in LDS once per reactivation.  The packed model records in HBM are written through on
+// every store and never read back during the call; recency T is kept as a store stamp per experience and a
 // table of decay powers instead of a vector that is rescaled on every store.
 //
 // Reference behaviour restated (paths relative to /root/reference/src/cobel):
@@ -41,11 +42,12 @@ struct sfma_lds {
   double* I;     // [S]  inhibition
   double* Dc;    // [S]  similarity row of the current state
   double* Dn;    // [S]  similarity row of the next state
-  uint16_t* NS;  // [4S] model successor of experience j
+  float* R;      // [4S] model reward estimate of experience j
+  uint16_t* NS;  // [4S] model successor of experience j | nonterminal flag << 15
 };
 
 __host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
-  return ((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 8) + 15) & ~(size_t)15;
+  return ((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15;
 }
 
 __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
@@ -63,6 +65,8 @@ __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
   off += (size_t)S * 8;
   L.Dn = reinterpret_cast<double*>(base + off);
   off += (size_t)S * 8;
+  L.R = reinterpret_cast<float*>(base + off);
+  off += (size_t)S * 16;
   L.NS = reinterpret_cast<uint16_t*>(base + off);
   return L;
 }
@@ -81,27 +85,49 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
   const uint32_t w = (a & 2) ? w1 : w0;
   return (a & 1) ? (w >> 16) : (w & 0xffffu);
 }
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+// Cross-lane data movement on the VALU (DPP) instead of ds_bpermute through the LDS crossbar: a
+// reactivation is a chain of five dependent wave-wide reductions / scans, so their latency is the
+// critical path.  Controls: quad_perm 0x00-0xff, row_shr:n 0x110+n, wave_shr:1 0x138, row_mirror
+// 0x140, row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v), o = __builtin_bit_cast(uint64_t, old);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)b,
+                                                            CTRL, ROW_MASK, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32),
+                                                            (int)(uint32_t)(b >> 32), CTRL,
+                                                            ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+// max over the wave, returned in every lane (scalar registers)
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v, v));         // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_f64<0x4E>(v, v));         // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_f64<0x141>(v, v));        // row_half_mirror
+  v = fmax(v, dpp_f64<0x140>(v, v));        // row_mirror: every lane holds its row's max
+  v = fmax(v, dpp_f64<0x142, 0xa>(v, v));   // row_bcast:15 into rows 1, 3
+  v = fmax(v, dpp_f64<0x143, 0xc>(v, v));   // row_bcast:31 into rows 2, 3
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
   return v;
 }
-__device__ __forceinline__ double wave_scan_f64(double v, int lane) {  // inclusive
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double t = __shfl_up(v, o);
-    if (lane >= o) v = v + t;
-  }
+// inclusive prefix sum over the lanes
+__device__ __forceinline__ double wave_scan_f64(double v) {
+  v = v + dpp_f64<0x111>(0.0, v);           // row_shr:1
+  v = v + dpp_f64<0x112>(0.0, v);           // row_shr:2
+  v = v + dpp_f64<0x114>(0.0, v);           // row_shr:4
+  v = v + dpp_f64<0x118>(0.0, v);           // row_shr:8: prefix within each row of 16
+  v = v + dpp_f64<0x142, 0xa>(0.0, v);      // rows 1, 3 += last lane of the row before
+  v = v + dpp_f64<0x143, 0xc>(0.0, v);      // rows 2, 3 += lane 31
   return v;
 }
 __device__ __forceinline__ float max4_masked(const float4 q, uint32_t mask) {
@@ -126,29 +152,28 @@ __device__ __forceinline__ int wave_first_equal(const double* P, int n4, int chu
 }
 
 // Generator.choice(arange(n4), p = w / sum(w)) for the weights w >= 0 in P, driven by the uniform
-// u: the number of experiences whose normalised cumulative weight is <= u.  Wave-uniform result.
+// u: the number of experiences whose cumulative weight is <= u * total.  Wave-uniform result.
 __device__ __forceinline__ int wave_choice(const double* P, int n4, int chunk, int lane, double u,
                                            double wmax) {
   const int j0 = lane * chunk;
   double loc = 0.0;
   for (int k = 0; k < chunk; ++k)
     if (j0 + k < n4) loc = loc + P[j0 + k];
-  const double incl = wave_scan_f64(loc, lane);
-  double excl = __shfl_up(incl, 1);
-  if (lane == 0) excl = 0.0;
+  const double incl = wave_scan_f64(loc);
+  const double excl = dpp_f64<0x138>(0.0, incl);   // wave_shr:1, lane 0 keeps 0
   // the cumulative weight at the last experience; lanes behind it hold nothing
-  const double total = __shfl(excl + loc, (n4 - 1) / chunk);
-  int cnt = 0;
+  const double total = readlane_f64(excl + loc, (n4 - 1) / chunk);
+  const double thr = u * total;
+  int idx = 0;
   double run = 0.0;
-  for (int k = 0; k < chunk; ++k)
-    if (j0 + k < n4) {
-      run = run + P[j0 + k];
-      cnt += ((excl + run) / total <= u) ? 1 : 0;
-    }
-  int idx = wave_sum_i32(cnt);
+  for (int k = 0; k < chunk; ++k) {
+    const bool in = j0 + k < n4;
+    if (in) run = run + P[j0 + k];
+    idx += __popcll(__ballot(in && (excl + run <= thr)));
+  }
   idx = idx < n4 ? idx : n4 - 1;
   // an experience of weight zero has probability zero; rounding at a lane boundary of the scan
-  // is the only way to land on one
+  // (or of u * total at u -> 1) is the only way to land on one
   if (!(P[idx] > 0.0)) idx = wave_first_equal(P, n4, chunk, lane, wmax);
   return idx;
 }
@@ -174,7 +199,10 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   }
   for (int e = lane; e < n4; e += 64) {
     L.C[e] = Cg[e];
-    L.NS[(e & 3) * S + (e >> 2)] = (uint16_t)((Mg[e] >> 32) & 0xffffu);
+    const uint64_t rec = Mg[e];
+    const int j = (e & 3) * S + (e >> 2);
+    L.R[j] = __builtin_bit_cast(float, (uint32_t)rec);
+    L.NS[j] = (uint16_t)(((rec >> 32) & 0x7fffu) | (((rec >> 48) & 1u) << 15));
   }
   wsync();
 
@@ -208,8 +236,18 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   const double alpha = A.r.alpha, gamma = A.r.gamma;
   const float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
 
-  cobel_u4 pblk = {0, 0, 0, 0};
-  uint32_t pb_idx = ~0u;
+  cobel_u4 pblk = {0, 0, 0, 0}, mblk = {0, 0, 0, 0};
+  uint32_t pb_idx = ~0u, mb_idx = ~0u;
+  // scalar double draw number cm of the memory stream (sub 1): one block serves two counters
+  auto mem_u01 = [&]() -> double {
+    if ((cm >> 1) != mb_idx) {
+      mb_idx = cm >> 1;
+      mblk = cobel_philox(mb_idx, COBEL_SUB_DOUBLE, g, COBEL_STREAM_MEMORY, seed);
+    }
+    const double u = (cm & 1u) ? cobel_u01(mblk.z, mblk.w) : cobel_u01(mblk.x, mblk.y);
+    cm += 1u;
+    return u;
+  };
   unsigned long long executed = 0, replayed = 0;
   int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
 
@@ -260,14 +298,13 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
         }
       wmax = wave_max_f64(wmax);
       wsync();
-      const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE, g, COBEL_STREAM_MEMORY, seed);
-      cm += 1u;
+      const double u = mem_u01();
       const int pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
       action = pick / S;
       cur = pick - action * S;
       wsync();
     }
-    int nxt = (int)L.NS[action * S + cur];
+    int nxt = (int)(L.NS[action * S + cur] & 0x7fffu);
     for (int e = lane; e < S; e += 64) L.I[e] = 0.0;
     double cmax = 1.0;
     if (sf & COBEL_SF_C_NORMALIZE) {
@@ -308,12 +345,12 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
             double d;
             if (mode == COBEL_SFMA_DEFAULT) d = L.Dc[s];
             else if (mode == COBEL_SFMA_FORWARD) d = L.Dn[s];
-            else if (mode == COBEL_SFMA_REVERSE) d = L.Dc[L.NS[j]];
+            else if (mode == COBEL_SFMA_REVERSE) d = L.Dc[L.NS[j] & 0x7fffu];
             else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + A.r.blend * L.Dn[s];
-            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + A.r.blend * L.Dc[L.NS[j]];
+            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + A.r.blend * L.Dc[L.NS[j] & 0x7fffu];
             else if (mode == COBEL_SFMA_INTERPOLATE)
-              d = A.r.interp_fwd * L.Dn[s] + A.r.interp_rev * L.Dc[L.NS[j]];
-            else d = L.Dn[L.NS[j]];
+              d = A.r.interp_fwd * L.Dn[s] + A.r.interp_rev * L.Dc[L.NS[j] & 0x7fffu];
+            else d = L.Dn[L.NS[j] & 0x7fffu];
             double R = c * d;
             R = R * (1.0 - L.I[s]);
             if (sf & COBEL_SF_RECENCY) {
@@ -358,22 +395,21 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
           wmax = 1.0;
         }
         wsync();
-        const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE, g, COBEL_STREAM_MEMORY, seed);
-        cm += 1u;
+        const double u = mem_u01();
         pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
       }
       action = pick / S;
       cur = pick - action * S;
-      nxt = (int)L.NS[pick];
+      const uint32_t nrec = L.NS[pick];
+      const float R = L.R[pick];
+      nxt = (int)(nrec & 0x7fffu);
+      const uint32_t nt = nrec >> 15;
       wsync();
       // inhibition (:336-337)
       for (int e = lane; e < S; e += 64) L.I[e] = L.I[e] * A.r.decay_inhibition;
       wsync();
       if (lane == 0) L.I[cur] = fmin(L.I[cur] + A.r.i_step, 1.0);
       // the reactivated experience
-      const uint64_t rec = Mg[cur * 4 + action];
-      const float R = __builtin_bit_cast(float, (uint32_t)rec);
-      const uint32_t nt = (uint32_t)(rec >> 48) & 1u;
       double td = __builtin_nan("");
       if (update) td = replay_td(cur, action, nxt, R, nt);
       record(cur, action, nxt, R, nt, kind, tr, td);
@@ -388,16 +424,15 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
     for (int b = 0; b < A.r.batch; ++b) {
       const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE + (uint32_t)b, g, COBEL_STREAM_MEMORY,
                                       seed);
-      int cnt = 0;
+      int idx = 0;
       for (int k = 0; k < chunk; ++k)
-        if (j0 + k < n4) cnt += (A.r.random_cdf[j0 + k] <= u) ? 1 : 0;
-      int idx = wave_sum_i32(cnt);
+        idx += __popcll(__ballot(j0 + k < n4 && A.r.random_cdf[j0 + k] <= u));
       idx = idx < n4 ? idx : n4 - 1;
       const int a = idx / S, s = idx - a * S;   // unravel_index(order='F')
-      const int ns = (int)L.NS[idx];
-      const uint64_t rec = Mg[s * 4 + a];
-      const float R = __builtin_bit_cast(float, (uint32_t)rec);
-      const uint32_t nt = (uint32_t)(rec >> 48) & 1u;
+      const uint32_t nrec = L.NS[idx];
+      const int ns = (int)(nrec & 0x7fffu);
+      const float R = L.R[idx];
+      const uint32_t nt = nrec >> 15;
       const double td = replay_td(s, a, ns, R, nt);
       record(s, a, ns, R, nt, 0, tr, td);
       replayed += 1ull;
@@ -442,12 +477,13 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
     if (learn) {
       const int sa = state * 4 + a, j = a * S + state;
       // M.store (memory/sfma.py:204-236)
-      const float Rold = __builtin_bit_cast(float, (uint32_t)Mg[sa]);
+      const float Rold = L.R[j];
       const float d = r - Rold;
       const float Rnew = Rold + mlr_f * d;
       if (lane == 0) {
-        Mg[sa] = cobel_model_pack(Rnew, (uint32_t)ns, nt);
-        L.NS[j] = (uint16_t)ns;
+        Mg[sa] = cobel_model_pack(Rnew, (uint32_t)ns, nt);   // written through
+        L.R[j] = Rnew;
+        L.NS[j] = (uint16_t)((uint32_t)ns | (nt << 15));
       }
       if (A.r.decay_strength != 1.0) {
         for (int e = lane; e < n4; e += 64) L.C[e] = L.C[e] * A.r.decay_strength;
