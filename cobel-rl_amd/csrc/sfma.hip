@@ -178,6 +178,10 @@ __device__ __forceinline__ int wave_choice(const double* P, int n4, int chunk, i
   return idx;
 }
 
+// CH > 0: the common switches (no recency, no C / D normalisation, R normalisation on, softmax
+// draw) with exactly CH experiences per lane, which then live in registers from the priority
+// rating to the draw.  CH = 0: every switch, any number of experiences per lane, through LDS.
+template <int CH>
 __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S, n4 = 4 * A.S, chunk = A.chunk;
@@ -233,8 +237,30 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   const uint64_t seed = A.r.seed;
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
-  const double alpha = A.r.alpha, gamma = A.r.gamma;
-  const float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  // Everything in this kernel is wave-uniform, so the compiler wants it all in scalar registers
+  // and then spills (1 300 of 3 000 vector instructions were v_readlane / v_writelane).  Constants
+  // that only feed vector arithmetic are pinned to vector registers instead.
+  double alpha = A.r.alpha, gamma = A.r.gamma, beta = A.r.beta, r_thr = A.r.r_threshold;
+  double dec_inh = A.r.decay_inhibition, i_step = A.r.i_step, blend = A.r.blend;
+  double ip_fwd = A.r.interp_fwd, ip_rev = A.r.interp_rev;
+  float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  cobel_eps_bb ebb = A.eps;
+  asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(beta), "+v"(r_thr), "+v"(dec_inh), "+v"(i_step),
+               "+v"(blend), "+v"(ip_fwd), "+v"(ip_rev), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
+#pragma unroll
+  for (int k = 1; k <= 4; ++k) asm volatile("" : "+v"(ebb.base[k]), "+v"(ebb.bonus[k]));
+
+  // CH > 0: this lane's experiences j = lane * CH + k, their states and whether they exist
+  constexpr int CHN = CH > 0 ? CH : 1;
+  int jj[CHN], sid[CHN];
+  bool inb[CHN];
+#pragma unroll
+  for (int k = 0; k < CHN; ++k) {
+    const int j = lane * CHN + k;
+    inb[k] = j < n4;
+    jj[k] = inb[k] ? j : n4 - 1;
+    sid[k] = jj[k] % S;
+  }
 
   cobel_u4 pblk = {0, 0, 0, 0}, mblk = {0, 0, 0, 0};
   uint32_t pb_idx = ~0u, mb_idx = ~0u;
@@ -333,6 +359,103 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
         }
       }
       wsync();
+      int pick;
+      if (CH > 0) {
+        // similarity of every experience to the one replayed last, by mode (:284-307)
+        double d[CHN];
+        uint32_t nsv[CHN];
+#pragma unroll
+        for (int k = 0; k < CHN; ++k) nsv[k] = L.NS[jj[k]] & 0x7fffu;
+        switch (mode) {
+          case COBEL_SFMA_DEFAULT:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]];
+            break;
+          case COBEL_SFMA_FORWARD:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dn[sid[k]];
+            break;
+          case COBEL_SFMA_REVERSE:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[nsv[k]];
+            break;
+          case COBEL_SFMA_BLEND_FORWARD:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + blend * L.Dn[sid[k]];
+            break;
+          case COBEL_SFMA_BLEND_REVERSE:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + blend * L.Dc[nsv[k]];
+            break;
+          case COBEL_SFMA_INTERPOLATE:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k)
+              d[k] = ip_fwd * L.Dn[sid[k]] + ip_rev * L.Dc[nsv[k]];
+            break;
+          default:
+#pragma unroll
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dn[nsv[k]];
+            break;
+        }
+        // priority ratings (:308-318)
+        double p[CHN];
+        double rmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < CHN; ++k) {
+          double R = L.C[jj[k]] * d[k];
+          R = R * (1.0 - L.I[sid[k]]);
+          if (R < r_thr) R = 0.0;
+          p[k] = inb[k] ? R : 0.0;
+          rmax = fmax(rmax, p[k]);
+        }
+        rmax = wave_max_f64(rmax);
+        if (!(rmax > 0.0)) break;
+        // softmax weights exp(beta R / max R) - 1 (:319-327, :349-372)
+        bool some = false;
+#pragma unroll
+        for (int k = 0; k < CHN; ++k) {
+          const double w = exp((p[k] / rmax) * beta) + -1.0;
+          p[k] = inb[k] ? w : 0.0;
+          some = some || p[k] > 0.0;
+        }
+        if (!__ballot(some)) {  // np.sum(exp) == 0 -> exp.fill(1)
+#pragma unroll
+          for (int k = 0; k < CHN; ++k) p[k] = inb[k] ? 1.0 : 0.0;
+        }
+        // the draw: experiences whose cumulative weight is <= u * total
+        const double u = mem_u01();
+        double loc = p[0];
+#pragma unroll
+        for (int k = 1; k < CHN; ++k) loc = loc + p[k];
+        const double incl = wave_scan_f64(loc);
+        const double excl = dpp_f64<0x138>(0.0, incl);
+        const double total = readlane_f64(excl + loc, (n4 - 1) / CHN);
+        const double thr = u * total;
+        int idx = 0;
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k < CHN; ++k) {
+          run = run + p[k];
+          idx += __popcll(__ballot(inb[k] && (excl + run <= thr)));
+        }
+        idx = idx < n4 ? idx : n4 - 1;
+        bool ok = false;
+#pragma unroll
+        for (int k = 0; k < CHN; ++k) ok = ok || (inb[k] && jj[k] == idx && p[k] > 0.0);
+        if (!__ballot(ok)) {
+          // rounding put the draw on an experience of weight zero: take the argmax instead
+          double wmax = 0.0;
+#pragma unroll
+          for (int k = 0; k < CHN; ++k) {
+            if (inb[k]) L.P[jj[k]] = p[k];
+            wmax = fmax(wmax, p[k]);
+          }
+          wmax = wave_max_f64(wmax);
+          wsync();
+          idx = wave_first_equal(L.P, n4, CHN, lane, wmax);
+        }
+        pick = idx;
+      } else {
       // priority ratings (:288-316)
       double rmax = 0.0;
       {
@@ -346,10 +469,10 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
             if (mode == COBEL_SFMA_DEFAULT) d = L.Dc[s];
             else if (mode == COBEL_SFMA_FORWARD) d = L.Dn[s];
             else if (mode == COBEL_SFMA_REVERSE) d = L.Dc[L.NS[j] & 0x7fffu];
-            else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + A.r.blend * L.Dn[s];
-            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + A.r.blend * L.Dc[L.NS[j] & 0x7fffu];
+            else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + blend * L.Dn[s];
+            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + blend * L.Dc[L.NS[j] & 0x7fffu];
             else if (mode == COBEL_SFMA_INTERPOLATE)
-              d = A.r.interp_fwd * L.Dn[s] + A.r.interp_rev * L.Dc[L.NS[j] & 0x7fffu];
+              d = ip_fwd * L.Dn[s] + ip_rev * L.Dc[L.NS[j] & 0x7fffu];
             else d = L.Dn[L.NS[j] & 0x7fffu];
             double R = c * d;
             R = R * (1.0 - L.I[s]);
@@ -363,7 +486,7 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
               }
               R = R * t;
             }
-            if (R < A.r.r_threshold) R = 0.0;
+            if (R < r_thr) R = 0.0;
             L.P[j] = R;
             rmax = fmax(rmax, R);
           }
@@ -374,7 +497,6 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
       rmax = wave_max_f64(rmax);
       if (!(rmax > 0.0)) break;  // np.sum(R) == 0: nothing left to reactivate (:317-318)
       wsync();
-      int pick;
       if (sf & COBEL_SF_DETERMINISTIC) {
         pick = wave_first_equal(L.P, n4, chunk, lane, rmax);
       } else {
@@ -384,7 +506,7 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
           if (j0 + k < n4) {
             double R = L.P[j0 + k];
             if (sf & COBEL_SF_R_NORMALIZE) R = R / rmax;
-            const double w = exp(R * A.r.beta) + -1.0;
+            const double w = exp(R * beta) + -1.0;
             L.P[j0 + k] = w;
             wmax = fmax(wmax, w);
           }
@@ -398,7 +520,8 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
         const double u = mem_u01();
         pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
       }
-      action = pick / S;
+      }
+      action = (int)(pick >= S) + (int)(pick >= 2 * S) + (int)(pick >= 3 * S);   // pick / S
       cur = pick - action * S;
       const uint32_t nrec = L.NS[pick];
       const float R = L.R[pick];
@@ -406,9 +529,9 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
       const uint32_t nt = nrec >> 15;
       wsync();
       // inhibition (:336-337)
-      for (int e = lane; e < S; e += 64) L.I[e] = L.I[e] * A.r.decay_inhibition;
+      for (int e = lane; e < S; e += 64) L.I[e] = L.I[e] * dec_inh;
       wsync();
-      if (lane == 0) L.I[cur] = fmin(L.I[cur] + A.r.i_step, 1.0);
+      if (lane == 0) L.I[cur] = fmin(L.I[cur] + i_step, 1.0);
       // the reactivated experience
       double td = __builtin_nan("");
       if (update) td = replay_td(cur, action, nxt, R, nt);
@@ -465,7 +588,7 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
     const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
     cp += 1u;
     const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
-                                                                  A.eps, lane));
+                                                                  ebb, lane));
     const uint4 wc = W4[state];
     const int ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
     const uint4 wn = W4[ns];
@@ -607,6 +730,16 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   }
 }
 
+template <int CH>
+int launch_sfma(const sfma_args& A, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sfma<CH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_sfma<CH>), dim3(A.r.n), dim3(64), lds, st, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
 }  // namespace
 
 static const size_t kSfmaLdsLimit = 160 * 1024;
@@ -667,10 +800,22 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
-  if ((size_t)lds > 64 * 1024)
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sfma),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_sfma, dim3(r.n), dim3(64), (size_t)lds, (hipStream_t)stream, A);
-  COBEL_HIP_TRY(hipGetLastError());
-  return COBEL_OK;
+  const uint32_t special = COBEL_SF_RECENCY | COBEL_SF_C_NORMALIZE | COBEL_SF_D_NORMALIZE |
+                           COBEL_SF_DETERMINISTIC;
+  const bool plain = !(r.sfma_flags & special) && (r.sfma_flags & COBEL_SF_R_NORMALIZE) &&
+                     !(r.flags & COBEL_F_FORCE_WAVE);
+  hipStream_t st = (hipStream_t)stream;
+  if (plain && A.chunk <= 2) {
+    A.chunk = 2;
+    return launch_sfma<2>(A, (size_t)lds, st);
+  }
+  if (plain && A.chunk <= 4) {
+    A.chunk = 4;
+    return launch_sfma<4>(A, (size_t)lds, st);
+  }
+  if (plain && A.chunk <= 8) {
+    A.chunk = 8;
+    return launch_sfma<8>(A, (size_t)lds, st);
+  }
+  return launch_sfma<0>(A, (size_t)lds, st);
 }

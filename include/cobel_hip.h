@@ -191,7 +191,8 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
 #define COBEL_F_EPISODIC 4u       /* DynaQ.episodic_replay: one batch per trial              */
 #define COBEL_F_MASK_ACTIONS 8u   /* agent.mask_actions                                      */
 #define COBEL_F_TEST_STREAM 16u   /* draw u from COBEL_STREAM_POLICY_TEST (separate policy)  */
-#define COBEL_F_FORCE_WAVE 32u    /* always use the wave-per-instance kernel (testing)       */
+#define COBEL_F_FORCE_WAVE 32u    /* always use the wave-per-instance kernel (testing); SFMA: always
+                                     use the general kernel instead of a specialised one      */
 #define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 #define COBEL_F_NO_PREFETCH 128u   /* SR: load value rows at the top of each step (testing)        */
 

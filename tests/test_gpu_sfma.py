@@ -250,6 +250,24 @@ def test_sfma_vs_oracle_larger_worlds(Z, cfg):
         assert agent.td[i] == float(ag.td), i
 
 
+@pytest.mark.parametrize('name', ['dr_reverse_f32', 'w67_sr_blendf_f32', 'w67_eu_interp_f32',
+                                  'w67_dr_dynamic_f32'])
+def test_sfma_general_kernel_on_plain_configurations(Z, name):
+    """Plain configurations normally take a kernel specialised on the experiences per lane; the
+    general kernel must reproduce the same fixtures."""
+    g, world, D, opts = sfma_case(Z, name)
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    env, agent = build(world, D, opts, 2, inst)
+    agent.force_general_kernel = True
+    run_schedule(env, agent, opts, trials, steps, B)
+    rp = np.stack([g(k).astype(np.float64) for k in
+                   ('rp_trial', 'rp_kind', 'rp_state', 'rp_action', 'rp_reward', 'rp_next',
+                    'rp_nonterminal', 'rp_td')], axis=1)
+    check_events(events_of(agent, 0), rp)
+    assert np.array_equal(agent.Q[0].cpu().numpy().astype(np.float64), g('Q'))
+    assert np.array_equal(agent.M.C[0], g('C'))
+
+
 def test_sfma_chunking_and_sharding_invariance(Z):
     """The same 16 instances as one launch, as 5-step launches (callbacks force per-trial/-step
     driving only for n_envs = 1, so chunk by train() calls) and as two shards: identical tables."""
