@@ -61,7 +61,7 @@ class SFMAMemory:
         self.stamp = torch.zeros((n_envs, 4 * S), dtype=torch.int32, device=device)
         self.state = torch.zeros((n_envs, _lib.SI_WORDS), dtype=torch.int32, device=device)
         self.state[:, _lib.SI_FLAGS] = 1       # agent.td starts as a weak Python float
-        self.state[:, _lib.SI_MODE] = _lib.SFMA_MODES.index(self.mode)
+        self.state[:, _lib.SI_MODE] = self._mode_id()
         self._mode_seen = self.mode
         self.counter = torch.zeros(n_envs, dtype=torch.int32, device=device)
 
@@ -94,9 +94,14 @@ class SFMAMemory:
                              torch.as_tensor(np.array(vals, dtype=np.float64), device=device))
         return self._recency[1]
 
+    def _mode_id(self) -> int:
+        # memory/sfma.py:289-307 is an if/elif chain over the known names: any other string
+        # (unit_tests/test_sfma.py assigns 'dynamic') leaves the similarity as in 'default'
+        return _lib.SFMA_MODES.index(self.mode) if self.mode in _lib.SFMA_MODES else 0
+
     def _sync_mode(self) -> None:
         if self.mode != self._mode_seen:
-            self.state[:, _lib.SI_MODE] = _lib.SFMA_MODES.index(self.mode)
+            self.state[:, _lib.SI_MODE] = self._mode_id()
             self._mode_seen = self.mode
 
     def _read_mode(self) -> None:

@@ -1,0 +1,139 @@
+"""Drop-in check: with ``cobel_amd.install_as_cobel()`` the import lines and call sequences of the
+reference's own smoke tests and gridworld demos for this path run unchanged on the HIP library
+(unit_tests/test_gridworld.py, test_dyna_q.py, test_q.py [Gridworld case], test_sr.py, test_sfma.py;
+demo/gridworld/demo_dyna_q.py, demo_sfma.py without the Qt widget).  The reference's scripts
+assert nothing beyond "runs"; here every simulation additionally has to leave finite tables and
+the documented attribute surface."""
+from itertools import product
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cobel():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    import cobel_amd
+    cobel_amd.install_as_cobel()
+    import cobel
+    return cobel
+
+
+def test_dyna_q_simulations(cobel):
+    from cobel.agent import DynaQ
+    from cobel.interface import Gridworld
+    from cobel.misc.gridworld_tools import make_open_field
+    from cobel.policy import EpsilonGreedy
+    for use_test_policy, mask_actions in product([True, False], [True, False]):
+        env = Gridworld(make_open_field(5, 5, 0, 1))
+        policy_test = EpsilonGreedy(0.) if use_test_policy else None
+        agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(), policy_test)
+        agent.mask_actions = mask_actions
+        agent.train(env, 5, 20, 32)
+        agent.train(env, 5, 20, 32, True)
+        agent.test(env, 5, 20)
+        assert agent.current_trial == 15 and agent.Q.shape == (25, 4) and np.isfinite(agent.Q).all()
+        assert agent.M.states.shape == (25, 4)
+
+
+def test_q_and_sr_simulations(cobel):
+    from cobel.agent import SR, QAgent
+    from cobel.interface import Gridworld
+    from cobel.misc.gridworld_tools import make_open_field
+    from cobel.policy import EpsilonGreedy
+    for use_test_policy in (True, False):
+        env = Gridworld(make_open_field(5, 5, 0, 1))
+        agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(),
+                       EpsilonGreedy(0.) if use_test_policy else None)
+        agent.train(env, 5, 20, 32)
+        agent.test(env, 5, 20)
+        assert agent.current_trial == 10 and np.isfinite(agent.Q).all()
+    for use_test_policy, mask_actions in product([True, False], [True, False]):
+        env = Gridworld(make_open_field(5, 5, 0, 1))
+        agent = SR(env.observation_space, env.action_space, EpsilonGreedy(),
+                   EpsilonGreedy(0.) if use_test_policy else None)
+        agent.mask_actions = mask_actions
+        agent.train(env, 5, 20)
+        agent.test(env, 5, 20)
+        assert agent.current_trial == 10
+        assert np.isfinite(agent.predict_on_batch(np.arange(25))).all()
+
+
+def test_sfma_simulations(cobel):
+    """The 120 combinations of unit_tests/test_sfma.py:98-107."""
+    from cobel.agent import SFMA
+    from cobel.interface import Gridworld
+    from cobel.memory import SFMAMemory
+    from cobel.memory.utils import DR, SR, Euclidean
+    from cobel.misc.gridworld_tools import make_gridworld
+    from cobel.policy import EpsilonGreedy
+    walls = [(3, 4), (4, 3), (8, 9), (9, 8), (13, 14), (14, 13)]
+    metrics = ['DR', 'SR', 'Euclidean']
+    modes = ['default', 'reverse', 'forward', 'dynamic', 'sweeping']
+    for metric, mode, use_test_policy, mask_actions, random_replay in product(
+            metrics, modes, [True, False], [True, False], [True, False]):
+        gridworld = make_gridworld(5, 5, terminals=[4], rewards=np.array([[4, 10]]), goals=[4],
+                                   invalid_transitions=walls)
+        gridworld['starting_states'] = np.array([12])
+        env = Gridworld(gridworld)
+        if metric == 'DR':
+            sim = DR(env.world['width'], env.world['height'], env.world['sas'], 0.9,
+                     env.world['invalid_transitions'])
+        elif metric == 'SR':
+            sim = SR(env.world['sas'], 0.9)
+        else:
+            sim = Euclidean(env.world['width'], env.world['height'])
+        memory = SFMAMemory(sim, env.world['states'], 4)
+        agent = SFMA(env.observation_space, env.action_space, EpsilonGreedy(), memory,
+                     EpsilonGreedy(0.) if use_test_policy else None)
+        agent.M.mode = mode
+        agent.mask_actions = mask_actions
+        agent.random = random_replay
+        agent.train(env, 5, 50, 32)
+        agent.train(env, 5, 50, 32, True)
+        agent.test(env, 5, 50)
+        assert agent.current_trial == 15 and agent.M.mode == mode
+        assert np.isfinite(agent.Q).all() and np.isfinite(agent.M.C).all()
+        assert agent.M.C.sum() == agent.M.state[0, 0].item()   # one unit of strength per store
+
+
+def test_demo_dyna_q_and_sfma_flows(cobel):
+    """demo/gridworld/demo_dyna_q.py:36-56 and demo_sfma.py:30-75 (widget=None): monitors through
+    on_trial_end, per-step hooks, Q readable afterwards."""
+    from cobel.agent import SFMA, DynaQ
+    from cobel.interface import Gridworld
+    from cobel.memory import SFMAMemory
+    from cobel.memory.utils import DR
+    from cobel.misc.gridworld_tools import make_gridworld, make_open_field
+    from cobel.monitor import EscapeLatencyMonitor
+    from cobel.policy import EpsilonGreedy
+    env = Gridworld(make_open_field(5, 5, 0, 1))
+    el = EscapeLatencyMonitor(80, 50)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(), EpsilonGreedy(0.0),
+                  custom_callbacks={'on_trial_end': [el.update]})
+    agent.train(env, 50, 50, 32)
+    agent.test(env, 30, 50)
+    trace = np.asarray(el.get_trace())
+    assert np.isfinite(trace[:80]).all() and trace[50:80].mean() < trace[:10].mean()
+
+    walls = [(3, 4), (4, 3), (8, 9), (9, 8), (13, 14), (14, 13), (18, 19), (19, 18)]
+    gridworld = make_gridworld(5, 5, terminals=[4], rewards=np.array([[4, 10]]), goals=[4],
+                               invalid_transitions=walls)
+    gridworld['starting_states'] = np.array([12])
+    env = Gridworld(gridworld)
+    steps_seen = []
+    el = EscapeLatencyMonitor(60, 50)
+    metric = DR(env.world['width'], env.world['height'], env.world['sas'], 0.9,
+                env.world['invalid_transitions'])
+    agent = SFMA(env.observation_space, env.action_space, EpsilonGreedy(),
+                 SFMAMemory(metric, env.world['states'], 4),
+                 custom_callbacks={'on_step_end': [lambda logs: steps_seen.append(logs['state'])],
+                                   'on_trial_end': [el.update]})
+    agent.M.mode = 'reverse'
+    agent.mask_actions = True
+    agent.train(env, 60, 50, 32)
+    assert len(steps_seen) > 60 and agent.Q.max() > 0
+    assert np.isfinite(agent.predict_on_batch(np.arange(25))).all()
