@@ -155,10 +155,13 @@ class FusedAgent(Agent):
         super().__init__(observation_space, action_space, custom_callbacks)
         self.policy = policy
         self.policy_test = policy if policy_test is None else policy_test
-        self.n_states = int(observation_space.n)
+        # Box observations (a Topology's poses): the state count is the node count of the
+        # environment the agent is first trained on
+        self.n_states = int(observation_space.n) if hasattr(observation_space, 'n') else None
         self.n_actions = int(action_space.n)
         assert self.n_actions == 4, 'the fused kernels cover 4-action worlds'
-        self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
+        self.action_mask = (np.ones((self.n_states, self.n_actions), dtype=bool)
+                            if self.n_states is not None else None)
         self.mask_actions = False
         self.track_occupancy = False
         self.track_responses = False   # per-trial count of rewarded instances (ResponseMonitor)
@@ -220,7 +223,12 @@ class FusedAgent(Agent):
                 'an agent stays bound to the instance count / device it first trained on'
             return
         self.n_envs, self.device = interface.n_envs, interface.device
-        assert int(interface.observation_space.n) == self.n_states
+        if self.n_states is None:
+            self.n_states = interface.handle.n_states
+            self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
+            self._poses = np.asarray(interface.pose, dtype=np.float64)
+        else:
+            assert int(interface.observation_space.n) == self.n_states
         self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)
         self.monitors = DeviceMonitors(self.device, interface.handle.n_worlds, self.n_states,
                                        self.track_occupancy, self.track_responses)

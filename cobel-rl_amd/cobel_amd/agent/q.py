@@ -1,7 +1,8 @@
 """Tabular Q-learning with experience replay — ``cobel.agent.QAgent`` (agent/q.py:26-354).
 
-Discrete observations only (the gridworld case): the reference's lazily created dict rows are a
-dense zero table here.  The replay memory is the per-instance log of experienced transitions
+Discrete observations (gridworlds) and the pose observations of a ``Topology`` (Box; the
+reference keys Q by ``tuple(pose)``, here the key is the node index and ``predict_on_batch`` /
+``Q_dict`` translate): the reference's lazily created dict rows are a dense zero table.  The replay memory is the per-instance log of experienced transitions
 (q.py:143,213), kept on device; its capacity must be announced with ``reserve_replay`` (or is
 sized from the first ``train`` call).  ``batch_size=0`` disables replay (demo/topology/demo.py:76).
 """
@@ -10,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
-from ..spaces import Discrete
+from ..spaces import Box, Discrete
 from .tabular import TabularAgent
 
 
@@ -20,7 +21,8 @@ class QAgent(TabularAgent):
     def __init__(self, observation_space, action_space, policy, policy_test=None,
                  learning_rate: float = 0.9, gamma: float = 0.8, custom_callbacks=None,
                  rng=None) -> None:
-        assert type(observation_space) is Discrete, 'only Discrete observations are accelerated'
+        assert type(observation_space) in (Discrete, Box), \
+            'Discrete observations and Topology poses (Box) are accelerated'
         assert type(action_space) is Discrete, 'Wrong action space!'
         super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
                          gamma, custom_callbacks)
@@ -50,6 +52,14 @@ class QAgent(TabularAgent):
         return [{'state': (int(h & 0x3FFF),), 'action': int((h >> 28) & 3), 'reward': float(r),
                  'next_state': (int((h >> 14) & 0x3FFF),), 'terminal': int((h >> 30) & 1)}
                 for r, h in zip(lo, hi)]
+
+    @property
+    def Q_dict(self) -> dict:
+        """The reference's view of Q for instance 0: ``{observation tuple: float32[4]}``."""
+        q = self._q[0].cpu().numpy() if self._q is not None else self._q_host
+        if self._poses is not None:
+            return {tuple(p.flatten()): q[i] for i, p in enumerate(self._poses)}
+        return {(i,): q[i] for i in range(q.shape[0])}
 
     def _extra(self, run) -> None:
         run.replay_log = _lib.ptr(self._log)

@@ -21,7 +21,9 @@ class TabularAgent(FusedAgent):
         self.learning_rate = learning_rate
         self.gamma = gamma
         self._q = None
-        self._q_host = np.zeros((self.n_states, self.n_actions), dtype=np.float32)
+        self._q_host = (np.zeros((self.n_states, self.n_actions), dtype=np.float32)
+                        if self.n_states is not None else None)
+        self._poses = None      # node poses when the observations are a Topology's (Box)
 
     # -- tables -----------------------------------------------------------------------------
     def _alloc_tables(self) -> None:
@@ -30,7 +32,8 @@ class TabularAgent(FusedAgent):
                                               C.byref(per_block)))
         self._q = torch.zeros((self.n_envs, self.n_states, 4), dtype=torch.float32,
                               device=self.device)
-        self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
+        if self._q_host is not None:
+            self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
 
     @property
     def Q(self):
@@ -51,12 +54,24 @@ class TabularAgent(FusedAgent):
 
     def predict_on_batch(self, batch):
         """Q-values of a batch of observations, ``[len(batch), 4]`` (dyna_q.py:303-317)."""
-        idx = np.array(batch).astype(int)
+        if self._poses is not None:
+            idx = self._node_index(batch)
+        else:
+            idx = np.array(batch).astype(int)
         if self._q is None:
             return self._q_host[idx]
         if self.n_envs == 1:
             return self._q[0][torch.as_tensor(idx, device=self.device)].cpu().numpy()
         return self._q[:, torch.as_tensor(idx, device=self.device)]
+
+    def _node_index(self, batch) -> np.ndarray:
+        """Pose observations -> node indices (the reference keys Q by tuple(pose), q.py:154-155;
+        an unseen pose is a KeyError there as well)."""
+        obs = np.asarray(batch, dtype=np.float64).reshape(-1, self._poses.shape[1])
+        hit = (obs[:, None, :] == self._poses[None, :, :]).all(axis=2)
+        if not hit.any(axis=1).all():
+            raise KeyError(tuple(obs[~hit.any(axis=1)][0]))
+        return hit.argmax(axis=1)
 
     # -- launch -----------------------------------------------------------------------------
     def _extra(self, run: _lib.TabRun) -> None:

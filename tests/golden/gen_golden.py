@@ -381,6 +381,61 @@ def gen_qagent(worlds):
     np.savez_compressed(os.path.join(HERE, 'qagent_traces.npz'), **out)
 
 
+def gen_qagent_topology():
+    """QAgent on a Topology (unit_tests/test_q.py:57-78 "Topology", demo/topology/demo.py):
+    observations are 6-float poses, Q is keyed by tuple(pose) (agent/q.py:154-155)."""
+    from cobel.interface import Topology
+    from cobel.misc import topology_tools as tt
+    cases = {
+        # name: (builder args, instance, f32, trials, steps, B)
+        'track_b0_f32': ((10, 2, 1., 20., 'right'), 0, True, 25, 100, 0),
+        'track_b8_f32': ((10, 2, 1., 20., 'right'), 1, True, 20, 100, 8),
+        'track_b8_f64': ((10, 2, 1., 20., 'right'), 1, False, 20, 100, 8),
+        'track5_b4_f32': ((5, 1, 0.5, 2., 'left'), 2, True, 25, 12, 4),
+    }
+    out = {}
+    for name, (args, inst, f32, trials, steps, B) in cases.items():
+        nodes, starts = tt.linear_track(*args)
+        env = Topology(nodes, starts, rng=TapeRNG(SEED, inst, STREAM_ENV))
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        ag = QAgent(env.observation_space, env.action_space, pol,
+                    rng=TapeRNG(SEED, inst, STREAM_MEMORY))
+        ids = list(nodes.keys())
+        key = {tuple(np.array(nodes[k]['pose']).flatten()): i for i, k in enumerate(ids)}
+        if f32:
+            for k in key:
+                ag.Q[k] = np.zeros(4, dtype=np.float32)
+        sarsn, tds, steps_log, rewards = [], [], [], []
+
+        def on_step_end(logs, sarsn=sarsn, tds=tds, key=key):
+            sarsn.append((key[logs['state']], logs['action'], logs['reward'],
+                          key[logs['next_state']], logs['terminal']))
+            tds.append(float(logs['td']))
+
+        def on_trial_end(logs, steps_log=steps_log, rewards=rewards):
+            steps_log.append(logs['steps'])
+            rewards.append(float(logs['trial_reward']))
+
+        ag.callbacks.custom_callbacks = {'on_step_end': [on_step_end], 'on_trial_end': [on_trial_end],
+                                         'on_trial_begin': [], 'on_step_begin': []}
+        ag.train(env, trials, steps, B)
+        a = np.array(sarsn, dtype=np.float64).reshape(-1, 5)
+        Q = np.zeros((len(ids), 4))
+        for k, row in ag.Q.items():
+            Q[key[k]] = row
+        probe = np.array([nodes[k]['pose'] for k in ids[:5]], dtype=np.float64)
+        d = dict(state=a[:, 0].astype(np.int16), action=a[:, 1].astype(np.int8), reward=a[:, 2],
+                 next_state=a[:, 3].astype(np.int16), nonterminal=a[:, 4].astype(np.int8),
+                 td=np.array(tds), steps=np.array(steps_log, dtype=np.int32),
+                 trial_reward=np.array(rewards), Q=Q, log_len=np.int64(len(ag.M)),
+                 cfg=np.array([inst, f32, trials, steps, B], dtype=np.int64),
+                 track=np.array(args[:4], dtype=np.float64), side=np.array(args[4]),
+                 probe=probe, probe_q=np.array(ag.predict_on_batch(probe), dtype=np.float64))
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'qagent_topology_traces.npz'), **out)
+
+
 def gen_sr(worlds):
     cases = {
         'open5_f64': ('open_5x5', 0, False, 30, 50, False),
@@ -875,6 +930,7 @@ def main():
     gen_sr(worlds)
     gen_monitor(worlds)
     gen_sfma()
+    gen_qagent_topology()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-24s %8d B' % (f, os.path.getsize(os.path.join(HERE, f))))

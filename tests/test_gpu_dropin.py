@@ -137,3 +137,50 @@ def test_demo_dyna_q_and_sfma_flows(cobel):
     agent.train(env, 60, 50, 32)
     assert len(steps_seen) > 60 and agent.Q.max() > 0
     assert np.isfinite(agent.predict_on_batch(np.arange(25))).all()
+
+
+@pytest.mark.parametrize('name', ['track_b0_f32', 'track_b8_f32', 'track5_b4_f32'])
+def test_qagent_on_topology_matches_reference(cobel, golden, name):
+    """QAgent on pose observations (unit_tests/test_q.py "Topology", demo/topology/demo.py): the
+    reference keys Q by tuple(pose); trajectory in node indices, TD errors, Q rows and
+    predict_on_batch on poses match its float32 run bit for bit."""
+    from conftest import SEED
+    from cobel.agent import QAgent
+    from cobel.interface import Topology
+    from cobel.misc.topology_tools import linear_track
+    from cobel.policy import EpsilonGreedy
+    Z = golden('qagent_topology_traces')
+    g = lambda k: Z['%s/%s' % (name, k)]      # noqa: E731
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    a, b, sp, rw = g('track')
+    nodes, starts = linear_track(int(a), int(b), float(sp), float(rw), str(g('side')))
+    env = Topology(nodes, starts, seed=SEED, instance_base=inst)
+    sarsn, tds, steps_log = [], [], []
+    cbs = {'on_step_end': [lambda l: (sarsn.append((l['state'], l['action'], l['reward'],
+                                                    l['next_state'], l['terminal'])),
+                                      tds.append(l['td']))],
+           'on_trial_end': [lambda l: steps_log.append(l['steps'])]}
+    agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1),
+                   custom_callbacks=cbs)
+    agent.train(env, trials, steps, B)
+    arr = np.array(sarsn, dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(arr[:, col], g(key)), key
+    if B == 0:
+        # with replay the reference's logs['td'] is whatever update_q wrote LAST into the experience
+        # dict, which also sits in the replay memory and may be re-sampled in the same step
+        # (q.py:213-216, :353-354); the kernel reports the online TD error
+        assert np.array_equal(np.array(tds, dtype=np.float64), g('td'))
+    assert np.array_equal(steps_log, g('steps'))
+    assert np.array_equal(np.asarray(agent.Q, dtype=np.float64), g('Q'))
+    assert np.array_equal(agent.predict_on_batch(g('probe')).astype(np.float64), g('probe_q'))
+    assert len(agent.M) == int(g('log_len')) if B else True
+    qd = agent.Q_dict
+    assert len(qd) == len(nodes) and all(len(k) == 6 for k in qd)
+    with pytest.raises(KeyError):
+        agent.predict_on_batch(np.full((1, 6), 123.0))
+    # vectorised: instance `inst` of a batch behaves the same
+    env2 = Topology(nodes, starts, n_envs=inst + 2, seed=SEED)
+    ag2 = QAgent(env2.observation_space, env2.action_space, EpsilonGreedy(0.1))
+    ag2.train(env2, trials, steps, B)
+    assert np.array_equal(ag2.Q[inst].cpu().numpy().astype(np.float64), g('Q'))
