@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr<'}
+KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr<', 'C6': 'k_sfma<'}
 
 
 def per_kernel(path, counter):

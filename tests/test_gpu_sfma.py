@@ -308,3 +308,48 @@ def test_sfma_edges(Z):
     agent.M.error_mod = True
     with pytest.raises(KeyError):
         agent.train(env, 1, 5, 4)
+
+
+def test_full_size_c6_sample_and_conservation(Z):
+    """bench.py's C6 at full size (65 536 instances of the demo_sfma.py world, DR metric, reverse
+    mode, action mask on), 6 trials in one launch: 12 instances spread over the range bit-exact
+    against the restatement; strengths, step counts and reactivations conserved over all."""
+    import torch
+    import bench
+    from cobel_amd import _lib
+    from oracle import sfma_loop
+    n, trials = 65536, 6
+    cfg = bench.CONFIGS['C6']
+    env, agent = bench.build_agent('C6', cfg, n, 0, torch.device('cuda', 0))
+    agent.track_instances = True
+    agent.train(env, trials, cfg['steps_per_trial'], cfg['batch'])
+    torch.cuda.synchronize()
+    world = bench.make_worlds('C6')[0]
+    tabs = world.compact()
+    ow = dict(next=tabs['next'], reward=tabs['reward'].astype(np.float64),
+              terminal=tabs['terminal'], starts=tabs['starts'])
+    D = np.asarray(agent.M.metric.D)
+    opts = {'mask': np.ones((25, 4), dtype=bool)}
+    lat = agent.monitors.lat_trace
+    for i in (0, 1, 63, 64, 4097, 8191, 20000, 32768, 40001, 65000, 65534, 65535):
+        ag, _ = sfma_loop.run_case(ow, D, bench.SEED, i, True, 'reverse', opts, trials,
+                                   cfg['steps_per_trial'], cfg['batch'])
+        assert np.array_equal(lat[i].cpu().numpy()[:trials], ag.steps), i
+        assert np.array_equal(agent._q[i].cpu().numpy(), ag.Q), i
+        assert np.array_equal(agent.M.strength[i].cpu().numpy(), ag.M.C), i
+        assert int(agent.M.counter[i]) == ag.M.rng.index, i
+    inst = agent.inst.cpu().numpy()
+    st = agent.M.state.cpu().numpy()
+    steps = inst[:, 10].astype(np.int64)
+    assert (inst[:, 2] == trials).all()
+    assert agent.env_steps() == int(steps.sum())
+    assert np.array_equal(steps, (lat[:, :trials].to(torch.int64).sum(dim=1) + trials).cpu().numpy())
+    # one unit of strength and one clock tick per stored experience
+    assert np.array_equal(agent.M.strength.sum(dim=1).cpu().numpy(), steps.astype(np.float64))
+    assert np.array_equal(st[:, _lib.SI_CLOCK].astype(np.int64), steps)
+    assert (st[:, _lib.SI_EPOCH] == st[:, _lib.SI_CLOCK]).all()     # T.fill(0) after every trial
+    done = int(agent.replays_done.item())
+    assert 0 < done <= n * trials * cfg['batch']
+    # every scalar double draw of the memory stream is one reactivation or one strength-start;
+    # each replay also takes one integer draw
+    assert int(agent.M.counter.to(torch.int64).sum().item()) >= done + n * trials
