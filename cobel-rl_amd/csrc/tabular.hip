@@ -41,6 +41,7 @@ struct tab_args {
   int32_t use_hash;  // LDS holds the replay dependency hash table
   int32_t hash_buckets;
   int32_t hash_exact;  // S * 4 <= 4096: the two-table exact dependency lookup applies
+  int32_t lpw;         // lane-per-instance kernel: instances per wave (64, 32 or 16)
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 // Lane-per-instance variant for runs without planning (QAgent with batch 0, or Agent.test()):
 // with nothing to spread over the lanes of a wave, 64 instances share one wavefront and every
 // instruction of the select -> step -> TD chain serves 64 env steps.  Each lane keeps its
-// instance's Q table in its own LDS column (row s of lane l at ((s * 64 + l) * 16) bytes, so a
+// instance's Q table in its own LDS column (row s of lane l at ((s * LPW + l) * 16) bytes, so a
 // 16-byte row read is bank-conflict free across the wave), plus its own stream counters and
 // cached Philox blocks.  Usable while 1 KiB * S fits in LDS.
 //
@@ -735,24 +736,29 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   const int S = A.S;
   float4* const Ql = reinterpret_cast<float4*>(lds_raw);
   float* const Qlf = reinterpret_cast<float*>(lds_raw);
-  uint64_t* const thr = reinterpret_cast<uint64_t*>(lds_raw + (size_t)S * 1024);
-  uint4* const Wl = reinterpret_cast<uint4*>(lds_raw + (size_t)S * 1024 + kThrBytes);
-  unsigned char* const mon_raw = lds_raw + (size_t)S * 1024 + kThrBytes + (size_t)S * 16;
+  // LPW instances per wave (lanes >= LPW idle): 64, or fewer when the Q columns of 64 instances
+  // would not fit in LDS.
+  const int LPW = A.lpw;
+  const size_t qbytes = (size_t)S * LPW * 16;
+  uint64_t* const thr = reinterpret_cast<uint64_t*>(lds_raw + qbytes);
+  uint4* const Wl = reinterpret_cast<uint4*>(lds_raw + qbytes + kThrBytes);
+  unsigned char* const mon_raw = lds_raw + qbytes + kThrBytes + (size_t)S * 16;
   double* const wrew = reinterpret_cast<double*>(mon_raw);                      // [kMonSlots]
   uint32_t* const wsum = reinterpret_cast<uint32_t*>(mon_raw + kMonSlots * 8);  // [kMonSlots]
   uint32_t* const wcnt = wsum + kMonSlots;                                      // [kMonSlots]
   int32_t* const wtag = reinterpret_cast<int32_t*>(wcnt + kMonSlots);           // [kMonSlots]
 
   const int lane = (int)threadIdx.x;
-  const int i = (int)blockIdx.x * 64 + lane;
-  const bool active = i < A.r.n;
+  const int i = (int)blockIdx.x * LPW + lane;
+  const bool active = lane < LPW && i < A.r.n;
   const int ii = active ? i : 0;
   const uint32_t g = A.r.instance_base + (uint32_t)ii;
   const int world = ONE_WORLD ? 0 : (int)(g % (uint32_t)A.n_worlds);
   const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
   float4* const Qg = reinterpret_cast<float4*>(A.r.q) + (size_t)ii * S;
 
-  for (int s = 0; s < S; ++s) Ql[s * 64 + lane] = Qg[s];
+  if (lane < LPW)
+    for (int s = 0; s < S; ++s) Ql[s * LPW + lane] = Qg[s];
   if (ONE_WORLD)
     for (int s = lane; s < S; s += 64) Wl[s] = W4[s];
   if (lane < 48) thr[lane] = A.eps.thr[lane / 3][lane % 3];
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
       }
       const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x, w1 = (cp & 1u) ? pblk.w : pblk.y;
       cp += 1u;
-      const float4 q = Ql[state * 64 + lane];
+      const float4 q = Ql[state * LPW + lane];
       const uint32_t mask = amask ? (uint32_t)amask[state] & 15u : 15u;
       int a;
       if (mask == 15u) {
@@ -862,8 +868,8 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
       const uint32_t end = nrec.w, nt = 1u - end;
       float td_online = 0.0f;
       if (learn) {   // online TD (agent/q.py:305-313), float32
-        const float4 nrow = Ql[ns * 64 + lane];
-        const int cell = (state * 64 + lane) * 4 + a;
+        const float4 nrow = Ql[ns * LPW + lane];
+        const int cell = (state * LPW + lane) * 4 + a;
         const float qsa = Qlf[cell];
         const float gnt = nt ? gamma_f : 0.0f;
         float td = r + gnt * max4(nrow);
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   __syncthreads();
   if (active) {
     if (learn)
-      for (int s = 0; s < S; ++s) Qg[s] = Ql[s * 64 + lane];
+      for (int s = 0; s < S; ++s) Qg[s] = Ql[s * LPW + lane];
     inst[COBEL_I_STATE] = state;
     inst[COBEL_I_STEP] = step;
     inst[COBEL_I_TRIAL] = trial;
@@ -1099,7 +1105,20 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   hipStream_t st = (hipStream_t)stream;
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
   const bool learn = (r.flags & COBEL_F_LEARN) != 0;
-  const size_t lds_lpi = (size_t)world->n_states * 1024 + kThrBytes + (size_t)world->n_states * 16;
+  // instances per wave: 64 unless the Q columns of a full wave do not fit in LDS.  (Narrower waves
+  // to give each SIMD more than one resident wave were measured on C2 — 65 536 instances are one
+  // wave per SIMD — and lose: 1.25 ms per launch at 64, 1.45 ms at 32, 2.57 ms at 16 instances per
+  // wave; the step is as much issue- as latency-bound.  COBEL_DEBUG_LPW overrides.)
+  int lpw = 64;
+  if (const char* e = getenv("COBEL_DEBUG_LPW")) {
+    const int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64) lpw = v;
+  }
+  while (lpw > 16 && (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 16 +
+                              kMonBytes > (size_t)kLdsLimit)
+    lpw >>= 1;   // larger worlds: fewer columns per wave so that the Q tables still fit
+  A.lpw = lpw;
+  const size_t lds_lpi = (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 16;
   // (per-instance parameter sets: the lane-per-instance kernel keeps ONE threshold table per wave)
   if (!replay && !occ && !r.param_index && (!learn || r.agent == COBEL_AGENT_Q) &&
       lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
@@ -1107,7 +1126,7 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     const bool one = world->n_worlds == 1;
     const bool mon = r.lat_sum || r.lat_cnt || r.reward_sum || r.resp_cnt;
     const size_t bytes = lds_lpi + (mon ? (size_t)kMonBytes : 0);
-    const dim3 grid((unsigned)((r.n + 63) / 64));
+    const dim3 grid((unsigned)((r.n + lpw - 1) / lpw));
 #define COBEL_LPI(ONE, MON)                                                                    \
   do {                                                                                         \
     if (bytes > 64 * 1024)                                                                     \

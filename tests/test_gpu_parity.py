@@ -652,10 +652,11 @@ def test_grid_search_vectorised_equals_sequential(torch_cuda, golden_worlds, tmp
     assert len(set(fit_v.values())) > 1
 
 
-@pytest.mark.parametrize('n,worlds', [(4100, 1), (200, 3)])
-def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds):
-    """Runs without planning take the lane-per-instance kernel (64 instances per wave): Q-learning
-    with batch 0 over several budgeted launches (partial last wave, 1 or 3 worlds), then a
+@pytest.mark.parametrize('n,worlds,side', [(4100, 1, 5), (200, 3, 5), (300, 2, 14), (130, 1, 20)])
+def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds, side):
+    """Runs without planning take the lane-per-instance kernel (64 instances per wave; 32 at
+    14x14 and 16 at 20x20, where the Q columns of a full wave no longer fit in LDS): Q-learning
+    with batch 0 over several budgeted launches (partial last wave, 1 to 3 worlds), then a
     greedy test() phase with an action mask — all against the C oracle, and against the
     wave-per-instance kernel forced on the same inputs."""
     torch = torch_cuda
@@ -665,7 +666,8 @@ def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds
     from cobel_amd.misc.gridworld_tools import make_open_field
     from cobel_amd.policy import EpsilonGreedy
     from oracle import c_oracle
-    ws = [make_open_field(5, 5, g, 1.0 + g) for g in (0, 12, 24)][:worlds]
+    S = side * side
+    ws = [make_open_field(side, side, g, 1.0 + g) for g in (0, S // 2, S - 1)][:worlds]
 
     def run(force_wave):
         env = Gridworld(ws, n_envs=n, seed=77, instance_base=9)
@@ -683,7 +685,7 @@ def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds
         ag.current_trial = 64
         ag.inst[:, _lib.I_TRIAL] = 64          # start the test phase at a common trial index
         ag.mask_actions = True
-        ag.action_mask = np.ones((25, 4), dtype=bool)
+        ag.action_mask = np.ones((S, 4), dtype=bool)
         ag.action_mask[:, 0] = False           # never move left
         ag.action_mask[0] = True
         ag.test(env, 3, 20)
@@ -697,7 +699,7 @@ def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds
 
     tabs = [dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'],
                  starts=w['starting_states']) for w in ws]
-    mask = np.ones((25, 4), dtype=bool)
+    mask = np.ones((S, 4), dtype=bool)
     mask[:, 0] = False
     mask[0] = True
     o = c_oracle.TabOracle(c_oracle.OracleWorld(tabs), n, c_oracle.AG_Q, 77, True, instance_base=9,
