@@ -69,7 +69,7 @@ CONFIGS = {
 SEED = 0xC0BE1
 
 
-def run_c5(device, dtype_name, n=8192, iters=64, warm=4):
+def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=True):
     """C5: 8192 linear_track(10, 2) Topology envs, DQN 6-64-64-4 (gamma .8, eps .3, Adam 1e-3, MSE,
     tau .01, batch 32, 100 steps/trial) through PyTorch-ROCm with one network per instance."""
     from collections import OrderedDict
@@ -90,6 +90,7 @@ def run_c5(device, dtype_name, n=8192, iters=64, warm=4):
     agent = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
                 TorchNetwork(net, optimizer_params={'lr': 1e-3}), gamma=0.8,
                 memory=DQNMemory(capacity=256))
+    agent.use_graph = graph
     agent._run(env, 10**6, 100, 32, True, budget=warm)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -100,7 +101,8 @@ def run_c5(device, dtype_name, n=8192, iters=64, warm=4):
             'dtype': dtype_name,
             'config': {'workload': 'C5: %d x linear_track(10,2) Topology, DQN 6-64-64-4 %s, one '
                                    'network + replay ring per instance, batch 32, via PyTorch-ROCm'
-                                   % (n, dtype_name), 'instances_per_gpu': n,
+                                   '%s' % (n, dtype_name, ', one step captured as a HIP graph and '
+                                           'replayed' if graph else ''), 'instances_per_gpu': n,
                        'lockstep_iterations': iters},
             'roofline': None}
 

@@ -39,6 +39,7 @@ class DQN(Agent):
         self.last_update = 0
         self.gamma = gamma
         self.DDQN = False
+        self.use_graph = False     # fixed-budget runs: replay one captured step from a HIP graph
         self.n_envs = None
         self.monitors = None
         self._online = self._target = None
@@ -152,11 +153,13 @@ class DQN(Agent):
         obs, _ = interface.reset()
         obs = interface.observe().to(self.dtype).clone()
         active = torch.ones(n, dtype=torch.bool, device=dev)
-        iters = 0
-        all_active = True     # host-side knowledge; exact because it is refreshed every step
         zero64 = torch.zeros(n, dtype=torch.int64, device=dev)
         cap = self.monitors.cap
-        while True:
+        all_active = True     # host-side knowledge; exact because it is refreshed every step
+
+        def iteration() -> None:
+            """One lockstep step of every instance; all state lives in tensors updated in place
+            (so that the same sequence of launches can be replayed from a HIP graph)."""
             q = self._q_values(obs)
             idle = None if all_active else ~active
             action = self._select(pol, q, interface.instance_base, idle)
@@ -167,7 +170,7 @@ class DQN(Agent):
                 self.M.store_batch(obs, action, reward, nxt, (~done), None if all_active else active)
                 if not getattr(self, '_no_replay', False):
                     self.replay(batch_size, None if all_active else active)
-            trew += torch.where(active, reward.to(torch.float64), torch.zeros_like(trew))
+            trew.add_(torch.where(active, reward.to(torch.float64), torch.zeros_like(trew)))
             # trial ends, entirely masked (no host round trip per step)
             over = active & (done | (step + 1 >= steps))
             idx = torch.where(over, self.trial.to(torch.int64), zero64).clamp_(0, cap - 1)
@@ -175,22 +178,41 @@ class DQN(Agent):
             self.monitors.lat_sum.index_add_(0, idx, torch.where(ok, step.to(torch.int64), zero64))
             self.monitors.lat_cnt.index_add_(0, idx, ok.to(torch.int64))
             self.monitors.reward_sum.index_add_(0, idx, torch.where(ok, trew, torch.zeros_like(trew)))
-            self.trial += over.to(torch.int32)
-            trew = torch.where(over, torch.zeros_like(trew), trew)
-            active = active & (self.trial < first + trials)
+            self.trial.add_(over.to(torch.int32))
+            trew.copy_(torch.where(over, torch.zeros_like(trew), trew))
+            active.logical_and_(self.trial < first + trials)
             restart = over & active
             interface.reset(restart)
             nxt = torch.where(restart[:, None], interface.observe().to(self.dtype), nxt)
-            step = torch.where(over, torch.zeros_like(step), step + active.to(torch.int32))
-            obs = nxt
-            iters += 1
-            if budget and iters >= budget:
-                break
-            if not budget:   # train(): one look at the device per step keeps idle instances frozen
-                left = int(active.sum().item())      # exactly; the fixed-budget (bench) mode never
-                if left == 0:                        # has idle instances and never synchronises
+            step.copy_(torch.where(over, torch.zeros_like(step), step + active.to(torch.int32)))
+            obs.copy_(nxt)
+
+        if budget and learn and self.use_graph and budget > 4:
+            # Fixed-budget runs never look at the device between steps: after a few eager steps
+            # (lazy initialisations, optimizer state) ONE iteration is captured into a HIP graph and
+            # replayed — ~180 kernel launches per step become one graph launch.
+            for _ in range(3):
+                iteration()
+            self._online.make_capturable()
+            iteration()
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration()
+            for _ in range(budget - 4):
+                graph.replay()
+        else:
+            iters = 0
+            while True:
+                iteration()
+                iters += 1
+                if budget and iters >= budget:
                     break
-                all_active = left == n
+                if not budget:   # train(): one look at the device per step keeps idle instances frozen
+                    left = int(active.sum().item())      # exactly; the fixed-budget (bench) mode never
+                    if left == 0:                        # has idle instances and never synchronises
+                        break
+                    all_active = left == n
         self.current_trial = first + trials
         if self.callbacks.has('on_trial_end'):
             lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()

@@ -230,6 +230,19 @@ class StackedTorchNetwork:
                     mask = active.view(self.n, *([1] * (p.dim() - 1)))
                     p.copy_(torch.where(mask, p, old))
 
+    def make_capturable(self) -> None:
+        """Prepare the optimizer for HIP-graph capture: its step counters move to the device
+        (torch's ``capturable`` mode), so that a replayed graph advances them."""
+        opt = self.optimizer
+        for group in opt.param_groups:
+            if 'capturable' in group:
+                group['capturable'] = True
+        for st in opt.state.values():
+            if 'step' in st and torch.is_tensor(st['step']):
+                # float64: in capturable mode the bias corrections beta ** step are formed from this
+                # tensor (torch's default float32 counter would cost ~1e-7 relative per step)
+                st['step'] = st['step'].to(device=self.device, dtype=torch.float64)
+
     @torch.no_grad()
     def _adam_masked(self, active: torch.Tensor) -> None:
         """torch.optim.Adam's update (same operation order) applied to the active instances only;

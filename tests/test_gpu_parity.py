@@ -826,6 +826,45 @@ def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     assert np.allclose(agent.predict_on_batch(pose), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
 
 
+def test_dqn_graph_replay_equals_eager_steps(torch_cuda, golden):
+    """Fixed-budget DQN runs replay one captured step from a HIP graph: same transitions, same
+    monitors, weights equal to float64 round-off (torch's capturable Adam forms the bias
+    corrections on the device) as the eager loop over the same number of steps."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.memory import DQNMemory
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+
+    def run(graph):
+        env = Topology(nodes, starts, n_envs=64, seed=SEED)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(_mlp(torch, init)), gamma=0.8, memory=DQNMemory(capacity=64))
+        ag.use_graph = graph
+        ag._run(env, 10 ** 6, 12, 32, True, budget=40)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (eager, e1), (graph, e2) = run(False), run(True)
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.env_ctr, e2.env_ctr)
+    assert torch.equal(eager.M.actions, graph.M.actions)
+    assert torch.equal(eager.M.next_states, graph.M.next_states)
+    assert torch.equal(eager.trial, graph.trial)
+    assert torch.equal(eager.monitors.lat_sum, graph.monitors.lat_sum)
+    assert torch.equal(eager.monitors.lat_cnt, graph.monitors.lat_cnt)
+    assert int(eager.monitors.lat_cnt.sum()) > 64            # trials did end and restart
+    for i in (0, 31, 63):
+        for a, b in zip(eager._online.get_weights(i), graph._online.get_weights(i)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+        for a, b in zip(eager._target.get_weights(i), graph._target.get_weights(i)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
 def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
     """8 instances in lockstep (stacked networks, per-instance rings and streams) give exactly
     the trajectories of the single-instance runs; weights agree to float64 round-off."""
