@@ -51,3 +51,38 @@ for name, world, kind, B, steps in (('C1 5x5 Dyna-Q B=32', gt.make_open_field(5,
         port = time_it(lambda: rag.train(renv, 1, steps, trace=tr), lambda: len(tr['sarsn']))
     rows.append((name, ref, port, port / ref))
     print('%-32s reference %8.0f  port %8.0f  ratio %.2f' % rows[-1])
+
+# SFMA (bench.py's C6): the reference's SFMA / SFMAMemory / DR against oracle/sfma_loop.py
+from cobel.agent import SFMA
+from cobel.memory import SFMAMemory
+from cobel.memory.utils import DR
+from oracle import sfma_loop
+
+walls = [(3, 4), (4, 3), (8, 9), (9, 8), (13, 14), (14, 13), (18, 19), (19, 18)]
+world = gt.make_gridworld(5, 5, terminals=[4], rewards=np.array([[4, 10]]), goals=[4],
+                          invalid_transitions=walls)
+world['starting_states'] = np.array([12])
+env = Gridworld(world, rng=np.random.default_rng(0))
+metric = DR(5, 5, world['sas'], 0.9, world['invalid_transitions'])
+cnt = [0, 0]
+cb = {'on_step_end': [lambda logs: cnt.__setitem__(0, cnt[0] + 1)],
+      'on_replay_end': [lambda logs: cnt.__setitem__(1, cnt[1] + len(logs['replay']))]}
+ag = SFMA(env.observation_space, env.action_space, EpsilonGreedy(0.1, rng=np.random.default_rng(1)),
+          SFMAMemory(metric, 25, 4, rng=np.random.default_rng(2)), custom_callbacks=cb,
+          rng=np.random.default_rng(3))
+ag.M.mode = 'reverse'
+ag.mask_actions = True
+ref = time_it(lambda: ag.train(env, 1, 50, 32), lambda: cnt[0])
+ref_replays = cnt[1] / max(cnt[0], 1)
+tabs = dict(next=np.argmax(world['sas'], axis=2), reward=world['rewards'], terminal=world['terminals'],
+            starts=world['starting_states'])
+renv = ref_loop.RefGridworld(tabs, np.random.default_rng(0))
+mem = sfma_loop.RefSFMAMemory(metric.D, 25, 4, np.random.default_rng(2))
+mem.mode = 'reverse'
+rag = sfma_loop.RefSFMA(25, 4, ref_loop.RefEpsilonGreedy(0.1, np.random.default_rng(1)), mem,
+                        rng=np.random.default_rng(3))
+rag.mask_actions = True
+port = time_it(lambda: rag.train(renv, 1, 50, 32), lambda: len(rag.sarsn))
+print('%-32s reference %8.0f  port %8.0f  ratio %.2f   (reactivations per env step: %.2f vs %.2f)'
+      % ('C6 5x5 SFMA DR reverse B=32', ref, port, port / ref, ref_replays,
+         len(rag.replayed) / max(len(rag.sarsn), 1)))
