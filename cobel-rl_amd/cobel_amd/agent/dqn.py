@@ -39,7 +39,10 @@ class DQN(Agent):
         self.last_update = 0
         self.gamma = gamma
         self.DDQN = False
-        self.use_graph = False     # fixed-budget runs: replay one captured step from a HIP graph
+        # replay one captured lockstep step from a HIP graph wherever no look at the device is
+        # needed: True / False, or None = from 256 instances on (fixed-budget runs: only if True)
+        self.use_graph = None
+        self.graph_replays = 0     # lockstep steps executed from a graph so far
         self.n_envs = None
         self.monitors = None
         self._online = self._target = None
@@ -187,7 +190,7 @@ class DQN(Agent):
             step.copy_(torch.where(over, torch.zeros_like(step), step + active.to(torch.int32)))
             obs.copy_(nxt)
 
-        if budget and learn and self.use_graph and budget > 4:
+        if budget and learn and self.use_graph is True and budget > 4:
             # Fixed-budget runs never look at the device between steps: after a few eager steps
             # (lazy initialisations, optimizer state) ONE iteration is captured into a HIP graph and
             # replayed — ~180 kernel launches per step become one graph launch.
@@ -201,16 +204,40 @@ class DQN(Agent):
                 iteration()
             for _ in range(budget - 4):
                 graph.replay()
+            self.graph_replays += budget - 4
         else:
-            iters = 0
+            # train() / test(): one look at the device per step keeps finished instances frozen
+            # exactly.  While every instance still has more trials to run than steps in a chunk,
+            # none can finish inside it (a step ends at most one trial), so the chunk needs no
+            # look at all and is replayed from a HIP graph of one step.
+            iters, graph = 0, None
+            graphable = learn and budget == 0 and (self.use_graph or
+                                                   (self.use_graph is None and n >= 256))
             while True:
+                if graphable and all_active and iters >= 3:
+                    rem = int((first + trials - self.trial).min().item())
+                    k = min(rem - 1, 512)
+                    if k >= 8:
+                        if graph is None:
+                            self._online.make_capturable()
+                            iteration()
+                            k -= 1
+                            torch.cuda.synchronize(dev)
+                            graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph):
+                                iteration()
+                        for _ in range(k):
+                            graph.replay()
+                        iters += k
+                        self.graph_replays += k
+                        continue
                 iteration()
                 iters += 1
                 if budget and iters >= budget:
                     break
-                if not budget:   # train(): one look at the device per step keeps idle instances frozen
-                    left = int(active.sum().item())      # exactly; the fixed-budget (bench) mode never
-                    if left == 0:                        # has idle instances and never synchronises
+                if not budget:
+                    left = int(active.sum().item())
+                    if left == 0:
                         break
                     all_active = left == n
         self.current_trial = first + trials

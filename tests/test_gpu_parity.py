@@ -851,6 +851,7 @@ def test_dqn_graph_replay_equals_eager_steps(torch_cuda, golden):
         return ag, env
 
     (eager, e1), (graph, e2) = run(False), run(True)
+    assert eager.graph_replays == 0 and graph.graph_replays == 36
     assert torch.equal(e1.state, e2.state) and torch.equal(e1.env_ctr, e2.env_ctr)
     assert torch.equal(eager.M.actions, graph.M.actions)
     assert torch.equal(eager.M.next_states, graph.M.next_states)
@@ -862,6 +863,40 @@ def test_dqn_graph_replay_equals_eager_steps(torch_cuda, golden):
         for a, b in zip(eager._online.get_weights(i), graph._online.get_weights(i)):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
         for a, b in zip(eager._target.get_weights(i), graph._target.get_weights(i)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_dqn_train_graph_chunks_equal_eager(torch_cuda, golden):
+    """train() with many instances replays graph chunks while no instance can finish and steps
+    eagerly (with exact freezing) at the tail: same result as the all-eager run."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+
+    def run(graph):
+        env = Topology(nodes, starts, n_envs=256, seed=SEED)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(_mlp(torch, init)), gamma=0.8)
+        ag.use_graph = graph
+        ag.train(env, 14, 6, 16)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (eager, e1), (auto, e2) = run(False), run(None)
+    assert eager.graph_replays == 0 and auto.graph_replays >= 8
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.env_ctr, e2.env_ctr)
+    assert torch.equal(eager.M.size, auto.M.size) and torch.equal(eager.M.actions, auto.M.actions)
+    assert torch.equal(eager.trial, auto.trial) and int(auto.trial.min()) == 14
+    assert torch.equal(eager.monitors.lat_sum, auto.monitors.lat_sum)
+    assert torch.equal(eager.monitors.lat_cnt, auto.monitors.lat_cnt)
+    for i in (0, 100, 255):
+        for a, b in zip(eager._online.get_weights(i), auto._online.get_weights(i)):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
