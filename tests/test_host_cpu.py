@@ -31,16 +31,45 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors of the run structs have the size the C compiler gives them."""
     from cobel_amd import _lib
-    src = ('#include "cobel_hip.h"\n#include <stdio.h>\n'
-           'int main(){printf("%zu %zu %zu\\n", sizeof(cobel_tab_run_t), sizeof(cobel_sr_run_t), '
-           'sizeof(cobel_param_set_t));}')
+    src = ('#include "cobel_hip.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cobel_tab_run_t), '
+           'sizeof(cobel_sr_run_t), sizeof(cobel_param_set_t), sizeof(cobel_sfma_run_t), '
+           'offsetof(cobel_sfma_run_t, alpha), offsetof(cobel_sfma_run_t, seed), '
+           'sizeof(cobel_sfma_event_t));}')
     exe = '/tmp/cobel_sizeof_%d' % os.getpid()
     subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe],
                    input=src.encode(), check=True)
-    a, b, c = subprocess.check_output([exe]).split()
+    a, b, c, d, e, f, g = [int(x) for x in subprocess.check_output([exe]).split()]
     os.remove(exe)
-    assert int(a) == C.sizeof(_lib.TabRun) and int(b) == C.sizeof(_lib.SRRun)
-    assert int(c) == C.sizeof(_lib.ParamSet) == 512
+    assert a == C.sizeof(_lib.TabRun) and b == C.sizeof(_lib.SRRun)
+    assert c == C.sizeof(_lib.ParamSet) == 512
+    assert d == C.sizeof(_lib.SFMARun) and e == _lib.SFMARun.alpha.offset
+    assert f == _lib.SFMARun.seed.offset and g == _lib.SFMA_EVENT_BYTES
+    from cobel_amd.agent.sfma import EVENT
+    assert EVENT.itemsize == g
+
+
+def test_sfma_metrics_match_reference(golden):
+    """cobel_amd.memory.utils (host NumPy, as in the reference): Euclidean / SR / DR equal the
+    matrices the reference's classes produce, from the dense sas tensor and from the compact
+    successor table alike."""
+    from cobel_amd.memory.utils import DR, SR, Euclidean, Metric
+    Z = golden('sfma_traces')
+    for wname in ('sfma_5x5', 'sfma_6x7'):
+        nxt = Z['world/%s/next' % wname].astype(np.int64)
+        W, H = int(Z['world/%s/width' % wname]), int(Z['world/%s/height' % wname])
+        inv = [tuple(t) for t in Z['world/%s/invalid_transitions' % wname]]
+        S = W * H
+        sas = np.zeros((S, 4, S))
+        sas[np.arange(S)[:, None], np.arange(4)[None, :], nxt] = 1.0
+        for table in (nxt, sas):
+            eu, sr, dr = Euclidean(W, H), SR(table, 0.9), DR(W, H, table, 0.9, inv)
+            assert all(isinstance(m, Metric) for m in (eu, sr, dr))
+            assert np.array_equal(eu.D, Z['metric/%s/Euclidean' % wname])
+            np.testing.assert_allclose(sr.D, Z['metric/%s/SR' % wname], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(dr.D, Z['metric/%s/DR' % wname], rtol=1e-12, atol=1e-14)
+        dr.update_transitions()
+        np.testing.assert_allclose(dr.D, Z['metric/%s/DR' % wname], rtol=1e-12, atol=1e-14)
 
 
 @pytest.mark.parametrize('eps', [0.0, 0.1, 0.3, 1.0])
