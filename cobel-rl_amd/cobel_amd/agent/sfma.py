@@ -51,6 +51,7 @@ class SFMA(TabularAgent):
         self.random = self.dynamic = self.offline = self.start_replay = False
         self.keep_replay_trace = False     # collect replayed experiences in `replay_events`
         self.force_general_kernel = False  # testing: skip the specialised kernels
+        self.force_one_wave = False        # testing: general kernel with one wave per instance
         self.replay_events = []
         self._fired = 0
         self._trace = self._trace_len = self._cdf = self._cdf_key = None
@@ -206,7 +207,8 @@ class SFMA(TabularAgent):
     def train(self, interface, trials: int, steps: int, batch_size: int = 32,
               no_replay: bool = False) -> None:
         extra = (_lib.F_NO_REPLAY if no_replay else 0) | \
-                (_lib.F_FORCE_WAVE if self.force_general_kernel else 0)
+                (_lib.F_FORCE_WAVE if self.force_general_kernel else 0) | \
+                ((_lib.F_FORCE_WAVE | _lib.F_NO_PREFETCH) if self.force_one_wave else 0)
         self._session(interface, trials, steps, batch_size, True, extra)
 
     def test(self, interface, trials: int, steps: int) -> None:

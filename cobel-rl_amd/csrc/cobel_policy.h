@@ -32,8 +32,13 @@ struct cobel_eps_bb {
 // Constant lookup written as selects: a runtime index into a by-value kernel argument would send
 // the struct to scratch memory.
 #if defined(__HIPCC__)
+// (and written as a one-hot SUM rather than a select chain: the optimizer turns a chain of selects
+// over t[1..4] back into t[n], i.e. a table in scratch memory with a dynamic load on the critical
+// path of every action selection.  Exactly one term is non-zero and all are >= 0, so the sum is
+// exact.)
 __device__ __forceinline__ double cobel_pick(const double* t, int n) {
-  return n <= 1 ? t[1] : (n == 2 ? t[2] : (n == 3 ? t[3] : t[4]));
+  return (((n <= 1 ? t[1] : 0.0) + (n == 2 ? t[2] : 0.0)) + (n == 3 ? t[3] : 0.0)) +
+         (n >= 4 ? t[4] : 0.0);
 }
 #endif
 

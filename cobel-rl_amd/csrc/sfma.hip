@@ -44,10 +44,11 @@ struct sfma_lds {
   double* Dn;    // [S]  similarity row of the next state
   float* R;      // [4S] model reward estimate of experience j
   uint16_t* NS;  // [4S] model successor of experience j | nonterminal flag << 15
+  double* red;   // [4][8] scratch of the cross-wave reductions (several waves per instance)
 };
 
 __host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
-  return ((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15;
+  return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256;
 }
 
 __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
@@ -68,6 +69,8 @@ __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
   L.R = reinterpret_cast<float*>(base + off);
   off += (size_t)S * 16;
   L.NS = reinterpret_cast<uint16_t*>(base + off);
+  off = (off + (size_t)S * 8 + 15) & ~(size_t)15;
+  L.red = reinterpret_cast<double*>(base + off);
   return L;
 }
 
@@ -151,43 +154,112 @@ __device__ __forceinline__ int wave_first_equal(const double* P, int n4, int chu
   return wave_min_i32(first);
 }
 
-// Generator.choice(arange(n4), p = w / sum(w)) for the weights w >= 0 in P, driven by the uniform
-// u: the number of experiences whose cumulative weight is <= u * total.  Wave-uniform result.
-__device__ __forceinline__ int wave_choice(const double* P, int n4, int chunk, int lane, double u,
-                                           double wmax) {
-  const int j0 = lane * chunk;
-  double loc = 0.0;
-  for (int k = 0; k < chunk; ++k)
-    if (j0 + k < n4) loc = loc + P[j0 + k];
-  const double incl = wave_scan_f64(loc);
-  const double excl = dpp_f64<0x138>(0.0, incl);   // wave_shr:1, lane 0 keeps 0
-  // the cumulative weight at the last experience; lanes behind it hold nothing
-  const double total = readlane_f64(excl + loc, (n4 - 1) / chunk);
-  const double thr = u * total;
-  int idx = 0;
-  double run = 0.0;
-  for (int k = 0; k < chunk; ++k) {
-    const bool in = j0 + k < n4;
-    if (in) run = run + P[j0 + k];
-    idx += __popcll(__ballot(in && (excl + run <= thr)));
-  }
-  idx = idx < n4 ? idx : n4 - 1;
-  // an experience of weight zero has probability zero; rounding at a lane boundary of the scan
-  // (or of u * total at u -> 1) is the only way to land on one
-  if (!(P[idx] > 0.0)) idx = wave_first_equal(P, n4, chunk, lane, wmax);
-  return idx;
-}
-
 // CH > 0: the common switches (no recency, no C / D normalisation, R normalisation on, softmax
 // draw) with exactly CH experiences per lane, which then live in registers from the priority
 // rating to the draw.  CH = 0: every switch, any number of experiences per lane, through LDS.
-template <int CH>
-__device__ __forceinline__ void sfma_body(const sfma_args& A) {
+// NW: waves per instance.  1 for the small worlds the reference's demos use; 4 (with CH = 0) for
+// worlds of several hundred states, whose 4S experiences would otherwise sit 16-64 deep in each
+// lane of a single wave.  Every wave carries the scalar state of the instance redundantly; thread
+// 0 does the single-cell writes; the wave-wide reductions are completed across waves through a
+// few LDS words and one workgroup barrier each.
+template <int CH, int NW>
+__device__ __forceinline__ void sfma_body(const sfma_args A) {
+  static_assert(CH == 0 || NW == 1, "the register path is one wave per instance");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NT = 64 * NW;
   const int S = A.S, n4 = 4 * A.S, chunk = A.chunk;
   const sfma_lds L = carve(lds_raw, S);
-  const int lane = (int)threadIdx.x;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
+  int slot = 0;   // rotating scratch slot: one barrier per cross-wave reduction
+  auto bsync = [&]() {
+    if (NW == 1) wsync();
+    else __syncthreads();
+  };
+  auto block_max = [&](double v) -> double {
+    v = wave_max_f64(v);
+    if (NW == 1) return v;
+    double* const r = L.red + (slot++ & 3) * 8;
+    if (lane == 0) r[wave] = v;
+    __syncthreads();
+    double m = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmax(m, r[w]);
+    return m;
+  };
+  auto block_min_i32 = [&](int v) -> int {
+    v = wave_min_i32(v);
+    if (NW == 1) return v;
+    int* const r = reinterpret_cast<int*>(L.red + (slot++ & 3) * 8);
+    if (lane == 0) r[wave] = v;
+    __syncthreads();
+    int m = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = min(m, r[w]);
+    return m;
+  };
+  auto block_sum_i32 = [&](int v) -> int {   // v: one value per wave
+    if (NW == 1) return v;
+    int* const r = reinterpret_cast<int*>(L.red + (slot++ & 3) * 8);
+    if (lane == 0) r[wave] = v;
+    __syncthreads();
+    int m = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m += r[w];
+    return m;
+  };
+  // np.argmax over L.P: the first experience whose weight equals vmax
+  auto first_equal = [&](double vmax) -> int {
+    const int j0 = t * chunk;
+    int first = 0x7fffffff;
+    for (int k = chunk - 1; k >= 0; --k) {
+      const int j = j0 + k;
+      if (j < n4 && L.P[j] == vmax) first = j;
+    }
+    return block_min_i32(first);
+  };
+  // Generator.choice(arange(n4), p = w / sum(w)) for the weights w >= 0 in L.P, driven by the
+  // uniform u: the number of experiences whose cumulative weight is <= u * total.
+  auto choice = [&](double u, double wmax) -> int {
+    const int j0 = t * chunk;
+    double loc = 0.0;
+    for (int k = 0; k < chunk; ++k)
+      if (j0 + k < n4) loc = loc + L.P[j0 + k];
+    const double incl = wave_scan_f64(loc);
+    double excl = dpp_f64<0x138>(0.0, incl);   // wave_shr:1, lane 0 keeps 0
+    if (NW > 1) {   // add the totals of the waves before this one
+      double* const r = L.red + (slot++ & 3) * 8;
+      if (lane == 63) r[wave] = incl;
+      __syncthreads();
+      double off = 0.0;
+      for (int w = 0; w < wave; ++w) off = off + r[w];
+      excl = off + excl;
+    }
+    // the cumulative weight at the last experience; threads behind it hold nothing
+    double total;
+    if (NW == 1) {
+      total = readlane_f64(excl + loc, (n4 - 1) / chunk);
+    } else {
+      double* const r = L.red + (slot++ & 3) * 8;
+      if (t == (n4 - 1) / chunk) r[0] = excl + loc;
+      __syncthreads();
+      total = r[0];
+    }
+    const double thr = u * total;
+    int idx = 0;
+    double run = 0.0;
+    for (int k = 0; k < chunk; ++k) {
+      const bool in = j0 + k < n4;
+      if (in) run = run + L.P[j0 + k];
+      idx += __popcll(__ballot(in && (excl + run <= thr)));
+    }
+    idx = block_sum_i32(idx);
+    idx = idx < n4 ? idx : n4 - 1;
+    // an experience of weight zero has probability zero; rounding at a lane boundary of the scan
+    // (or of u * total at u -> 1) is the only way to land on one
+    if (!(L.P[idx] > 0.0)) idx = first_equal(wmax);
+    return idx;
+  };
   const uint32_t g = A.r.instance_base + (uint32_t)i;
   const int world = (int)(g % (uint32_t)A.n_worlds);
   const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
@@ -197,18 +269,18 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
   double* const Cg = A.r.strength + (size_t)i * n4;
   uint32_t* const stamp = A.r.stamp + (size_t)i * n4;
 
-  for (int e = lane; e < S; e += 64) {
+  for (int e = t; e < S; e += NT) {
     L.Q[e] = reinterpret_cast<const float4*>(Qg)[e];
     L.I[e] = 0.0;
   }
-  for (int e = lane; e < n4; e += 64) {
+  for (int e = t; e < n4; e += NT) {
     L.C[e] = Cg[e];
     const uint64_t rec = Mg[e];
     const int j = (e & 3) * S + (e >> 2);
     L.R[j] = __builtin_bit_cast(float, (uint32_t)rec);
     L.NS[j] = (uint16_t)(((rec >> 32) & 0x7fffu) | (((rec >> 48) & 1u) << 15));
   }
-  wsync();
+  bsync();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
   int32_t* const sinst = A.r.sfma_inst + (size_t)i * COBEL_SI_WORDS;
@@ -244,11 +316,39 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
   double dec_inh = A.r.decay_inhibition, i_step = A.r.i_step, blend = A.r.blend;
   double ip_fwd = A.r.interp_fwd, ip_rev = A.r.interp_rev;
   float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
-  cobel_eps_bb ebb = A.eps;
   asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(beta), "+v"(r_thr), "+v"(dec_inh), "+v"(i_step),
                "+v"(blend), "+v"(ip_fwd), "+v"(ip_rev), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
-#pragma unroll
-  for (int k = 1; k <= 4; ++k) asm volatile("" : "+v"(ebb.base[k]), "+v"(ebb.bonus[k]));
+  // (named scalars, not the struct members: pinning a member sends the whole struct to scratch)
+  double eb1 = A.eps.base[1], eb2 = A.eps.base[2], eb3 = A.eps.base[3], eb4 = A.eps.base[4];
+  double en1 = A.eps.bonus[1], en2 = A.eps.bonus[2], en3 = A.eps.bonus[3], en4 = A.eps.bonus[4];
+  asm volatile("" : "+v"(eb1), "+v"(eb2), "+v"(eb3), "+v"(eb4), "+v"(en1), "+v"(en2), "+v"(en3),
+               "+v"(en4));
+  // cobel_eps_greedy_select_wave (cobel_policy.h) on those scalars: lanes 0..2 take one float64
+  // division each, a ballot counts the thresholds of the normalised CDF that u has passed
+  auto select_action = [&](const float4 v, uint32_t mask, double u) -> int {
+    const float ninf = -__builtin_huge_valf();
+    const bool a0 = mask & 1u, a1 = mask & 2u, a2 = mask & 4u, a3 = mask & 8u;
+    float m = ninf;
+    m = a0 ? fmaxf(m, v.x) : m;
+    m = a1 ? fmaxf(m, v.y) : m;
+    m = a2 ? fmaxf(m, v.z) : m;
+    m = a3 ? fmaxf(m, v.w) : m;
+    const bool t0 = a0 && v.x == m, t1 = a1 && v.y == m, t2 = a2 && v.z == m, t3 = a3 && v.w == m;
+    const int n = __popc(mask & 15u);
+    const int nt = (int)t0 + (int)t1 + (int)t2 + (int)t3;
+    // one-hot sums, not select chains (which the optimizer turns into a table in scratch memory)
+    const double base = (((n <= 1 ? eb1 : 0.0) + (n == 2 ? eb2 : 0.0)) + (n == 3 ? eb3 : 0.0)) +
+                        (n >= 4 ? eb4 : 0.0);
+    const double bonus = (((nt <= 1 ? en1 : 0.0) + (nt == 2 ? en2 : 0.0)) + (nt == 3 ? en3 : 0.0)) +
+                         (nt >= 4 ? en4 : 0.0);
+    const double p0 = a0 ? base + (t0 ? bonus : 0.0) : 0.0;
+    const double p1 = a1 ? base + (t1 ? bonus : 0.0) : 0.0;
+    const double p2 = a2 ? base + (t2 ? bonus : 0.0) : 0.0;
+    const double p3 = a3 ? base + (t3 ? bonus : 0.0) : 0.0;
+    const double c0 = p0, c1 = c0 + p1, c2 = c1 + p2, c3 = c2 + p3;
+    const double mine = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+    return __popcll(__ballot(lane < 3 && (mine / c3 <= u)));
+  };
 
   // CH > 0: this lane's experiences j = lane * CH + k, their states and whether they exist
   constexpr int CHN = CH > 0 ? CH : 1;
@@ -256,7 +356,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
   bool inb[CHN];
 #pragma unroll
   for (int k = 0; k < CHN; ++k) {
-    const int j = lane * CHN + k;
+    const int j = t * CHN + k;
     inb[k] = j < n4;
     jj[k] = inb[k] ? j : n4 - 1;
     sid[k] = jj[k] % S;
@@ -286,15 +386,15 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
     const double gnt = gamma * (double)nt;
     double td = (double)R + gnt * (double)m;
     td = td - (double)q;
-    wsync();
-    if (lane == 0) reinterpret_cast<float*>(L.Q)[s * 4 + a] = (float)((double)q + alpha * td);
-    wsync();
+    bsync();
+    if (t == 0) reinterpret_cast<float*>(L.Q)[s * 4 + a] = (float)((double)q + alpha * td);
+    bsync();
     td_acc = ((sflags & 1u) ? (double)(float)td_acc : td_acc) + fabs(td);
     sflags &= ~1u;
     return td;
   };
   auto record = [&](int s, int a, int ns, float R, uint32_t nt, int kind, int tr, double td) {
-    if (A.r.replay_trace && lane == 0 && tpos < A.r.trace_cap) {
+    if (A.r.replay_trace && t == 0 && tpos < A.r.trace_cap) {
       cobel_sfma_event_t ev;
       ev.sa = (uint32_t)s | ((uint32_t)a << 16) | (nt << 24) | ((uint32_t)kind << 25);
       ev.next = (uint32_t)ns;
@@ -311,7 +411,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
     int action = (int)cobel_draw_bounded(cm, 0u, g, COBEL_STREAM_MEMORY, seed, 4u);
     cm += 1u;
     int cur = start_state;
-    const int j0 = lane * chunk;
+    const int j0 = t * chunk;
     if (cur < 0) {
       // no terminal state was reached: start from an experience drawn by strength (:262-270)
       double wmax = 0.0;
@@ -322,23 +422,23 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
           L.P[j0 + k] = w;
           wmax = fmax(wmax, w);
         }
-      wmax = wave_max_f64(wmax);
-      wsync();
+      wmax = block_max(wmax);
+      bsync();
       const double u = mem_u01();
-      const int pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
+      const int pick = choice(u, wmax);
       action = pick / S;
       cur = pick - action * S;
-      wsync();
+      bsync();
     }
     int nxt = (int)(L.NS[action * S + cur] & 0x7fffu);
-    for (int e = lane; e < S; e += 64) L.I[e] = 0.0;
+    for (int e = t; e < S; e += NT) L.I[e] = 0.0;
     double cmax = 1.0;
     if (sf & COBEL_SF_C_NORMALIZE) {
       double m = -__builtin_huge_val();
-      for (int e = lane; e < n4; e += 64) m = fmax(m, L.C[e]);
-      cmax = wave_max_f64(m);
+      for (int e = t; e < n4; e += NT) m = fmax(m, L.C[e]);
+      cmax = block_max(m);
     }
-    wsync();
+    bsync();
     const bool need_next = mode == COBEL_SFMA_FORWARD || mode == COBEL_SFMA_BLEND_FORWARD ||
                            mode == COBEL_SFMA_INTERPOLATE || mode == COBEL_SFMA_SWEEPING;
     for (int it = 0; it < A.r.batch; ++it) {
@@ -349,16 +449,16 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
         double dmax = 1.0;
         if (sf & COBEL_SF_D_NORMALIZE) {
           double m = -__builtin_huge_val();
-          for (int e = lane; e < S; e += 64) m = fmax(m, rc[e]);
-          dmax = wave_max_f64(m);
+          for (int e = t; e < S; e += NT) m = fmax(m, rc[e]);
+          dmax = block_max(m);
         }
-        for (int e = lane; e < S; e += 64) {
+        for (int e = t; e < S; e += NT) {
           const double d = rc[e];
           L.Dc[e] = (sf & COBEL_SF_D_NORMALIZE) ? d / dmax : d;
           if (need_next) L.Dn[e] = rn[e];
         }
       }
-      wsync();
+      bsync();
       int pick;
       if (CH > 0) {
         // similarity of every experience to the one replayed last, by mode (:284-307)
@@ -408,7 +508,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
           p[k] = inb[k] ? R : 0.0;
           rmax = fmax(rmax, p[k]);
         }
-        rmax = wave_max_f64(rmax);
+        rmax = block_max(rmax);
         if (!(rmax > 0.0)) break;
         // softmax weights exp(beta R / max R) - 1 (:319-327, :349-372)
         bool some = false;
@@ -450,8 +550,8 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
             if (inb[k]) L.P[jj[k]] = p[k];
             wmax = fmax(wmax, p[k]);
           }
-          wmax = wave_max_f64(wmax);
-          wsync();
+          wmax = block_max(wmax);
+          bsync();
           idx = wave_first_equal(L.P, n4, CHN, lane, wmax);
         }
         pick = idx;
@@ -494,11 +594,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
           if (s == S) s = 0;
         }
       }
-      rmax = wave_max_f64(rmax);
+      rmax = block_max(rmax);
       if (!(rmax > 0.0)) break;  // np.sum(R) == 0: nothing left to reactivate (:317-318)
-      wsync();
+      bsync();
       if (sf & COBEL_SF_DETERMINISTIC) {
-        pick = wave_first_equal(L.P, n4, chunk, lane, rmax);
+        pick = first_equal(rmax);
       } else {
         // softmax(R, offset -1, beta) = exp(beta R) - 1 (:349-372), then the draw
         double wmax = 0.0;
@@ -510,15 +610,15 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
             L.P[j0 + k] = w;
             wmax = fmax(wmax, w);
           }
-        wmax = wave_max_f64(wmax);
+        wmax = block_max(wmax);
         if (!(wmax > 0.0)) {  // np.sum(exp) == 0 -> exp.fill(1)
           for (int k = 0; k < chunk; ++k)
             if (j0 + k < n4) L.P[j0 + k] = 1.0;
           wmax = 1.0;
         }
-        wsync();
+        bsync();
         const double u = mem_u01();
-        pick = wave_choice(L.P, n4, chunk, lane, u, wmax);
+        pick = choice(u, wmax);
       }
       }
       action = (int)(pick >= S) + (int)(pick >= 2 * S) + (int)(pick >= 3 * S);   // pick / S
@@ -527,29 +627,30 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
       const float R = L.R[pick];
       nxt = (int)(nrec & 0x7fffu);
       const uint32_t nt = nrec >> 15;
-      wsync();
+      bsync();
       // inhibition (:336-337)
-      for (int e = lane; e < S; e += 64) L.I[e] = L.I[e] * dec_inh;
-      wsync();
-      if (lane == 0) L.I[cur] = fmin(L.I[cur] + i_step, 1.0);
+      for (int e = t; e < S; e += NT) L.I[e] = L.I[e] * dec_inh;
+      bsync();
+      if (t == 0) L.I[cur] = fmin(L.I[cur] + i_step, 1.0);
       // the reactivated experience
       double td = __builtin_nan("");
       if (update) td = replay_td(cur, action, nxt, R, nt);
       record(cur, action, nxt, R, nt, kind, tr, td);
       replayed += 1ull;
-      wsync();
+      bsync();
     }
   };
 
   // SFMAMemory.retrieve_random_batch (:374-416) + the TD updates
   auto random_replay = [&](int tr) {
-    const int j0 = lane * chunk;
+    const int j0 = t * chunk;
     for (int b = 0; b < A.r.batch; ++b) {
       const double u = cobel_draw_u01(cm, COBEL_SUB_DOUBLE + (uint32_t)b, g, COBEL_STREAM_MEMORY,
                                       seed);
       int idx = 0;
       for (int k = 0; k < chunk; ++k)
         idx += __popcll(__ballot(j0 + k < n4 && A.r.random_cdf[j0 + k] <= u));
+      idx = block_sum_i32(idx);
       idx = idx < n4 ? idx : n4 - 1;
       const int a = idx / S, s = idx - a * S;   // unravel_index(order='F')
       const uint32_t nrec = L.NS[idx];
@@ -587,8 +688,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
     }
     const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
     cp += 1u;
-    const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
-                                                                  ebb, lane));
+    const int a = (int)rfl((uint32_t)select_action(q, mask_cur, u));
     const uint4 wc = W4[state];
     const int ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
     const uint4 wn = W4[ns];
@@ -603,33 +703,33 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
       const float Rold = L.R[j];
       const float d = r - Rold;
       const float Rnew = Rold + mlr_f * d;
-      if (lane == 0) {
+      if (t == 0) {
         Mg[sa] = cobel_model_pack(Rnew, (uint32_t)ns, nt);   // written through
         L.R[j] = Rnew;
         L.NS[j] = (uint16_t)((uint32_t)ns | (nt << 15));
       }
       if (A.r.decay_strength != 1.0) {
-        for (int e = lane; e < n4; e += 64) L.C[e] = L.C[e] * A.r.decay_strength;
-        wsync();
+        for (int e = t; e < n4; e += NT) L.C[e] = L.C[e] * A.r.decay_strength;
+        bsync();
       }
       clock += 1u;
-      if (lane == 0) {
+      if (t == 0) {
         double c = L.C[j] + A.r.c_step;
         if (sf & COBEL_SF_REWARD_MOD_LOCAL) c = c + (double)r * A.r.reward_modulation;
         L.C[j] = c;
         stamp[j] = clock;
       }
       if (sf & COBEL_SF_REWARD_MOD) {
-        wsync();
+        bsync();
         const double* const row = Dm + (size_t)state * S;
-        for (int e = lane; e < n4; e += 64) {
+        for (int e = t; e < n4; e += NT) {
           const int s2 = e % S;
           L.C[e] = L.C[e] + ((double)r * row[s2]) * A.r.reward_modulation;
         }
       }
       if (sf & COBEL_SF_STATE_MOD) {
-        wsync();
-        if (lane < 4) L.C[lane * S + state] = L.C[lane * S + state] + 1.0;
+        bsync();
+        if (t < 4) L.C[t * S + state] = L.C[t * S + state] + 1.0;
       }
       // agent.update_q online (agent/sfma.py:437-455), float32
       const float4 nrow = L.Q[ns];
@@ -638,15 +738,15 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
       const float gnt = nt ? gamma_f : 0.0f;
       float td = r + gnt * m;
       td = td - qsa;
-      wsync();
-      if (lane == 0) reinterpret_cast<float*>(L.Q)[sa] = qsa + alpha_f * td;
-      wsync();
+      bsync();
+      if (t == 0) reinterpret_cast<float*>(L.Q)[sa] = qsa + alpha_f * td;
+      bsync();
       td_online = td;
       if (sflags & 1u) td_acc = (double)((float)td_acc + fabsf(td));
       else td_acc = td_acc + (double)fabsf(td);
     }
 
-    if (A.r.last_exp && lane == 0) {
+    if (A.r.last_exp && t == 0) {
       int32_t* const e = A.r.last_exp + (size_t)i * 6;
       e[0] = state;
       e[1] = a;
@@ -658,13 +758,13 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
     trew += (double)r;
     nsteps += 1ull;
     executed += 1ull;
-    if (A.r.occupancy && lane == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
+    if (A.r.occupancy && t == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
     state = ns;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     if (!trial_over) {
       step += 1;
     } else {
-      if (lane == 0 && trial >= 0 && trial < A.r.trial_cap) {
+      if (t == 0 && trial >= 0 && trial < A.r.trial_cap) {
         if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
         if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
         if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
@@ -705,10 +805,10 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
     }
   }
 
-  wsync();
-  for (int e = lane; e < S; e += 64) reinterpret_cast<float4*>(Qg)[e] = L.Q[e];
-  for (int e = lane; e < n4; e += 64) Cg[e] = L.C[e];
-  if (lane == 0) {
+  bsync();
+  for (int e = t; e < S; e += NT) reinterpret_cast<float4*>(Qg)[e] = L.Q[e];
+  for (int e = t; e < n4; e += NT) Cg[e] = L.C[e];
+  if (t == 0) {
     inst[COBEL_I_STATE] = state;
     inst[COBEL_I_STEP] = step;
     inst[COBEL_I_TRIAL] = trial;
@@ -732,14 +832,18 @@ __device__ __forceinline__ void sfma_body(const sfma_args& A) {
 
 template <int CH>
 __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
-  sfma_body<CH>(A);
+  sfma_body<CH, 1>(A);
 }
 // Two experiences per lane (worlds up to 32 states, the reference's demos): five waves per SIMD
 // instead of the four the register allocation settles on by itself — +12 % on C6.  The same hint
 // costs the wider variants 20-25 % (spills into scratch), so they keep the default.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2(
     const sfma_args A) {
-  sfma_body<2>(A);
+  sfma_body<2, 1>(A);
+}
+// Four waves per instance, all switches: worlds of several hundred states.
+__global__ __launch_bounds__(256) void k_sfma_wg(const sfma_args A) {
+  sfma_body<0, 4>(A);
 }
 
 template <int CH>
@@ -750,6 +854,14 @@ int launch_sfma(const sfma_args& A, size_t lds, hipStream_t st) {
     COBEL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (CH == 2) hipLaunchKernelGGL(k_sfma_2, dim3(A.r.n), dim3(64), lds, st, A);
   else hipLaunchKernelGGL((k_sfma<CH>), dim3(A.r.n), dim3(64), lds, st, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+int launch_sfma_wg(const sfma_args& A, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024)
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sfma_wg),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sfma_wg, dim3(A.r.n), dim3(256), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -830,6 +942,14 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
   if (plain && A.chunk <= 8) {
     A.chunk = 8;
     return launch_sfma<8>(A, (size_t)lds, st);
+  }
+  // the general kernel: one wave per instance up to 800 experiences, four waves beyond
+  // (measured: 14x14 = 784 experiences 9.3e7 vs 7.9e7 reactivations/s in favour of one wave,
+  // 20x20 = 1 600 experiences 6.4e6 vs 5.2e7 in favour of four)
+  // (COBEL_F_NO_PREFETCH, otherwise unused here, pins the one-wave form for tests)
+  if (4 * S > 800 && !(r.flags & COBEL_F_NO_PREFETCH)) {
+    A.chunk = (4 * S + 255) / 256;
+    return launch_sfma_wg(A, (size_t)lds, st);
   }
   return launch_sfma<0>(A, (size_t)lds, st);
 }

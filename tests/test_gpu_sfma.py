@@ -215,6 +215,13 @@ def _oracle_world(world):
          opts={'decay_strength': 0.97, 'reward_mod': True, 'C_normalize': True}),
     dict(h=16, w=16, metric='SR', mode='blend_reverse', steps=80, B=12, opts={'random': False}),
     dict(h=10, w=10, metric='DR', mode='default', steps=40, B=40, opts={'random': True}),
+    # more than 800 experiences: four waves per instance
+    dict(h=15, w=15, metric='DR', mode='reverse', steps=60, B=24,
+         opts={'recency': True, 'D_normalize': True}),
+    dict(h=16, w=16, metric='Euclidean', mode='default', steps=70, B=30, opts={'random': True}),
+    dict(h=15, w=14, metric='SR', mode='sweeping', steps=50, B=16,
+         opts={'deterministic': True, 'start_replay': True, 'dynamic': True}),
+    dict(h=23, w=23, metric='DR', mode='forward', steps=90, B=20, opts={'state_mod': True}),
 ])
 def test_sfma_vs_oracle_larger_worlds(Z, cfg):
     """48 instances in one launch, 6 of them re-run by the NumPy restatement: trajectories,
@@ -266,6 +273,30 @@ def test_sfma_general_kernel_on_plain_configurations(Z, name):
     check_events(events_of(agent, 0), rp)
     assert np.array_equal(agent.Q[0].cpu().numpy().astype(np.float64), g('Q'))
     assert np.array_equal(agent.M.C[0], g('C'))
+
+
+def test_sfma_four_waves_equal_one_wave():
+    """The general kernel with four waves per instance (worlds beyond 800 experiences) against the
+    same kernel with one wave: identical tables, counters and reactivations."""
+    import torch
+    from cobel_amd.memory.utils import DR
+    world = _field(15, 15, 14, 1.0, [(16, 17), (17, 16)])
+    D = DR(15, 15, world['next'], 0.9, world['invalid_transitions']).D
+    tab = dict(world.compact(), height=15, width=15, coordinates=world['coordinates'])
+    runs = []
+    for one_wave in (False, True):
+        env, agent = build(tab, D, {'mode': 'blend_reverse', 'recency': True}, 40, 300)
+        agent.force_one_wave = one_wave
+        agent.train(env, 5, 60, 28)
+        torch.cuda.synchronize()
+        runs.append(agent)
+    a, b = runs
+    assert torch.equal(a._q, b._q) and torch.equal(a.M.strength, b.M.strength)
+    assert torch.equal(a.M.table, b.M.table) and torch.equal(a.M.stamp, b.M.stamp)
+    assert torch.equal(a.inst, b.inst) and torch.equal(a.M.state, b.M.state)
+    for i in (0, 39):
+        ea, eb = events_of(a, i), events_of(b, i)
+        assert len(ea) > 50 and np.array_equal(ea, eb)
 
 
 def test_sfma_chunking_and_sharding_invariance(Z):
