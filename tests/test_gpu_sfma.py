@@ -384,3 +384,34 @@ def test_full_size_c6_sample_and_conservation(Z):
     # every scalar double draw of the memory stream is one reactivation or one strength-start;
     # each replay also takes one integer draw
     assert int(agent.M.counter.to(torch.int64).sum().item()) >= done + n * trials
+
+
+def test_sfma_several_worlds_with_their_own_metrics(Z):
+    """Instances alternate between two different worlds (instance g lives in world g % 2), each
+    with its own similarity matrix: every checked instance equals the restatement run in its
+    world with its metric."""
+    import torch
+    from cobel_amd.agent import SFMA
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.memory import SFMAMemory
+    from cobel_amd.memory.utils import DR
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import sfma_loop
+    wa = _field(6, 6, 5, 1.0, [(7, 8), (8, 7)])
+    wb = _field(6, 6, 30, 2.0, [(13, 19), (19, 13), (14, 20), (20, 14)])
+    Ds = [DR(6, 6, w['next'], 0.9, w['invalid_transitions']).D for w in (wa, wb)]
+    env = Gridworld([wa, wb], n_envs=10, seed=SEED, instance_base=4)
+    mem = SFMAMemory(np.stack(Ds), 36, 4)
+    agent = SFMA(env.observation_space, env.action_space, EpsilonGreedy(0.1), mem)
+    agent.M.mode = 'reverse'
+    agent.track_instances = True
+    agent.train(env, 6, 30, 20)
+    torch.cuda.synchronize()
+    for i in range(10):
+        g = 4 + i
+        w = (wa, wb)[g % 2]
+        ag, _ = sfma_loop.run_case(_oracle_world(w), Ds[g % 2], SEED, g, True, 'reverse', {}, 6,
+                                   30, 20)
+        assert np.array_equal(agent.monitors.lat_trace[i].cpu().numpy()[:6], ag.steps), i
+        assert np.array_equal(agent.Q[i].cpu().numpy(), ag.Q), i
+        assert np.array_equal(agent.M.C[i], ag.M.C), i
