@@ -23,12 +23,15 @@ __version__ = '0.1.0'
 
 
 def install_as_cobel() -> None:
-    """Alias this package as ``cobel`` (drop-in for demo/gridworld and unit_tests scripts)."""
+    """Alias this package as ``cobel`` (drop-in for demo/gridworld, demo/topology and unit_tests
+    scripts): every module of the package is registered under the corresponding ``cobel.`` name."""
     import importlib
+    import pkgutil
 
     me = sys.modules[__name__]
     sys.modules.setdefault('cobel', me)
-    for sub in ('misc', 'misc.gridworld_tools', 'interface', 'policy', 'memory', 'memory.utils',
-                'memory.utils.metrics', 'memory.sfma', 'agent',
-                'monitor', 'analysis', 'spaces'):
-        sys.modules.setdefault('cobel.' + sub, importlib.import_module(__name__ + '.' + sub))
+    for info in pkgutil.walk_packages(me.__path__, prefix=__name__ + '.'):
+        if info.name.rsplit('.', 1)[-1].startswith('_'):
+            continue
+        mod = importlib.import_module(info.name)
+        sys.modules.setdefault('cobel' + info.name[len(__name__):], mod)

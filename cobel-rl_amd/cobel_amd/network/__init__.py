@@ -1,2 +1,3 @@
 from .network import Network  # noqa: F401
-from .network_torch import StackedTorchNetwork, TorchNetwork  # noqa: F401
+from .network_torch import (FlexibleTorchNetwork, StackedTorchNetwork,  # noqa: F401
+                            TorchNetwork)

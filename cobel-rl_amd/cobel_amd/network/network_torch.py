@@ -168,6 +168,30 @@ class TorchNetwork(Network):
         return StackedTorchNetwork(self, n)
 
 
+class FlexibleTorchNetwork(TorchNetwork):
+    """``cobel.network.FlexibleTorchNetwork`` (network/network_torch.py:454-1050) for the case the
+    accelerated path meets: ONE array-valued input and one output head, where the reference class
+    behaves exactly like ``TorchNetwork`` (``prepare_batch`` just wraps the array).  Multi-input /
+    multi-head models (dict or list batches, per-head losses and ``loss_weights``) belong to the
+    simulator-backed interfaces and are outside this path."""
+
+    def __init__(self, model: nn.Module, optimizer=None, loss=None, optimizer_params=None,
+                 loss_params=None, loss_weights=None, activations=None,
+                 device: str = 'cpu') -> None:
+        if isinstance(loss, (list, dict)) or loss_weights is not None:
+            raise NotImplementedError('multi-head losses are outside the accelerated path')
+        super().__init__(model, optimizer, loss, optimizer_params, loss_params, activations, device)
+
+    def clone(self):
+        net = copy.deepcopy(self.model)
+        twin = type(self)(net, type(self.optimizer)(params=net.parameters()),
+                          copy.deepcopy(self.criterion),
+                          activations=copy.deepcopy(self.activations), device=str(self.device))
+        twin.criterion.load_state_dict(self.criterion.state_dict())
+        twin.optimizer.load_state_dict(self.optimizer.state_dict())
+        return twin
+
+
 class StackedTorchNetwork:
     """n independent copies of one architecture with parameters stacked on axis 0."""
 

@@ -184,3 +184,108 @@ def test_qagent_on_topology_matches_reference(cobel, golden, name):
     ag2 = QAgent(env2.observation_space, env2.action_space, EpsilonGreedy(0.1))
     ag2.train(env2, trials, steps, B)
     assert np.array_equal(ag2.Q[inst].cpu().numpy().astype(np.float64), g('Q'))
+
+
+class _Model:
+    """The MLP of the reference's network demos (demo_dyna_dqn.py:29-46, demo_dqn.py:44-66)."""
+
+    def __new__(cls, input_size, output_size):
+        from torch import reshape
+        from torch.nn import Linear, Module
+        from torch.nn.functional import relu
+
+        class Model(Module):
+            def __init__(self):
+                super().__init__()
+                units = input_size if type(input_size) is int else int(np.prod(input_size))
+                self.layer_dense_1 = Linear(in_features=units, out_features=64)
+                self.layer_dense_2 = Linear(in_features=64, out_features=64)
+                self.layer_output = Linear(in_features=64, out_features=output_size)
+                self.double()
+
+            def forward(self, layer_input):
+                x = reshape(layer_input, (len(layer_input), -1))
+                x = relu(self.layer_dense_1(x))
+                x = relu(self.layer_dense_2(x))
+                return self.layer_output(x)
+
+        return Model()
+
+
+def test_topology_and_sr_demo_flows(cobel):
+    """demo/topology/demo.py (QAgent without replay on linear / grid / t-maze graphs, escape
+    latency monitor) and demo/gridworld/demo_sr.py."""
+    from cobel.agent import SR, QAgent
+    from cobel.interface import Gridworld, Topology
+    from cobel.misc.gridworld_tools import make_open_field
+    from cobel.misc.topology_tools import grid, linear_track, t_maze
+    from cobel.monitor import EscapeLatencyMonitor
+    from cobel.policy import EpsilonGreedy
+    from cobel.typing import CallbackDict, Node, NodeID  # noqa: F401
+    for nodes, starting_nodes in (linear_track(10, 2, 1.0, 20, 'right'), grid(5, (0.0, 1.0)),
+                                  t_maze(6, 3, 2, 1.0)):
+        interface = Topology(nodes, starting_nodes, None, None)
+        el_monitor = EscapeLatencyMonitor(120, 50, None)
+        callbacks = {'on_trial_end': [el_monitor.update]}
+        agent = QAgent(interface.observation_space, interface.action_space, EpsilonGreedy(0.1),
+                       custom_callbacks=callbacks)
+        agent.train(interface, 120, 50, 0)
+        trace = np.asarray(el_monitor.get_trace())
+        assert np.isfinite(trace).all() and trace[-20:].mean() <= trace[:20].mean()
+    env = Gridworld(make_open_field(5, 5, 0, 1))
+    el_monitor = EscapeLatencyMonitor(60, 50)
+    agent = SR(env.observation_space, env.action_space, EpsilonGreedy(), EpsilonGreedy(0.0),
+               custom_callbacks={'on_trial_end': [el_monitor.update]})
+    agent.train(env, 40, 50)
+    agent.test(env, 20, 50)
+    assert np.isfinite(el_monitor.get_trace()).all()
+    assert agent.predict_on_batch(np.arange(25)).shape == (25, 4)
+
+
+def test_network_demo_flows(cobel):
+    """demo/gridworld/demo_dyna_dqn.py, demo_dyna_dsr.py and demo/topology/demo_dqn.py with short
+    schedules (widget None): constructors, keyword arguments, callbacks and the returned
+    Q-function shapes as in the scripts."""
+    from cobel.agent import DQN, DynaDQN, DynaDSR
+    from cobel.interface import Gridworld, Topology
+    from cobel.misc.gridworld_tools import make_open_field
+    from cobel.misc.topology_tools import linear_track
+    from cobel.monitor import EscapeLatencyMonitor
+    from cobel.network import FlexibleTorchNetwork, TorchNetwork
+    from cobel.policy import EpsilonGreedy
+    trials_train, trials_test, steps = 6, 3, 20
+    env = Gridworld(make_open_field(5, 5, 0, 1), widget=None)
+    el_monitor = EscapeLatencyMonitor(trials_train + trials_test, steps, None)
+    custom_callbacks = {'on_trial_end': [el_monitor.update],
+                        'on_step_end': [env.update_visualization]}
+    agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(),
+                    TorchNetwork(_Model(25, 4)), gamma=0.8, policy_test=EpsilonGreedy(0.0),
+                    custom_callbacks=custom_callbacks)
+    agent.train(env, trials_train, steps, 32)
+    agent.test(env, trials_test, steps)
+    q = agent.predict_on_batch(np.arange(25))
+    assert q.shape == (25, 4) and np.isfinite(q).all()
+    assert np.isfinite(el_monitor.get_trace()).all()
+
+    env = Gridworld(make_open_field(5, 5, 0, 1), widget=None)
+    el_monitor = EscapeLatencyMonitor(trials_train + trials_test, steps, None)
+    agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(),
+                    TorchNetwork(_Model(25, 25)), TorchNetwork(_Model(25, 1)), gamma=0.8,
+                    policy_test=EpsilonGreedy(0.0),
+                    custom_callbacks={'on_trial_end': [el_monitor.update],
+                                      'on_step_end': [env.update_visualization]})
+    agent.train(env, trials_train, steps, 32)
+    agent.test(env, trials_test, steps)
+    q = agent.predict_on_batch(np.arange(25))
+    assert q.shape == (25, 4) and np.isfinite(q).all()
+
+    nodes, starting_nodes = linear_track(10, 2, 1.0, 20, 'right')
+    interface = Topology(nodes, starting_nodes, None, None)
+    el_monitor = EscapeLatencyMonitor(9, 30, None)
+    assert type(interface.observation_space.shape) is tuple
+    model = FlexibleTorchNetwork(_Model(interface.observation_space.shape, 4))
+    agent = DQN(interface.observation_space, interface.action_space, EpsilonGreedy(0.3), model,
+                policy_test=EpsilonGreedy(0.0), custom_callbacks={'on_trial_end': [el_monitor.update]})
+    agent.train(interface, 6, 30)
+    agent.test(interface, 3, 30)
+    assert np.isfinite(el_monitor.get_trace()).all()
