@@ -35,7 +35,8 @@ class Topology(Interface):
             starting_nodes = [k for k, nd in nodes.items() if not nd['terminal']]
         self.starting_nodes = starting_nodes
         for nd in nodes.values():
-            assert len(nd['neighbors']) == 4, 'the env kernels serve 4-neighbour topologies'
+            assert len(nd['neighbors']) == 4, \
+                'the env kernels serve 4-neighbour topologies (hexagonal graphs have 6 actions)'
         S = len(self.ids)
         self.pose = np.array([nodes[k]['pose'] for k in self.ids], dtype=np.float64).reshape(S, 6)
         world = dict(

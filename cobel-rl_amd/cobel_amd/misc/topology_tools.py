@@ -4,8 +4,9 @@ Call surface of the reference's ``cobel.misc.topology_tools`` (misc/topology_too
 ``linear_track``, ``grid``, ``t_maze`` and ``cross``: same arguments, same ``(nodes, starting_nodes)`` result
 with ``nodes[id] = {'id', 'pose', 'terminal', 'reward', 'neighbors'}``; ids are ``str(n)`` in
 construction order, neighbours are ordered [left, up, right, down] and point back at the node
-itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` (six neighbours, i.e.
-six actions) and the shapely-based obstacle pruning are outside the accelerated path.
+itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` builds the six-neighbour
+graph as the reference does, but the env kernels cover four actions, so ``Topology`` refuses it;
+the shapely-based obstacle pruning is outside the accelerated path.
 """
 from __future__ import annotations
 
@@ -133,3 +134,39 @@ def cross(nb_nodes_arm: int, nb_nodes_width: int, spacing: float = 1.0, rotation
         nodes[str(i)] = {'id': str(i), 'pose': (float(x), float(y), 0.0, 0.0, 0.0, 0.0),
                          'terminal': False, 'reward': 0.0, 'neighbors': neighbors}
     return nodes, list(nodes.keys())
+
+
+def hexagonal(nb_nodes: int, limits=(0.0, 1.0), reward: float = 1.0, location=None):
+    """Hexagonal lattice (topology_tools.py:175-272): every other row is shifted by half a
+    spacing and loses the node that leaves the range; neighbours are the nodes closer than 1.5
+    spacings, sorted into six 60-degree sectors and listed clockwise starting at the left; a
+    missing neighbour is the node itself.  Six actions: not served by the 4-action kernels."""
+    assert nb_nodes > 1, 'Invalid number of nodes!'
+    assert limits[1] > limits[0], 'Invalid coordinate range!'
+    spacing = (limits[1] - limits[0]) / (nb_nodes - 1)
+    line = np.linspace(limits[0], limits[1], nb_nodes)
+    coords = np.array([[x, y] for y, x in product(line, line)])
+    odd_rows = (np.arange(nb_nodes * nb_nodes) // nb_nodes) % 2 == 1
+    coords[odd_rows, 0] += spacing / 2
+    coords = coords[coords[:, 0] <= limits[1]]
+    pose_xy = np.stack([coords[:, 0], limits[1] - (coords[:, 1] - limits[0])], axis=1)
+    n = len(pose_xy)
+    delta = pose_xy[None, :, :] - pose_xy[:, None, :]          # [from, to]
+    dist = np.sqrt(np.sum(delta ** 2, axis=2))
+    sectors = np.array([(i * 60 - 120) % 360 for i in range(6)])
+    nodes = {}
+    for i in range(n):
+        slots = {int(a): str(i) for a in sectors}
+        # the reference walks [self] * 6 first (angle 0) and then the real neighbours in id order
+        for j in [i] + [k for k in range(n) if k != i and dist[i, k] < spacing * 1.5]:
+            angle = np.angle(complex(delta[i, j, 0], delta[i, j, 1]), deg=True) % 360
+            slots[int(sectors[int(np.argmin(np.abs(sectors - angle)))])] = str(j)
+        nodes[str(i)] = {'id': str(i),
+                         'pose': (pose_xy[i, 0], pose_xy[i, 1], 0.0, 0.0, 0.0, 0.0),
+                         'terminal': False, 'reward': 0.0,
+                         'neighbors': list(slots.values())[::-1]}
+    if location is None or location not in nodes:
+        location = str(nb_nodes - 1)
+    nodes[location].update({'terminal': True, 'reward': reward})
+    starting_nodes = [k for k in nodes if k != location]
+    return nodes, starting_nodes

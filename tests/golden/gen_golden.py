@@ -690,7 +690,8 @@ def gen_topology():
              'linear_5x1_left': tt.linear_track(5, 1, 0.5, 2., 'left'),
              't_maze_4_3_1': tt.t_maze(4, 3, 1), 't_maze_3_2_2_left': tt.t_maze(3, 2, 2, 2.0, 3.0, 'left'),
              'grid_4x3': tt.grid((4, 3)), 'grid_5': tt.grid(5, (0.0, 2.0), 7.0, '12'),
-             'cross_2_1_rot30': tt.cross(2, 1, 0.5, 30.0), 'cross_3_2': tt.cross(3, 2, 2.0)}
+             'cross_2_1_rot30': tt.cross(2, 1, 0.5, 30.0), 'cross_3_2': tt.cross(3, 2, 2.0),
+             'hex_4': tt.hexagonal(4), 'hex_5_goal7': tt.hexagonal(5, (0.0, 2.0), 3.0, '7')}
     for name, (nodes, starts) in built.items():
         ids = list(nodes.keys())
         idx = {k: i for i, k in enumerate(ids)}
