@@ -9,8 +9,12 @@
 //   * the rows needed by the TD update (SR[s], SR[ns]) are taken from those four LDS copies when
 //     T[s][.] already points at them (always, once (s, a) has been visited) and fetched only
 //     otherwise; the updated row is written back with coalesced 16-byte stores;
-//   * the reward estimate R (4 B per state) and the agent's transition table T (8 B per state)
-//     live in LDS for the whole call and are written through to HBM as they change.
+//   * the reward estimate R (4 B per state) lives in LDS for the whole call and is written through;
+//     the agent's transition table T (8 B per state) stays in HBM / L2: the row of the current state
+//     travels in registers from step to step and the row of the state being entered is one 8-byte
+//     load.  Keeping T, a sixth row buffer and 58 unused leaf sums out of LDS takes an instance from
+//     39.1 to 26 KiB: six workgroups per CU instead of four, and the step is latency-bound
+//     (measured: 1 / 2 / 3 / 4 workgroups per CU -> 0.65 / 1.23 / 1.71 / 2.10e8 steps/s).
 //
 // Reference behaviour restated (paths relative to /root/reference/src/cobel):
 //   agent/sr.py:155-197 (train loop), :267-284 (update), :302-308 (retrieve_q)
@@ -23,13 +27,14 @@
 namespace {
 
 constexpr int kMaxLeaves = 64;
-constexpr int kRows = 6;  // four value rows + two spare rows for the update
+constexpr int kRows = 5;  // four value rows + one spare row (the new SR[s], or SR[s] fetched)
 
 struct sr_args {
   const cobel_wrec* rec;
   const uint16_t* starts;
   const int32_t* start_off;
   int32_t S, n_worlds;
+  int32_t leaves;   // leaves of the pairwise-sum tree over S elements (leaf sums kept per wave)
   cobel_sr_run_t r;
   cobel_eps_consts eps;
   float alpha_f, gamma_f;
@@ -176,37 +181,53 @@ __device__ __forceinline__ void load_row(float* dst, const float* __restrict__ s
 
 struct sr_lds {
   float* rw;
-  uint16_t* T;
   float* rows;
   sr_plan* plan;
-  float* leafsum;  // [4][kMaxLeaves]
+  float* leafsum;  // [4][LS], LS = leaf_stride(leaves)
   float* V;        // [4]
-  int PS;
+  uint32_t* occ;   // [S] visit counts (OCC only)
+  int PS, LS;
 };
 
-__device__ __forceinline__ sr_lds carve(unsigned char* base, int S) {
+// Leaves of NumPy's pairwise sum over n elements, and the per-wave stride of the leaf sums.
+int count_leaves(int n) {
+  if (n <= 128) return 1;
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return count_leaves(n2) + count_leaves(n - n2);
+}
+__host__ __device__ __forceinline__ int leaf_stride(int leaves) { return (leaves + 3) & ~3; }
+
+__device__ __forceinline__ sr_lds carve(unsigned char* base, int S, int leaves) {
   sr_lds L;
   L.PS = padded(S);
+  L.LS = leaf_stride(leaves);
   size_t off = 0;
   L.rows = reinterpret_cast<float*>(base + off);
   off += (size_t)kRows * L.PS * 4;
   L.rw = reinterpret_cast<float*>(base + off);
   off += (size_t)L.PS * 4;
   L.leafsum = reinterpret_cast<float*>(base + off);
-  off += 4 * kMaxLeaves * 4;
+  off += (size_t)4 * L.LS * 4;
   L.V = reinterpret_cast<float*>(base + off);
   off += 16;
   L.plan = reinterpret_cast<sr_plan*>(base + off);
   off += (sizeof(sr_plan) + 15) & ~(size_t)15;
-  L.T = reinterpret_cast<uint16_t*>(base + off);
+  L.occ = reinterpret_cast<uint32_t*>(base + off);
   return L;
 }
 
-size_t sr_lds_bytes(int S, bool with_T) {
-  size_t b = (size_t)(kRows + 1) * padded(S) * 4 + 4 * kMaxLeaves * 4 + 16 +
+size_t sr_lds_bytes(int S, int leaves, bool occ) {
+  size_t b = (size_t)(kRows + 1) * padded(S) * 4 + (size_t)4 * leaf_stride(leaves) * 4 + 16 +
              ((sizeof(sr_plan) + 15) & ~(size_t)15);
-  if (with_T) b += (size_t)S * 8;
+  if (occ) b += (size_t)S * 4;
   return (b + 15) & ~(size_t)15;
+}
+
+// The four 16-bit successors of one state in the agent's transition table, as one 64-bit word.
+__device__ __forceinline__ int t_of(uint64_t row, int k) { return (int)((row >> (16 * k)) & 0xffffu); }
+__device__ __forceinline__ uint64_t t_set(uint64_t row, int k, uint32_t v) {
+  return (row & ~(0xffffull << (16 * k))) | ((uint64_t)v << (16 * k));
 }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -225,11 +246,14 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
 // rows overlaps the row update of this step.  The one row that cannot be prefetched — SR[s], which
 // this step rewrites — is taken from the LDS copy the update leaves behind.
 // PSETS: hyper-parameters from per-instance parameter sets (run.param_index).
+// Five waves per SIMD = five workgroups per CU (96 registers; the allocator's own choice of 98
+// stops at four, and six — 80 registers — spills: 10.0 / 8.9 / 9.3 ms per launch on C4).
 template <bool VEC, bool OCC, bool PRE, bool PSETS>
-__global__ __launch_bounds__(256) void k_sr(const sr_args A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sr(
+    const sr_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
-  const sr_lds L = carve(lds_raw, S);
+  const sr_lds L = carve(lds_raw, S, A.leaves);
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
   const uint32_t g = A.r.instance_base + (uint32_t)i;
@@ -237,15 +261,15 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
   float* const SRg = A.r.sr + (size_t)i * S * S;
   uint16_t* const Tg = A.r.trans + (size_t)i * S * 4;
+  const uint64_t* const T8 = reinterpret_cast<const uint64_t*>(Tg);   // one row per load
   float* const Rg = A.r.rewards + (size_t)i * S;
-  uint32_t* const occ = reinterpret_cast<uint32_t*>(L.T + (size_t)S * 4);  // only if OCC
+  uint32_t* const occ = L.occ;  // only if OCC
 
   for (int e = t; e < S; e += 256) {
     L.rw[phys(e)] = Rg[e];
     if (OCC) occ[e] = 0u;
   }
-  for (int e = t; e < S * 4; e += 256) L.T[e] = Tg[e];
-  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.leafsum));
+  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.rows));   // rows: free scratch here
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -284,6 +308,15 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
   uint32_t cw0 = 0, cw1 = 0;
   uint4 cand = {0, 0, 0, 0};
   uint32_t mask_cur = 15u;
+  uint64_t tcur = 0;   // T[state][0..3]: carried from step to step, loaded only at trial starts
+  // The row of the state just left, after that step's write: a step straight back reads it from
+  // here instead of racing the 2-byte store through the cache.  Older writes are read from L2
+  // (agent-scope loads bypass the CU's L1), at least a whole step after they were issued.
+  uint64_t tleft = 0;
+  int left_state = -1;
+  auto load_trow = [&](int s) -> uint64_t {
+    return __hip_atomic_load(T8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   cobel_u4 pblk = {0, 0, 0, 0};
   uint32_t pb_idx = ~0u;
   auto enter_state = [&](int s) {
@@ -292,6 +325,8 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     cw1 = rfl(c.y);
     if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
+    tcur = load_trow(s);
+    left_state = -1;
   };
   if (iflags & 1u) enter_state(state);
 
@@ -319,7 +354,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     budget -= 1;
 
     // ---- retrieve_q (sr.py:302-306): wave a evaluates V[T[s][a]] ----------------------------
-    const int my_row = (int)L.T[state * 4 + wave];
+    const int my_row = t_of(tcur, wave);
     float* const my_buf = L.rows + (size_t)wave * L.PS;
     const int e0 = lane * 4;
     if (PRE && pre_mode == 1) {
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
       load_row<VEC>(my_buf, SRg + (size_t)my_row * S, S, lane, 64);
     }
     __builtin_amdgcn_wave_barrier();
-    const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * kMaxLeaves, lane);
+    const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * L.LS, lane);
     if (lane == 0) L.V[wave] = v;
     lds_barrier();
     const float4 q = *reinterpret_cast<const float4*>(L.V);
@@ -359,11 +394,14 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     const uint32_t end = rl(cand.w, a);
     const uint32_t nt = 1u - end;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    // T[ns][.] as it stands before this step's write (one 8-byte load, the same for all threads)
+    uint64_t tnxt = tcur;
+    if (!trial_over && ns != state) tnxt = ns == left_state ? tleft : load_trow(ns);
     if (PRE) {
       pre_mode = 0;
       if (!trial_over) {
         // T[state][a] becomes ns in this step; every other entry of T[ns][.] is already final
-        const int nrow = (learn && ns == state && wave == a) ? ns : (int)L.T[ns * 4 + wave];
+        const int nrow = (learn && ns == state && wave == a) ? ns : t_of(tnxt, wave);
         if (learn && nrow == state) {
           pre_mode = 2;
         } else {
@@ -383,20 +421,23 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
       int src_s = -1, src_ns = -1;
 #pragma unroll
       for (int k2 = 3; k2 >= 0; --k2) {
-        const int rowk = (int)L.T[state * 4 + k2];
+        const int rowk = t_of(tcur, k2);
         if (rowk == state) src_s = k2;
         if (rowk == ns) src_ns = k2;
       }
       if (ns == state && src_ns < 0) src_ns = 4;  // shares the spare row with SR[s]
       const bool need_ns = nt != 0u;
-      lds_barrier();  // every wave has read T[s][.] before it changes
+      // (every wave is past its dot product — the barrier behind L.V — so the value rows that are
+      //  not a source of this update are free, and the spare row is no longer being copied from)
       if (src_s < 0) {
         load_row<VEC>(L.rows + (size_t)4 * L.PS, SRg + (size_t)state * S, S, t, 256);
         src_s = 4;
       }
       if (need_ns && src_ns < 0) {
-        load_row<VEC>(L.rows + (size_t)5 * L.PS, SRg + (size_t)ns * S, S, t, 256);
-        src_ns = 5;
+        // first visit of (s, a): SR[ns] is not among the value rows yet; it goes into one of them
+        // that this update does not read
+        src_ns = src_s == 0 ? 1 : 0;
+        load_row<VEC>(L.rows + (size_t)src_ns * L.PS, SRg + (size_t)ns * S, S, t, 256);
       }
       if (t == 0) {
         // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
@@ -405,9 +446,9 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
         const float upd = old + d * alpha_f;
         L.rw[phys(ns)] = upd;
         Rg[ns] = upd;
-        L.T[state * 4 + a] = (uint16_t)ns;
         Tg[state * 4 + a] = (uint16_t)ns;
       }
+      tcur = t_set(tcur, a, (uint32_t)ns);
       lds_barrier();
       // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
       const float* const row_s = L.rows + (size_t)src_s * L.PS;
@@ -456,6 +497,11 @@ __global__ __launch_bounds__(256) void k_sr(const sr_args A) {
     nsteps += 1ull;
     executed += 1ull;
     if (OCC && t == 0) occ[ns] += 1u;
+    if (ns != state) {   // (a bumping move stays in the row just updated)
+      tleft = tcur;
+      left_state = state;
+      tcur = tnxt;
+    }
     state = ns;
     cw0 = nw0;
     cw1 = nw1;
@@ -507,21 +553,21 @@ __global__ __launch_bounds__(256) void k_sr_q(const float* __restrict__ sr,
                                               const uint16_t* __restrict__ trans,
                                               const float* __restrict__ rewards,
                                               const int32_t* __restrict__ states,
-                                              float* __restrict__ q_out, int S) {
+                                              float* __restrict__ q_out, int S, int leaves) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const sr_lds L = carve(lds_raw, S);
+  const sr_lds L = carve(lds_raw, S, leaves);
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
   const float* const SRg = sr + (size_t)i * S * S;
   for (int e = t; e < S; e += 256) L.rw[phys(e)] = rewards[(size_t)i * S + e];
-  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.leafsum));
+  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.rows + (size_t)4 * L.PS));
   __syncthreads();
   const int s = states[i];
   const int row = (int)trans[((size_t)i * S + s) * 4 + wave];
   float* const buf = L.rows + (size_t)wave * L.PS;
   load_row<VEC>(buf, SRg + (size_t)row * S, S, lane, 64);
   __builtin_amdgcn_wave_barrier();
-  const float v = wave_pairwise_dot(buf, L.rw, L.plan, L.leafsum + wave * kMaxLeaves, lane);
+  const float v = wave_pairwise_dot(buf, L.rw, L.plan, L.leafsum + wave * L.LS, lane);
   if (lane == 0) q_out[(size_t)i * 4 + wave] = v;
 }
 
@@ -584,7 +630,9 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
                 "cobel_sr_run: mask_actions set without an action mask");
   const int S = world->n_states;
   const bool occ = r.occupancy != nullptr;
-  const size_t lds = sr_lds_bytes(S, true) + (occ ? (size_t)S * 4 : 0);
+  const int leaves = count_leaves(S);
+  size_t lds = sr_lds_bytes(S, leaves, occ);
+  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
   COBEL_REQUIRE(S <= 4096 && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
                 "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu)", S, lds,
                 kLdsLimit);
@@ -595,6 +643,7 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   A.start_off = world->start_off;
   A.S = S;
   A.n_worlds = world->n_worlds;
+  A.leaves = leaves;
   A.r = r;
   A.eps = cobel_make_eps_consts(r.epsilon);
   A.alpha_f = (float)r.alpha;
@@ -624,7 +673,8 @@ extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const
   COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 4096, COBEL_E_RANGE,
                 "cobel_sr_retrieve_q: bad sizes");
   if (n == 0) return COBEL_OK;
-  const size_t lds = sr_lds_bytes(n_states, false);
+  const int leaves = count_leaves(n_states);
+  const size_t lds = sr_lds_bytes(n_states, leaves, false);
   COBEL_REQUIRE(lds <= kLdsLimit, COBEL_E_UNSUPPORTED, "cobel_sr_retrieve_q: LDS %zu", lds);
   hipStream_t st = (hipStream_t)stream;
   if ((n_states % 4) == 0 && ((uintptr_t)sr & 15u) == 0) {
@@ -632,13 +682,13 @@ extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const
       COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_q<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_sr_q<true>), dim3(n), dim3(256), lds, st, sr, trans, rewards, states,
-                       q_out, n_states);
+                       q_out, n_states, leaves);
   } else {
     if (lds > 64 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_q<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_sr_q<false>), dim3(n), dim3(256), lds, st, sr, trans, rewards, states,
-                       q_out, n_states);
+                       q_out, n_states, leaves);
   }
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
