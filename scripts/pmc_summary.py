@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr<', 'C6': 'k_sfma<'}
+KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr<', 'C6': 'k_sfma'}
 
 
 def per_kernel(path, counter):
@@ -59,7 +59,8 @@ def main():
         assert len(names) == 1 and names[0] in write, (cfg, names)
         f, w = fetch[names[0]][1:], write[names[0]][1:]
         fk, wk = sum(f) / len(f), sum(w) / len(w)
-        short = names[0][names[0].index(tag[:-1]):names[0].index('>(') + 1]
+        start = names[0].index(tag.rstrip('<'))
+        short = names[0][start:names[0].index('(', start)]
         out[cfg] = {'kernel': short, 'launches': len(f), 'FETCH_SIZE_KiB': fk,
                     'WRITE_SIZE_KiB': wk, 'hbm_bytes_per_launch': (2 * fk + wk) * 1024}
     with open(os.path.join(root, 'r%02d_pmc_traffic.json' % rnd), 'w') as fh:
