@@ -308,8 +308,10 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    # defaults = the run shapes of SURVEY.md §8d: 4 launches x env_steps_per_launch = T steps per
+    # instance (C3 1 024, C2 4 096, C4 512)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=sorted(CONFIGS))
     ap.add_argument('--also', default='C2,C4,C6', help='extra configs reported under "other_configs"')
     ap.add_argument('--instances', type=int, default=0)

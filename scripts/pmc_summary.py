@@ -7,7 +7,7 @@
     python scripts/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> NN
 
 Per launch of the dominant kernel of each config (mean over the TIMED launches, i.e. all but the
-first two dispatches of that kernel, which are the warm-up launches).  Units and the gfx950 correction
+first dispatch of that kernel, which is the warm-up launch).  Units and the gfx950 correction
 follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE
 count KiB; FETCH_SIZE reports half the bytes of wide coalesced reads, so
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -48,7 +48,7 @@ def main():
     fetch, write = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
     out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 '
                     'bench.py --no-cpu-baseline --no-c5` on MI355X, per launch of the dominant '
-                    'kernel, mean over the timed launches (the two warm-up launches are dropped). '
+                    'kernel, mean over the timed launches (the warm-up launch is dropped). '
                     'FETCH_SIZE and WRITE_SIZE are in KiB. Per MI355X_MICROARCH.md (HBM section) '
                     'FETCH_SIZE on gfx950 reports exactly half of the bytes of a wide coalesced '
                     'read, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; the table loads '
@@ -57,7 +57,7 @@ def main():
     for cfg, tag in KERNELS.items():
         names = [k for k in fetch if tag in k]
         assert len(names) == 1 and names[0] in write, (cfg, names)
-        f, w = fetch[names[0]][2:], write[names[0]][2:]   # bench.py's two warm-up launches
+        f, w = fetch[names[0]][1:], write[names[0]][1:]   # bench.py's warm-up launch
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         start = names[0].index(tag.rstrip('<'))
         short = names[0][start:names[0].index('(', start)]
