@@ -50,7 +50,9 @@ CONFIGS = {
                bytes_per_step=67, agent='q',
                desc='65536 x 5x5 open gridworld, tabular Q-learning (alpha .9, gamma .8, eps .1, '
                     'no replay), 50 steps/trial'),
-    'C3': dict(instances=65536, env_steps_per_launch=256, steps_per_trial=200, batch=50,
+    # (512 steps per launch: loading and storing the 16 KiB Q table of an instance once per launch
+    #  is 2 GB of traffic for 65 536 instances; at 256 steps per launch C3 runs 3 % slower)
+    'C3': dict(instances=65536, env_steps_per_launch=512, steps_per_trial=200, batch=50,
                bytes_per_step=1628, agent='dynaq',
                desc='65536 instances over 64 32x32 obstacle mazes (p_wall .20, seeds 1234..1297), '
                     'Dyna-Q (alpha .99, gamma .99, eps .1, model lr .9), 50 planning updates/step, '
@@ -308,8 +310,8 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults = the run shapes of SURVEY.md §8d: 4 launches x env_steps_per_launch = T steps per
-    # instance (C3 1 024, C2 4 096, C4 512)
+    # defaults: 4 launches x env_steps_per_launch = the T steps per instance of SURVEY.md §8d for
+    # C2 (4 096) and C4 (512), twice that for C3 (2 048)
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=sorted(CONFIGS))
