@@ -747,6 +747,8 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   uint32_t* const wsum = reinterpret_cast<uint32_t*>(mon_raw + kMonSlots * 8);  // [kMonSlots]
   uint32_t* const wcnt = wsum + kMonSlots;                                      // [kMonSlots]
   int32_t* const wtag = reinterpret_cast<int32_t*>(wcnt + kMonSlots);           // [kMonSlots]
+  // ONE_WORLD: the start list next to the world records (a trial start is then LDS-only)
+  uint16_t* const Sl = reinterpret_cast<uint16_t*>(mon_raw + (MON ? kMonBytes : 0));
 
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x * LPW + lane;
@@ -759,8 +761,11 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
 
   if (lane < LPW)
     for (int s = 0; s < S; ++s) Ql[s * LPW + lane] = Qg[s];
-  if (ONE_WORLD)
+  if (ONE_WORLD) {
     for (int s = lane; s < S; s += 64) Wl[s] = W4[s];
+    const int ns0 = A.start_off[1] - A.start_off[0];
+    for (int k = lane; k < ns0; k += 64) Sl[k] = A.starts[A.start_off[0] + k];
+  }
   if (lane < 48) thr[lane] = A.eps.thr[lane / 3][lane % 3];
   if (MON)
     for (int k = lane; k < kMonSlots; k += 64) {
@@ -829,7 +834,8 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
           eb_idx = ce >> 2;
           eblk = cobel_philox(eb_idx, 0u, g, COBEL_STREAM_ENV, seed);
         }
-        state = (int)A.starts[start_lo + (int)cobel_bounded(cobel_word(eblk, ce & 3u), start_cnt)];
+        const int pick = (int)cobel_bounded(cobel_word(eblk, ce & 3u), start_cnt);
+        state = ONE_WORLD ? (int)Sl[pick] : (int)A.starts[start_lo + pick];
         ce += 1u;
         step = 0;
         trew = 0.0;
@@ -1114,11 +1120,12 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     const int v = atoi(e);
     if (v == 16 || v == 32 || v == 64) lpw = v;
   }
-  while (lpw > 16 && (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 16 +
-                              kMonBytes > (size_t)kLdsLimit)
+  while (lpw > 16 && (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 18 +
+                              16 + kMonBytes > (size_t)kLdsLimit)
     lpw >>= 1;   // larger worlds: fewer columns per wave so that the Q tables still fit
   A.lpw = lpw;
-  const size_t lds_lpi = (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 16;
+  const size_t lds_lpi = (size_t)world->n_states * lpw * 16 + kThrBytes +
+                         (size_t)world->n_states * 16 + (((size_t)world->n_states * 2 + 15) & ~(size_t)15);
   // (per-instance parameter sets: the lane-per-instance kernel keeps ONE threshold table per wave)
   if (!replay && !occ && !r.param_index && (!learn || r.agent == COBEL_AGENT_Q) &&
       lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
