@@ -109,6 +109,103 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=True):
             'roofline': None}
 
 
+def _mlp(n_in, n_out, dtype_name='f64'):
+    from collections import OrderedDict
+    net = torch.nn.Sequential(OrderedDict([
+        ('flatten', torch.nn.Flatten()),
+        ('dense_1', torch.nn.Linear(n_in, 64)), ('relu_1', torch.nn.ReLU()),
+        ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+        ('output', torch.nn.Linear(64, n_out))]))
+    return net.double() if dtype_name == 'f64' else net.float()
+
+
+def run_next_rows(device):
+    """SURVEY.md §8f rows beside SFMA (C6), each with its own number: rank 1 Dyna-DQN and Dyna-DSR
+    (demo/gridworld/demo_dyna_dqn.py / demo_dyna_dsr.py: 5x5 open field, one-hot inputs, 64-64
+    float64 networks, gamma .8, batch 32, 50 steps/trial) with one set of networks per instance;
+    rank 4 the grid search with all combinations x runs as instances of one launch."""
+    import tempfile
+    from cobel_amd.agent import DynaDQN, DynaDSR, DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.optimizer import GridSearchOptimizer, spread_over_instances
+    from cobel_amd.policy import EpsilonGreedy
+    out = {}
+    torch.manual_seed(0)
+
+    def timed(agent, env, n, iters, warm=4):
+        agent._run(env, 10**6, 50, 32, True, budget=warm)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        agent._run(env, 10**6, 50, 32, True, budget=iters)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
+                'dtype': 'f64', 'roofline': None}
+
+    n = 8192
+    env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
+    agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.1),
+                    TorchNetwork(_mlp(25, 4)), gamma=0.8)
+    agent.use_graph = True
+    r = timed(agent, env, n, 128)
+    r['config'] = {'workload': 'Dyna-DQN: %d x 5x5 open field, MLP 25-64-64-4 f64 per instance, '
+                               'model-sampled batches of 32, one step replayed from a HIP graph' % n,
+                   'instances_per_gpu': n, 'lockstep_iterations': 128}
+    out['dyna_dqn'] = r
+    del agent, env
+
+    n = 2048
+    env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
+    agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.1),
+                    TorchNetwork(_mlp(25, 25)), TorchNetwork(_mlp(25, 1)), gamma=0.8)
+    agent.use_graph = False
+    r = timed(agent, env, n, 32)
+    r['config'] = {'workload': 'Dyna-DSR: %d x 5x5 open field, four online + four target successor '
+                               'networks 25-64-64-25 and one reward network f64 per instance, batches '
+                               'of 32' % n, 'instances_per_gpu': n, 'lockstep_iterations': 32}
+    out['dyna_dsr'] = r
+    del agent, env
+
+    # grid search: learning_rate x gamma x epsilon, every combination x run one instance
+    grid = {'learning_rate': list(np.linspace(0.1, 0.99, 16)), 'gamma': list(np.linspace(0.5, 0.99, 16)),
+            'epsilon': [0.05, 0.1, 0.2, 0.3]}
+    runs, trials, steps = 16, 50, 50
+    world = make_open_field(5, 5, 0, 1)
+    stats = {}
+
+    def simulation_batch(task, combinations, nb_runs):
+        arrays, which = spread_over_instances(combinations, nb_runs)
+        env = Gridworld(world, n_envs=len(which), seed=SEED, device=device)
+        ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(arrays['epsilon']),
+                   learning_rate=arrays['learning_rate'], gamma=arrays['gamma'])
+        ag.track_instances = True
+        ag.train(env, trials, steps, 32)
+        lat = ag.monitors.lat_trace[:, :trials].double().mean(dim=1).cpu().numpy()
+        stats['env_steps'] = stats.get('env_steps', 0) + ag.env_steps()
+        return [list(lat[which == c]) for c in range(len(combinations))]
+
+    with tempfile.TemporaryDirectory() as tmp:
+        opt = GridSearchOptimizer(tmp + '/', grid, nb_runs=runs)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        opt.fit_vectorised(simulation_batch, {'demo': {}}, {'demo': [5.0] * runs},
+                           lambda sim, data: float(np.mean(sim['demo'])))
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+    combos = 16 * 16 * 4
+    out['grid_search'] = {
+        'value': combos * runs / dt, 'unit': 'simulations/s',
+        'env_steps_per_s': stats['env_steps'] / dt, 'seconds': dt,
+        'config': {'workload': 'GridSearchOptimizer.fit_vectorised: %d combinations x %d runs of '
+                               'Dyna-Q (5x5, 32 planning updates, %d trials x <= %d steps) as %d '
+                               'instances of one launch, files written as the reference does'
+                               % (combos, runs, trials, steps, combos * runs)},
+        'roofline': None}
+    return out
+
+
 def make_worlds(cfg_name):
     from cobel_amd.misc.gridworld_tools import make_obstacle_maze, make_open_field
     if cfg_name == 'C2':
@@ -355,6 +452,11 @@ def main():
                 others['C5_' + dt_name] = run_c5(device, dt_name)
             except Exception as e:
                 others['C5_' + dt_name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if not args.no_c5:
+            try:
+                others.update(run_next_rows(device))
+            except Exception as e:
+                others['next_rows'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.config, cfg)
