@@ -160,11 +160,12 @@ def run_next_rows(device):
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 25)), TorchNetwork(_mlp(25, 1)), gamma=0.8)
-    agent.use_graph = False
-    r = timed(agent, env, n, 32)
+    agent.use_graph = True
+    r = timed(agent, env, n, 64)
     r['config'] = {'workload': 'Dyna-DSR: %d x 5x5 open field, four online + four target successor '
                                'networks 25-64-64-25 and one reward network f64 per instance, batches '
-                               'of 32' % n, 'instances_per_gpu': n, 'lockstep_iterations': 32}
+                               'of 32, one step replayed from a HIP graph' % n,
+                   'instances_per_gpu': n, 'lockstep_iterations': 64}
     out['dyna_dsr'] = r
     del agent, env
 

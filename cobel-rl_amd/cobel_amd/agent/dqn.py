@@ -92,6 +92,10 @@ class DQN(Agent):
             pol.counter -= idle.to(torch.int32)
         return act
 
+    def _make_capturable(self) -> None:
+        """Every optimizer that steps inside the captured iteration."""
+        self._online.make_capturable()
+
     def _q_values(self, obs: torch.Tensor) -> torch.Tensor:
         """Q-values ``[N, A]`` of the per-instance online networks for observations ``[N, D]``."""
         return self._online.predict_on_device(obs[:, None, :])[:, 0]
@@ -196,7 +200,7 @@ class DQN(Agent):
             # replayed — ~180 kernel launches per step become one graph launch.
             for _ in range(3):
                 iteration()
-            self._online.make_capturable()
+            self._make_capturable()
             iteration()
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
@@ -219,7 +223,7 @@ class DQN(Agent):
                     k = min(rem - 1, 512)
                     if k >= 8:
                         if graph is None:
-                            self._online.make_capturable()
+                            self._make_capturable()
                             iteration()
                             k -= 1
                             torch.cuda.synchronize(dev)

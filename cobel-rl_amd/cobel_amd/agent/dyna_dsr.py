@@ -69,6 +69,10 @@ class DynaDSR(DynaDQN):
         self._bind_memory(interface, slots)
 
     # -- values ---------------------------------------------------------------------------------
+    def _make_capturable(self) -> None:
+        self._online.make_capturable()
+        self._reward_net.make_capturable()
+
     def _per_action(self, net, obs: torch.Tensor) -> torch.Tensor:
         """obs [n, B, D] -> successor features [n, A, B, F] of the n x A networks of ``net``."""
         n, A = self.n_envs, self.n_actions

@@ -900,6 +900,46 @@ def test_dqn_train_graph_chunks_equal_eager(torch_cuda, golden):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize('kind', ['dyna_dqn', 'dyna_dsr'])
+def test_dyna_network_agents_graph_replay_equals_eager(torch_cuda, kind):
+    """Fixed-budget Dyna-DQN / Dyna-DSR runs from a HIP graph (Dyna-DSR: masked per-network Adam
+    and a second optimizer inside the captured step) against the eager loop."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd.agent import DynaDQN, DynaDSR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+
+    def run(graph):
+        torch.manual_seed(3)
+        env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=48, seed=SEED)
+        if kind == 'dyna_dqn':
+            ag = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.1),
+                         TorchNetwork(bench._mlp(25, 4)), gamma=0.8)
+        else:
+            ag = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.1),
+                         TorchNetwork(bench._mlp(25, 25)), TorchNetwork(bench._mlp(25, 1)),
+                         gamma=0.8)
+        ag.use_graph = graph
+        ag._run(env, 10 ** 6, 15, 16, True, budget=30)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (eager, e1), (graph, e2) = run(False), run(True)
+    assert eager.graph_replays == 0 and graph.graph_replays == 26
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.env_ctr, e2.env_ctr)
+    assert torch.equal(eager.trial, graph.trial)
+    assert torch.equal(eager.monitors.lat_sum, graph.monitors.lat_sum)
+    assert torch.equal(eager.M.states, graph.M.states)
+    nets = [('_online', 0), ('_online', 47)] if kind == 'dyna_dqn' else \
+        [('_online', 0), ('_online', 4 * 47 + 3), ('_reward_net', 20)]
+    for attr, i in nets:
+        for a, b in zip(getattr(eager, attr).get_weights(i), getattr(graph, attr).get_weights(i)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
 def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
     """8 instances in lockstep (stacked networks, per-instance rings and streams) give exactly
     the trajectories of the single-instance runs; weights agree to float64 round-off."""
