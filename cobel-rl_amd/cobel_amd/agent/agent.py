@@ -77,31 +77,62 @@ class Agent(abc.ABC):
 
 class DeviceMonitors:
     """Per-trial reductions written by the kernels: escape latency (``logs['steps']``,
-    monitor/behavior.py:82), trial reward, and per-state visit counts."""
+    monitor/behavior.py:82), trial reward, and per-state visit counts.
+
+    The four per-trial arrays may be kept as ``stripes`` copies ``[stripes, cap]`` (workgroup b of a
+    kernel adds into copy ``b % stripes``, see ``cobel_tab_run_t.mon_stripes``); ``lat_sum`` /
+    ``lat_cnt`` / ``reward_sum`` / ``resp_cnt`` are the sums over the copies, ``raw(name)`` the
+    striped tensors the kernels take.  With one stripe the attribute IS the tensor (in-place ops
+    on it are seen by the kernels)."""
+
+    _PER_TRIAL = {'lat_sum': torch.int64, 'lat_cnt': torch.int64, 'reward_sum': torch.float64,
+                  'resp_cnt': torch.int64}
 
     def __init__(self, device, n_worlds: int, n_states: int, occupancy: bool = False,
-                 responses: bool = False) -> None:
+                 responses: bool = False, stripes: int = 1) -> None:
         self.device = device
         self.cap = 0
-        self.lat_sum = self.lat_cnt = self.reward_sum = self.resp_cnt = None
+        self.stripes = max(1, int(stripes))
+        self._raw = {name: None for name in self._PER_TRIAL}
         self.responses = responses    # count rewarded trials (ResponseMonitor) — opt-in
         self.occupancy = (torch.zeros((n_worlds, n_states), dtype=torch.int64, device=device)
                           if occupancy else None)
         self.steps_done = torch.zeros(1, dtype=torch.int64, device=device)
         self.lat_trace = None
 
+    def raw(self, name: str):
+        """The striped tensor ``[stripes, cap]`` handed to the kernels (or None)."""
+        return self._raw[name]
+
+    def _get(self, name: str):
+        t = self._raw[name]
+        if t is None:
+            return None
+        return t[0] if self.stripes == 1 else t.sum(dim=0)
+
+    def _set(self, name: str, value) -> None:
+        # (also what `monitors.lat_sum += x` ends in: the in-place result, a view of the raw tensor)
+        if value is not None and value.dim() == 1:
+            assert self.stripes == 1, 'assign striped monitors through raw tensors'
+            value = value.reshape(1, -1)
+        self._raw[name] = value
+
+    lat_sum = property(lambda self: self._get('lat_sum'), lambda self, v: self._set('lat_sum', v))
+    lat_cnt = property(lambda self: self._get('lat_cnt'), lambda self, v: self._set('lat_cnt', v))
+    reward_sum = property(lambda self: self._get('reward_sum'),
+                          lambda self, v: self._set('reward_sum', v))
+    resp_cnt = property(lambda self: self._get('resp_cnt'), lambda self, v: self._set('resp_cnt', v))
+
     def reserve(self, trials: int, n_envs: int = 0, per_instance: bool = False) -> None:
         if trials > self.cap:
-            def grow(t, dtype):
-                new = torch.zeros(trials, dtype=dtype, device=self.device)
-                if t is not None:
-                    new[: t.numel()] = t
-                return new
-            self.lat_sum = grow(self.lat_sum, torch.int64)
-            self.lat_cnt = grow(self.lat_cnt, torch.int64)
-            self.reward_sum = grow(self.reward_sum, torch.float64)
-            if self.responses:
-                self.resp_cnt = grow(self.resp_cnt, torch.int64)
+            for name, dtype in self._PER_TRIAL.items():
+                if name == 'resp_cnt' and not self.responses:
+                    continue
+                new = torch.zeros((self.stripes, trials), dtype=dtype, device=self.device)
+                old = self._raw[name]
+                if old is not None:
+                    new[:, : old.shape[1]] = old
+                self._raw[name] = new
             if per_instance or self.lat_trace is not None:
                 new = torch.full((n_envs, trials), -1, dtype=torch.int32, device=self.device)
                 if self.lat_trace is not None:
@@ -117,8 +148,8 @@ class DeviceMonitors:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        bufs = [b for b in (self.lat_sum, self.lat_cnt, self.resp_cnt, self.occupancy,
-                            self.steps_done)
+        bufs = [b for b in (self._raw['lat_sum'], self._raw['lat_cnt'], self._raw['resp_cnt'],
+                            self.occupancy, self.steps_done)
                 if b is not None]
         flat = torch.cat([b.reshape(-1) for b in bufs])
         dist.all_reduce(flat)
@@ -126,8 +157,8 @@ class DeviceMonitors:
         for b in bufs:
             b.copy_(flat[off: off + b.numel()].reshape(b.shape))
             off += b.numel()
-        if self.reward_sum is not None:
-            dist.all_reduce(self.reward_sum)
+        if self._raw['reward_sum'] is not None:
+            dist.all_reduce(self._raw['reward_sum'])
 
     def mean_latency(self) -> np.ndarray:
         s, c = self.lat_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
@@ -166,6 +197,7 @@ class FusedAgent(Agent):
         self.track_occupancy = False
         self.track_responses = False   # per-trial count of rewarded instances (ResponseMonitor)
         self.track_instances = False   # keep per-instance latency traces [N, trials]
+        self.monitor_stripes = 1       # copies of the per-trial monitor arrays (kernels that take them)
         self.device = None
         self.n_envs = None
         self.inst = None
@@ -231,7 +263,8 @@ class FusedAgent(Agent):
             assert int(interface.observation_space.n) == self.n_states
         self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)
         self.monitors = DeviceMonitors(self.device, interface.handle.n_worlds, self.n_states,
-                                       self.track_occupancy, self.track_responses)
+                                       self.track_occupancy, self.track_responses,
+                                       self.monitor_stripes if self.n_envs >= 4096 else 1)
         self._last_exp = torch.zeros((self.n_envs, 6), dtype=torch.int32, device=self.device)
         self._alloc_tables()
 

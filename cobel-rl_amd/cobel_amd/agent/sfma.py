@@ -45,6 +45,7 @@ class SFMA(TabularAgent):
         super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
                          gamma, custom_callbacks)
         self.callbacks = CallbacksSFMA(self, custom_callbacks)
+        self.monitor_stripes = 1       # cobel_sfma_run takes single per-trial monitor arrays
         self.rng = rng
         self.M = memory
         self.nb_replays = 1

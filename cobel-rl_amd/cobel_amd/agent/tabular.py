@@ -21,6 +21,7 @@ class TabularAgent(FusedAgent):
         self.learning_rate = learning_rate
         self.gamma = gamma
         self._q = None
+        self.monitor_stripes = 16      # cobel_tab_run takes striped per-trial monitors
         self._q_host = (np.zeros((self.n_states, self.n_actions), dtype=np.float32)
                         if self.n_states is not None else None)
         self._poses = None      # node poses when the observations are a Topology's (Box)
@@ -87,8 +88,10 @@ class TabularAgent(FusedAgent):
         run.inst = _lib.ptr(self.inst)
         self._mask_dev = self._mask_bits() if (flags & _lib.F_MASK_ACTIONS) else None
         run.action_mask = _lib.ptr(self._mask_dev)
-        run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
-        run.reward_sum, run.resp_cnt = _lib.ptr(mon.reward_sum), _lib.ptr(mon.resp_cnt)
+        run.lat_sum, run.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
+        run.reward_sum = _lib.ptr(mon.raw('reward_sum'))
+        run.resp_cnt = _lib.ptr(mon.raw('resp_cnt'))
+        run.mon_stripes = mon.stripes
         run.lat_trace = _lib.ptr(mon.lat_trace)
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done = _lib.ptr(mon.steps_done)

@@ -257,7 +257,10 @@ typedef struct {
   const cobel_param_set_t* param_sets; /* [dev] [n_param_sets]                               */
   const uint16_t* param_index;         /* [dev] [N]                                          */
   int32_t n_param_sets;
-  int32_t reserved_;
+  int32_t mon_stripes;   /* > 1: lat_sum / lat_cnt / reward_sum / resp_cnt are [mon_stripes][trial_cap]
+                            and workgroup b adds into copy b % mon_stripes (spreads the atomics of
+                            many instances finishing the same trials over L2 channels); the caller
+                            sums the copies.  0 or 1: one copy.                                 */
 } cobel_tab_run_t;
 
 #define COBEL_MAX_BATCH 62

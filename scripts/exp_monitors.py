@@ -15,6 +15,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'C6'
 for monitors in (True, False):
     cfg = dict(bench.CONFIGS[name])
     env, agent = bench.build_agent(name, cfg, cfg['instances'], 0, torch.device('cuda', 0))
+    if os.environ.get('STRIPES'):
+        agent.monitor_stripes = int(os.environ['STRIPES'])
     runner = bench.Runner(cfg, env, agent)
     if not monitors:
         m = agent.monitors
@@ -22,8 +24,10 @@ for monitors in (True, False):
     runner.launch()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(4):
+    times = []
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
+        t1 = time.perf_counter()
         runner.launch()
-    torch.cuda.synchronize()
-    print(name, 'monitors' if monitors else 'no monitors', '%.2f ms per launch' %
-          ((time.perf_counter() - t0) / 4 * 1e3))
+        torch.cuda.synchronize()
+        times.append(round((time.perf_counter() - t1) * 1e3, 2))
+    print(name, 'monitors' if monitors else 'no monitors', times)

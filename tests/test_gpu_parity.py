@@ -721,6 +721,40 @@ def test_lane_per_instance_kernel_vs_oracle(torch_cuda, golden_worlds, n, worlds
     assert np.array_equal(got[:, 0], o.inst['state']) and np.array_equal(got[:, 3], o.inst['ctr_env'].astype(np.int32))
 
 
+def test_lane_per_instance_monitor_window_overflow(torch_cuda):
+    """One-step trials: 900 trials per instance in one launch run past the 512-trial window of
+    per-wave monitor accumulators (the rest goes to the global arrays directly); striped monitor
+    copies (n >= 4096) sum to the same totals as the wave-per-instance kernel's."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    n, trials = 4200, 900
+
+    def run(force_wave):
+        env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=5)
+        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        ag.track_responses = True
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False) | \
+            (_lib.F_FORCE_WAVE if force_wave else 0)
+        ag.monitors.reserve(trials, n, False)
+        ag._launch(env, ag.policy, flags, trials, 1, 0, 0)
+        torch.cuda.synchronize()
+        return ag
+
+    lpi, wpi = run(False), run(True)
+    assert lpi.monitors.stripes == 16 and lpi.monitors.raw('lat_cnt').shape == (16, trials)
+    assert torch.equal(lpi._q, wpi._q) and torch.equal(lpi.inst, wpi.inst)
+    for name in ('lat_sum', 'lat_cnt', 'resp_cnt'):
+        assert torch.equal(getattr(lpi.monitors, name), getattr(wpi.monitors, name)), name
+    assert torch.allclose(lpi.monitors.reward_sum, wpi.monitors.reward_sum, rtol=1e-12, atol=0)
+    assert int(lpi.monitors.lat_cnt.min()) == n and int(lpi.monitors.lat_sum.sum()) == 0
+
+
 def test_topology_kat_and_walk(torch_cuda, golden):
     """unit_tests/test_topology.py:64-109 (pose observations) and a draw-injected random walk on
     linear_track(10, 2) recorded from the reference: nodes, pose observations, rewards, terminals,
