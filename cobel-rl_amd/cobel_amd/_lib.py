@@ -84,7 +84,7 @@ class SFMARun(C.Structure):
         ('recency_len', C.c_int32), ('instance_base', C.c_uint32),
         ('flags', C.c_uint32), ('sfma_flags', C.c_uint32),
         ('trials_target', C.c_int32), ('steps_per_trial', C.c_int32), ('step_budget', C.c_int32),
-        ('batch', C.c_int32), ('nb_replays', C.c_int32), ('reserved_', C.c_int32),
+        ('batch', C.c_int32), ('nb_replays', C.c_int32), ('mon_stripes', C.c_int32),
         ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
         ('model_lr', C.c_double),
         ('decay_inhibition', C.c_double), ('decay_strength', C.c_double),
@@ -111,7 +111,7 @@ class SRRun(C.Structure):
         ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
         ('seed', C.c_uint64),
         ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
-        ('reserved_', C.c_int32),
+        ('mon_stripes', C.c_int32),
     ]
 
 

@@ -197,7 +197,7 @@ class FusedAgent(Agent):
         self.track_occupancy = False
         self.track_responses = False   # per-trial count of rewarded instances (ResponseMonitor)
         self.track_instances = False   # keep per-instance latency traces [N, trials]
-        self.monitor_stripes = 1       # copies of the per-trial monitor arrays (kernels that take them)
+        self.monitor_stripes = 16      # copies of the per-trial monitor arrays (from 4096 instances on)
         self.device = None
         self.n_envs = None
         self.inst = None

@@ -45,7 +45,6 @@ class SFMA(TabularAgent):
         super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
                          gamma, custom_callbacks)
         self.callbacks = CallbacksSFMA(self, custom_callbacks)
-        self.monitor_stripes = 1       # cobel_sfma_run takes single per-trial monitor arrays
         self.rng = rng
         self.M = memory
         self.nb_replays = 1
@@ -118,8 +117,10 @@ class SFMA(TabularAgent):
             run.random_cdf = _lib.ptr(self._random_cdf())
         self._mask_dev = self._mask_bits() if (flags & _lib.F_MASK_ACTIONS) else None
         run.action_mask = _lib.ptr(self._mask_dev)
-        run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
-        run.reward_sum, run.resp_cnt = _lib.ptr(mon.reward_sum), _lib.ptr(mon.resp_cnt)
+        run.lat_sum, run.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
+        run.reward_sum = _lib.ptr(mon.raw('reward_sum'))
+        run.resp_cnt = _lib.ptr(mon.raw('resp_cnt'))
+        run.mon_stripes = mon.stripes
         run.lat_trace = _lib.ptr(mon.lat_trace)
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done, run.replays_done = _lib.ptr(mon.steps_done), _lib.ptr(self.replays_done)

@@ -70,9 +70,10 @@ class SR(FusedAgent):
         run.inst = _lib.ptr(self.inst)
         self._mask_dev = self._mask_bits() if (flags & _lib.F_MASK_ACTIONS) else None
         run.action_mask = _lib.ptr(self._mask_dev)
-        run.lat_sum, run.lat_cnt = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt)
-        run.reward_sum, run.lat_trace = _lib.ptr(mon.reward_sum), _lib.ptr(mon.lat_trace)
-        run.resp_cnt = _lib.ptr(mon.resp_cnt)
+        run.lat_sum, run.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
+        run.reward_sum, run.lat_trace = _lib.ptr(mon.raw('reward_sum')), _lib.ptr(mon.lat_trace)
+        run.resp_cnt = _lib.ptr(mon.raw('resp_cnt'))
+        run.mon_stripes = mon.stripes
         run.occupancy, run.steps_done = _lib.ptr(mon.occupancy), _lib.ptr(mon.steps_done)
         run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap

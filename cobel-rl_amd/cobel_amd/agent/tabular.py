@@ -21,7 +21,6 @@ class TabularAgent(FusedAgent):
         self.learning_rate = learning_rate
         self.gamma = gamma
         self._q = None
-        self.monitor_stripes = 16      # cobel_tab_run takes striped per-trial monitors
         self._q_host = (np.zeros((self.n_states, self.n_actions), dtype=np.float32)
                         if self.n_states is not None else None)
         self._poses = None      # node poses when the observations are a Topology's (Box)

@@ -765,10 +765,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       step += 1;
     } else {
       if (t == 0 && trial >= 0 && trial < A.r.trial_cap) {
-        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + trial, (unsigned long long)step);
-        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + trial, 1ull);
-        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + trial, trew);
-        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + trial, 1ull);
+        const size_t m = cobel_mon_offset(A.r.mon_stripes, A.r.trial_cap) + (size_t)trial;
+        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + m, (unsigned long long)step);
+        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + m, 1ull);
+        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + m, trew);
+        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + m, 1ull);
         if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
       }
       const int tr = trial;

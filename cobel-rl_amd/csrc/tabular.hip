@@ -44,13 +44,8 @@ struct tab_args {
   int32_t lpw;         // lane-per-instance kernel: instances per wave (64, 32 or 16)
 };
 
-// Per-trial monitors are striped: workgroup b adds into copy b % mon_stripes of each array, so
-// that the atomics of thousands of workgroups finishing the same trial indices do not all queue on
-// the same few cache lines of one L2 channel (measured on C2: 600 000 atomics per launch onto ~150
-// hot addresses cost 1.1 ms of a 2.8 ms launch).  The caller sums the copies.
 __device__ __forceinline__ size_t mon_stripe_offset(const cobel_tab_run_t& r) {
-  const unsigned stripes = r.mon_stripes > 1 ? (unsigned)r.mon_stripes : 1u;
-  return (size_t)((unsigned)blockIdx.x % stripes) * (size_t)r.trial_cap;
+  return cobel_mon_offset(r.mon_stripes, r.trial_cap);
 }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {

@@ -313,7 +313,7 @@ typedef struct {
   const cobel_param_set_t* param_sets; /* as in cobel_tab_run_t (model_lr unused)            */
   const uint16_t* param_index;
   int32_t n_param_sets;
-  int32_t reserved_;
+  int32_t mon_stripes;   /* as in cobel_tab_run_t                                             */
 } cobel_sr_run_t;
 
 COBEL_API int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n, int32_t n_states,
@@ -421,7 +421,7 @@ typedef struct {
   int32_t trials_target, steps_per_trial, step_budget;
   int32_t batch;          /* replay length                                                    */
   int32_t nb_replays;     /* agent.nb_replays                                                 */
-  int32_t reserved_;
+  int32_t mon_stripes;    /* as in cobel_tab_run_t                                            */
   double alpha, gamma, epsilon, model_lr;        /* agent lr, discount, policy eps, M.learning_rate */
   double decay_inhibition, decay_strength;       /* M.decay_inhibition, M.decay_strength      */
   double c_step, i_step, r_threshold, beta;      /* M.C_step, M.I_step, M.R_threshold, M.beta */
