@@ -16,7 +16,7 @@ for n, B in [(65536, 50)]:
         mon = agent.monitors
         run = _lib.TabRun()
         run.q = _lib.ptr(agent._q); run.inst = _lib.ptr(agent.inst); run.model = _lib.ptr(agent.M.table); run.model_index = _lib.ptr(agent.M.index)
-        run.lat_sum, run.lat_cnt, run.reward_sum = _lib.ptr(mon.lat_sum), _lib.ptr(mon.lat_cnt), _lib.ptr(mon.reward_sum)
+        run.lat_sum, run.lat_cnt, run.reward_sum = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt')), _lib.ptr(mon.raw('reward_sum')); run.mon_stripes = mon.stripes
         run.steps_done = _lib.ptr(mon.steps_done); run.last_exp = _lib.ptr(agent._last_exp)
         run.n, run.trial_cap, run.instance_base = agent.n_envs, mon.cap, interface.instance_base
         run.agent, run.flags, run.trials_target, run.steps_per_trial, run.step_budget, run.batch = 1, flags, tt, steps, budget, batch
