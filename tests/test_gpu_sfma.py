@@ -415,3 +415,49 @@ def test_sfma_several_worlds_with_their_own_metrics(Z):
         assert np.array_equal(agent.monitors.lat_trace[i].cpu().numpy()[:6], ag.steps), i
         assert np.array_equal(agent.Q[i].cpu().numpy(), ag.Q), i
         assert np.array_equal(agent.M.C[i], ag.M.C), i
+
+
+def test_sfma_abi_argument_checks_and_zero_work(Z):
+    """cobel_sfma_run refuses malformed requests before any launch (mapped to the exceptions the
+    reference would raise) and treats n = 0 / zero trials as no-ops."""
+    import ctypes as C
+    import torch
+    from cobel_amd import _lib
+    lib = _lib.lib()
+    g, world, D, opts = sfma_case(Z, 'dr_default_f32')
+    env, agent = build(world, D, opts, 2, 0)
+    before = env.state.clone()
+    agent.train(env, 0, 10, 8)
+    assert torch.equal(env.state, before) and agent.env_steps() == 0 and agent.current_trial == 0
+    assert float(agent.Q.abs().sum()) == 0.0 and float(agent.M.strength.sum()) == 0.0
+
+    z = torch.zeros(64, dtype=torch.int64, device='cuda')
+    run = _lib.SFMARun()
+    for f in ('q', 'model', 'strength', 'stamp', 'inst', 'sfma_inst', 'metric'):
+        setattr(run, f, _lib.ptr(z))
+    run.n, run.steps_per_trial, run.epsilon, run.batch, run.nb_replays = 0, 5, 0.1, 4, 1
+    _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))        # n = 0: no-op
+    run.n = 2
+    run.metric = None
+    with pytest.raises(AssertionError):                                        # missing table
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    run.metric = _lib.ptr(z)
+    run.steps_per_trial = 0
+    with pytest.raises(IndexError):
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    run.steps_per_trial, run.epsilon = 5, 1.5
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    run.epsilon, run.sfma_flags = 0.1, _lib.SF_RANDOM
+    with pytest.raises(AssertionError):                                        # random replay without its CDF
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    run.sfma_flags = _lib.SF_RECENCY
+    with pytest.raises(AssertionError):                                        # recency without the decay table
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    run.sfma_flags, run.flags = 0, _lib.F_MASK_ACTIONS
+    with pytest.raises(AssertionError):                                        # mask_actions without a mask
+        _lib.check(lib.cobel_sfma_run(env.handle.ptr, C.byref(run), None))
+    lds = C.c_int32()
+    assert lib.cobel_sfma_query(25, C.byref(lds)) == 0 and lds.value > 25 * 128
+    with pytest.raises(NotImplementedError):                                   # table larger than LDS
+        _lib.check(lib.cobel_sfma_query(40 * 40, C.byref(lds)))
