@@ -440,3 +440,32 @@ def test_graft_entry_build_runs_on_a_gpu_less_host():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     entry.build()
+
+
+def test_sfma_host_surface_defaults():
+    """SFMAMemory / SFMA carry the reference's attribute names and defaults
+    (memory/sfma.py:142-193, agent/sfma.py:174-231) before any device is touched."""
+    from cobel_amd.agent import SFMA
+    from cobel_amd.memory import SFMAMemory
+    from cobel_amd.memory.utils import Euclidean
+    from cobel_amd.policy import EpsilonGreedy
+    from cobel_amd.spaces import Box, Discrete
+    m = SFMAMemory(Euclidean(3, 3), 9, 4)
+    expect = dict(decay_inhibition=0.9, decay_strength=1.0, decay_recency=0.9, learning_rate=0.9,
+                  beta=20, C_step=1.0, I_step=1.0, R_threshold=1e-6, deterministic=False,
+                  recency=False, C_normalize=False, D_normalize=False, R_normalize=True,
+                  mode='default', reward_modulation=1.0, blend=0.1, interpolation_fwd=0.5,
+                  interpolation_rev=0.5, reward_mod_local=False, error_mod_local=False,
+                  reward_mod=False, error_mod=False, policy_mod=False, state_mod=False)
+    for k, v in expect.items():
+        assert getattr(m, k) == v, k
+    a = SFMA(Discrete(9), Discrete(4), EpsilonGreedy(), m)
+    assert (a.learning_rate, a.gamma, a.nb_replays) == (0.99, 0.99, 1)
+    assert not (a.random or a.dynamic or a.offline or a.start_replay or a.mask_actions)
+    assert a.Q.shape == (9, 4) and a.action_mask.shape == (9, 4) and a.td == 0.0
+    assert a.policy_test is a.policy and set(a.callbacks.custom_callbacks) == set()
+    assert hasattr(a.callbacks, 'on_replay_begin') and hasattr(a.callbacks, 'on_replay_end')
+    with pytest.raises(AssertionError):
+        SFMA(Box(np.zeros(2), np.ones(2)), Discrete(4), EpsilonGreedy(), m)
+    with pytest.raises(AssertionError):
+        SFMAMemory(Euclidean(3, 3), 9, 6)
