@@ -239,6 +239,9 @@ class StackedTorchNetwork:
             kept = per_sample * sample_mask[..., None].to(per_sample.dtype)
             count = sample_mask.sum(dim=1).clamp(min=1).to(per_sample.dtype)
             (kept.sum(dim=(1, 2)) / (count * width)).sum().backward()
+        if self._fused_adam_ok():
+            self._adam_fused(active)
+            return
         if active is None and getattr(self, '_diverged', False):
             # per-instance step counts exist: torch's optimizer (one shared count) no longer fits
             active = torch.ones(self.n, dtype=torch.bool, device=self.device)
@@ -253,6 +256,61 @@ class StackedTorchNetwork:
                 for p, old in zip(self.params.values(), keep):
                     mask = active.view(self.n, *([1] * (p.dim() - 1)))
                     p.copy_(torch.where(mask, p, old))
+
+    # -- fused Adam (libcobel_hip: cobel_adam_step) ---------------------------------------------
+    fused_adam = True      # False keeps torch's own optimizer step (tests compare the two)
+
+    def _fused_adam_ok(self) -> bool:
+        opt = self.optimizer
+        if not self.fused_adam or type(opt) is not optim.Adam or self.device.type != 'cuda':
+            return False
+        g = opt.param_groups[0]
+        return (len(opt.param_groups) == 1 and not g.get('amsgrad') and not g.get('maximize')
+                and not torch.is_tensor(g['lr'])
+                and all(p.dtype in (torch.float32, torch.float64) for p in self.params.values()))
+
+    @torch.no_grad()
+    def _adam_fused(self, active) -> None:
+        """torch.optim.Adam's update for the active instances in one kernel per parameter tensor;
+        per-instance step counts as in ``_adam_masked`` (which it replaces on the GPU)."""
+        from .. import _lib
+        self._diverged = True
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+        steps = getattr(self, '_steps', None)
+        if steps is None:    # seeded from whatever the optimizer has counted so far
+            seen = [float(st['steps'].max()) if 'steps' in st else float(st.get('step', 0.0))
+                    for st in opt.state.values()]
+            steps = self._steps = torch.full((self.n,), max(seen, default=0.0),
+                                             dtype=torch.float64, device=self.device)
+            for p in self.params.values():
+                st = opt.state[p]
+                if 'steps' in st:
+                    steps.copy_(st['steps'])
+                    break
+        if active is None:
+            steps += 1.0
+            mask = None
+        else:
+            steps += active.to(torch.float64)
+            mask = active.to(torch.uint8)
+        stream = _lib.current_stream(self.device)
+        for p in self.params.values():
+            if p.grad is None:
+                continue
+            st = opt.state[p]
+            if 'exp_avg' not in st:
+                st['exp_avg'] = torch.zeros_like(p)
+                st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st['steps'] = steps          # one shared count per instance for all tensors
+            grad = p.grad.contiguous()
+            _lib.check(_lib.lib().cobel_adam_step(
+                _lib.ptr(p), _lib.ptr(grad), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
+                _lib.ptr(steps), _lib.ptr(mask), self.n, p.numel() // self.n,
+                1 if p.dtype == torch.float64 else 0, float(lr), float(b1), float(b2), float(eps),
+                float(wd), stream))
 
     def make_capturable(self) -> None:
         """Prepare the optimizer for HIP-graph capture: its step counters move to the device

@@ -433,6 +433,22 @@ typedef struct {
 COBEL_API int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes);
 COBEL_API int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused Adam step for network parameters stacked over instances (the DQN path keeps one network
+ * per agent-env instance, parameters [N][...] per tensor).  Replaces optimizer.step() behind
+ * TorchNetwork.train_on_batch (network/network_torch.py:160-167) for torch.optim.Adam without
+ * amsgrad: one pass over param / grad / exp_avg / exp_avg_sq instead of ~10 elementwise kernels.
+ *   steps[i]  : Adam step count of instance i INCLUDING this step (bias corrections 1 - beta^step)
+ *   active[i] : 0 = instance i keeps parameters and optimizer state untouched; NULL = all step
+ * Elements [i * per_instance, (i + 1) * per_instance) of every tensor belong to instance i.
+ * ------------------------------------------------------------------------------------------ */
+COBEL_API int cobel_adam_step(void* param /* [dev] [N][per_instance] */,
+                              const void* grad /* [dev] */, void* exp_avg /* [dev] */,
+                              void* exp_avg_sq /* [dev] */, const double* steps /* [dev] [N] */,
+                              const uint8_t* active /* [dev] [N] or NULL */, int64_t n_instances,
+                              int64_t per_instance, int32_t is_float64, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -974,6 +974,46 @@ def test_dyna_network_agents_graph_replay_equals_eager(torch_cuda, kind):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize('dtype_name', ['f64', 'f32'])
+def test_fused_adam_equals_torch_adam(torch_cuda, dtype_name):
+    """cobel_adam_step against torch.optim.Adam on stacked networks: all instances stepping, and
+    with an activity mask that changes from step to step (per-instance step counts, frozen
+    optimizer state) — parameters and both moment estimates."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd.network import TorchNetwork
+    dt = torch.float64 if dtype_name == 'f64' else torch.float32
+    tol = dict(rtol=1e-12, atol=1e-14) if dtype_name == 'f64' else dict(rtol=2e-5, atol=1e-7)
+    n, B = 37, 16
+    gen = torch.Generator(device='cuda').manual_seed(5)
+
+    def build(fused):
+        torch.manual_seed(11)
+        proto = TorchNetwork(bench._mlp(6, 4, dtype_name), optimizer_params={'lr': 3e-3,
+                                                                             'weight_decay': 1e-3})
+        proto.set_device(torch.device('cuda', 0))
+        net = proto.replicate(n)
+        net.fused_adam = fused
+        return net
+
+    fused, plain = build(True), build(False)
+    for step in range(12):
+        x = torch.rand((n, B, 6), generator=gen, device='cuda', dtype=dt)
+        y = torch.rand((n, B, 4), generator=gen, device='cuda', dtype=dt)
+        active = None if step < 4 else (torch.rand(n, generator=gen, device='cuda') < 0.6)
+        if active is not None and not bool(active.any()):
+            active[0] = True
+        for net in (fused, plain):
+            net.train_on_device(x, y, active)
+    assert fused._diverged and hasattr(fused, '_steps')
+    for (k, a), b in zip(fused.params.items(), plain.params.values()):
+        assert torch.allclose(a, b, **tol), k
+        sa, sb = fused.optimizer.state[a], plain.optimizer.state[b]
+        assert torch.allclose(sa['exp_avg'], sb['exp_avg'], **tol), k
+        assert torch.allclose(sa['exp_avg_sq'], sb['exp_avg_sq'], **tol), k
+        assert torch.equal(sa['steps'], sb['steps'])
+
+
 def test_dqn_vectorised_equals_single_instances(torch_cuda, golden):
     """8 instances in lockstep (stacked networks, per-instance rings and streams) give exactly
     the trajectories of the single-instance runs; weights agree to float64 round-off."""
