@@ -151,7 +151,8 @@ _SIGNATURES = {
     'cobel_sfma_query': (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
     'cobel_sfma_run': (C.c_int, [_P, C.POINTER(SFMARun), _P]),
     'cobel_adam_step': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
-                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P,
+                                  C.c_double, _P]),
 }
 EXPORTS = tuple(sorted(_SIGNATURES))
 

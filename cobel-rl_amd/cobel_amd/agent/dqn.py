@@ -131,10 +131,13 @@ class DQN(Agent):
             boot = torch.gather(boot, 2, pick[..., None])[..., 0]
             new = rewards + boot * terminals * self.gamma
             targets.scatter_(2, actions[..., None], new[..., None])
+        if self.target_update < 1.0:    # optimizer step and target blend in one pass
+            self._online.train_on_device(states, targets, active, blend_into=self._target,
+                                         tau=self.target_update)
+            return {'states': states, 'actions': actions, 'rewards': rewards,
+                    'next_states': next_states, 'terminals': terminals}
         self._online.train_on_device(states, targets, active)
-        if self.target_update < 1.0:
-            self._target.blend_from(self._online, self.target_update, active)
-        elif self.last_update >= self.target_update:
+        if self.last_update >= self.target_update:
             self._target.copy_from(self._online, active)
             self.last_update = 1
         else:

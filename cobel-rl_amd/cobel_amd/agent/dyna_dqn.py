@@ -129,11 +129,13 @@ class DynaDQN(DQN):
             boot = torch.gather(boot, 2, pick[..., None])[..., 0]
             new = r.to(self.dtype) + boot * nt.to(self.dtype) * self.gamma
             targets.scatter_(2, a[..., None], new[..., None])
-        self._online.train_on_device(states, targets, active)
         self.last_update += 1
-        if self.target_update < 1.0:
-            self._target.blend_from(self._online, self.target_update, active)
-        elif self.last_update == self.target_update:
+        if self.target_update < 1.0:    # optimizer step and target blend in one pass
+            self._online.train_on_device(states, targets, active, blend_into=self._target,
+                                         tau=self.target_update)
+            return
+        self._online.train_on_device(states, targets, active)
+        if self.last_update == self.target_update:
             self._target.copy_from(self._online, active)
             self.last_update = 0
 

@@ -221,14 +221,17 @@ class StackedTorchNetwork:
             return self.forward(batch)
 
     def train_on_device(self, batch: torch.Tensor, targets: torch.Tensor, active=None,
-                        sample_mask=None) -> None:
+                        sample_mask=None, blend_into=None, tau: float = 0.0) -> None:
         """Per instance: mean over the per-sample losses, summed over instances so that every
         instance receives exactly the gradient it would compute alone.  ``active`` ([n] bool)
         freezes the other instances completely — parameters AND optimizer state — as if their
         own single-instance run had simply not executed this step (Adam / AdamW-free path;
         other optimizers only get their parameters restored).  ``sample_mask`` ([n, B] bool):
         instance i trains on the samples it marks only, exactly as if it had been handed that
-        sub-batch (mean over its elements); instances that mark none must be outside ``active``."""
+        sub-batch (mean over its elements); instances that mark none must be outside ``active``.
+        ``blend_into`` (another stack of the same shape) receives ``w += tau * (w_new - w)`` for
+        the instances that stepped — the DQN target update, fused into the optimizer kernel where
+        that one runs."""
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.criterion(self.forward(batch), targets)
         if sample_mask is None:
@@ -240,8 +243,15 @@ class StackedTorchNetwork:
             count = sample_mask.sum(dim=1).clamp(min=1).to(per_sample.dtype)
             (kept.sum(dim=(1, 2)) / (count * width)).sum().backward()
         if self._fused_adam_ok():
-            self._adam_fused(active)
+            self._adam_fused(active, blend_into, tau)
             return
+        if blend_into is not None:
+            self._train_step_torch(active)
+            blend_into.blend_from(self, tau, active)
+            return
+        self._train_step_torch(active)
+
+    def _train_step_torch(self, active) -> None:
         if active is None and getattr(self, '_diverged', False):
             # per-instance step counts exist: torch's optimizer (one shared count) no longer fits
             active = torch.ones(self.n, dtype=torch.bool, device=self.device)
@@ -270,7 +280,7 @@ class StackedTorchNetwork:
                 and all(p.dtype in (torch.float32, torch.float64) for p in self.params.values()))
 
     @torch.no_grad()
-    def _adam_fused(self, active) -> None:
+    def _adam_fused(self, active, blend_into=None, tau: float = 0.0) -> None:
         """torch.optim.Adam's update for the active instances in one kernel per parameter tensor;
         per-instance step counts as in ``_adam_masked`` (which it replaces on the GPU)."""
         from .. import _lib
@@ -296,7 +306,7 @@ class StackedTorchNetwork:
             steps += active.to(torch.float64)
             mask = active.to(torch.uint8)
         stream = _lib.current_stream(self.device)
-        for p in self.params.values():
+        for name, p in self.params.items():
             if p.grad is None:
                 continue
             st = opt.state[p]
@@ -306,11 +316,18 @@ class StackedTorchNetwork:
                 st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
             st['steps'] = steps          # one shared count per instance for all tensors
             grad = p.grad.contiguous()
+            tgt = None if blend_into is None else blend_into.params[name]
             _lib.check(_lib.lib().cobel_adam_step(
                 _lib.ptr(p), _lib.ptr(grad), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
                 _lib.ptr(steps), _lib.ptr(mask), self.n, p.numel() // self.n,
                 1 if p.dtype == torch.float64 else 0, float(lr), float(b1), float(b2), float(eps),
-                float(wd), stream))
+                float(wd), _lib.ptr(tgt), float(tau), stream))
+        if blend_into is not None and self.buffers:
+            for k, v in blend_into.buffers.items():
+                if v.is_floating_point():
+                    w = tau if active is None else \
+                        active.view(self.n, *([1] * (v.dim() - 1))).to(v.dtype) * tau
+                    v.lerp_(self.buffers[k], w)
 
     def make_capturable(self) -> None:
         """Prepare the optimizer for HIP-graph capture: its step counters move to the device

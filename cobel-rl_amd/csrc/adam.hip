@@ -7,7 +7,9 @@
 //     param.addcdiv_(exp_avg, denom, value = -(lr / (1 - beta1 ** step)))
 // runs as ~10 elementwise kernels per parameter tensor, each streaming the stacked tensors through
 // HBM again (8 192 instances x 4 932 float64 parameters = 323 MB per tensor role).  Here one
-// kernel reads p, g, m, v once and writes p, m, v once.  Every instance has its own step count
+// kernel reads p, g, m, v once and writes p, m, v once — and, if asked, blends the new parameters
+// into the target network's copy on the way (w_t += tau (w - w_t)), which the reference does on
+// the host weight by weight after every step (agent/dqn.py:366-371).  Every instance has its own step count
 // (steps[inst], already incremented for this step) and may be switched off by `active`
 // (instances that have finished their trials keep parameters AND optimizer state untouched, as if
 // their own single-instance run had simply not executed this step).
@@ -24,7 +26,8 @@ __global__ __launch_bounds__(256) void k_adam(T* __restrict__ p, const T* __rest
                                               const double* __restrict__ steps,
                                               const uint8_t* __restrict__ active, int64_t total,
                                               int64_t per_inst, double lr, double b1, double b2,
-                                              double eps, double wd) {
+                                              double eps, double wd, T* __restrict__ target,
+                                              double tau) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int64_t inst = e / per_inst;
@@ -40,9 +43,14 @@ __global__ __launch_bounds__(256) void k_adam(T* __restrict__ p, const T* __rest
     const T mn = mo + (T)(1.0 - b1) * (ge - mo);
     const T vn = vo * (T)b2 + ((T)(1.0 - b2) * ge) * ge;
     const T denom = sqrt(vn) / bc2_sqrt + (T)eps;
+    const T pn = pe - step_size * (mn / denom);
     m[e] = mn;
     v[e] = vn;
-    p[e] = pe - step_size * (mn / denom);
+    p[e] = pn;
+    if (target) {   // w_target += tau * (w_online - w_target)  (agent/dqn.py:366-371)
+      const T te = target[e];
+      target[e] = te + (T)tau * (pn - te);
+    }
   }
 }
 
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(256) void k_adam(T* __restrict__ p, const T* __rest
 extern "C" int cobel_adam_step(void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
                                const double* steps, const uint8_t* active, int64_t n_instances,
                                int64_t per_instance, int32_t is_float64, double lr, double beta1,
-                               double beta2, double eps, double weight_decay, void* stream) {
+                               double beta2, double eps, double weight_decay, void* target,
+                               double tau, void* stream) {
   COBEL_REQUIRE(param && grad && exp_avg && exp_avg_sq && steps, COBEL_E_ARG,
                 "cobel_adam_step: NULL tensor");
   COBEL_REQUIRE(n_instances >= 0 && per_instance > 0, COBEL_E_RANGE,
@@ -65,11 +74,11 @@ extern "C" int cobel_adam_step(void* param, const void* grad, void* exp_avg, voi
   if (is_float64)
     hipLaunchKernelGGL(k_adam<double>, dim3(blocks), dim3(256), 0, st, (double*)param,
                        (const double*)grad, (double*)exp_avg, (double*)exp_avg_sq, steps, active,
-                       total, per_instance, lr, beta1, beta2, eps, weight_decay);
+                       total, per_instance, lr, beta1, beta2, eps, weight_decay, (double*)target, tau);
   else
     hipLaunchKernelGGL(k_adam<float>, dim3(blocks), dim3(256), 0, st, (float*)param,
                        (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, steps, active, total,
-                       per_instance, lr, beta1, beta2, eps, weight_decay);
+                       per_instance, lr, beta1, beta2, eps, weight_decay, (float*)target, tau);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }

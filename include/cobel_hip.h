@@ -447,7 +447,11 @@ COBEL_API int cobel_adam_step(void* param /* [dev] [N][per_instance] */,
                               void* exp_avg_sq /* [dev] */, const double* steps /* [dev] [N] */,
                               const uint8_t* active /* [dev] [N] or NULL */, int64_t n_instances,
                               int64_t per_instance, int32_t is_float64, double lr, double beta1,
-                              double beta2, double eps, double weight_decay, void* stream);
+                              double beta2, double eps, double weight_decay,
+                              void* target /* [dev] same shape, or NULL: target[e] += tau *
+                                              (param_new[e] - target[e]) for stepping instances
+                                              (the DQN target blend, agent/dqn.py:366-371) */,
+                              double tau, void* stream);
 
 #ifdef __cplusplus
 }

@@ -997,15 +997,18 @@ def test_fused_adam_equals_torch_adam(torch_cuda, dtype_name):
         return net
 
     fused, plain = build(True), build(False)
+    fused_target, plain_target = fused.clone(), plain.clone()
     for step in range(12):
         x = torch.rand((n, B, 6), generator=gen, device='cuda', dtype=dt)
         y = torch.rand((n, B, 4), generator=gen, device='cuda', dtype=dt)
         active = None if step < 4 else (torch.rand(n, generator=gen, device='cuda') < 0.6)
         if active is not None and not bool(active.any()):
             active[0] = True
-        for net in (fused, plain):
-            net.train_on_device(x, y, active)
+        for net, tgt in ((fused, fused_target), (plain, plain_target)):
+            net.train_on_device(x, y, active, blend_into=tgt, tau=0.05)
     assert fused._diverged and hasattr(fused, '_steps')
+    for a, b in zip(fused_target.params.values(), plain_target.params.values()):
+        assert torch.allclose(a, b, **tol)        # the target blend rides on the same kernel
     for (k, a), b in zip(fused.params.items(), plain.params.values()):
         assert torch.allclose(a, b, **tol), k
         sa, sb = fused.optimizer.state[a], plain.optimizer.state[b]
