@@ -20,22 +20,25 @@
 
 namespace {
 
+// grid = (instances, chunks of the instance's elements): a workgroup works inside one instance, so
+// the bias corrections (two pow() and a sqrt in float64) are formed once per thread, not per element.
 template <typename T>
 __global__ __launch_bounds__(256) void k_adam(T* __restrict__ p, const T* __restrict__ g,
                                               T* __restrict__ m, T* __restrict__ v,
                                               const double* __restrict__ steps,
-                                              const uint8_t* __restrict__ active, int64_t total,
-                                              int64_t per_inst, double lr, double b1, double b2,
-                                              double eps, double wd, T* __restrict__ target,
-                                              double tau) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int64_t inst = e / per_inst;
-    if (active && !active[inst]) continue;
-    const double t = steps[inst];
-    const T bc1 = (T)(1.0 - pow(b1, t));
-    const T bc2_sqrt = (T)sqrt(1.0 - pow(b2, t));
-    const T step_size = (T)lr / bc1;
+                                              const uint8_t* __restrict__ active, int64_t per_inst,
+                                              double lr, double b1, double b2, double eps, double wd,
+                                              T* __restrict__ target, double tau) {
+  const int64_t inst = blockIdx.x;
+  if (active && !active[inst]) return;
+  const double t = steps[inst];
+  const T bc1 = (T)(1.0 - pow(b1, t));
+  const T bc2_sqrt = (T)sqrt(1.0 - pow(b2, t));
+  const T step_size = (T)lr / bc1;
+  const int64_t base = inst * per_inst;
+  const int64_t stride = (int64_t)gridDim.y * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; k < per_inst; k += stride) {
+    const int64_t e = base + k;
     const T pe = p[e];
     T ge = g[e];
     if (wd != 0.0) ge = ge + (T)wd * pe;
@@ -66,19 +69,20 @@ extern "C" int cobel_adam_step(void* param, const void* grad, void* exp_avg, voi
   COBEL_REQUIRE(n_instances >= 0 && per_instance > 0, COBEL_E_RANGE,
                 "cobel_adam_step: bad sizes %lld x %lld", (long long)n_instances,
                 (long long)per_instance);
-  const int64_t total = n_instances * per_instance;
-  if (total == 0) return COBEL_OK;
-  const int64_t want = (total + 255) / 256;
-  const unsigned blocks = (unsigned)(want < 65536 ? want : 65536);
+  if (n_instances == 0) return COBEL_OK;
+  COBEL_REQUIRE(n_instances <= 0x7fffffffLL, COBEL_E_RANGE, "cobel_adam_step: %lld instances",
+                (long long)n_instances);
+  const int64_t chunks = (per_instance + 1023) / 1024;    // <= 4 elements per thread
+  const dim3 grid((unsigned)n_instances, (unsigned)(chunks < 65535 ? chunks : 65535));
   hipStream_t st = (hipStream_t)stream;
   if (is_float64)
-    hipLaunchKernelGGL(k_adam<double>, dim3(blocks), dim3(256), 0, st, (double*)param,
-                       (const double*)grad, (double*)exp_avg, (double*)exp_avg_sq, steps, active,
-                       total, per_instance, lr, beta1, beta2, eps, weight_decay, (double*)target, tau);
+    hipLaunchKernelGGL(k_adam<double>, grid, dim3(256), 0, st, (double*)param, (const double*)grad,
+                       (double*)exp_avg, (double*)exp_avg_sq, steps, active, per_instance, lr,
+                       beta1, beta2, eps, weight_decay, (double*)target, tau);
   else
-    hipLaunchKernelGGL(k_adam<float>, dim3(blocks), dim3(256), 0, st, (float*)param,
-                       (const float*)grad, (float*)exp_avg, (float*)exp_avg_sq, steps, active, total,
-                       per_instance, lr, beta1, beta2, eps, weight_decay, (float*)target, tau);
+    hipLaunchKernelGGL(k_adam<float>, grid, dim3(256), 0, st, (float*)param, (const float*)grad,
+                       (float*)exp_avg, (float*)exp_avg_sq, steps, active, per_instance, lr, beta1,
+                       beta2, eps, weight_decay, (float*)target, tau);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
