@@ -93,10 +93,10 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=True):
                 TorchNetwork(net, optimizer_params={'lr': 1e-3}), gamma=0.8,
                 memory=DQNMemory(capacity=256))
     agent.use_graph = graph
-    agent._run(env, 10**6, 100, 32, True, budget=warm)
+    agent._run(env, 4096, 100, 32, True, budget=warm)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    agent._run(env, 10**6, 100, 32, True, budget=iters)
+    agent._run(env, 4096, 100, 32, True, budget=iters)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
@@ -135,10 +135,10 @@ def run_next_rows(device):
     torch.manual_seed(0)
 
     def timed(agent, env, n, iters, warm=4):
-        agent._run(env, 10**6, 50, 32, True, budget=warm)
+        agent._run(env, 4096, 50, 32, True, budget=warm)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        agent._run(env, 10**6, 50, 32, True, budget=iters)
+        agent._run(env, 4096, 50, 32, True, budget=iters)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,

@@ -56,7 +56,11 @@ class DQN(Agent):
             self._target = self.model_target.replicate(self.n_envs)
             self._online = self.model_online.replicate(self.n_envs)
             self.dtype = next(iter(self._online.params.values())).dtype
-            self.monitors = DeviceMonitors(self.device, 1, 1, False)
+            # (striped like the fused kernels' monitors: the masked index_add_ below sends every
+            #  instance that did NOT finish a trial to index 0 with a zero, and thousands of atomics on
+            #  one address cost 0.3 ms per step at 8 192 instances)
+            self.monitors = DeviceMonitors(self.device, 1, 1, False,
+                                           stripes=16 if self.n_envs >= 1024 else 1)
             self.trial = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
         self._bind_memory(interface, slots)
 
@@ -165,6 +169,10 @@ class DQN(Agent):
         active = torch.ones(n, dtype=torch.bool, device=dev)
         zero64 = torch.zeros(n, dtype=torch.int64, device=dev)
         cap = self.monitors.cap
+        mon = self.monitors
+        stripe_off = (torch.arange(n, device=dev) % mon.stripes) * cap      # copy of each instance
+        lat_sum, lat_cnt = mon.raw('lat_sum').view(-1), mon.raw('lat_cnt').view(-1)
+        reward_sum = mon.raw('reward_sum').view(-1)
         all_active = True     # host-side knowledge; exact because it is refreshed every step
 
         def iteration() -> None:
@@ -185,9 +193,10 @@ class DQN(Agent):
             over = active & (done | (step + 1 >= steps))
             idx = torch.where(over, self.trial.to(torch.int64), zero64).clamp_(0, cap - 1)
             ok = over & (self.trial < cap)
-            self.monitors.lat_sum.index_add_(0, idx, torch.where(ok, step.to(torch.int64), zero64))
-            self.monitors.lat_cnt.index_add_(0, idx, ok.to(torch.int64))
-            self.monitors.reward_sum.index_add_(0, idx, torch.where(ok, trew, torch.zeros_like(trew)))
+            idx = idx + stripe_off
+            lat_sum.index_add_(0, idx, torch.where(ok, step.to(torch.int64), zero64))
+            lat_cnt.index_add_(0, idx, ok.to(torch.int64))
+            reward_sum.index_add_(0, idx, torch.where(ok, trew, torch.zeros_like(trew)))
             self.trial.add_(over.to(torch.int32))
             trew.copy_(torch.where(over, torch.zeros_like(trew), trew))
             active.logical_and_(self.trial < first + trials)
