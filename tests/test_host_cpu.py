@@ -469,3 +469,28 @@ def test_sfma_host_surface_defaults():
         SFMA(Box(np.zeros(2), np.ones(2)), Discrete(4), EpsilonGreedy(), m)
     with pytest.raises(AssertionError):
         SFMAMemory(Euclidean(3, 3), 9, 6)
+
+
+def test_device_monitors_stripes_on_cpu():
+    """DeviceMonitors keeps [stripes, cap] copies for the kernels and exposes their sums; growing
+    the capacity keeps what was accumulated; one stripe behaves like a plain tensor."""
+    import torch
+    from cobel_amd.agent.agent import DeviceMonitors
+    m = DeviceMonitors(torch.device('cpu'), 1, 4, occupancy=False, responses=True, stripes=4)
+    m.reserve(5)
+    assert m.raw('lat_sum').shape == (4, 5) and m.raw('resp_cnt').shape == (4, 5)
+    m.raw('lat_sum')[1, 2] += 7
+    m.raw('lat_sum')[3, 2] += 5
+    m.raw('lat_cnt')[0, 2] += 2
+    m.raw('reward_sum')[2, 4] += 1.5
+    assert m.lat_sum.tolist() == [0, 0, 12, 0, 0] and m.lat_cnt.tolist() == [0, 0, 2, 0, 0]
+    m.reserve(9)
+    assert m.raw('lat_sum').shape == (4, 9) and m.lat_sum.tolist()[:5] == [0, 0, 12, 0, 0]
+    assert np.allclose(m.mean_latency()[2], 6.0) and np.isnan(m.mean_latency()[0])
+    assert float(m.reward_sum[4]) == 1.5
+    one = DeviceMonitors(torch.device('cpu'), 1, 4)
+    one.reserve(3)
+    one.lat_sum += torch.tensor([1, 2, 3])          # in place on the single copy
+    assert one.raw('lat_sum').tolist() == [[1, 2, 3]] and one.lat_sum.data_ptr() == one.raw('lat_sum').data_ptr()
+    one.lat_sum = None
+    assert one.raw('lat_sum') is None and one.lat_sum is None
