@@ -664,7 +664,17 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     cm += 1u;   // one vector draw per batch
   };
 
+  // Replays are requested (trial start: one without TD updates; trial end: nb_replays with) and
+  // served at ONE place at the top of the loop, so the reactivation code exists once.
+  int req_count = 0, req_start = -1, req_kind = 0, req_trial = 0;
   while (true) {
+    if (req_count > 0) {
+      req_count -= 1;
+      if (req_kind == 0 && (sf & COBEL_SF_RANDOM)) random_replay(req_trial);
+      else sfma_replay(req_start, req_kind == 0, req_kind, req_trial);
+      if (req_count == 0 && req_kind == 0) epoch = clock;  // M.T.fill(0) after a trial's replays
+      continue;
+    }
     if (!(iflags & 1u)) {
       if (trial >= A.r.trials_target) break;
       if (budget == 0) break;
@@ -674,7 +684,13 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       step = 0;
       trew = 0.0;
       iflags |= 1u;
-      if (learn && (sf & COBEL_SF_START_REPLAY)) sfma_replay(state, false, 1, trial);
+      if (learn && (sf & COBEL_SF_START_REPLAY)) {
+        req_count = 1;
+        req_start = state;
+        req_kind = 1;
+        req_trial = trial;
+        continue;
+      }
     }
     if (budget == 0) break;
     budget -= 1;
@@ -797,11 +813,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           td_acc = 0.0;
           sflags |= 1u;
         }
-        for (int rep = 0; rep < A.r.nb_replays; ++rep) {
-          if (sf & COBEL_SF_RANDOM) random_replay(tr);
-          else sfma_replay(end ? ns : -1, true, 0, tr);
-        }
-        epoch = clock;  // M.T.fill(0)
+        req_count = A.r.nb_replays;
+        req_start = end ? ns : -1;
+        req_kind = 0;
+        req_trial = tr;
+        if (req_count == 0) epoch = clock;  // M.T.fill(0)
       }
     }
   }
