@@ -32,6 +32,7 @@ struct sfma_args {
   int32_t chunk;  // experiences per lane: ceil(4S / 64)
   cobel_sfma_run_t r;
   cobel_eps_bb eps;
+  uint64_t eps_thr[16][3];   // integer CDF thresholds of the unmasked selection (cobel_policy.h)
   float alpha_f, gamma_f, model_lr_f;
 };
 
@@ -45,10 +46,11 @@ struct sfma_lds {
   float* R;      // [4S] model reward estimate of experience j
   uint16_t* NS;  // [4S] model successor of experience j | nonterminal flag << 15
   double* red;   // [4][8] scratch of the cross-wave reductions (several waves per instance)
+  uint64_t* thr; // [48] epsilon-greedy thresholds, entry t * 3 + k
 };
 
 __host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
-  return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256;
+  return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256 + 384;
 }
 
 __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
@@ -71,6 +73,8 @@ __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
   L.NS = reinterpret_cast<uint16_t*>(base + off);
   off = (off + (size_t)S * 8 + 15) & ~(size_t)15;
   L.red = reinterpret_cast<double*>(base + off);
+  off += 256;
+  L.thr = reinterpret_cast<uint64_t*>(base + off);
   return L;
 }
 
@@ -273,6 +277,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     L.Q[e] = reinterpret_cast<const float4*>(Qg)[e];
     L.I[e] = 0.0;
   }
+  if (t < 48) L.thr[t] = A.eps_thr[t / 3][t % 3];
   for (int e = t; e < n4; e += NT) {
     L.C[e] = Cg[e];
     const uint64_t rec = Mg[e];
@@ -702,9 +707,15 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       pb_idx = cp >> 1;
       pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
     }
-    const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
+    const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x, w1 = (cp & 1u) ? pblk.w : pblk.y;
     cp += 1u;
-    const int a = (int)rfl((uint32_t)select_action(q, mask_cur, u));
+    // all actions allowed (no mask, or the reference's default all-true mask): the draw is compared
+    // with integer thresholds of the tie pattern's CDF, no floating point (cobel_policy.h) — the
+    // float64 selection with its three divisions was 30 % of an online step
+    const int a = mask_cur == 15u
+                      ? (int)rfl((uint32_t)cobel_eps_greedy_select_thr(q.x, q.y, q.z, q.w,
+                                                                        cobel_u53(w0, w1), L.thr, lane))
+                      : (int)rfl((uint32_t)select_action(q, mask_cur, cobel_u01(w0, w1)));
     const uint4 wc = W4[state];
     const int ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
     const uint4 wn = W4[ns];
@@ -940,6 +951,8 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
     A.eps.base[k] = ec.base[k];
     A.eps.bonus[k] = ec.bonus[k];
   }
+  for (int k = 0; k < 16; ++k)
+    for (int j = 0; j < 3; ++j) A.eps_thr[k][j] = ec.thr[k][j];
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
