@@ -185,6 +185,7 @@ struct sr_lds {
   sr_plan* plan;
   float* leafsum;  // [4][LS], LS = leaf_stride(leaves)
   float* V;        // [4]
+  uint64_t* thr;   // [48] epsilon-greedy thresholds, entry t * 3 + k (cobel_policy.h)
   uint32_t* occ;   // [S] visit counts (OCC only)
   int PS, LS;
 };
@@ -213,13 +214,15 @@ __device__ __forceinline__ sr_lds carve(unsigned char* base, int S, int leaves) 
   off += 16;
   L.plan = reinterpret_cast<sr_plan*>(base + off);
   off += (sizeof(sr_plan) + 15) & ~(size_t)15;
+  L.thr = reinterpret_cast<uint64_t*>(base + off);
+  off += 384;
   L.occ = reinterpret_cast<uint32_t*>(base + off);
   return L;
 }
 
 size_t sr_lds_bytes(int S, int leaves, bool occ) {
   size_t b = (size_t)(kRows + 1) * padded(S) * 4 + (size_t)4 * leaf_stride(leaves) * 4 + 16 +
-             ((sizeof(sr_plan) + 15) & ~(size_t)15);
+             ((sizeof(sr_plan) + 15) & ~(size_t)15) + 384;
   if (occ) b += (size_t)S * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -305,6 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     ebb.bonus[n] = PSETS ? P->eps_bonus[n] : A.eps.bonus[n];
   }
 
+  if (t < 48) L.thr[t] = PSETS ? P->eps_thr[t / 3][t % 3] : A.eps.thr[t / 3][t % 3];
+  __syncthreads();
   uint32_t cw0 = 0, cw1 = 0;
   uint4 cand = {0, 0, 0, 0};
   uint32_t mask_cur = 15u;
@@ -384,10 +389,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
       pb_idx = cp >> 1;
       pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
     }
-    const double u = (cp & 1u) ? cobel_u01(pblk.z, pblk.w) : cobel_u01(pblk.x, pblk.y);
+    const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x, w1 = (cp & 1u) ? pblk.w : pblk.y;
     cp += 1u;
-    const int a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q.x, q.y, q.z, q.w, mask_cur, u,
-                                                                  ebb, lane));
+    // all actions allowed: integer thresholds of the tie pattern's CDF instead of the float64
+    // selection with its three divisions (cobel_policy.h; same result, a third of the latency)
+    const int a = mask_cur == 15u
+                      ? (int)rfl((uint32_t)cobel_eps_greedy_select_thr(q.x, q.y, q.z, q.w,
+                                                                        cobel_u53(w0, w1), L.thr, lane))
+                      : (int)rfl((uint32_t)cobel_eps_greedy_select_wave(
+                            q.x, q.y, q.z, q.w, mask_cur, cobel_u01(w0, w1), ebb, lane));
     const int ns = (int)next_of(cw0, cw1, a);
     const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
     const float r = __builtin_bit_cast(float, rl(cand.z, a));
