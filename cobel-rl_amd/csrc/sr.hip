@@ -210,8 +210,8 @@ __device__ __forceinline__ sr_lds carve(unsigned char* base, int S, int leaves) 
   off += (size_t)L.PS * 4;
   L.leafsum = reinterpret_cast<float*>(base + off);
   off += (size_t)4 * L.LS * 4;
-  L.V = reinterpret_cast<float*>(base + off);
-  off += 16;
+  L.V = reinterpret_cast<float*>(base + off);   // [4] values + the two words of the action draw
+  off += 32;
   L.plan = reinterpret_cast<sr_plan*>(base + off);
   off += (sizeof(sr_plan) + 15) & ~(size_t)15;
   L.thr = reinterpret_cast<uint64_t*>(base + off);
@@ -221,7 +221,7 @@ __device__ __forceinline__ sr_lds carve(unsigned char* base, int S, int leaves) 
 }
 
 size_t sr_lds_bytes(int S, int leaves, bool occ) {
-  size_t b = (size_t)(kRows + 1) * padded(S) * 4 + (size_t)4 * leaf_stride(leaves) * 4 + 16 +
+  size_t b = (size_t)(kRows + 1) * padded(S) * 4 + (size_t)4 * leaf_stride(leaves) * 4 + 32 +
              ((sizeof(sr_plan) + 15) & ~(size_t)15) + 384;
   if (occ) b += (size_t)S * 4;
   return (b + 15) & ~(size_t)15;
@@ -379,17 +379,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
       load_row<VEC>(my_buf, SRg + (size_t)my_row * S, S, lane, 64);
     }
     __builtin_amdgcn_wave_barrier();
+    // The action draw is the same for the whole workgroup: only wave 0 evaluates Philox (one block
+    // per two draws) and hands the two words over through LDS with the values.  A wave pays for
+    // an instruction whatever the number of live lanes, and the four waves sit on four SIMDs that
+    // they share with the other workgroups, so evaluating it in all four cost 16 % of a step.
+    if (wave == 0) {
+      if ((cp >> 1) != pb_idx) {
+        pb_idx = cp >> 1;
+        pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
+      }
+      if (lane == 0) {
+        uint32_t* const dw = reinterpret_cast<uint32_t*>(L.V + 4);
+        dw[0] = (cp & 1u) ? pblk.z : pblk.x;
+        dw[1] = (cp & 1u) ? pblk.w : pblk.y;
+      }
+    }
     const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * L.LS, lane);
     if (lane == 0) L.V[wave] = v;
     lds_barrier();
     const float4 q = *reinterpret_cast<const float4*>(L.V);
 
     // ---- select + env.step -------------------------------------------------------------------
-    if ((cp >> 1) != pb_idx) {   // one Philox block serves two action draws
-      pb_idx = cp >> 1;
-      pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
-    }
-    const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x, w1 = (cp & 1u) ? pblk.w : pblk.y;
+    const uint32_t w0 = rfl(reinterpret_cast<const uint32_t*>(L.V + 4)[0]);
+    const uint32_t w1 = rfl(reinterpret_cast<const uint32_t*>(L.V + 4)[1]);
     cp += 1u;
     // all actions allowed: integer thresholds of the tie pattern's CDF instead of the float64
     // selection with its three divisions (cobel_policy.h; same result, a third of the latency)
