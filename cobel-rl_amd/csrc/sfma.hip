@@ -166,7 +166,11 @@ __device__ __forceinline__ int wave_first_equal(const double* P, int n4, int chu
 // lane of a single wave.  Every wave carries the scalar state of the instance redundantly; thread
 // 0 does the single-cell writes; the wave-wide reductions are completed across waves through a
 // few LDS words and one workgroup barrier each.
-template <int CH, int NW>
+// FAST (with CH > 0): the plain training case — learning on, one replay per trial, no start /
+// random / dynamic replays, no strength modulation or decay, no per-step host log, occupancy,
+// replay trace or per-instance latency trace — with those run-time switches fixed at compile time,
+// so that the flags and pointers behind them do not have to stay live across the step loop.
+template <int CH, int NW, bool FAST = false>
 __device__ __forceinline__ void sfma_body(const sfma_args A) {
   static_assert(CH == 0 || NW == 1, "the register path is one wave per instance");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -307,7 +311,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
   int tpos = A.r.trace_len ? A.r.trace_len[i] : 0;
 
   const uint32_t flags = A.r.flags, sf = A.r.sfma_flags;
-  const bool learn = flags & COBEL_F_LEARN;
+  const bool learn = FAST || (flags & COBEL_F_LEARN);
   const uint32_t pol_stream =
       (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
   const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
@@ -399,7 +403,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     return td;
   };
   auto record = [&](int s, int a, int ns, float R, uint32_t nt, int kind, int tr, double td) {
-    if (A.r.replay_trace && t == 0 && tpos < A.r.trace_cap) {
+    if (!FAST && A.r.replay_trace && t == 0 && tpos < A.r.trace_cap) {
       cobel_sfma_event_t ev;
       ev.sa = (uint32_t)s | ((uint32_t)a << 16) | (nt << 24) | ((uint32_t)kind << 25);
       ev.next = (uint32_t)ns;
@@ -675,7 +679,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
   while (true) {
     if (req_count > 0) {
       req_count -= 1;
-      if (req_kind == 0 && (sf & COBEL_SF_RANDOM)) random_replay(req_trial);
+      if (!FAST && req_kind == 0 && (sf & COBEL_SF_RANDOM)) random_replay(req_trial);
       else sfma_replay(req_start, req_kind == 0, req_kind, req_trial);
       if (req_count == 0 && req_kind == 0) epoch = clock;  // M.T.fill(0) after a trial's replays
       continue;
@@ -689,7 +693,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       step = 0;
       trew = 0.0;
       iflags |= 1u;
-      if (learn && (sf & COBEL_SF_START_REPLAY)) {
+      if (!FAST && learn && (sf & COBEL_SF_START_REPLAY)) {
         req_count = 1;
         req_start = state;
         req_kind = 1;
@@ -735,18 +739,18 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
         L.R[j] = Rnew;
         L.NS[j] = (uint16_t)((uint32_t)ns | (nt << 15));
       }
-      if (A.r.decay_strength != 1.0) {
+      if (!FAST && A.r.decay_strength != 1.0) {
         for (int e = t; e < n4; e += NT) L.C[e] = L.C[e] * A.r.decay_strength;
         bsync();
       }
       clock += 1u;
       if (t == 0) {
         double c = L.C[j] + A.r.c_step;
-        if (sf & COBEL_SF_REWARD_MOD_LOCAL) c = c + (double)r * A.r.reward_modulation;
+        if (!FAST && (sf & COBEL_SF_REWARD_MOD_LOCAL)) c = c + (double)r * A.r.reward_modulation;
         L.C[j] = c;
         stamp[j] = clock;
       }
-      if (sf & COBEL_SF_REWARD_MOD) {
+      if (!FAST && (sf & COBEL_SF_REWARD_MOD)) {
         bsync();
         const double* const row = Dm + (size_t)state * S;
         for (int e = t; e < n4; e += NT) {
@@ -754,7 +758,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           L.C[e] = L.C[e] + ((double)r * row[s2]) * A.r.reward_modulation;
         }
       }
-      if (sf & COBEL_SF_STATE_MOD) {
+      if (!FAST && (sf & COBEL_SF_STATE_MOD)) {
         bsync();
         if (t < 4) L.C[t * S + state] = L.C[t * S + state] + 1.0;
       }
@@ -773,7 +777,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       else td_acc = td_acc + (double)fabsf(td);
     }
 
-    if (A.r.last_exp && t == 0) {
+    if (!FAST && A.r.last_exp && t == 0) {
       int32_t* const e = A.r.last_exp + (size_t)i * 6;
       e[0] = state;
       e[1] = a;
@@ -785,7 +789,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     trew += (double)r;
     nsteps += 1ull;
     executed += 1ull;
-    if (A.r.occupancy && t == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
+    if (!FAST && A.r.occupancy && t == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
     state = ns;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     if (!trial_over) {
@@ -797,13 +801,13 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
         if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + m, 1ull);
         if (A.r.reward_sum) atomicAdd(A.r.reward_sum + m, trew);
         if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + m, 1ull);
-        if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
+        if (!FAST && A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
       }
       const int tr = trial;
       trial += 1;
       iflags &= ~1u;
-      if (learn && !(flags & COBEL_F_NO_REPLAY)) {
-        if (sf & COBEL_SF_DYNAMIC) {
+      if (FAST || (learn && !(flags & COBEL_F_NO_REPLAY))) {
+        if (!FAST && (sf & COBEL_SF_DYNAMIC)) {
           // agent/sfma.py:308-316: p(reverse) = 1 / (1 + exp(-(5 td - 2))), in the type the
           // |TD| sum has at this point
           double p0, p1;
@@ -824,7 +828,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           td_acc = 0.0;
           sflags |= 1u;
         }
-        req_count = A.r.nb_replays;
+        req_count = FAST ? 1 : A.r.nb_replays;
         req_start = end ? ns : -1;
         req_kind = 0;
         req_trial = tr;
@@ -868,6 +872,10 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2(
     const sfma_args A) {
   sfma_body<2, 1>(A);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2_fast(
+    const sfma_args A) {
+  sfma_body<2, 1, true>(A);
 }
 // Four waves per instance, all switches: worlds of several hundred states.
 __global__ __launch_bounds__(256) void k_sfma_wg(const sfma_args A) {
@@ -963,6 +971,17 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
   hipStream_t st = (hipStream_t)stream;
   if (plain && A.chunk <= 2) {
     A.chunk = 2;
+    const uint32_t slow_sf = COBEL_SF_RANDOM | COBEL_SF_DYNAMIC | COBEL_SF_START_REPLAY |
+                             COBEL_SF_REWARD_MOD_LOCAL | COBEL_SF_REWARD_MOD | COBEL_SF_STATE_MOD;
+    const bool fast = (r.flags & COBEL_F_LEARN) &&
+                      !(r.flags & (COBEL_F_NO_REPLAY | COBEL_F_TEST_STREAM)) &&
+                      !(r.sfma_flags & slow_sf) && r.nb_replays == 1 && r.decay_strength == 1.0 &&
+                      !r.last_exp && !r.occupancy && !r.replay_trace && !r.lat_trace;
+    if (fast) {
+      hipLaunchKernelGGL(k_sfma_2_fast, dim3(A.r.n), dim3(64), (size_t)lds, st, A);
+      COBEL_HIP_TRY(hipGetLastError());
+      return COBEL_OK;
+    }
     return launch_sfma<2>(A, (size_t)lds, st);
   }
   if (plain && A.chunk <= 4) {

@@ -299,6 +299,35 @@ def test_sfma_four_waves_equal_one_wave():
         assert len(ea) > 50 and np.array_equal(ea, eb)
 
 
+@pytest.mark.parametrize('name', ['dr_reverse_f32', 'dr_default_f32', 'sr_forward_f32',
+                                  'eu_sweeping_f32'])
+def test_sfma_fast_kernel_equals_traced_run(Z, name):
+    """Plain training runs on worlds up to 32 states without per-instance traces take a kernel
+    with the run-time switches fixed at compile time; it must leave exactly the tables, counters
+    and monitors of the traced run (which is the one pinned to the fixtures above)."""
+    import torch
+    g, world, D, opts = sfma_case(Z, name)
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    runs = []
+    for traced in (True, False):
+        env, agent = build(world, D, opts, 70, 0)
+        agent.track_instances = traced
+        agent.keep_replay_trace = traced
+        agent.train(env, trials, steps, B)
+        torch.cuda.synchronize()
+        runs.append((env, agent))
+    (e1, a), (e2, b) = runs
+    assert torch.equal(a._q, b._q) and torch.equal(a.M.strength, b.M.strength)
+    assert torch.equal(a.M.table, b.M.table) and torch.equal(a.M.stamp, b.M.stamp)
+    assert torch.equal(a.inst, b.inst) and torch.equal(a.M.state, b.M.state)
+    assert torch.equal(e1.state, e2.state) and torch.equal(a.M.counter, b.M.counter)
+    assert torch.equal(a.monitors.lat_sum, b.monitors.lat_sum)
+    assert torch.equal(a.monitors.lat_cnt, b.monitors.lat_cnt)
+    assert torch.equal(a.monitors.reward_sum, b.monitors.reward_sum)
+    assert int(a.replays_done) == int(b.replays_done) > 0
+    assert np.array_equal(a.Q[inst].cpu().numpy().astype(np.float64), g('Q'))
+
+
 def test_sfma_chunking_and_sharding_invariance(Z):
     """The same 16 instances as one launch, as 5-step launches (callbacks force per-trial/-step
     driving only for n_envs = 1, so chunk by train() calls) and as two shards: identical tables."""
