@@ -266,6 +266,15 @@ class Runner:
         self.agent._launch(self.env, self.agent.policy, self.flags, 0x7fffffff,
                            c['steps_per_trial'], c['env_steps_per_launch'], c['batch'])
 
+    def describe(self):
+        """Kernel variant / LDS footprint of the launches (tabular agents: cobel_tab_describe)."""
+        if not hasattr(self.agent, 'describe_launch'):
+            return None
+        c = self.cfg
+        return self.agent.describe_launch(self.env, self.agent.policy, self.flags, 0x7fffffff,
+                                          c['steps_per_trial'], c['env_steps_per_launch'],
+                                          c['batch'])
+
 
 def cpu_baseline(cfg_name, cfg, seconds=12.0):
     """NumPy restatement of the reference loop, 1 core, bounded sample of the same workload."""
@@ -399,6 +408,10 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
                      'launch_ms_mean': mean_launch_s * 1e3,
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
+    what = runner.describe()
+    if what is not None:
+        res['roofline']['lds_bytes_per_workgroup'] = what['lds_bytes']
+        res['roofline']['workgroups_per_cu_by_lds'] = what['workgroups_per_cu']
     if sfma:
         res['reactivations_per_s'] = replays * world_size / elapsed
         res['roofline']['algorithmic_bytes_per_reactivation'] = cfg['bytes_per_reactivation']

@@ -18,6 +18,7 @@ SUB_DOUBLE = 1
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
 F_FORCE_LDS_MODEL, F_NO_PREFETCH = 64, 128
+TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX = range(4)
 MAX_BATCH = 62
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
  I_REWARD_LO, I_REWARD_HI, I_STEPS_LO, I_STEPS_HI, I_WORDS) = range(13)
@@ -140,6 +141,7 @@ _SIGNATURES = {
     'cobel_tab_query': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),
     'cobel_tab_run': (C.c_int, [_P, C.POINTER(TabRun), _P]),
+    'cobel_tab_describe': (C.c_int, [_P, C.POINTER(TabRun), C.POINTER(C.c_int32)]),
     'cobel_pack_model': (C.c_uint64, [C.c_float, C.c_uint16, C.c_uint8]),
     'cobel_unpack_model': (None, [C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint16),
                                   C.POINTER(C.c_uint8)]),

@@ -80,7 +80,8 @@ class TabularAgent(FusedAgent):
     def _model_lr(self):
         return 0.9
 
-    def _launch(self, interface, pol, flags, trials_target, steps, budget, batch) -> None:
+    def _launch(self, interface, pol, flags, trials_target, steps, budget, batch,
+                describe=None) -> None:
         mon = self.monitors
         run = _lib.TabRun()
         run.q = _lib.ptr(self._q)
@@ -103,5 +104,16 @@ class TabularAgent(FusedAgent):
         run.seed = interface.seed
         self._hyper(run, self.learning_rate, self.gamma, pol.epsilon, self._model_lr())
         self._extra(run)
+        if describe is not None:
+            _lib.check(_lib.lib().cobel_tab_describe(interface.handle.ptr, C.byref(run), describe))
+            return
         _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
                                             _lib.current_stream(self.device)))
+
+    def describe_launch(self, interface, pol, flags, trials_target, steps, budget, batch) -> dict:
+        """Which kernel ``_launch`` would take with these arguments (``cobel_tab_describe``)."""
+        out = (C.c_int32 * 4)()
+        TabularAgent._launch(self, interface, pol, flags, trials_target, steps, budget, batch,
+                             describe=out)
+        return {'kernel': int(out[0]), 'lds_bytes': int(out[1]), 'workgroups_per_cu': int(out[2]),
+                'instances_per_workgroup': int(out[3])}

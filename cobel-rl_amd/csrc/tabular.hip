@@ -82,6 +82,14 @@ constexpr int kThrBytes = 16 * 3 * 8;
 constexpr int kHashBuckets = 256;
 constexpr int kHashBucketsSmall = 128;   // with MIDX: keeps the footprint at 17 KiB (nine per CU)
 
+// LDS is handed out in blocks of 1 280 bytes, 128 per CU — not in KiB (measured on MI355X with
+// scripts/exp_occupancy.py: the launch time of k_tab_wpi steps down at 15 360 and at 14 080 bytes
+// per workgroup and is flat in between; 17 408 B, a 32 x 32 world, are 14 blocks: nine per CU).
+inline int lds_workgroups_per_cu(size_t bytes) {
+  const size_t blocks = (bytes + 1279) / 1280;
+  return blocks ? (int)(128 / blocks) : 128;
+}
+
 __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool replay, bool wlds,
                                                          bool occ, bool midx = false) {
   size_t b = (size_t)S * 16;
@@ -1052,8 +1060,9 @@ extern "C" int cobel_model_index_build(const uint64_t* model, uint16_t* index, i
   return COBEL_OK;
 }
 
-extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* run,
-                             void* stream) {
+// describe != NULL: report which kernel the run would take instead of launching it
+static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream,
+                        int32_t* describe) {
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_tab_run: NULL world/run");
   const cobel_tab_run_t& r = *run;
   COBEL_REQUIRE(r.q && r.inst, COBEL_E_ARG, "cobel_tab_run: q and inst are required");
@@ -1130,6 +1139,13 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     const bool mon = r.lat_sum || r.lat_cnt || r.reward_sum || r.resp_cnt;
     const size_t bytes = lds_lpi + (mon ? (size_t)kMonBytes : 0);
     const dim3 grid((unsigned)((r.n + lpw - 1) / lpw));
+    if (describe) {
+      describe[0] = COBEL_TAB_KERNEL_LPI;
+      describe[1] = (int32_t)bytes;
+      describe[2] = lds_workgroups_per_cu(bytes);
+      describe[3] = lpw;
+      return COBEL_OK;
+    }
 #define COBEL_LPI(ONE, MON)                                                                    \
   do {                                                                                         \
     if (bytes > 64 * 1024)                                                                     \
@@ -1146,7 +1162,28 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;
   }
+  if (describe) {
+    describe[0] = midx ? COBEL_TAB_KERNEL_WPI_INDEX
+                       : (fast ? COBEL_TAB_KERNEL_WPI_FAST : COBEL_TAB_KERNEL_WPI);
+    describe[1] = (int32_t)lds;
+    describe[2] = lds_workgroups_per_cu(lds);
+    describe[3] = 1;
+    return COBEL_OK;
+  }
   if (r.agent == COBEL_AGENT_DYNAQ)
     return dispatch_wpi<COBEL_AGENT_DYNAQ>(A, occ, wlds, fast, midx, lds, st);
   return dispatch_wpi<COBEL_AGENT_Q>(A, occ, wlds, false, false, lds, st);
+}
+
+extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* run,
+                             void* stream) {
+  return tab_run_impl(world, run, stream, nullptr);
+}
+
+extern "C" int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run_t* run,
+                                  int32_t* out) {
+  COBEL_REQUIRE(out, COBEL_E_ARG, "cobel_tab_describe: NULL out");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (world && run && run->n == 0) return COBEL_OK;
+  return tab_run_impl(world, run, nullptr, out);
 }

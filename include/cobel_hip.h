@@ -269,6 +269,18 @@ typedef struct {
 COBEL_API int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch, int32_t* lds_bytes,
                     int32_t* instances_per_block);
 COBEL_API int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream);
+/* Which kernel cobel_tab_run would take for this run, without launching anything (same argument
+ * checks): out[0] = COBEL_TAB_KERNEL_*, out[1] = LDS bytes per workgroup, out[2] = workgroups a CU
+ * can hold by LDS (1 280-byte blocks, 128 per CU), out[3] = instances per workgroup.  For tests
+ * and benchmark reports; all zero for n = 0. */
+enum {
+  COBEL_TAB_KERNEL_LPI = 0,       /* one lane per instance (runs without planning)              */
+  COBEL_TAB_KERNEL_WPI = 1,       /* one wavefront per instance, every run-time switch          */
+  COBEL_TAB_KERNEL_WPI_FAST = 2,  /* ... plain Dyna-Q training, model digest in LDS             */
+  COBEL_TAB_KERNEL_WPI_INDEX = 3  /* ... plain Dyna-Q training, model digest in HBM (model_index) */
+};
+COBEL_API int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run_t* run,
+                                 int32_t* out /* [host] [4] */);
 
 /* Host helpers for the packed 8-byte records (so bindings never re-derive the layout). */
 COBEL_API uint64_t cobel_pack_model(float reward, uint16_t next_state, uint8_t nonterminal);

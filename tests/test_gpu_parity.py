@@ -1136,6 +1136,9 @@ def test_edge_empty_and_zero_work(torch_cuda):
     run.q, run.inst, run.model = _lib.ptr(z32), _lib.ptr(z32), _lib.ptr(z32)
     run.n, run.agent, run.steps_per_trial, run.epsilon = 0, 1, 5, 0.1
     _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
+    what = (C.c_int32 * 4)(9, 9, 9, 9)
+    _lib.check(lib.cobel_tab_describe(env.handle.ptr, C.byref(run), what))
+    assert list(what) == [0, 0, 0, 0]
     # zero trials: nothing moves, nothing is drawn
     agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
     before = env.state.clone()
@@ -1455,3 +1458,33 @@ def test_full_size_c4_sample_and_conservation(torch_cuda):
     sr = agent._sr[:128]
     changed = (sr != torch.eye(1024, device='cuda')[None]).any(dim=2).sum(dim=1)
     assert int(changed.max().item()) <= launches * budget and int(changed.min().item()) > 0
+
+
+def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
+    """cobel_tab_describe: the benchmark workloads take the kernels DESIGN.md says they take, with
+    the LDS footprint and the workgroups per CU (1 280-byte LDS blocks, 128 per CU) it states;
+    describing a run launches nothing."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd import _lib
+    dev = torch.device('cuda', 0)
+    for name, n, kernel, lds, per_cu, per_wg in [
+            ('C3', 256, _lib.TAB_KERNEL_WPI_INDEX, 1024 * 16 + 1024, 9, 1),
+            ('C2', 256, _lib.TAB_KERNEL_LPI, None, None, 64)]:
+        cfg = dict(bench.CONFIGS[name], instances=n)
+        env, ag = bench.build_agent(name, cfg, n, 0, dev)
+        r = bench.Runner(cfg, env, ag)
+        got = ag.describe_launch(env, ag.policy, r.flags, 0x7fffffff, cfg['steps_per_trial'],
+                                 cfg['env_steps_per_launch'], cfg['batch'])
+        torch.cuda.synchronize()
+        assert got['kernel'] == kernel and got['instances_per_workgroup'] == per_wg, (name, got)
+        if lds is not None:
+            assert (got['lds_bytes'], got['workgroups_per_cu']) == (lds, per_cu), (name, got)
+        assert ag.env_steps() == 0 and int(ag.inst[:, _lib.I_STEPS_LO].sum().item()) == 0
+    # the generic wave-per-instance kernel (masked actions) keeps the model digest in LDS
+    cfg = dict(bench.CONFIGS['C3'], instances=64)
+    env, ag = bench.build_agent('C3', cfg, 64, 0, dev)
+    ag.mask_actions = True
+    r = bench.Runner(cfg, env, ag)
+    got = ag.describe_launch(env, ag.policy, r.flags | _lib.F_MASK_ACTIONS, 0x7fffffff, 200, 16, 50)
+    assert got['kernel'] == _lib.TAB_KERNEL_WPI and got['lds_bytes'] == 1024 * 24 + 2048

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1003
+    assert lib.cobel_abi_version() == 1004
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -108,6 +108,12 @@ def test_argument_errors_map_to_reference_exceptions():
         _lib.check(lib.cobel_world_create(None, None, None, None, None, 25, 1, 0, None))
     with pytest.raises(AssertionError):
         _lib.check(lib.cobel_tab_run(None, None, None))
+    out = (C.c_int32 * 4)(7, 7, 7, 7)
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_tab_describe(None, None, out))
+    assert list(out) == [0, 0, 0, 0]
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_tab_describe(None, None, None))
     with pytest.raises(NotImplementedError):
         _lib.check(lib.cobel_tab_query(1000000, 1, 10, None, None))
     with pytest.raises(NotImplementedError):
