@@ -40,6 +40,24 @@ class ParamSet(C.Structure):
     ]
 
 
+class DQNReplay(C.Structure):
+    """``cobel_dqn_replay_t``."""
+    _fields_ = [
+        ('w', C.c_void_p * 3), ('b', C.c_void_p * 3),
+        ('w_target', C.c_void_p * 3), ('b_target', C.c_void_p * 3),
+        ('m_w', C.c_void_p * 3), ('m_b', C.c_void_p * 3),
+        ('v_w', C.c_void_p * 3), ('v_b', C.c_void_p * 3),
+        ('steps', C.c_void_p), ('active', C.c_void_p),
+        ('states', C.c_void_p), ('next_states', C.c_void_p), ('actions', C.c_void_p),
+        ('rewards', C.c_void_p), ('nonterminal', C.c_void_p),
+        ('n', C.c_int32), ('n_inputs', C.c_int32), ('n_hidden1', C.c_int32),
+        ('n_hidden2', C.c_int32), ('n_actions', C.c_int32), ('batch', C.c_int32),
+        ('is_float64', C.c_int32), ('ddqn', C.c_int32),
+        ('gamma', C.c_double), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+        ('eps', C.c_double), ('weight_decay', C.c_double), ('tau', C.c_double),
+    ]
+
+
 class TabRun(C.Structure):
     """``cobel_tab_run_t``."""
     _fields_ = [
@@ -156,6 +174,8 @@ _SIGNATURES = {
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P,
                                   C.c_double, _P]),
 }
+_SIGNATURES['cobel_dqn_replay_query'] = (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)])
+_SIGNATURES['cobel_dqn_replay'] = (C.c_int, [C.POINTER(DQNReplay), _P])
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

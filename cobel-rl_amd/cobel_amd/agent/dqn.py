@@ -128,6 +128,12 @@ class DQN(Agent):
         states, actions, rewards, next_states, terminals = self.M.retrieve(batch_size)
         if active is not None:      # instances that are done do not consume their streams
             self.M.counter -= (~active & (self.M.size > 0)).to(torch.int32)
+        if self.target_update < 1.0 and self._online.dqn_replay_fused(
+                self._target, states, actions, rewards, next_states, terminals, self.gamma,
+                self.DDQN, self.target_update, active):
+            # 64-64 ReLU networks: the whole step in one kernel (cobel_dqn_replay)
+            return {'states': states, 'actions': actions, 'rewards': rewards,
+                    'next_states': next_states, 'terminals': terminals}
         with torch.no_grad():
             targets = self._online.forward(states).clone()
             boot = self._target.forward(next_states)

@@ -122,6 +122,11 @@ class DynaDQN(DQN):
         s, a, r, ns, nt = self.M.sample(batch_size, active)
         table = self._table.to(self.dtype)
         states, next_states = table[s], table[ns]
+        if self.target_update < 1.0 and self._online.dqn_replay_fused(
+                self._target, states, a, r, next_states, nt, self.gamma, self.DDQN,
+                self.target_update, active):
+            self.last_update += 1
+            return
         with torch.no_grad():
             targets = self._online.forward(states).clone()
             boot = self._target.forward(next_states)

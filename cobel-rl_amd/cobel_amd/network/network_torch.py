@@ -16,6 +16,7 @@ n separate optimizers would).
 from __future__ import annotations
 
 import copy
+import ctypes as C
 
 import numpy as np
 import torch
@@ -328,6 +329,95 @@ class StackedTorchNetwork:
                     w = tau if active is None else \
                         active.view(self.n, *([1] * (v.dim() - 1))).to(v.dtype) * tau
                     v.lerp_(self.buffers[k], w)
+
+    # -- fused DQN replay step (libcobel_hip: cobel_dqn_replay) -----------------------------------
+    fused_mlp = True       # False keeps the PyTorch forward / backward (tests compare the two)
+
+    def _mlp3_names(self):
+        """Names of the three Linear layers if the architecture is [Flatten -] Linear - ReLU -
+        Linear - ReLU - Linear with every parameter trainable, else None (cached)."""
+        if not hasattr(self, '_mlp3'):
+            self._mlp3 = None
+            kids = list(self.base.named_children()) if isinstance(self.base, nn.Sequential) else []
+            if kids and type(kids[0][1]) is nn.Flatten:
+                kids = kids[1:]
+            kinds = [type(m) for _, m in kids]
+            if kinds == [nn.Linear, nn.ReLU, nn.Linear, nn.ReLU, nn.Linear] and not self.buffers:
+                names = [kids[0][0], kids[2][0], kids[4][0]]
+                want = [n + s for n in names for s in ('.weight', '.bias')]
+                if sorted(want) == sorted(self.params) and \
+                        all(p.requires_grad for p in self.params.values()):
+                    self._mlp3 = names
+        return self._mlp3
+
+    def dqn_replay_fused(self, target: 'StackedTorchNetwork', states, actions, rewards, next_states,
+                         nonterminal, gamma: float, ddqn: bool, tau: float, active=None) -> bool:
+        """The whole replay step of ``DQN.replay`` (targets, MSE backward, Adam step, target blend
+        with ``tau``; 0 = no blend) in one kernel per call.  Returns False — and does nothing — if
+        the network, loss, optimizer or batch is not of the shape ``cobel_dqn_replay`` covers; the
+        caller then takes the PyTorch path."""
+        from .. import _lib
+        names = self._mlp3_names() if self.fused_mlp else None
+        if names is None or not self._fused_adam_ok() or type(self.criterion) is not nn.MSELoss \
+                or getattr(self.criterion, 'reduction', '') != 'none' \
+                or target._mlp3_names() != names or states.dim() != 3:
+            return False
+        w = [self.params[n + '.weight'] for n in names]
+        dtype = w[0].dtype
+        dims = (w[0].shape[2], w[0].shape[1], w[1].shape[1], w[2].shape[1])
+        if w[1].shape[2] != dims[1] or w[2].shape[2] != dims[2] or states.dtype != dtype or \
+                _lib.lib().cobel_dqn_replay_query(dims[0], dims[1], dims[2], dims[3],
+                                                  states.shape[1], int(dtype == torch.float64),
+                                                  None) != _lib.OK:
+            return False
+        self._diverged = True
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        steps = getattr(self, '_steps', None)
+        if steps is None:    # seeded from whatever the optimizer has counted so far
+            seen = [float(st['steps'].max()) if 'steps' in st else float(st.get('step', 0.0))
+                    for st in opt.state.values()]
+            steps = self._steps = torch.full((self.n,), max(seen, default=0.0),
+                                             dtype=torch.float64, device=self.device)
+            for p in self.params.values():
+                if 'steps' in opt.state[p]:
+                    steps.copy_(opt.state[p]['steps'])
+                    break
+        mask = None
+        if active is None:
+            steps += 1.0
+        else:
+            steps += active.to(torch.float64)
+            mask = active.to(torch.uint8)
+        run = _lib.DQNReplay()
+        keep = [mask, steps]
+        for k, n in enumerate(names):
+            for kind, dst_p, dst_t, dst_m, dst_v in (('.weight', run.w, run.w_target, run.m_w, run.v_w),
+                                                     ('.bias', run.b, run.b_target, run.m_b, run.v_b)):
+                p = self.params[n + kind]
+                st = opt.state[p]
+                if 'exp_avg' not in st:
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                    st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st['steps'] = steps
+                dst_p[k], dst_t[k] = _lib.ptr(p), _lib.ptr(target.params[n + kind])
+                dst_m[k], dst_v[k] = _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq'])
+        tensors = [states.contiguous(), next_states.contiguous(),
+                   actions.to(torch.int64).contiguous(), rewards.to(dtype).contiguous(),
+                   nonterminal.to(dtype).contiguous()]
+        keep += tensors
+        run.steps, run.active = _lib.ptr(steps), _lib.ptr(mask)
+        run.states, run.next_states, run.actions = (_lib.ptr(t) for t in tensors[:3])
+        run.rewards, run.nonterminal = _lib.ptr(tensors[3]), _lib.ptr(tensors[4])
+        run.n, run.batch = self.n, states.shape[1]
+        run.n_inputs, run.n_hidden1, run.n_hidden2, run.n_actions = dims
+        run.is_float64, run.ddqn = int(dtype == torch.float64), int(bool(ddqn))
+        run.gamma, run.lr = float(gamma), float(group['lr'])
+        run.beta1, run.beta2 = (float(b) for b in group['betas'])
+        run.eps, run.weight_decay, run.tau = float(group['eps']), float(group['weight_decay']), float(tau)
+        _lib.check(_lib.lib().cobel_dqn_replay(C.byref(run), _lib.current_stream(self.device)))
+        return True
 
     def make_capturable(self) -> None:
         """Prepare the optimizer for HIP-graph capture: its step counters move to the device

@@ -1,0 +1,455 @@
+// One DQN replay step per instance as ONE kernel: forward of the target network on the sampled
+// next states, forward of the online network on the sampled states, the Q-learning targets, the
+// backward pass of the mean-squared error, torch.optim.Adam's update of the online network and the
+// blend of the new weights into the target network — for networks of the shape every DQN demo and
+// test of the reference uses: Linear(D, 64) - ReLU - Linear(64, 64) - ReLU - Linear(64, 4).
+//
+// Replaces, per step and instance (paths relative to /root/reference/src/cobel):
+//   agent/dqn.py:346-364      targets = Q_online(s); targets[a] = r + gamma * nt * max_a' Q_target(s')
+//                             (DDQN, :352-355: the action is chosen by the online network)
+//   network/network_torch.py:160-167  train_on_batch: MSELoss(reduction='none')(model(s), targets)
+//                             .mean().backward(); optimizer.step()
+//   agent/dqn.py:366-371      w_target += tau * (w_online - w_target)
+// which through PyTorch is three batched forward passes, one backward pass and the optimizer: ~60
+// GEMM / elementwise launches and ~25 passes over the stacked parameters (8 192 instances x 4 932
+// float64 parameters = 323 MB per pass).  Here a workgroup of 256 threads owns one instance:
+//   * the parameters of one network at a time are staged in LDS (first the target network's, then
+//     the online network's into the same buffer), the 64 x 64 matrix transposed so that every
+//     product below reads it along its contiguous axis;
+//   * activations stay in LDS with a row stride of 66 elements (rows of different samples fall
+//     into different banks); the backward pass overwrites them in place with the deltas;
+//   * every thread applies Adam to the gradient elements it has just accumulated in registers —
+//     gradients never exist in memory; p, m, v are read once and written once, the target network's
+//     copy is read once (its forward pass) plus once and written once (the blend).
+// HBM traffic per instance and step: 8 streams over the parameters (online read + write, two
+// moments read + write, target read + write) + one more read of the target = 9 x 39 KB (float64).
+//
+// Arithmetic: products are accumulated with fused multiply-adds in the network's dtype, one
+// accumulator per output in index order — not torch's GEMM order, so results agree with the
+// PyTorch path to rounding (1e-12 relative in float64 on single steps; tests bound it), not bit for
+// bit.  The optimizer update is k_adam's (adam.hip), operation for operation.
+#include "cobel_common.h"
+
+namespace {
+
+constexpr int kH = 64;        // hidden width (both layers)
+constexpr int kA = 4;         // actions
+constexpr int kB = 32;        // replay batch
+constexpr int kRow = 66;      // LDS row stride of activations and of the transposed 64 x 64 matrix
+constexpr int kMaxD = 32;     // input width limit
+
+struct mlp_args {
+  cobel_dqn_replay_t r;
+};
+
+template <typename T>
+struct mlp_lds {
+  T* wt2;   // [64][66]  wt2[k * 66 + j] = W2[j][k]
+  T* wt1;   // [D][64]   wt1[d * 64 + j] = W1[j][d]
+  T* w3;    // [4][64]
+  T* b1;    // [64]
+  T* b2;    // [64]
+  T* b3;    // [4] (+ 4 pad)
+  T* x;     // [32][D]
+  T* h1;    // [32][66]
+  T* h2;    // [32][66]
+  T* q;     // [32][4]   online Q(s) -> delta3
+  T* qt;    // [32][4]   target Q(s')
+  T* boot;  // [32]
+  int* pick;  // [32] DDQN: argmax_a Q_online(s')
+};
+
+__host__ __device__ inline size_t mlp_lds_elems(int D) {
+  return (size_t)kH * kRow + (size_t)D * kH + kA * kH + kH + kH + 8 + (size_t)kB * D +
+         2 * (size_t)kB * kRow + 2 * kB * kA + kB + kB /* pick, as T-sized slots */;
+}
+
+template <typename T>
+__device__ __forceinline__ T fma_t(T a, T b, T c);
+template <>
+__device__ __forceinline__ double fma_t<double>(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+template <>
+__device__ __forceinline__ float fma_t<float>(float a, float b, float c) {
+  return __builtin_fmaf(a, b, c);
+}
+
+// torch.optim.Adam, one element (same operation order as k_adam in adam.hip)
+template <typename T>
+struct adam_consts {
+  T bc2_sqrt, step_size, one_m_b1, b2, one_m_b2, eps, wd, tau;
+  bool has_wd, blend;
+};
+
+template <typename T>
+__device__ __forceinline__ void adam_apply(T* __restrict__ p, T* __restrict__ m,
+                                           T* __restrict__ v, T* __restrict__ tgt, size_t e,
+                                           T p_old, T g, const adam_consts<T>& c) {
+  if (c.has_wd) g = g + c.wd * p_old;
+  const T mo = m[e], vo = v[e];
+  const T mn = mo + c.one_m_b1 * (g - mo);
+  const T vn = vo * c.b2 + (c.one_m_b2 * g) * g;
+  const T denom = sqrt(vn) / c.bc2_sqrt + c.eps;
+  const T pn = p_old - c.step_size * (mn / denom);
+  m[e] = mn;
+  v[e] = vn;
+  p[e] = pn;
+  if (c.blend) {
+    const T te = tgt[e];
+    tgt[e] = te + c.tau * (pn - te);
+  }
+}
+
+// Stage one network's parameters (torch.nn.Linear layout [out][in]) into LDS.
+template <typename T>
+__device__ void stage_params(const mlp_lds<T>& L, const T* w1, const T* b1, const T* w2,
+                             const T* b2, const T* w3, const T* b3, int D, int t) {
+  for (int e = t; e < kH * kH; e += 256) {   // coalesced read along k, transposed write
+    const int j = e >> 6, k = e & 63;
+    L.wt2[k * kRow + j] = w2[e];
+  }
+  for (int e = t; e < kH * D; e += 256) {
+    const int j = e / D, d = e - j * D;
+    L.wt1[d * kH + j] = w1[e];
+  }
+  L.w3[t] = w3[t];   // 4 * 64 = 256 elements
+  if (t < kH) {
+    L.b1[t] = b1[t];
+    L.b2[t] = b2[t];
+  }
+  if (t < kA) L.b3[t] = b3[t];
+}
+
+// h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), out[s][a] = W3 h2 + b3 for the 32 rows of L.x.
+// Thread tile of the two hidden layers: 2 samples x 4 neurons.
+template <typename T>
+__device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
+  const int jg = t & 15, sg = t >> 4;
+  const int j0 = jg * 4, s0 = sg * 2;
+  {
+    T acc[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = L.b1[j0 + c];
+    for (int d = 0; d < D; ++d) {
+      const T x0 = L.x[s0 * D + d], x1 = L.x[(s0 + 1) * D + d];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T w = L.wt1[d * kH + j0 + c];
+        acc[0][c] = fma_t<T>(w, x0, acc[0][c]);
+        acc[1][c] = fma_t<T>(w, x1, acc[1][c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      L.h1[s0 * kRow + j0 + c] = acc[0][c] > (T)0 ? acc[0][c] : (T)0;
+      L.h1[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
+    }
+  }
+  __syncthreads();
+  {
+    T acc[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = L.b2[j0 + c];
+#pragma unroll 8
+    for (int k = 0; k < kH; ++k) {
+      const T x0 = L.h1[s0 * kRow + k], x1 = L.h1[(s0 + 1) * kRow + k];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T w = L.wt2[k * kRow + j0 + c];
+        acc[0][c] = fma_t<T>(w, x0, acc[0][c]);
+        acc[1][c] = fma_t<T>(w, x1, acc[1][c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      L.h2[s0 * kRow + j0 + c] = acc[0][c] > (T)0 ? acc[0][c] : (T)0;
+      L.h2[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
+    }
+  }
+  __syncthreads();
+  if (t < kB * kA) {
+    const int s = t >> 2, a = t & 3;
+    T acc = L.b3[a];
+#pragma unroll 8
+    for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[a * kH + k], L.h2[s * kRow + k], acc);
+    out[s * kA + a] = acc;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ void load_rows(T* dst, const T* src, int count, int t) {
+  for (int e = t; e < count; e += 256) dst[e] = src[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const cobel_dqn_replay_t& R = A.r;
+  const int i = (int)blockIdx.x;
+  if (R.active && !R.active[i]) return;
+  const int t = (int)threadIdx.x;
+  const int D = R.n_inputs;
+  mlp_lds<T> L;
+  {
+    T* p = reinterpret_cast<T*>(lds_raw);
+    L.wt2 = p; p += kH * kRow;
+    L.wt1 = p; p += D * kH;
+    L.w3 = p;  p += kA * kH;
+    L.b1 = p;  p += kH;
+    L.b2 = p;  p += kH;
+    L.b3 = p;  p += 8;
+    L.x = p;   p += kB * D;
+    L.h1 = p;  p += kB * kRow;
+    L.h2 = p;  p += kB * kRow;
+    L.q = p;   p += kB * kA;
+    L.qt = p;  p += kB * kA;
+    L.boot = p; p += kB;
+    L.pick = reinterpret_cast<int*>(p);
+  }
+  const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)kA * kH;
+  T* const w1 = (T*)R.w[0] + (size_t)i * n1;
+  T* const b1 = (T*)R.b[0] + (size_t)i * kH;
+  T* const w2 = (T*)R.w[1] + (size_t)i * n2;
+  T* const b2 = (T*)R.b[1] + (size_t)i * kH;
+  T* const w3 = (T*)R.w[2] + (size_t)i * n3;
+  T* const b3 = (T*)R.b[2] + (size_t)i * kA;
+  T* const tw1 = (T*)R.w_target[0] + (size_t)i * n1;
+  T* const tb1 = (T*)R.b_target[0] + (size_t)i * kH;
+  T* const tw2 = (T*)R.w_target[1] + (size_t)i * n2;
+  T* const tb2 = (T*)R.b_target[1] + (size_t)i * kH;
+  T* const tw3 = (T*)R.w_target[2] + (size_t)i * n3;
+  T* const tb3 = (T*)R.b_target[2] + (size_t)i * kA;
+  const T* const xs = (const T*)R.states + (size_t)i * kB * D;
+  const T* const xn = (const T*)R.next_states + (size_t)i * kB * D;
+
+  // ---- Q_target(s') ---------------------------------------------------------------------------
+  stage_params<T>(L, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
+  load_rows<T>(L.x, xn, kB * D, t);
+  __syncthreads();
+  forward<T>(L, L.qt, D, t);
+  // ---- online network -------------------------------------------------------------------------
+  stage_params<T>(L, w1, b1, w2, b2, w3, b3, D, t);
+  __syncthreads();
+  if (R.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
+    forward<T>(L, L.q, D, t);
+    if (t < kB) {
+      int best = 0;
+      T bv = L.q[t * kA];
+#pragma unroll
+      for (int a = 1; a < kA; ++a)
+        if (L.q[t * kA + a] > bv) {   // first maximum, as torch.argmax
+          bv = L.q[t * kA + a];
+          best = a;
+        }
+      L.pick[t] = best;
+    }
+    __syncthreads();
+  }
+  load_rows<T>(L.x, xs, kB * D, t);
+  __syncthreads();
+  forward<T>(L, L.q, D, t);
+
+  // ---- targets and the loss gradient at the output ----------------------------------------------
+  // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the 32 x 4
+  // outputs of (Q - targets)^2 with targets == Q except at the action taken, so the gradient is
+  // 2 (Q[s][a] - new[s]) / 128 there and zero elsewhere.
+  if (t < kB) {
+    T boot;
+    if (R.ddqn) {
+      boot = L.qt[t * kA + L.pick[t]];
+    } else {
+      boot = L.qt[t * kA];
+#pragma unroll
+      for (int a = 1; a < kA; ++a) boot = L.qt[t * kA + a] > boot ? L.qt[t * kA + a] : boot;
+    }
+    const T r = ((const T*)R.rewards)[(size_t)i * kB + t];
+    const T nt = ((const T*)R.nonterminal)[(size_t)i * kB + t];
+    L.boot[t] = r + (boot * nt) * (T)R.gamma;
+  }
+  __syncthreads();
+  if (t < kB * kA) {
+    const int s = t >> 2, a = t & 3;
+    const int act = (int)R.actions[(size_t)i * kB + s];
+    const T d = L.q[t] - L.boot[s];
+    const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
+    L.q[t] = (a == act) ? g : (T)0;   // delta3
+  }
+  __syncthreads();
+
+  // ---- Adam constants of this instance ----------------------------------------------------------
+  adam_consts<T> c;
+  {
+    const double st = R.steps[i];
+    const T bc1 = (T)(1.0 - pow(R.beta1, st));
+    c.bc2_sqrt = (T)sqrt(1.0 - pow(R.beta2, st));
+    c.step_size = (T)R.lr / bc1;
+    c.one_m_b1 = (T)(1.0 - R.beta1);
+    c.b2 = (T)R.beta2;
+    c.one_m_b2 = (T)(1.0 - R.beta2);
+    c.eps = (T)R.eps;
+    c.wd = (T)R.weight_decay;
+    c.has_wd = R.weight_decay != 0.0;
+    c.tau = (T)R.tau;
+    c.blend = R.tau != 0.0;
+  }
+  T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
+  T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
+  T* const m_w3 = (T*)R.m_w[2] + (size_t)i * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)i * n3;
+  T* const m_b1 = (T*)R.m_b[0] + (size_t)i * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)i * kH;
+  T* const m_b2 = (T*)R.m_b[1] + (size_t)i * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)i * kH;
+  T* const m_b3 = (T*)R.m_b[2] + (size_t)i * kA; T* const v_b3 = (T*)R.v_b[2] + (size_t)i * kA;
+
+  // ---- output layer: dW3[a][k] = sum_s delta3[s][a] h2[s][k], db3[a] = sum_s delta3[s][a] --------
+  {
+    const int a = t >> 6, k = t & 63;
+    T g = (T)0;
+#pragma unroll 8
+    for (int s = 0; s < kB; ++s) g = fma_t<T>(L.q[s * kA + a], L.h2[s * kRow + k], g);
+    adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, c);
+    if (t < kA) {
+      T gb = (T)0;
+      for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kA + t];
+      adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, c);
+    }
+  }
+  __syncthreads();
+  // delta2[s][k] = (sum_a W3[a][k] delta3[s][a]) * (h2[s][k] > 0), in place over h2
+  for (int e = t; e < kB * kH; e += 256) {
+    const int s = e >> 6, k = e & 63;
+    T d = (T)0;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) d = fma_t<T>(L.w3[a * kH + k], L.q[s * kA + a], d);
+    const T h = L.h2[s * kRow + k];
+    L.h2[s * kRow + k] = h > (T)0 ? d : (T)0;
+  }
+  __syncthreads();
+
+  // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k]; thread tile 4 j x 4 k -----------------
+  {
+    const int kg = t & 15, jg = t >> 4;
+    const int j0 = jg * 4, k0 = kg * 4;
+    T g[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) g[a][b] = (T)0;
+#pragma unroll 4
+    for (int s = 0; s < kB; ++s) {
+      T dj[4], hk[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        dj[a] = L.h2[s * kRow + j0 + a];
+        hk[a] = L.h1[s * kRow + k0 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = fma_t<T>(dj[a], hk[b], g[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = j0 + a, k = k0 + b;
+        adam_apply<T>(w2, m_w2, v_w2, tw2, (size_t)j * kH + k, L.wt2[k * kRow + j], g[a][b], c);
+      }
+    if (t < kH) {
+      T gb = (T)0;
+      for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
+      adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, c);
+    }
+  }
+  __syncthreads();
+  // delta1[s][k] = (sum_j W2[j][k] delta2[s][j]) * (h1[s][k] > 0), in place over h1 (LDS still holds
+  // the weights this step started from: the update above went to global memory only).
+  // Thread tile 2 samples x 4 inputs k, k interleaved by 16 so that the rows of wt2 read by the
+  // lanes of a wave fall into different banks.
+  {
+    const int kg = t & 15, sg = t >> 4;
+    const int s0 = sg * 2;
+    T acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[0][b] = acc[1][b] = (T)0;
+#pragma unroll 4
+    for (int j = 0; j < kH; ++j) {
+      const T d0 = L.h2[s0 * kRow + j], d1 = L.h2[(s0 + 1) * kRow + j];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const T w = L.wt2[(kg + 16 * b) * kRow + j];
+        acc[0][b] = fma_t<T>(w, d0, acc[0][b]);
+        acc[1][b] = fma_t<T>(w, d1, acc[1][b]);
+      }
+    }
+    __syncthreads();   // every read of h1's activations by the tiles above is done (none here),
+                       // and every thread has its sums: now the buffer can be overwritten
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int k = kg + 16 * b;
+      const T h0 = L.h1[s0 * kRow + k], h1v = L.h1[(s0 + 1) * kRow + k];
+      L.h1[s0 * kRow + k] = h0 > (T)0 ? acc[0][b] : (T)0;
+      L.h1[(s0 + 1) * kRow + k] = h1v > (T)0 ? acc[1][b] : (T)0;
+    }
+  }
+  __syncthreads();
+
+  // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
+  for (int e = t; e < kH * D; e += 256) {
+    const int j = e / D, d = e - j * D;
+    T g = (T)0;
+#pragma unroll 8
+    for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
+    adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, c);
+  }
+  if (t < kH) {
+    T gb = (T)0;
+    for (int s = 0; s < kB; ++s) gb = gb + L.h1[s * kRow + t];
+    adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, c);
+  }
+}
+
+}  // namespace
+
+extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
+                                      int32_t n_actions, int32_t batch, int32_t is_float64,
+                                      int32_t* lds_bytes) {
+  COBEL_REQUIRE(n_inputs >= 1 && n_inputs <= kMaxD && n_hidden1 == kH && n_hidden2 == kH &&
+                    n_actions == kA && batch == kB,
+                COBEL_E_UNSUPPORTED,
+                "cobel_dqn_replay: the fused step covers Linear(D <= %d, 64)-ReLU-Linear(64, 64)-"
+                "ReLU-Linear(64, 4) on batches of 32 (got D %d, %d-%d, %d actions, batch %d)",
+                kMaxD, n_inputs, n_hidden1, n_hidden2, n_actions, batch);
+  if (lds_bytes) *lds_bytes = (int32_t)(mlp_lds_elems(n_inputs) * (is_float64 ? 8 : 4));
+  return COBEL_OK;
+}
+
+extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
+  COBEL_REQUIRE(run, COBEL_E_ARG, "cobel_dqn_replay: NULL run");
+  const cobel_dqn_replay_t& r = *run;
+  int32_t lds = 0;
+  if (int rc = cobel_dqn_replay_query(r.n_inputs, r.n_hidden1, r.n_hidden2, r.n_actions, r.batch,
+                                      r.is_float64, &lds))
+    return rc;
+  for (int l = 0; l < 3; ++l)
+    COBEL_REQUIRE(r.w[l] && r.b[l] && r.w_target[l] && r.b_target[l] && r.m_w[l] && r.m_b[l] &&
+                      r.v_w[l] && r.v_b[l],
+                  COBEL_E_ARG, "cobel_dqn_replay: NULL parameter / moment tensor (layer %d)", l);
+  COBEL_REQUIRE(r.states && r.next_states && r.actions && r.rewards && r.nonterminal && r.steps,
+                COBEL_E_ARG, "cobel_dqn_replay: NULL batch tensor or step counts");
+  COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_dqn_replay: n = %d", r.n);
+  if (r.n == 0) return COBEL_OK;
+  mlp_args A;
+  A.r = r;
+  hipStream_t st = (hipStream_t)stream;
+  if (r.is_float64) {
+    if (lds > 64 * 1024)
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dqn_replay<double>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k_dqn_replay<double>, dim3(r.n), dim3(256), lds, st, A);
+  } else {
+    hipLaunchKernelGGL(k_dqn_replay<float>, dim3(r.n), dim3(256), lds, st, A);
+  }
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

@@ -465,6 +465,46 @@ COBEL_API int cobel_adam_step(void* param /* [dev] [N][per_instance] */,
                                               (the DQN target blend, agent/dqn.py:366-371) */,
                               double tau, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One DQN replay step per instance in ONE kernel, for networks of the shape the reference's DQN
+ * demos and tests use — Linear(D, 64) - ReLU - Linear(64, 64) - ReLU - Linear(64, 4), D <= 32,
+ * batches of 32, float64 or float32, MSE loss, torch.optim.Adam without amsgrad:
+ *   targets = Q_online(s); targets[a] = r + gamma * nt * max_a' Q_target(s')   (agent/dqn.py:346-364;
+ *             ddqn != 0: a' = argmax Q_online(s'), :352-355)
+ *   loss = mean((Q_online(s) - targets)^2); backward; Adam step   (network/network_torch.py:160-167)
+ *   w_target += tau * (w_online - w_target)                       (agent/dqn.py:366-371; tau 0 = none)
+ * Parameters are torch.nn.Linear tensors stacked over instances: w[l] [N][out][in], b[l] [N][out]
+ * for the online network, *_target for the target network, m_* / v_* Adam's exp_avg / exp_avg_sq
+ * of the online network.  steps / active as for cobel_adam_step.  The batch is given gathered:
+ * states / next_states [N][32][D], actions int64 [N][32], rewards and the non-terminal flags
+ * (1 - end_trial, agent/dqn.py:191) [N][32] in the network's dtype.  All device memory, caller-owned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  void* w[3];
+  void* b[3];
+  void* w_target[3];
+  void* b_target[3];
+  void* m_w[3];
+  void* m_b[3];
+  void* v_w[3];
+  void* v_b[3];
+  const double* steps;      /* [N] Adam step count INCLUDING this step                          */
+  const uint8_t* active;    /* [N] or NULL                                                      */
+  const void* states;       /* [N][batch][n_inputs]                                             */
+  const void* next_states;
+  const int64_t* actions;   /* [N][batch]                                                       */
+  const void* rewards;      /* [N][batch]                                                       */
+  const void* nonterminal;  /* [N][batch]                                                       */
+  int32_t n, n_inputs, n_hidden1, n_hidden2, n_actions, batch;
+  int32_t is_float64, ddqn;
+  double gamma, lr, beta1, beta2, eps, weight_decay, tau;
+} cobel_dqn_replay_t;
+/* 0 = the fused step covers this network / batch shape; fills *lds_bytes (per instance). */
+COBEL_API int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
+                                     int32_t n_actions, int32_t batch, int32_t is_float64,
+                                     int32_t* lds_bytes);
+COBEL_API int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

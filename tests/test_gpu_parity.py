@@ -1488,3 +1488,78 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
     r = bench.Runner(cfg, env, ag)
     got = ag.describe_launch(env, ag.policy, r.flags | _lib.F_MASK_ACTIONS, 0x7fffffff, 200, 16, 50)
     assert got['kernel'] == _lib.TAB_KERNEL_WPI and got['lds_bytes'] == 1024 * 24 + 2048
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused DQN replay step (cobel_dqn_replay) against the PyTorch path it replaces
+@pytest.mark.parametrize('dtype_name,n_in,ddqn', [('f64', 6, False), ('f64', 25, True),
+                                                  ('f32', 6, False), ('f64', 1, False)])
+def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn):
+    """targets -> MSE backward -> Adam -> target blend in one kernel == the same step through
+    vmap'ed forward passes, autograd and the optimizer kernel: online and target parameters and
+    both Adam moments after every one of 10 steps fed with the same batches (duplicated samples,
+    terminal transitions, an activity mask that changes from step to step, weight decay)."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd.network import TorchNetwork
+    dt = torch.float64 if dtype_name == 'f64' else torch.float32
+    tol = dict(rtol=1e-10, atol=1e-13) if dtype_name == 'f64' else dict(rtol=2e-4, atol=1e-6)
+    n, B, gamma, tau = 23, 32, 0.8, 0.01
+    gen = torch.Generator(device='cuda').manual_seed(7)
+
+    def build(fused):
+        torch.manual_seed(3)
+        proto = TorchNetwork(bench._mlp(n_in, 4, dtype_name), optimizer_params={
+            'lr': 2e-3, 'weight_decay': 1e-3 if n_in == 25 else 0.0})
+        proto.set_device(torch.device('cuda', 0))
+        net = proto.replicate(n)
+        with torch.no_grad():   # one network per instance, all different
+            for p in net.params.values():
+                p.add_(0.05 * torch.randn(p.shape, generator=gen, device='cuda', dtype=dt))
+        net.fused_mlp = fused
+        return net
+
+    gen.manual_seed(7)
+    fused = build(True)
+    gen.manual_seed(7)
+    plain = build(False)
+    fused_t, plain_t = fused.clone(), plain.clone()
+    with torch.no_grad():
+        for a, b in zip(fused_t.params.values(), plain_t.params.values()):
+            a.mul_(0.9)
+            b.mul_(0.9)
+    for step in range(10):
+        s = torch.rand((n, B, n_in), generator=gen, device='cuda', dtype=dt) * 2 - 0.5
+        ns = torch.rand((n, B, n_in), generator=gen, device='cuda', dtype=dt) * 2 - 0.5
+        s[:, 5] = s[:, 4]          # sampling is with replacement: repeated experiences
+        a = torch.randint(0, 4, (n, B), generator=gen, device='cuda')
+        a[:, 5] = a[:, 4]
+        r = torch.rand((n, B), generator=gen, device='cuda', dtype=dt)
+        nt = (torch.rand((n, B), generator=gen, device='cuda') < 0.8).to(dt)
+        active = None if step < 3 else (torch.rand(n, generator=gen, device='cuda') < 0.7)
+        if active is not None and not bool(active.any()):
+            active[0] = True
+        assert fused.dqn_replay_fused(fused_t, s, a, r, ns, nt, gamma, ddqn, tau, active)
+        assert not plain.dqn_replay_fused(plain_t, s, a, r, ns, nt, gamma, ddqn, tau, active)
+        with torch.no_grad():      # DQN.replay's PyTorch path (agent/dqn.py of this package)
+            targets = plain.forward(s).clone()
+            boot = plain_t.forward(ns)
+            pick = (plain.forward(ns) if ddqn else boot).argmax(dim=2)
+            boot = torch.gather(boot, 2, pick[..., None])[..., 0]
+            targets.scatter_(2, a[..., None], (r + boot * nt * gamma)[..., None])
+        plain.train_on_device(s, targets, active, blend_into=plain_t, tau=tau)
+        for (k, x), y in zip(fused.params.items(), plain.params.values()):
+            assert torch.allclose(x, y, **tol), (step, k, float((x - y).abs().max()))
+            sx, sy = fused.optimizer.state[x], plain.optimizer.state[y]
+            assert torch.allclose(sx['exp_avg'], sy['exp_avg'], **tol), (step, k)
+            assert torch.allclose(sx['exp_avg_sq'], sy['exp_avg_sq'], **tol), (step, k)
+            assert torch.equal(sx['steps'], sy['steps'])
+        for (k, x), y in zip(fused_t.params.items(), plain_t.params.values()):
+            assert torch.allclose(x, y, **tol), (step, k)
+    # networks of another shape are left to the PyTorch path
+    other = TorchNetwork(torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(),
+                                             torch.nn.Linear(32, 4)).to(dt))
+    other.set_device(torch.device('cuda', 0))
+    o = other.replicate(3)
+    assert not o.dqn_replay_fused(o.clone(), s[:3], a[:3], r[:3], ns[:3], nt[:3], gamma, False,
+                                  tau, None)
