@@ -20,14 +20,17 @@
 //     into different banks); the backward pass overwrites them in place with the deltas;
 //   * every thread applies Adam to the gradient elements it has just accumulated in registers —
 //     gradients never exist in memory; p, m, v are read once and written once, the target network's
-//     copy is read once (its forward pass) plus once and written once (the blend).
+//     copy is read once (its forward pass; each thread keeps the elements it will blend) and
+//     written once.
 // HBM traffic per instance and step: 8 streams over the parameters (online read + write, two
-// moments read + write, target read + write) + one more read of the target = 9 x 39 KB (float64).
+// moments read + write, target read + write) = 8 x 39 KB (float64).
 //
 // Arithmetic: products are accumulated with fused multiply-adds in the network's dtype, one
 // accumulator per output in index order — not torch's GEMM order, so results agree with the
 // PyTorch path to rounding (1e-12 relative in float64 on single steps; tests bound it), not bit for
 // bit.  The optimizer update is k_adam's (adam.hip), operation for operation.
+#include <stdlib.h>
+
 #include "cobel_common.h"
 
 namespace {
@@ -40,6 +43,9 @@ constexpr int kMaxD = 32;     // input width limit
 
 struct mlp_args {
   cobel_dqn_replay_t r;
+  int32_t skip;   // timing experiments only (COBEL_DEBUG_MLP_SKIP): phases left out, results invalid
+  int32_t stagger_ticks;   // span of the start delays of the first resident workgroups, 10 ns units
+  int32_t stagger_first;   // workgroups that are resident when the launch begins
 };
 
 template <typename T>
@@ -64,6 +70,18 @@ __host__ __device__ inline size_t mlp_lds_elems(int D) {
          2 * (size_t)kB * kRow + 2 * kB * kA + kB + kB /* pick, as T-sized slots */;
 }
 
+// Threads of a workgroup talk through LDS only, so its barriers wait for the LDS counter, not for
+// memory (__syncthreads() also drains vmcnt: the optimizer-state and parameter loads issued ahead
+// of their use, and the parameter stores of the previous phase, are meant to stay in flight).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T>
+struct alignas(4 * sizeof(T)) vec4 {
+  T x[4];
+};
+
 template <typename T>
 __device__ __forceinline__ T fma_t(T a, T b, T c);
 template <>
@@ -82,43 +100,86 @@ struct adam_consts {
   bool has_wd, blend;
 };
 
+// The optimizer state of an element (and the target network's copy of the parameter) is loaded
+// at the start of the kernel, long before the gradient exists: by the time the update runs, the
+// loads of all of a thread's elements have returned together instead of one after another.
+template <typename T>
+struct adam_slot {
+  T m, v, target;
+};
+
+template <typename T>
+__device__ __forceinline__ void adam_update(T p_old, T g, const adam_slot<T>& s,
+                                            const adam_consts<T>& c, T& pn, T& mn, T& vn, T& tn) {
+  if (c.has_wd) g = g + c.wd * p_old;
+  mn = s.m + c.one_m_b1 * (g - s.m);
+  vn = s.v * c.b2 + (c.one_m_b2 * g) * g;
+  const T denom = sqrt(vn) / c.bc2_sqrt + c.eps;
+  pn = p_old - c.step_size * (mn / denom);
+  tn = s.target + c.tau * (pn - s.target);
+}
+
 template <typename T>
 __device__ __forceinline__ void adam_apply(T* __restrict__ p, T* __restrict__ m,
                                            T* __restrict__ v, T* __restrict__ tgt, size_t e,
-                                           T p_old, T g, const adam_consts<T>& c) {
-  if (c.has_wd) g = g + c.wd * p_old;
-  const T mo = m[e], vo = v[e];
-  const T mn = mo + c.one_m_b1 * (g - mo);
-  const T vn = vo * c.b2 + (c.one_m_b2 * g) * g;
-  const T denom = sqrt(vn) / c.bc2_sqrt + c.eps;
-  const T pn = p_old - c.step_size * (mn / denom);
+                                           T p_old, T g, const adam_slot<T>& s,
+                                           const adam_consts<T>& c) {
+  T pn, mn, vn, tn;
+  adam_update<T>(p_old, g, s, c, pn, mn, vn, tn);
   m[e] = mn;
   v[e] = vn;
   p[e] = pn;
-  if (c.blend) {
-    const T te = tgt[e];
-    tgt[e] = te + c.tau * (pn - te);
-  }
+  if (c.blend) tgt[e] = tn;
 }
 
-// Stage one network's parameters (torch.nn.Linear layout [out][in]) into LDS.
+// One network's parameters (torch.nn.Linear layout [out][in]) on their way into LDS: loaded into
+// registers (the online network's while the target network's forward pass runs), written to LDS
+// when the buffer is free.
 template <typename T>
-__device__ void stage_params(const mlp_lds<T>& L, const T* w1, const T* b1, const T* w2,
-                             const T* b2, const T* w3, const T* b3, int D, int t) {
-  for (int e = t; e < kH * kH; e += 256) {   // coalesced read along k, transposed write
-    const int j = e >> 6, k = e & 63;
-    L.wt2[k * kRow + j] = w2[e];
+struct param_regs {
+  T w2[16], w1[kMaxD / 4], w3, b1, b2, b3;
+};
+
+template <typename T>
+__device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restrict__ w1,
+                                            const T* __restrict__ b1, const T* __restrict__ w2,
+                                            const T* __restrict__ b2, const T* __restrict__ w3,
+                                            const T* __restrict__ b3, int D, int t) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) P.w2[u] = w2[t + 256 * u];   // coalesced along k
+#pragma unroll
+  for (int u = 0; u < kMaxD / 4; ++u) {
+    const int e = t + 256 * u;
+    P.w1[u] = e < kH * D ? w1[e] : (T)0;
   }
-  for (int e = t; e < kH * D; e += 256) {
-    const int j = e / D, d = e - j * D;
-    L.wt1[d * kH + j] = w1[e];
+  P.w3 = w3[t];   // 4 * 64 = 256 elements
+  P.b1 = t < kH ? b1[t] : (T)0;
+  P.b2 = t < kH ? b2[t] : (T)0;
+  P.b3 = t < kA ? b3[t] : (T)0;
+}
+
+template <typename T>
+__device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T>& P, int D,
+                                             int t) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {   // transposed write
+    const int e = t + 256 * u;
+    L.wt2[(e & 63) * kRow + (e >> 6)] = P.w2[u];
   }
-  L.w3[t] = w3[t];   // 4 * 64 = 256 elements
+#pragma unroll
+  for (int u = 0; u < kMaxD / 4; ++u) {
+    const int e = t + 256 * u;
+    if (e < kH * D) {
+      const int j = e / D, d = e - j * D;
+      L.wt1[d * kH + j] = P.w1[u];
+    }
+  }
+  L.w3[t] = P.w3;
   if (t < kH) {
-    L.b1[t] = b1[t];
-    L.b2[t] = b2[t];
+    L.b1[t] = P.b1;
+    L.b2[t] = P.b2;
   }
-  if (t < kA) L.b3[t] = b3[t];
+  if (t < kA) L.b3[t] = P.b3;
 }
 
 // h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), out[s][a] = W3 h2 + b3 for the 32 rows of L.x.
@@ -146,7 +207,7 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
       L.h1[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
     }
   }
-  __syncthreads();
+  lds_barrier();
   {
     T acc[2][4];
 #pragma unroll
@@ -167,7 +228,7 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
       L.h2[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (t < kB * kA) {
     const int s = t >> 2, a = t & 3;
     T acc = L.b3[a];
@@ -175,7 +236,7 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
     for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[a * kH + k], L.h2[s * kRow + k], acc);
     out[s * kA + a] = acc;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 template <typename T>
@@ -191,6 +252,12 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   if (R.active && !R.active[i]) return;
   const int t = (int)threadIdx.x;
   const int D = R.n_inputs;
+  if (A.stagger_ticks > 0 && (int)blockIdx.x < A.stagger_first) {
+    const uint32_t phase = ((uint32_t)blockIdx.x * 2654435769u) >> 16;   // golden-ratio sequence
+    const unsigned long long wait = ((unsigned long long)phase * (uint32_t)A.stagger_ticks) >> 16;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   mlp_lds<T> L;
   {
     T* p = reinterpret_cast<T*>(lds_raw);
@@ -224,14 +291,52 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   const T* const xs = (const T*)R.states + (size_t)i * kB * D;
   const T* const xn = (const T*)R.next_states + (size_t)i * kB * D;
 
+  T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
+  T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
+  T* const m_w3 = (T*)R.m_w[2] + (size_t)i * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)i * n3;
+  T* const m_b1 = (T*)R.m_b[0] + (size_t)i * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)i * kH;
+  T* const m_b2 = (T*)R.m_b[1] + (size_t)i * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)i * kH;
+  T* const m_b3 = (T*)R.m_b[2] + (size_t)i * kA; T* const v_b3 = (T*)R.v_b[2] + (size_t)i * kA;
+
+  // ---- the elements this thread will update (see adam_slot) -----------------------------------
+  // second layer: the 4 x 4 tile (j0 .., k0 ..) of the backward pass; first layer: elements
+  // t, t + 256, ...; output layer: element t; biases: threads < 64 / < 4.  The moments are loaded
+  // at the start of the backward pass (kept in registers from the start of the kernel, or from
+  // before the online forward pass, they crowd the forward passes' inner loops: measured slower in
+  // float64, 902 -> 952 us per launch at 8 192 instances).
+  const int kg2 = t & 15, jg2 = t >> 4;
+  adam_slot<T> s2[4][4], s1[kMaxD / 4], s3, sb1, sb2, sb3;
   // ---- Q_target(s') ---------------------------------------------------------------------------
-  stage_params<T>(L, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
+  param_regs<T> P;
+  params_load<T>(P, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
+  params_store<T>(L, P, D, t);
   load_rows<T>(L.x, xn, kB * D, t);
-  __syncthreads();
-  forward<T>(L, L.qt, D, t);
+  lds_barrier();
+  params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);   // in flight during the target forward pass
+  // the target network's copies of this thread's elements, for the blend at the end
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      s2[a][b].target = L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a];
+#pragma unroll
+  for (int u = 0; u < kMaxD / 4; ++u) {
+    const int e = t + 256 * u;
+    s1[u].target = (T)0;
+    if (e < kH * D) {
+      const int j = e / D, d = e - j * D;
+      s1[u].target = L.wt1[d * kH + j];
+    }
+  }
+  s3.target = L.w3[t];
+  sb1.target = t < kH ? L.b1[t] : (T)0;
+  sb2.target = t < kH ? L.b2[t] : (T)0;
+  sb3.target = t < kA ? L.b3[t] : (T)0;
+  if (A.skip & 64) return;
+  if (!(A.skip & 1)) forward<T>(L, L.qt, D, t);
   // ---- online network -------------------------------------------------------------------------
-  stage_params<T>(L, w1, b1, w2, b2, w3, b3, D, t);
-  __syncthreads();
+  params_store<T>(L, P, D, t);
+  lds_barrier();
   if (R.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
     forward<T>(L, L.q, D, t);
     if (t < kB) {
@@ -245,11 +350,12 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
         }
       L.pick[t] = best;
     }
-    __syncthreads();
+    lds_barrier();
   }
   load_rows<T>(L.x, xs, kB * D, t);
-  __syncthreads();
-  forward<T>(L, L.q, D, t);
+  lds_barrier();
+  if (!(A.skip & 2)) forward<T>(L, L.q, D, t);
+  if (A.skip & 4) return;
 
   // ---- targets and the loss gradient at the output ----------------------------------------------
   // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the 32 x 4
@@ -268,7 +374,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     const T nt = ((const T*)R.nonterminal)[(size_t)i * kB + t];
     L.boot[t] = r + (boot * nt) * (T)R.gamma;
   }
-  __syncthreads();
+  lds_barrier();
   if (t < kB * kA) {
     const int s = t >> 2, a = t & 3;
     const int act = (int)R.actions[(size_t)i * kB + s];
@@ -276,7 +382,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
     L.q[t] = (a == act) ? g : (T)0;   // delta3
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- Adam constants of this instance ----------------------------------------------------------
   adam_consts<T> c;
@@ -294,12 +400,36 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     c.tau = (T)R.tau;
     c.blend = R.tau != 0.0;
   }
-  T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
-  T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
-  T* const m_w3 = (T*)R.m_w[2] + (size_t)i * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)i * n3;
-  T* const m_b1 = (T*)R.m_b[0] + (size_t)i * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)i * kH;
-  T* const m_b2 = (T*)R.m_b[1] + (size_t)i * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)i * kH;
-  T* const m_b3 = (T*)R.m_b[2] + (size_t)i * kA; T* const v_b3 = (T*)R.v_b[2] + (size_t)i * kA;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {   // 4 consecutive elements of a row: one 16- / 32-byte load each
+    const size_t e = (size_t)(jg2 * 4 + a) * kH + kg2 * 4;
+    const vec4<T> mv = *reinterpret_cast<const vec4<T>*>(m_w2 + e);
+    const vec4<T> vv = *reinterpret_cast<const vec4<T>*>(v_w2 + e);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      s2[a][b].m = mv.x[b];
+      s2[a][b].v = vv.x[b];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kMaxD / 4; ++u) {
+    const int e = t + 256 * u;
+    s1[u].m = s1[u].v = (T)0;
+    if (e < kH * D) {
+      s1[u].m = m_w1[e];
+      s1[u].v = v_w1[e];
+    }
+  }
+  s3.m = m_w3[t];
+  s3.v = v_w3[t];
+  sb1.m = sb1.v = sb2.m = sb2.v = sb3.m = sb3.v = (T)0;
+  if (t < kH) {
+    sb1.m = m_b1[t]; sb1.v = v_b1[t];
+    sb2.m = m_b2[t]; sb2.v = v_b2[t];
+  }
+  if (t < kA) {
+    sb3.m = m_b3[t]; sb3.v = v_b3[t];
+  }
 
   // ---- output layer: dW3[a][k] = sum_s delta3[s][a] h2[s][k], db3[a] = sum_s delta3[s][a] --------
   {
@@ -307,14 +437,14 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     T g = (T)0;
 #pragma unroll 8
     for (int s = 0; s < kB; ++s) g = fma_t<T>(L.q[s * kA + a], L.h2[s * kRow + k], g);
-    adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, c);
+    adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, s3, c);
     if (t < kA) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kA + t];
-      adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, c);
+      adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, sb3, c);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // delta2[s][k] = (sum_a W3[a][k] delta3[s][a]) * (h2[s][k] > 0), in place over h2
   for (int e = t; e < kB * kH; e += 256) {
     const int s = e >> 6, k = e & 63;
@@ -324,12 +454,11 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     const T h = L.h2[s * kRow + k];
     L.h2[s * kRow + k] = h > (T)0 ? d : (T)0;
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k]; thread tile 4 j x 4 k -----------------
   {
-    const int kg = t & 15, jg = t >> 4;
-    const int j0 = jg * 4, k0 = kg * 4;
+    const int j0 = jg2 * 4, k0 = kg2 * 4;
     T g[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -349,19 +478,25 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
         for (int b = 0; b < 4; ++b) g[a][b] = fma_t<T>(dj[a], hk[b], g[a][b]);
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      vec4<T> pn, mn, vn, tn;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = j0 + a, k = k0 + b;
-        adam_apply<T>(w2, m_w2, v_w2, tw2, (size_t)j * kH + k, L.wt2[k * kRow + j], g[a][b], c);
-      }
+      for (int b = 0; b < 4; ++b)
+        adam_update<T>(L.wt2[(k0 + b) * kRow + j0 + a], g[a][b], s2[a][b], c, pn.x[b], mn.x[b],
+                       vn.x[b], tn.x[b]);
+      const size_t e = (size_t)(j0 + a) * kH + k0;
+      *reinterpret_cast<vec4<T>*>(m_w2 + e) = mn;
+      *reinterpret_cast<vec4<T>*>(v_w2 + e) = vn;
+      *reinterpret_cast<vec4<T>*>(w2 + e) = pn;
+      if (c.blend) *reinterpret_cast<vec4<T>*>(tw2 + e) = tn;
+    }
     if (t < kH) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
-      adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, c);
+      adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // delta1[s][k] = (sum_j W2[j][k] delta2[s][j]) * (h1[s][k] > 0), in place over h1 (LDS still holds
   // the weights this step started from: the update above went to global memory only).
   // Thread tile 2 samples x 4 inputs k, k interleaved by 16 so that the rows of wt2 read by the
@@ -382,7 +517,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
         acc[1][b] = fma_t<T>(w, d1, acc[1][b]);
       }
     }
-    __syncthreads();   // every read of h1's activations by the tiles above is done (none here),
+    lds_barrier();   // every read of h1's activations by the tiles above is done (none here),
                        // and every thread has its sums: now the buffer can be overwritten
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -392,20 +527,24 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
       L.h1[(s0 + 1) * kRow + k] = h1v > (T)0 ? acc[1][b] : (T)0;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
-  for (int e = t; e < kH * D; e += 256) {
-    const int j = e / D, d = e - j * D;
-    T g = (T)0;
+#pragma unroll
+  for (int u = 0; u < kMaxD / 4; ++u) {
+    const int e = t + 256 * u;
+    if (e < kH * D) {
+      const int j = e / D, d = e - j * D;
+      T g = (T)0;
 #pragma unroll 8
-    for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
-    adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, c);
+      for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
+      adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
+    }
   }
   if (t < kH) {
     T gb = (T)0;
     for (int s = 0; s < kB; ++s) gb = gb + L.h1[s * kRow + t];
-    adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, c);
+    adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, sb1, c);
   }
 }
 
@@ -441,6 +580,15 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   if (r.n == 0) return COBEL_OK;
   mlp_args A;
   A.r = r;
+  const char* skip = getenv("COBEL_DEBUG_MLP_SKIP");
+  A.skip = skip ? atoi(skip) : 0;
+  // Workgroups that start together stay in step: all load, then all compute.  The ones resident
+  // at the start of a launch that needs several rounds begin at delays spread over 20 us (float64;
+  // 10 us float32), so that the memory phases of the workgroups sharing a CU fall into each
+  // other's compute phases (8 192 instances: 900 -> 770 us per launch in float64).
+  const char* stag = getenv("COBEL_DEBUG_MLP_STAGGER_US");
+  A.stagger_first = 256 * (r.is_float64 ? 2 : 3);
+  A.stagger_ticks = stag ? atoi(stag) * 100 : (r.n > 2 * A.stagger_first ? (r.is_float64 ? 2000 : 1000) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
     if (lds > 64 * 1024)
