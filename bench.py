@@ -71,9 +71,11 @@ CONFIGS = {
 SEED = 0xC0BE1
 
 
-def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=True):
+def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=None):
     """C5: 8192 linear_track(10, 2) Topology envs, DQN 6-64-64-4 (gamma .8, eps .3, Adam 1e-3, MSE,
-    tau .01, batch 32, 100 steps/trial) through PyTorch-ROCm with one network per instance."""
+    tau .01, batch 32, 100 steps/trial), one network and one replay ring per instance.  graph =
+    None: the two-kernel loop (cobel_dqn_act + cobel_dqn_replay); True: the PyTorch loop with one
+    step captured as a HIP graph (forward passes by vmap, the replay step still cobel_dqn_replay)."""
     from collections import OrderedDict
     from cobel_amd.agent import DQN
     from cobel_amd.interface import Topology
@@ -99,14 +101,24 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=True):
     agent._run(env, 4096, 100, 32, True, budget=iters)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    how = ('two launches per lockstep step: cobel_dqn_act + cobel_dqn_replay' if agent.fused_steps
+           else 'PyTorch-ROCm loop' + (', one step captured as a HIP graph and replayed' if graph
+                                       else ''))
+    # cobel_dqn_replay moves 8 streams over an instance's parameters (online, two Adam moments,
+    # target: read + write each) = the algorithmic HBM bytes of a step
+    n_params = sum(p.numel() for p in agent.model_online.model.parameters())
+    bytes_per_step = 8 * n_params * (8 if dtype_name == 'f64' else 4)
     return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
             'dtype': dtype_name,
             'config': {'workload': 'C5: %d x linear_track(10,2) Topology, DQN 6-64-64-4 %s, one '
-                                   'network + replay ring per instance, batch 32, via PyTorch-ROCm'
-                                   '%s' % (n, dtype_name, ', one step captured as a HIP graph and '
-                                           'replayed' if graph else ''), 'instances_per_gpu': n,
+                                   'network + replay ring per instance, batch 32, %s'
+                                   % (n, dtype_name, how), 'instances_per_gpu': n,
                        'lockstep_iterations': iters},
-            'roofline': None}
+            'roofline': {'bound': 'hbm', 'achieved': bytes_per_step * n * iters / dt / 1e9,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': bytes_per_step * n * iters / dt / 1e9 / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'k_dqn_replay',
+                         'algorithmic_bytes_per_env_step': bytes_per_step}}
 
 
 def _mlp(n_in, n_out, dtype_name='f64'):

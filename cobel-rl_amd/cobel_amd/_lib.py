@@ -55,6 +55,29 @@ class DQNReplay(C.Structure):
         ('is_float64', C.c_int32), ('ddqn', C.c_int32),
         ('gamma', C.c_double), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
         ('eps', C.c_double), ('weight_decay', C.c_double), ('tau', C.c_double),
+        ('batch_slots', C.c_void_p), ('ring_slots', C.c_int32), ('reserved_', C.c_int32),
+        ('obs_index', C.c_void_p), ('obs_table', C.c_void_p), ('q_out', C.c_void_p),
+    ]
+
+
+class DQNAct(C.Structure):
+    """``cobel_dqn_act_t``."""
+    _fields_ = [
+        ('state', C.c_void_p), ('env_ctr', C.c_void_p), ('obs_table', C.c_void_p),
+        ('q', C.c_void_p), ('policy_ctr', C.c_void_p), ('policy_stream', C.c_uint32),
+        ('is_float64', C.c_int32), ('epsilon', C.c_double),
+        ('ring_states', C.c_void_p), ('ring_next_states', C.c_void_p),
+        ('ring_actions', C.c_void_p), ('ring_rewards', C.c_void_p),
+        ('ring_nonterminal', C.c_void_p), ('ring_size', C.c_void_p), ('ring_head', C.c_void_p),
+        ('memory_ctr', C.c_void_p),
+        ('trial', C.c_void_p), ('step', C.c_void_p), ('trial_reward', C.c_void_p),
+        ('active', C.c_void_p), ('adam_steps', C.c_void_p),
+        ('lat_sum', C.c_void_p), ('lat_cnt', C.c_void_p), ('reward_sum', C.c_void_p),
+        ('stepped', C.c_void_p), ('batch_slots', C.c_void_p),
+        ('n', C.c_int32), ('n_obs', C.c_int32), ('slots', C.c_int32), ('batch', C.c_int32),
+        ('steps_per_trial', C.c_int32), ('trials_target', C.c_int32), ('trial_cap', C.c_int32),
+        ('mon_stripes', C.c_int32),
+        ('instance_base', C.c_uint32), ('reserved_', C.c_uint32), ('seed', C.c_uint64),
     ]
 
 
@@ -176,6 +199,7 @@ _SIGNATURES = {
 }
 _SIGNATURES['cobel_dqn_replay_query'] = (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)])
 _SIGNATURES['cobel_dqn_replay'] = (C.c_int, [C.POINTER(DQNReplay), _P])
+_SIGNATURES['cobel_dqn_act'] = (C.c_int, [_P, C.POINTER(DQNAct), _P])
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

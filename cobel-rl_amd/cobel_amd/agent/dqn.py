@@ -43,6 +43,10 @@ class DQN(Agent):
         # needed: True / False, or None = from 256 instances on (fixed-budget runs: only if True)
         self.use_graph = None
         self.graph_replays = 0     # lockstep steps executed from a graph so far
+        # two-kernel training step (cobel_dqn_act + cobel_dqn_replay) for 64-64 ReLU networks on a
+        # Topology: None = whenever the run qualifies (and use_graph is not forced), False = never
+        self.fused_loop = None
+        self.fused_steps = 0       # lockstep steps executed by the two-kernel loop so far
         self.n_envs = None
         self.monitors = None
         self._online = self._target = None
@@ -155,6 +159,119 @@ class DQN(Agent):
         return {'states': states, 'actions': actions, 'rewards': rewards,
                 'next_states': next_states, 'terminals': terminals}
 
+    # -- the two-kernel training loop --------------------------------------------------------------
+    def _fused_loop_ok(self, interface, pol, batch_size: int) -> bool:
+        """The run is one the two fused kernels cover: a plain DQN (replay ring, blended target)
+        with a 64-64 ReLU network and an epsilon-greedy policy on a Topology."""
+        from ..interface.topology import Topology
+        from ..policy.greedy import EpsilonGreedy
+        net = self._online
+        if type(self) is not DQN or self.fused_loop is False or self.use_graph is True \
+                or not isinstance(interface, Topology) or type(self.M) is not DQNMemory \
+                or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \
+                or getattr(self, '_no_replay', False) or not net.fused_mlp:
+            return False
+        names = net._mlp3_names()
+        if names is None or self._target._mlp3_names() != names or not net._fused_adam_ok() \
+                or type(net.criterion) is not torch.nn.MSELoss \
+                or getattr(net.criterion, 'reduction', '') != 'none':
+            return False
+        w = [net.params[k + '.weight'] for k in names]
+        if w[1].shape[2] != w[0].shape[1] or w[2].shape[2] != w[1].shape[1] \
+                or self.dtype not in (torch.float64, torch.float32):
+            return False
+        return _lib.lib().cobel_dqn_replay_query(
+            w[0].shape[2], w[0].shape[1], w[1].shape[1], w[2].shape[1], batch_size,
+            int(self.dtype == torch.float64), None) == _lib.OK
+
+    def _run_fused(self, interface, pol, trials: int, steps: int, batch_size: int,
+                   budget: int) -> None:
+        """Two launches per lockstep step and nothing else: cobel_dqn_act (select, env.step,
+        ring store, trial bookkeeping, batch draw) and cobel_dqn_replay (the optimisation step,
+        plus the Q-values of the next observation for the next cobel_dqn_act).  Same streams,
+        counters and arithmetic as the PyTorch loop in ``_run``; instances that have run their
+        trials are skipped by both kernels, so the loop only looks at the device between chunks."""
+        import ctypes as C
+        n, dev, net, M, mon = self.n_envs, self.device, self._online, self.M, self.monitors
+        first = self.current_trial
+        f64 = self.dtype == torch.float64
+        table = interface._pose_dev
+        q = self._q_values(interface.observe().to(self.dtype)).contiguous()
+        step = torch.zeros(n, dtype=torch.int32, device=dev)
+        trew = torch.zeros(n, dtype=torch.float64, device=dev)
+        active = torch.ones(n, dtype=torch.uint8, device=dev)
+        stepped = torch.zeros(n, dtype=torch.uint8, device=dev)
+        slots = torch.zeros((n, batch_size), dtype=torch.int32, device=dev)
+        # Adam step counts per instance (shared with the PyTorch path's fused optimizer kernel)
+        net._diverged = True
+        opt = net.optimizer
+        counts = getattr(net, '_steps', None)
+        if counts is None:
+            seen = [float(st['steps'].max()) if 'steps' in st else float(st.get('step', 0.0))
+                    for st in opt.state.values()]
+            counts = net._steps = torch.full((n,), max(seen, default=0.0), dtype=torch.float64,
+                                             device=dev)
+        names = net._mlp3_names()
+        rep = _lib.DQNReplay()
+        for k, name in enumerate(names):
+            for kind, dp, dt_, dm, dv in (('.weight', rep.w, rep.w_target, rep.m_w, rep.v_w),
+                                          ('.bias', rep.b, rep.b_target, rep.m_b, rep.v_b)):
+                p = net.params[name + kind]
+                st = opt.state[p]
+                if 'exp_avg' not in st:
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                    st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st['steps'] = counts
+                dp[k], dt_[k] = _lib.ptr(p), _lib.ptr(self._target.params[name + kind])
+                dm[k], dv[k] = _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq'])
+        w = [net.params[k + '.weight'] for k in names]
+        group = opt.param_groups[0]
+        rep.steps, rep.active = _lib.ptr(counts), _lib.ptr(stepped)
+        rep.states, rep.next_states = _lib.ptr(M.states), _lib.ptr(M.next_states)
+        rep.actions, rep.rewards = _lib.ptr(M.actions), _lib.ptr(M.rewards)
+        rep.nonterminal = _lib.ptr(M.terminals)
+        rep.n, rep.batch = n, batch_size
+        rep.n_inputs, rep.n_hidden1 = w[0].shape[2], w[0].shape[1]
+        rep.n_hidden2, rep.n_actions = w[1].shape[1], w[2].shape[1]
+        rep.is_float64, rep.ddqn = int(f64), int(bool(self.DDQN))
+        rep.gamma, rep.lr = float(self.gamma), float(group['lr'])
+        rep.beta1, rep.beta2 = (float(b) for b in group['betas'])
+        rep.eps, rep.weight_decay = float(group['eps']), float(group['weight_decay'])
+        rep.tau = float(self.target_update)
+        rep.batch_slots, rep.ring_slots = _lib.ptr(slots), M.slots
+        rep.obs_index, rep.obs_table, rep.q_out = _lib.ptr(interface.state), _lib.ptr(table), _lib.ptr(q)
+        act = _lib.DQNAct()
+        act.state, act.env_ctr = _lib.ptr(interface.state), _lib.ptr(interface.env_ctr)
+        act.obs_table, act.q = _lib.ptr(table), _lib.ptr(q)
+        act.policy_ctr, act.policy_stream = _lib.ptr(pol.counter), pol.stream
+        act.is_float64, act.epsilon = int(f64), float(pol.epsilon)
+        act.ring_states, act.ring_next_states = _lib.ptr(M.states), _lib.ptr(M.next_states)
+        act.ring_actions, act.ring_rewards = _lib.ptr(M.actions), _lib.ptr(M.rewards)
+        act.ring_nonterminal = _lib.ptr(M.terminals)
+        act.ring_size, act.ring_head = _lib.ptr(M.size), _lib.ptr(M.head)
+        act.memory_ctr = _lib.ptr(M.counter)
+        act.trial, act.step, act.trial_reward = _lib.ptr(self.trial), _lib.ptr(step), _lib.ptr(trew)
+        act.active, act.adam_steps = _lib.ptr(active), _lib.ptr(counts)
+        act.lat_sum, act.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
+        act.reward_sum = _lib.ptr(mon.raw('reward_sum'))
+        act.stepped, act.batch_slots = _lib.ptr(stepped), _lib.ptr(slots)
+        act.n, act.n_obs, act.slots, act.batch = n, table.shape[1], M.slots, batch_size
+        act.steps_per_trial, act.trials_target = steps, first + trials
+        act.trial_cap, act.mon_stripes = mon.cap, mon.stripes
+        act.instance_base, act.seed = interface.instance_base, interface.seed
+        lib, world, stream = _lib.lib(), interface.handle.ptr, _lib.current_stream(dev)
+        done = 0
+        while True:
+            chunk = (budget - done) if budget else min(steps, 64)
+            for _ in range(chunk):
+                _lib.check(lib.cobel_dqn_act(world, C.byref(act), stream))
+                _lib.check(lib.cobel_dqn_replay(C.byref(rep), stream))
+            done += chunk
+            if budget or int(active.sum().item()) == 0:
+                break
+        self.fused_steps += done
+
     def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool,
              budget: int = 0) -> None:
         """``budget`` > 0 stops after that many lockstep iterations (benchmarking)."""
@@ -171,6 +288,10 @@ class DQN(Agent):
             self.callbacks.on_trial_begin({'trial_reward': 0.0, 'trial': first + t,
                                            'trial_session': t})
         obs, _ = interface.reset()
+        if learn and self._fused_loop_ok(interface, pol, batch_size):
+            self._run_fused(interface, pol, trials, steps, batch_size, budget)
+            self._finish_run(first, trials)
+            return
         obs = interface.observe().to(self.dtype).clone()
         active = torch.ones(n, dtype=torch.bool, device=dev)
         zero64 = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -262,6 +383,9 @@ class DQN(Agent):
                     if left == 0:
                         break
                     all_active = left == n
+        self._finish_run(first, trials)
+
+    def _finish_run(self, first: int, trials: int) -> None:
         self.current_trial = first + trials
         if self.callbacks.has('on_trial_end'):
             lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()

@@ -63,11 +63,12 @@ struct mlp_lds {
   T* qt;    // [32][4]   target Q(s')
   T* boot;  // [32]
   int* pick;  // [32] DDQN: argmax_a Q_online(s')
+  int* slot;  // [32] row of each sample inside the instance's batch / replay ring
 };
 
 __host__ __device__ inline size_t mlp_lds_elems(int D) {
   return (size_t)kH * kRow + (size_t)D * kH + kA * kH + kH + kH + 8 + (size_t)kB * D +
-         2 * (size_t)kB * kRow + 2 * kB * kA + kB + kB /* pick, as T-sized slots */;
+         2 * (size_t)kB * kRow + 2 * kB * kA + kB + 2 * kB /* pick, slot: as T-sized cells */;
 }
 
 // Threads of a workgroup talk through LDS only, so its barriers wait for the LDS counter, not for
@@ -120,16 +121,17 @@ __device__ __forceinline__ void adam_update(T p_old, T g, const adam_slot<T>& s,
 }
 
 template <typename T>
-__device__ __forceinline__ void adam_apply(T* __restrict__ p, T* __restrict__ m,
-                                           T* __restrict__ v, T* __restrict__ tgt, size_t e,
-                                           T p_old, T g, const adam_slot<T>& s,
-                                           const adam_consts<T>& c) {
+__device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m,
+                                        T* __restrict__ v, T* __restrict__ tgt, size_t e,
+                                        T p_old, T g, const adam_slot<T>& s,
+                                        const adam_consts<T>& c) {
   T pn, mn, vn, tn;
   adam_update<T>(p_old, g, s, c, pn, mn, vn, tn);
   m[e] = mn;
   v[e] = vn;
   p[e] = pn;
   if (c.blend) tgt[e] = tn;
+  return pn;
 }
 
 // One network's parameters (torch.nn.Linear layout [out][in]) on their way into LDS: loaded into
@@ -240,8 +242,11 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
 }
 
 template <typename T>
-__device__ void load_rows(T* dst, const T* src, int count, int t) {
-  for (int e = t; e < count; e += 256) dst[e] = src[e];
+__device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
+  for (int e = t; e < kB * D; e += 256) {
+    const int s = e / D, d = e - s * D;
+    dst[e] = src[(size_t)slot[s] * D + d];
+  }
 }
 
 template <typename T>
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     L.q = p;   p += kB * kA;
     L.qt = p;  p += kB * kA;
     L.boot = p; p += kB;
-    L.pick = reinterpret_cast<int*>(p);
+    L.pick = reinterpret_cast<int*>(p); p += kB;
+    L.slot = reinterpret_cast<int*>(p);
   }
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)kA * kH;
   T* const w1 = (T*)R.w[0] + (size_t)i * n1;
@@ -288,8 +294,12 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   T* const tb2 = (T*)R.b_target[1] + (size_t)i * kH;
   T* const tw3 = (T*)R.w_target[2] + (size_t)i * n3;
   T* const tb3 = (T*)R.b_target[2] + (size_t)i * kA;
-  const T* const xs = (const T*)R.states + (size_t)i * kB * D;
-  const T* const xn = (const T*)R.next_states + (size_t)i * kB * D;
+  // the batch: gathered tensors [N][32][..], or rows batch_slots[i][s] of the replay rings
+  const size_t rows = R.batch_slots ? (size_t)R.ring_slots : (size_t)kB;
+  const T* const xs = (const T*)R.states + (size_t)i * rows * D;
+  const T* const xn = (const T*)R.next_states + (size_t)i * rows * D;
+  if (t < kB) L.slot[t] = R.batch_slots ? R.batch_slots[(size_t)i * kB + t] : t;
+  lds_barrier();
 
   T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
   T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   param_regs<T> P;
   params_load<T>(P, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
   params_store<T>(L, P, D, t);
-  load_rows<T>(L.x, xn, kB * D, t);
+  load_rows<T>(L.x, xn, L.slot, D, t);
   lds_barrier();
   params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);   // in flight during the target forward pass
   // the target network's copies of this thread's elements, for the blend at the end
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     }
     lds_barrier();
   }
-  load_rows<T>(L.x, xs, kB * D, t);
+  load_rows<T>(L.x, xs, L.slot, D, t);
   lds_barrier();
   if (!(A.skip & 2)) forward<T>(L, L.q, D, t);
   if (A.skip & 4) return;
@@ -370,14 +380,15 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
 #pragma unroll
       for (int a = 1; a < kA; ++a) boot = L.qt[t * kA + a] > boot ? L.qt[t * kA + a] : boot;
     }
-    const T r = ((const T*)R.rewards)[(size_t)i * kB + t];
-    const T nt = ((const T*)R.nonterminal)[(size_t)i * kB + t];
+    const size_t row = (size_t)i * rows + L.slot[t];
+    const T r = ((const T*)R.rewards)[row];
+    const T nt = ((const T*)R.nonterminal)[row];
     L.boot[t] = r + (boot * nt) * (T)R.gamma;
   }
   lds_barrier();
   if (t < kB * kA) {
     const int s = t >> 2, a = t & 3;
-    const int act = (int)R.actions[(size_t)i * kB + s];
+    const int act = (int)R.actions[(size_t)i * rows + L.slot[s]];
     const T d = L.q[t] - L.boot[s];
     const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
     L.q[t] = (a == act) ? g : (T)0;   // delta3
@@ -431,17 +442,21 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     sb3.m = m_b3[t]; sb3.v = v_b3[t];
   }
 
+  // The updated parameters also replace the old ones in LDS as soon as the backward pass no longer
+  // needs those (the output layer's after delta2, the second layer's after delta1): the Q-values of
+  // the next observation are computed from there at the end.
+  T new_w3 = (T)0;
   // ---- output layer: dW3[a][k] = sum_s delta3[s][a] h2[s][k], db3[a] = sum_s delta3[s][a] --------
   {
     const int a = t >> 6, k = t & 63;
     T g = (T)0;
 #pragma unroll 8
     for (int s = 0; s < kB; ++s) g = fma_t<T>(L.q[s * kA + a], L.h2[s * kRow + k], g);
-    adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, s3, c);
+    new_w3 = adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, s3, c);
     if (t < kA) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kA + t];
-      adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, sb3, c);
+      L.b3[t] = adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, sb3, c);
     }
   }
   lds_barrier();
@@ -455,15 +470,17 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     L.h2[s * kRow + k] = h > (T)0 ? d : (T)0;
   }
   lds_barrier();
+  L.w3[t] = new_w3;
 
   // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k]; thread tile 4 j x 4 k -----------------
+  T new_w2[4][4];   // the updated tile: into LDS once delta1 no longer needs the old weights
   {
     const int j0 = jg2 * 4, k0 = kg2 * 4;
-    T g[4][4];
+    T g2[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) g[a][b] = (T)0;
+      for (int b = 0; b < 4; ++b) g2[a][b] = (T)0;
 #pragma unroll 4
     for (int s = 0; s < kB; ++s) {
       T dj[4], hk[4];
@@ -475,15 +492,17 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) g[a][b] = fma_t<T>(dj[a], hk[b], g[a][b]);
+        for (int b = 0; b < 4; ++b) g2[a][b] = fma_t<T>(dj[a], hk[b], g2[a][b]);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       vec4<T> pn, mn, vn, tn;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        adam_update<T>(L.wt2[(k0 + b) * kRow + j0 + a], g[a][b], s2[a][b], c, pn.x[b], mn.x[b],
+      for (int b = 0; b < 4; ++b) {
+        adam_update<T>(L.wt2[(k0 + b) * kRow + j0 + a], g2[a][b], s2[a][b], c, pn.x[b], mn.x[b],
                        vn.x[b], tn.x[b]);
+        new_w2[a][b] = pn.x[b];
+      }
       const size_t e = (size_t)(j0 + a) * kH + k0;
       *reinterpret_cast<vec4<T>*>(m_w2 + e) = mn;
       *reinterpret_cast<vec4<T>*>(v_w2 + e) = vn;
@@ -493,12 +512,12 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     if (t < kH) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
-      adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
+      L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
     }
   }
   lds_barrier();
-  // delta1[s][k] = (sum_j W2[j][k] delta2[s][j]) * (h1[s][k] > 0), in place over h1 (LDS still holds
-  // the weights this step started from: the update above went to global memory only).
+  // delta1[s][k] = (sum_j W2[j][k] delta2[s][j]) * (h1[s][k] > 0), in place over h1, from the
+  // weights this step started from (LDS still holds them: the update above went to memory only).
   // Thread tile 2 samples x 4 inputs k, k interleaved by 16 so that the rows of wt2 read by the
   // lanes of a wave fall into different banks.
   {
@@ -517,17 +536,19 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
         acc[1][b] = fma_t<T>(w, d1, acc[1][b]);
       }
     }
-    lds_barrier();   // every read of h1's activations by the tiles above is done (none here),
-                       // and every thread has its sums: now the buffer can be overwritten
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 4; ++b) {   // (no other thread reads or writes these cells of h1 here)
       const int k = kg + 16 * b;
       const T h0 = L.h1[s0 * kRow + k], h1v = L.h1[(s0 + 1) * kRow + k];
       L.h1[s0 * kRow + k] = h0 > (T)0 ? acc[0][b] : (T)0;
       L.h1[(s0 + 1) * kRow + k] = h1v > (T)0 ? acc[1][b] : (T)0;
     }
   }
-  lds_barrier();
+  lds_barrier();   // every read of the old second-layer weights is done
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a] = new_w2[a][b];
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
 #pragma unroll
@@ -538,13 +559,42 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
       T g = (T)0;
 #pragma unroll 8
       for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
-      adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
+      L.wt1[d * kH + j] =
+          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
     }
   }
   if (t < kH) {
     T gb = (T)0;
     for (int s = 0; s < kB; ++s) gb = gb + L.h1[s * kRow + t];
-    adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, sb1, c);
+    const T nb = adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, sb1, c);
+    L.b1[t] = nb;
+  }
+
+  // ---- Q-values of the next observation with the updated online network ------------------------
+  // (what the next step's action selection needs: agent/dqn.py:174 -> retrieve_q)
+  if (R.q_out) {
+    lds_barrier();   // LDS holds the updated parameters; h1 / h2 / x are free
+    if (t < D) L.x[t] = (T)R.obs_table[(size_t)R.obs_index[i] * D + t];
+    lds_barrier();
+    if (t < kH) {
+      T acc = L.b1[t];
+      for (int d = 0; d < D; ++d) acc = fma_t<T>(L.wt1[d * kH + t], L.x[d], acc);
+      L.h1[t] = acc > (T)0 ? acc : (T)0;
+    }
+    lds_barrier();
+    if (t < kH) {
+      T acc = L.b2[t];
+#pragma unroll 8
+      for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.wt2[k * kRow + t], L.h1[k], acc);
+      L.h2[t] = acc > (T)0 ? acc : (T)0;
+    }
+    lds_barrier();
+    if (t < kA) {
+      T acc = L.b3[t];
+#pragma unroll 8
+      for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[t * kH + k], L.h2[k], acc);
+      ((T*)R.q_out)[(size_t)i * kA + t] = acc;
+    }
   }
 }
 
@@ -577,6 +627,10 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   COBEL_REQUIRE(r.states && r.next_states && r.actions && r.rewards && r.nonterminal && r.steps,
                 COBEL_E_ARG, "cobel_dqn_replay: NULL batch tensor or step counts");
   COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_dqn_replay: n = %d", r.n);
+  COBEL_REQUIRE(!r.batch_slots || r.ring_slots > 0, COBEL_E_RANGE,
+                "cobel_dqn_replay: batch_slots given with ring_slots = %d", r.ring_slots);
+  COBEL_REQUIRE(!r.q_out || (r.obs_index && r.obs_table), COBEL_E_ARG,
+                "cobel_dqn_replay: q_out needs obs_index and obs_table");
   if (r.n == 0) return COBEL_OK;
   mlp_args A;
   A.r = r;
@@ -591,9 +645,15 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   A.stagger_ticks = stag ? atoi(stag) * 100 : (r.n > 2 * A.stagger_first ? (r.is_float64 ? 2000 : 1000) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
-    if (lds > 64 * 1024)
+    // (raised once per device: the call is not free and this entry point runs every step)
+    static int raised_to[64] = {0};
+    int dev = 0;
+    COBEL_HIP_TRY(hipGetDevice(&dev));
+    if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || raised_to[dev] < lds)) {
       COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dqn_replay<double>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      if (dev >= 0 && dev < 64) raised_to[dev] = lds;
+    }
     hipLaunchKernelGGL(k_dqn_replay<double>, dim3(r.n), dim3(256), lds, st, A);
   } else {
     hipLaunchKernelGGL(k_dqn_replay<float>, dim3(r.n), dim3(256), lds, st, A);

@@ -498,12 +498,78 @@ typedef struct {
   int32_t n, n_inputs, n_hidden1, n_hidden2, n_actions, batch;
   int32_t is_float64, ddqn;
   double gamma, lr, beta1, beta2, eps, weight_decay, tau;
+  /* optional: the kernel gathers the batch from the replay rings itself.  With batch_slots != NULL
+     states / next_states / actions / rewards / nonterminal are the rings [N][ring_slots][..] and
+     sample s of instance i is row batch_slots[i][s] (as written by cobel_dqn_act). */
+  const int32_t* batch_slots; /* [N][batch] or NULL                                             */
+  int32_t ring_slots;
+  int32_t reserved_;
+  /* optional: Q-values of each instance's NEXT observation, computed with the updated online
+     network at the end of the step (what the next action selection needs, agent/dqn.py:174):
+     observation of instance i = row obs_index[i] of obs_table.  Instances outside `active` are
+     left alone. */
+  const int32_t* obs_index;   /* [N]                                                            */
+  const double* obs_table;    /* [rows][n_inputs] float64                                       */
+  void* q_out;                /* [N][n_actions] network dtype, or NULL                          */
 } cobel_dqn_replay_t;
 /* 0 = the fused step covers this network / batch shape; fills *lds_bytes (per instance). */
 COBEL_API int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
                                      int32_t n_actions, int32_t batch, int32_t is_float64,
                                      int32_t* lds_bytes);
 COBEL_API int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Everything of one lockstep DQN training step that is not the network: per instance
+ *   epsilon-greedy on the given Q-values (policy/greedy.py:40-88) -> env.step
+ *   (interface/topology.py:146-157, gridworld.py:115-126) -> append the experience to the replay
+ *   ring (memory/dqn.py:103-119; FIFO at capacity) -> trial bookkeeping and monitors
+ *   (agent/dqn.py:186-212, monitor/behavior.py:73-97) with auto-reset (topology.py:170) ->
+ *   draw the replay batch (memory/dqn.py:137: uniform over the stored entries, with replacement).
+ * One lane per instance; instances whose `active` flag is 0 are left untouched (they consume no
+ * draws).  Observations are rows of obs_table indexed by the env state (Topology poses, one-hot
+ * rows for a Gridworld).  Outputs for cobel_dqn_replay: `stepped` (1 = the instance took part
+ * in this step; its Adam step count adam_steps[i] has been incremented) and `batch_slots`.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  /* environment */
+  int32_t* state;           /* [N] in/out                                                       */
+  uint32_t* env_ctr;        /* [N] next index on COBEL_STREAM_ENV                               */
+  const double* obs_table;  /* [S][n_obs] float64                                               */
+  /* policy */
+  const void* q;            /* [N][4] Q-values of the current observations, network dtype       */
+  uint32_t* policy_ctr;     /* [N] next index on the policy stream                              */
+  uint32_t policy_stream;   /* COBEL_STREAM_POLICY or COBEL_STREAM_POLICY_TEST                  */
+  int32_t is_float64;       /* dtype of q and of the ring's floating-point arrays               */
+  double epsilon;
+  /* replay ring, [N][slots][..] */
+  void* ring_states;
+  void* ring_next_states;
+  int64_t* ring_actions;
+  void* ring_rewards;
+  void* ring_nonterminal;
+  int32_t* ring_size;       /* [N] stored entries                                               */
+  int64_t* ring_head;       /* [N] slot of the oldest entry                                     */
+  uint32_t* memory_ctr;     /* [N] next index on COBEL_STREAM_MEMORY                            */
+  /* trial bookkeeping */
+  int32_t* trial;           /* [N] trials finished                                              */
+  int32_t* step;            /* [N] steps taken in the running trial                             */
+  double* trial_reward;     /* [N]                                                              */
+  uint8_t* active;          /* [N] in/out: 0 once trial == trials_target                        */
+  double* adam_steps;       /* [N] += 1 for every instance that steps                           */
+  long long* lat_sum;       /* [mon_stripes][trial_cap] (instance i adds into copy i % mon_stripes) */
+  long long* lat_cnt;
+  double* reward_sum;
+  /* outputs */
+  uint8_t* stepped;         /* [N]                                                              */
+  int32_t* batch_slots;     /* [N][batch]                                                       */
+  /* sizes and parameters */
+  int32_t n, n_obs, slots, batch;
+  int32_t steps_per_trial, trials_target, trial_cap, mon_stripes;
+  uint32_t instance_base;
+  uint32_t reserved_;
+  uint64_t seed;
+} cobel_dqn_act_t;
+COBEL_API int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* run, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1563,3 +1563,53 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn):
     o = other.replicate(3)
     assert not o.dqn_replay_fused(o.clone(), s[:3], a[:3], r[:3], ns[:3], nt[:3], gamma, False,
                                   tau, None)
+
+
+@pytest.mark.parametrize('dtype_name', ['f64', 'f32'])
+def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, dtype_name):
+    """DQN.train through cobel_dqn_act + cobel_dqn_replay (two launches per lockstep step) against
+    the PyTorch loop it replaces: identical transitions in the replay rings, stream counters,
+    trial counts and monitors (instances finish at different times; a small ring wraps around;
+    a second train() call continues); weights to round-off in float64."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.memory import DQNMemory
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(6, 2, 1., 5., 'right')
+
+    def run(fused):
+        env = Topology(nodes, starts, n_envs=48, seed=4242, instance_base=9)
+        net = _mlp(torch, init)
+        net = net.double() if dtype_name == 'f64' else net.float()
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.4), TorchNetwork(net),
+                 gamma=0.8, memory=DQNMemory(capacity=40))
+        ag.fused_loop = None if fused else False
+        ag.use_graph = False if not fused else None
+        ag.train(env, 5, 14, 32)
+        ag.train(env, 3, 14, 32)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (a, ea), (b, eb) = run(True), run(False)
+    assert a.fused_steps > 0 and b.fused_steps == 0
+    assert torch.equal(a.M.size, b.M.size) and torch.equal(a.M.head, b.M.head)
+    assert torch.equal(a.M.actions, b.M.actions) and torch.equal(a.M.rewards, b.M.rewards)
+    assert torch.equal(a.M.states, b.M.states) and torch.equal(a.M.next_states, b.M.next_states)
+    assert torch.equal(a.M.terminals, b.M.terminals) and torch.equal(a.M.counter, b.M.counter)
+    assert torch.equal(a.policy.counter, b.policy.counter) and torch.equal(ea.env_ctr, eb.env_ctr)
+    assert torch.equal(a.trial, b.trial) and int(a.trial.min()) == 8
+    for k in ('lat_sum', 'lat_cnt', 'reward_sum'):
+        assert torch.equal(getattr(a.monitors, k), getattr(b.monitors, k)), k
+    assert len(set(a.M.size.cpu().numpy().tolist())) > 1 or int(a.M.size.max()) == 40
+    tol = dict(rtol=1e-9, atol=1e-12) if dtype_name == 'f64' else dict(rtol=5e-3, atol=1e-4)
+    for i in (0, 17, 47):
+        for x, y in zip(a._online.get_weights(i), b._online.get_weights(i)):
+            assert np.allclose(x, y, **tol), float(np.abs(x - y).max())
+        for x, y in zip(a._target.get_weights(i), b._target.get_weights(i)):
+            assert np.allclose(x, y, **tol)
+    assert a.current_trial == b.current_trial == 8

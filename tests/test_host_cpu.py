@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1004
+    assert lib.cobel_abi_version() == 1005
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -47,6 +47,18 @@ def test_struct_layouts_match_the_header():
     assert f == _lib.SFMARun.seed.offset and g == _lib.SFMA_EVENT_BYTES
     from cobel_amd.agent.sfma import EVENT
     assert EVENT.itemsize == g
+    src = ('#include "cobel_hip.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+           'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cobel_dqn_replay_t), '
+           'offsetof(cobel_dqn_replay_t, gamma), offsetof(cobel_dqn_replay_t, q_out), '
+           'sizeof(cobel_dqn_act_t), offsetof(cobel_dqn_act_t, epsilon), '
+           'offsetof(cobel_dqn_act_t, seed));}')
+    subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe],
+                   input=src.encode(), check=True)
+    a, b, c, d, e, f = [int(x) for x in subprocess.check_output([exe]).split()]
+    os.remove(exe)
+    assert a == C.sizeof(_lib.DQNReplay) and b == _lib.DQNReplay.gamma.offset
+    assert c == _lib.DQNReplay.q_out.offset and d == C.sizeof(_lib.DQNAct)
+    assert e == _lib.DQNAct.epsilon.offset and f == _lib.DQNAct.seed.offset
 
 
 def test_sfma_metrics_match_reference(golden):
