@@ -43,7 +43,6 @@ constexpr int kMaxD = 32;     // input width limit
 
 struct mlp_args {
   cobel_dqn_replay_t r;
-  int32_t skip;   // timing experiments only (COBEL_DEBUG_MLP_SKIP): phases left out, results invalid
   int32_t stagger_ticks;   // span of the start delays of the first resident workgroups, 10 ns units
   int32_t stagger_first;   // workgroups that are resident when the launch begins
 };
@@ -342,8 +341,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   sb1.target = t < kH ? L.b1[t] : (T)0;
   sb2.target = t < kH ? L.b2[t] : (T)0;
   sb3.target = t < kA ? L.b3[t] : (T)0;
-  if (A.skip & 64) return;
-  if (!(A.skip & 1)) forward<T>(L, L.qt, D, t);
+  forward<T>(L, L.qt, D, t);
   // ---- online network -------------------------------------------------------------------------
   params_store<T>(L, P, D, t);
   lds_barrier();
@@ -364,8 +362,7 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   }
   load_rows<T>(L.x, xs, L.slot, D, t);
   lds_barrier();
-  if (!(A.skip & 2)) forward<T>(L, L.q, D, t);
-  if (A.skip & 4) return;
+  forward<T>(L, L.q, D, t);
 
   // ---- targets and the loss gradient at the output ----------------------------------------------
   // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the 32 x 4
@@ -634,13 +631,11 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   if (r.n == 0) return COBEL_OK;
   mlp_args A;
   A.r = r;
-  const char* skip = getenv("COBEL_DEBUG_MLP_SKIP");
-  A.skip = skip ? atoi(skip) : 0;
   // Workgroups that start together stay in step: all load, then all compute.  The ones resident
   // at the start of a launch that needs several rounds begin at delays spread over 20 us (float64;
   // 10 us float32), so that the memory phases of the workgroups sharing a CU fall into each
   // other's compute phases (8 192 instances: 900 -> 770 us per launch in float64).
-  const char* stag = getenv("COBEL_DEBUG_MLP_STAGGER_US");
+  static const char* const stag = getenv("COBEL_DEBUG_MLP_STAGGER_US");   // experiments
   A.stagger_first = 256 * (r.is_float64 ? 2 : 3);
   A.stagger_ticks = stag ? atoi(stag) * 100 : (r.n > 2 * A.stagger_first ? (r.is_float64 ? 2000 : 1000) : 0);
   hipStream_t st = (hipStream_t)stream;

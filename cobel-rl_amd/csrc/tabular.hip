@@ -1110,9 +1110,13 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
-  A.hash_exact = (world->n_states * 4 <= 4096 && !getenv("COBEL_DEBUG_NO_EXACT_HASH")) ? 1 : 0;
+  // (debug switches are read once per process, not per launch)
+  static const bool no_exact_hash = getenv("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
+  const char* const lds_pad = getenv("COBEL_DEBUG_LDS_PAD");   // (per launch: scripts/exp_occupancy.py)
+  static const char* const lpw_env = getenv("COBEL_DEBUG_LPW");
+  A.hash_exact = (world->n_states * 4 <= 4096 && !no_exact_hash) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
-  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
+  if (lds_pad) lds += (size_t)atoi(lds_pad);  // occupancy experiments
   hipStream_t st = (hipStream_t)stream;
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
   const bool learn = (r.flags & COBEL_F_LEARN) != 0;
@@ -1121,8 +1125,8 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   // wave per SIMD — and lose: 1.25 ms per launch at 64, 1.45 ms at 32, 2.57 ms at 16 instances per
   // wave; the step is as much issue- as latency-bound.  COBEL_DEBUG_LPW overrides.)
   int lpw = 64;
-  if (const char* e = getenv("COBEL_DEBUG_LPW")) {
-    const int v = atoi(e);
+  if (lpw_env) {
+    const int v = atoi(lpw_env);
     if (v == 16 || v == 32 || v == 64) lpw = v;
   }
   while (lpw > 16 && (size_t)world->n_states * lpw * 16 + kThrBytes + (size_t)world->n_states * 18 +

@@ -1,4 +1,6 @@
-"""Scratch: launch time of cobel_dqn_replay alone (C5 shapes) with phases left out."""
+"""Scratch: launch time of cobel_dqn_replay alone (C5 shapes, gathered batches) for several spans of
+the staggered workgroup starts (COBEL_DEBUG_MLP_STAGGER_US; read once per process, so one span per
+run: `COBEL_DEBUG_MLP_STAGGER_US=20 python scripts/exp_mlp.py`)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
@@ -14,9 +16,7 @@ for dt_name in ('f64', 'f32'):
     s = torch.rand((n, B, 6), device=dev, dtype=dt); ns = torch.rand((n, B, 6), device=dev, dtype=dt)
     a = torch.randint(0, 4, (n, B), device=dev); r = torch.rand((n, B), device=dev, dtype=dt)
     nt = torch.ones((n, B), device=dev, dtype=dt)
-    for skip, stag in [(0, 0), (64, 0), (4, 0), (5, 0), (7, 0), (3, 0), (0, 10), (0, 20), (0, 30), (0, 45), (0, 60)]:
-        os.environ['COBEL_DEBUG_MLP_SKIP'] = str(skip)
-        os.environ['COBEL_DEBUG_MLP_STAGGER_US'] = str(stag)
+    for skip, stag in [(0, int(os.environ.get('COBEL_DEBUG_MLP_STAGGER_US', '-1')))]:
         for _ in range(2):
             assert net.dqn_replay_fused(tgt, s, a, r, ns, nt, 0.8, False, 0.01, None)
         torch.cuda.synchronize()
