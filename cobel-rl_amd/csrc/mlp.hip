@@ -20,8 +20,8 @@
 //     into different banks); the backward pass overwrites them in place with the deltas;
 //   * every thread applies Adam to the gradient elements it has just accumulated in registers —
 //     gradients never exist in memory; p, m, v are read once and written once, the target network's
-//     copy is read once (its forward pass; each thread keeps the elements it will blend) and
-//     written once.
+//     copy is read once (its forward pass; each thread keeps its tile of the 64 x 64 matrix for the
+//     blend; the small tensors, a sixth of the parameters, are read a second time) and written once.
 // HBM traffic per instance and step: 8 streams over the parameters (online read + write, two
 // moments read + write, target read + write) = 8 x 39 KB (float64).
 //
@@ -133,12 +133,13 @@ __device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m,
   return pn;
 }
 
-// One network's parameters (torch.nn.Linear layout [out][in]) on their way into LDS: loaded into
-// registers (the online network's while the target network's forward pass runs), written to LDS
-// when the buffer is free.
+// One network's parameters (torch.nn.Linear layout [out][in]) on their way into LDS: the 64 x 64
+// matrix, the output layer and the biases are loaded into registers (the online network's while
+// the target network's forward pass runs) and written to LDS when the buffer is free; the small
+// first layer goes straight from memory to LDS at that point.
 template <typename T>
 struct param_regs {
-  T w2[16], w1[kMaxD / 4], w3, b1, b2, b3;
+  T w2[16], w3, b1, b2, b3;
 };
 
 template <typename T>
@@ -148,11 +149,6 @@ __device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restric
                                             const T* __restrict__ b3, int D, int t) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) P.w2[u] = w2[t + 256 * u];   // coalesced along k
-#pragma unroll
-  for (int u = 0; u < kMaxD / 4; ++u) {
-    const int e = t + 256 * u;
-    P.w1[u] = e < kH * D ? w1[e] : (T)0;
-  }
   P.w3 = w3[t];   // 4 * 64 = 256 elements
   P.b1 = t < kH ? b1[t] : (T)0;
   P.b2 = t < kH ? b2[t] : (T)0;
@@ -160,20 +156,16 @@ __device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restric
 }
 
 template <typename T>
-__device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T>& P, int D,
-                                             int t) {
+__device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T>& P,
+                                             const T* __restrict__ w1, int D, int t) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) {   // transposed write
     const int e = t + 256 * u;
     L.wt2[(e & 63) * kRow + (e >> 6)] = P.w2[u];
   }
-#pragma unroll
-  for (int u = 0; u < kMaxD / 4; ++u) {
-    const int e = t + 256 * u;
-    if (e < kH * D) {
-      const int j = e / D, d = e - j * D;
-      L.wt1[d * kH + j] = P.w1[u];
-    }
+  for (int e = t; e < kH * D; e += 256) {
+    const int j = e / D, d = e - j * D;
+    L.wt1[d * kH + j] = w1[e];
   }
   L.w3[t] = P.w3;
   if (t < kH) {
@@ -249,7 +241,7 @@ __device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
+__device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_dqn_replay_t& R = A.r;
   const int i = (int)blockIdx.x;
@@ -314,36 +306,24 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
   // before the online forward pass, they crowd the forward passes' inner loops: measured slower in
   // float64, 902 -> 952 us per launch at 8 192 instances).
   const int kg2 = t & 15, jg2 = t >> 4;
-  adam_slot<T> s2[4][4], s1[kMaxD / 4], s3, sb1, sb2, sb3;
+  adam_slot<T> s2[4][4], s3, sb1, sb2, sb3;
   // ---- Q_target(s') ---------------------------------------------------------------------------
   param_regs<T> P;
   params_load<T>(P, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
-  params_store<T>(L, P, D, t);
+  params_store<T>(L, P, tw1, D, t);
   load_rows<T>(L.x, xn, L.slot, D, t);
   lds_barrier();
   params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);   // in flight during the target forward pass
-  // the target network's copies of this thread's elements, for the blend at the end
+  // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
+  // end (the other, small tensors are read again with their moments in the backward pass)
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
       s2[a][b].target = L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a];
-#pragma unroll
-  for (int u = 0; u < kMaxD / 4; ++u) {
-    const int e = t + 256 * u;
-    s1[u].target = (T)0;
-    if (e < kH * D) {
-      const int j = e / D, d = e - j * D;
-      s1[u].target = L.wt1[d * kH + j];
-    }
-  }
-  s3.target = L.w3[t];
-  sb1.target = t < kH ? L.b1[t] : (T)0;
-  sb2.target = t < kH ? L.b2[t] : (T)0;
-  sb3.target = t < kA ? L.b3[t] : (T)0;
   forward<T>(L, L.qt, D, t);
   // ---- online network -------------------------------------------------------------------------
-  params_store<T>(L, P, D, t);
+  params_store<T>(L, P, w1, D, t);
   lds_barrier();
   if (R.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
     forward<T>(L, L.q, D, t);
@@ -419,24 +399,17 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
       s2[a][b].v = vv.x[b];
     }
   }
-#pragma unroll
-  for (int u = 0; u < kMaxD / 4; ++u) {
-    const int e = t + 256 * u;
-    s1[u].m = s1[u].v = (T)0;
-    if (e < kH * D) {
-      s1[u].m = m_w1[e];
-      s1[u].v = v_w1[e];
-    }
-  }
   s3.m = m_w3[t];
   s3.v = v_w3[t];
-  sb1.m = sb1.v = sb2.m = sb2.v = sb3.m = sb3.v = (T)0;
+  s3.target = tw3[t];
+  sb1.m = sb1.v = sb1.target = sb2.m = sb2.v = sb2.target = (T)0;
+  sb3.m = sb3.v = sb3.target = (T)0;
   if (t < kH) {
-    sb1.m = m_b1[t]; sb1.v = v_b1[t];
-    sb2.m = m_b2[t]; sb2.v = v_b2[t];
+    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
+    sb2.m = m_b2[t]; sb2.v = v_b2[t]; sb2.target = tb2[t];
   }
   if (t < kA) {
-    sb3.m = m_b3[t]; sb3.v = v_b3[t];
+    sb3.m = m_b3[t]; sb3.v = v_b3[t]; sb3.target = tb3[t];
   }
 
   // The updated parameters also replace the old ones in LDS as soon as the backward pass no longer
@@ -548,17 +521,17 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
     for (int b = 0; b < 4; ++b) L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a] = new_w2[a][b];
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
-#pragma unroll
-  for (int u = 0; u < kMaxD / 4; ++u) {
-    const int e = t + 256 * u;
-    if (e < kH * D) {
-      const int j = e / D, d = e - j * D;
-      T g = (T)0;
+  for (int e = t; e < kH * D; e += 256) {   // (a small tensor: its state is loaded here)
+    adam_slot<T> s1;
+    s1.m = m_w1[e];
+    s1.v = v_w1[e];
+    s1.target = tw1[e];
+    const int j = e / D, d = e - j * D;
+    T g = (T)0;
 #pragma unroll 8
-      for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
-      L.wt1[d * kH + j] =
-          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
-    }
+    for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
+    L.wt1[d * kH + j] =
+        adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1, c);
   }
   if (t < kH) {
     T gb = (T)0;
@@ -593,6 +566,25 @@ __global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A) {
       ((T*)R.q_out)[(size_t)i * kA + t] = acc;
     }
   }
+}
+
+// float64: 78 KB of LDS allow two workgroups per CU, so the kernel may use 256 registers.
+// float32: 39 KB allow four, and four resident workgroups per CU with a few spilled registers
+// (128-register cap) beat three without: C5 float32 0.69 -> 0.51 ms per step.
+#ifndef COBEL_MLP_WAVES_F32
+#define COBEL_MLP_WAVES_F32 4
+#endif
+template <typename T>
+__global__ __launch_bounds__(256) void k_dqn_replay(const mlp_args A);
+template <>
+__global__ __launch_bounds__(256) void k_dqn_replay<double>(const mlp_args A) {
+  dqn_replay_body<double>(A);
+}
+template <>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(COBEL_MLP_WAVES_F32, COBEL_MLP_WAVES_F32)))
+void k_dqn_replay<float>(const mlp_args A) {
+  dqn_replay_body<float>(A);
 }
 
 }  // namespace
@@ -636,7 +628,7 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   // 10 us float32), so that the memory phases of the workgroups sharing a CU fall into each
   // other's compute phases (8 192 instances: 900 -> 770 us per launch in float64).
   static const char* const stag = getenv("COBEL_DEBUG_MLP_STAGGER_US");   // experiments
-  A.stagger_first = 256 * (r.is_float64 ? 2 : 3);
+  A.stagger_first = 256 * (r.is_float64 ? 2 : COBEL_MLP_WAVES_F32);
   A.stagger_ticks = stag ? atoi(stag) * 100 : (r.n > 2 * A.stagger_first ? (r.is_float64 ? 2000 : 1000) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
