@@ -117,8 +117,22 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=None):
             'roofline': {'bound': 'hbm', 'achieved': bytes_per_step * n * iters / dt / 1e9,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': bytes_per_step * n * iters / dt / 1e9 / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'k_dqn_replay',
+                         'traffic': _c5_traffic(dtype_name, n), 'kernel': 'k_dqn_replay',
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
+                         'algorithmic_bytes_per_launch': bytes_per_step * n,
                          'algorithmic_bytes_per_env_step': bytes_per_step}}
+
+
+def _c5_traffic(dtype_name, n):
+    """HBM bytes per launch of k_dqn_replay from the committed PMC passes (scripts/pmc_c5.py),
+    for the instance count they were collected with."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files or n != 8192:
+        return None
+    with open(files[-1]) as fh:
+        entry = json.load(fh).get('C5_' + dtype_name)
+    return entry['hbm_bytes_per_launch'] if entry else None
 
 
 def _mlp(n_in, n_out, dtype_name='f64'):
