@@ -82,6 +82,33 @@ struct alignas(4 * sizeof(T)) vec4 {
   T x[4];
 };
 
+// The three 64 x 64 products of a step (second-layer forward, its weight gradient, the delta of
+// the first layer: 85 % of the arithmetic) run on the matrix cores as 16 x 16 x 4 MFMAs in the
+// network's dtype.  Operand layout of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (probed on
+// gfx950): lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16]; of the 16 x 16 result it holds
+// column l % 16 and, in accumulator element v, row 4 v + l / 16 (float64) or 4 (l / 16) + v
+// (float32).
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <typename T>
+struct mfma_acc;
+template <>
+struct mfma_acc<double> {
+  typedef v4d type;
+  static __device__ __forceinline__ int row(int lane, int v) { return 4 * v + (lane >> 4); }
+};
+template <>
+struct mfma_acc<float> {
+  typedef v4f type;
+  static __device__ __forceinline__ int row(int lane, int v) { return 4 * (lane >> 4) + v; }
+};
+__device__ __forceinline__ v4d mfma(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ v4f mfma(float a, float b, v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ T fma_t(T a, T b, T c);
 template <>
@@ -202,23 +229,26 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
   }
   lds_barrier();
   {
-    T acc[2][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = L.b2[j0 + c];
-#pragma unroll 8
-    for (int k = 0; k < kH; ++k) {
-      const T x0 = L.h1[s0 * kRow + k], x1 = L.h1[(s0 + 1) * kRow + k];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const T w = L.wt2[k * kRow + j0 + c];
-        acc[0][c] = fma_t<T>(w, x0, acc[0][c]);
-        acc[1][c] = fma_t<T>(w, x1, acc[1][c]);
-      }
+    // h2[s][j] = relu(b2[j] + sum_k h1[s][k] W2[j][k]): M = s (two tiles), N = j (wave w takes
+    // columns 16 w ..), K = k.  A = h1 rows, B = wt2 (k-major: the transposed copy of W2).
+    typedef typename mfma_acc<T>::type acc_t;
+    const int lane = t & 63, jt = (t >> 6) * 16;
+    const int li = lane & 15, lq = lane >> 4;
+    const T bias = L.b2[jt + li];
+    acc_t acc0 = {bias, bias, bias, bias}, acc1 = acc0;
+#pragma unroll 4
+    for (int k0 = 0; k0 < kH; k0 += 4) {
+      const T b = L.wt2[(k0 + lq) * kRow + jt + li];
+      const T a0 = L.h1[li * kRow + k0 + lq];
+      const T a1 = L.h1[(16 + li) * kRow + k0 + lq];
+      acc0 = mfma(a0, b, acc0);
+      acc1 = mfma(a1, b, acc1);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      L.h2[s0 * kRow + j0 + c] = acc[0][c] > (T)0 ? acc[0][c] : (T)0;
-      L.h2[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
+    for (int v = 0; v < 4; ++v) {
+      const int r = mfma_acc<T>::row(lane, v);
+      L.h2[r * kRow + jt + li] = acc0[v] > (T)0 ? acc0[v] : (T)0;
+      L.h2[(16 + r) * kRow + jt + li] = acc1[v] > (T)0 ? acc1[v] : (T)0;
     }
   }
   lds_barrier();
@@ -305,7 +335,9 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // at the start of the backward pass (kept in registers from the start of the kernel, or from
   // before the online forward pass, they crowd the forward passes' inner loops: measured slower in
   // float64, 902 -> 952 us per launch at 8 192 instances).
-  const int kg2 = t & 15, jg2 = t >> 4;
+  // second layer: element (kt, v) of this thread is W2[j][k] with j = 16 (t / 64) + row(lane, v),
+  // k = 16 kt + lane % 16 — the accumulator layout of the MFMA tiles of the backward pass
+  const int lane2 = t & 63, jt2 = (t >> 6) * 16, li2 = lane2 & 15;
   adam_slot<T> s2[4][4], s3, sb1, sb2, sb3;
   // ---- Q_target(s') ---------------------------------------------------------------------------
   param_regs<T> P;
@@ -320,7 +352,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
-      s2[a][b].target = L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a];
+      s2[a][b].target = L.wt2[(16 * a + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, b)];
   forward<T>(L, L.qt, D, t);
   // ---- online network -------------------------------------------------------------------------
   params_store<T>(L, P, w1, D, t);
@@ -389,23 +421,19 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     c.blend = R.tau != 0.0;
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {   // 4 consecutive elements of a row: one 16- / 32-byte load each
-    const size_t e = (size_t)(jg2 * 4 + a) * kH + kg2 * 4;
-    const vec4<T> mv = *reinterpret_cast<const vec4<T>*>(m_w2 + e);
-    const vec4<T> vv = *reinterpret_cast<const vec4<T>*>(v_w2 + e);
+  for (int a = 0; a < 4; ++a)   // (16 lanes read 16 consecutive elements of a row)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      s2[a][b].m = mv.x[b];
-      s2[a][b].v = vv.x[b];
+      const size_t e = (size_t)(jt2 + mfma_acc<T>::row(lane2, b)) * kH + 16 * a + li2;
+      s2[a][b].m = m_w2[e];
+      s2[a][b].v = v_w2[e];
     }
-  }
   s3.m = m_w3[t];
   s3.v = v_w3[t];
   s3.target = tw3[t];
-  sb1.m = sb1.v = sb1.target = sb2.m = sb2.v = sb2.target = (T)0;
+  sb2.m = sb2.v = sb2.target = (T)0;
   sb3.m = sb3.v = sb3.target = (T)0;
   if (t < kH) {
-    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
     sb2.m = m_b2[t]; sb2.v = v_b2[t]; sb2.target = tb2[t];
   }
   if (t < kA) {
@@ -442,43 +470,36 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   lds_barrier();
   L.w3[t] = new_w3;
 
-  // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k]; thread tile 4 j x 4 k -----------------
-  T new_w2[4][4];   // the updated tile: into LDS once delta1 no longer needs the old weights
+  // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k] ------------------------------------
+  // M = j (wave w takes rows 16 w ..), N = k (four tiles), K = s.  A = delta2 (in h2), B = h1.
+  T new_w2[4][4];   // the updated elements: into LDS once delta1 no longer needs the old weights
   {
-    const int j0 = jg2 * 4, k0 = kg2 * 4;
-    T g2[4][4];
+    typedef typename mfma_acc<T>::type acc_t;
+    const int lq = lane2 >> 4;
+    acc_t g2[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) g2[a] = acc_t{(T)0, (T)0, (T)0, (T)0};
+#pragma unroll 2
+    for (int s0 = 0; s0 < kB; s0 += 4) {
+      const T a = L.h2[(s0 + lq) * kRow + jt2 + li2];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) g2[a][b] = (T)0;
-#pragma unroll 4
-    for (int s = 0; s < kB; ++s) {
-      T dj[4], hk[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        dj[a] = L.h2[s * kRow + j0 + a];
-        hk[a] = L.h1[s * kRow + k0 + a];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) g2[a][b] = fma_t<T>(dj[a], hk[b], g2[a][b]);
+      for (int kt = 0; kt < 4; ++kt)
+        g2[kt] = mfma(a, L.h1[(s0 + lq) * kRow + 16 * kt + li2], g2[kt]);
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      vec4<T> pn, mn, vn, tn;
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        adam_update<T>(L.wt2[(k0 + b) * kRow + j0 + a], g2[a][b], s2[a][b], c, pn.x[b], mn.x[b],
-                       vn.x[b], tn.x[b]);
-        new_w2[a][b] = pn.x[b];
+      for (int v = 0; v < 4; ++v) {
+        const int j = jt2 + mfma_acc<T>::row(lane2, v), k = 16 * kt + li2;
+        T pn, mn, vn, tn;
+        adam_update<T>(L.wt2[k * kRow + j], g2[kt][v], s2[kt][v], c, pn, mn, vn, tn);
+        new_w2[kt][v] = pn;
+        const size_t e = (size_t)j * kH + k;
+        m_w2[e] = mn;
+        v_w2[e] = vn;
+        w2[e] = pn;
+        if (c.blend) tw2[e] = tn;
       }
-      const size_t e = (size_t)(j0 + a) * kH + k0;
-      *reinterpret_cast<vec4<T>*>(m_w2 + e) = mn;
-      *reinterpret_cast<vec4<T>*>(v_w2 + e) = vn;
-      *reinterpret_cast<vec4<T>*>(w2 + e) = pn;
-      if (c.blend) *reinterpret_cast<vec4<T>*>(tw2 + e) = tn;
-    }
     if (t < kH) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
@@ -486,39 +507,38 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   lds_barrier();
-  // delta1[s][k] = (sum_j W2[j][k] delta2[s][j]) * (h1[s][k] > 0), in place over h1, from the
+  // delta1[s][k] = (sum_j delta2[s][j] W2[j][k]) * (h1[s][k] > 0), in place over h1, from the
   // weights this step started from (LDS still holds them: the update above went to memory only).
-  // Thread tile 2 samples x 4 inputs k, k interleaved by 16 so that the rows of wt2 read by the
-  // lanes of a wave fall into different banks.
+  // M = s (two tiles), N = k (wave w takes columns 16 w ..), K = j.  A = delta2 (in h2), B = W2
+  // read from its transposed copy wt2[k][j] (rows 66 apart: the 16 lanes of a group hit 16 banks).
   {
-    const int kg = t & 15, sg = t >> 4;
-    const int s0 = sg * 2;
-    T acc[2][4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[0][b] = acc[1][b] = (T)0;
+    typedef typename mfma_acc<T>::type acc_t;
+    const int lq = lane2 >> 4;
+    acc_t d0 = {(T)0, (T)0, (T)0, (T)0}, d1 = d0;
 #pragma unroll 4
-    for (int j = 0; j < kH; ++j) {
-      const T d0 = L.h2[s0 * kRow + j], d1 = L.h2[(s0 + 1) * kRow + j];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const T w = L.wt2[(kg + 16 * b) * kRow + j];
-        acc[0][b] = fma_t<T>(w, d0, acc[0][b]);
-        acc[1][b] = fma_t<T>(w, d1, acc[1][b]);
-      }
+    for (int j0 = 0; j0 < kH; j0 += 4) {
+      const T b = L.wt2[(jt2 + li2) * kRow + j0 + lq];
+      d0 = mfma(L.h2[li2 * kRow + j0 + lq], b, d0);
+      d1 = mfma(L.h2[(16 + li2) * kRow + j0 + lq], b, d1);
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {   // (no other thread reads or writes these cells of h1 here)
-      const int k = kg + 16 * b;
-      const T h0 = L.h1[s0 * kRow + k], h1v = L.h1[(s0 + 1) * kRow + k];
-      L.h1[s0 * kRow + k] = h0 > (T)0 ? acc[0][b] : (T)0;
-      L.h1[(s0 + 1) * kRow + k] = h1v > (T)0 ? acc[1][b] : (T)0;
+    for (int v = 0; v < 4; ++v) {   // (each cell of h1 is read and written by this lane only)
+      const int r = mfma_acc<T>::row(lane2, v), k = jt2 + li2;
+      const T h0 = L.h1[r * kRow + k], h1v = L.h1[(16 + r) * kRow + k];
+      L.h1[r * kRow + k] = h0 > (T)0 ? d0[v] : (T)0;
+      L.h1[(16 + r) * kRow + k] = h1v > (T)0 ? d1[v] : (T)0;
     }
   }
   lds_barrier();   // every read of the old second-layer weights is done
+  sb1.m = sb1.v = sb1.target = (T)0;
+  if (t < kH) {   // (state of the first layer's bias: used at the very end)
+    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
+  }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) L.wt2[(kg2 * 4 + b) * kRow + jg2 * 4 + a] = new_w2[a][b];
+    for (int v = 0; v < 4; ++v)
+      L.wt2[(16 * kt + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
   for (int e = t; e < kH * D; e += 256) {   // (a small tensor: its state is loaded here)

@@ -130,7 +130,25 @@ def test_argument_errors_map_to_reference_exceptions():
         _lib.check(lib.cobel_tab_query(1000000, 1, 10, None, None))
     with pytest.raises(NotImplementedError):
         _lib.check(lib.cobel_tab_query(25, 1, 63, None, None))
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_dqn_replay(None, None))
+    with pytest.raises(AssertionError):
+        _lib.check(lib.cobel_dqn_act(None, None, None))
+    with pytest.raises(NotImplementedError):      # only 64-64 networks with 4 outputs, batch 32
+        _lib.check(lib.cobel_dqn_replay_query(6, 32, 64, 4, 32, 1, None))
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_dqn_replay_query(33, 64, 64, 4, 32, 1, None))
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 16, 0, None))
     lds = C.c_int32()
+    _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 32, 1, C.byref(lds)))
+    assert 70000 < lds.value <= 80 * 1024          # two workgroups per CU in float64
+    _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 32, 0, C.byref(lds)))
+    assert lds.value <= 40 * 1024                  # four in float32
+    run = _lib.DQNReplay()
+    run.n_inputs, run.n_hidden1, run.n_hidden2, run.n_actions, run.batch = 6, 64, 64, 4, 32
+    with pytest.raises(AssertionError):            # NULL tensors are refused before any launch
+        _lib.check(lib.cobel_dqn_replay(C.byref(run), None))
     _lib.check(lib.cobel_tab_query(1024, 1, 50, C.byref(lds), None))
     assert lds.value == 1024 * (16 + 8 + 4) + 2048   # Q, compact model, visit counters, hash
     r, s, t = C.c_float(), C.c_uint16(), C.c_uint8()
