@@ -43,8 +43,6 @@ constexpr int kMaxD = 32;     // input width limit
 
 struct mlp_args {
   cobel_dqn_replay_t r;
-  int32_t stagger_ticks;   // span of the start delays of the first resident workgroups, 10 ns units
-  int32_t stagger_first;   // workgroups that are resident when the launch begins
 };
 
 template <typename T>
@@ -278,12 +276,6 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   if (R.active && !R.active[i]) return;
   const int t = (int)threadIdx.x;
   const int D = R.n_inputs;
-  if (A.stagger_ticks > 0 && (int)blockIdx.x < A.stagger_first) {
-    const uint32_t phase = ((uint32_t)blockIdx.x * 2654435769u) >> 16;   // golden-ratio sequence
-    const unsigned long long wait = ((unsigned long long)phase * (uint32_t)A.stagger_ticks) >> 16;
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
   mlp_lds<T> L;
   {
     T* p = reinterpret_cast<T*>(lds_raw);
@@ -332,20 +324,22 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // ---- the elements this thread will update (see adam_slot) -----------------------------------
   // second layer: the 4 x 4 tile (j0 .., k0 ..) of the backward pass; first layer: elements
   // t, t + 256, ...; output layer: element t; biases: threads < 64 / < 4.  The moments are loaded
-  // at the start of the backward pass (kept in registers from the start of the kernel, or from
-  // before the online forward pass, they crowd the forward passes' inner loops: measured slower in
-  // float64, 902 -> 952 us per launch at 8 192 instances).
+  // at the start of the backward pass (requested before the forward passes they cost registers
+  // there: measured slower, 0.80 -> 1.17 ms per C5 step in float64).
   // second layer: element (kt, v) of this thread is W2[j][k] with j = 16 (t / 64) + row(lane, v),
   // k = 16 kt + lane % 16 — the accumulator layout of the MFMA tiles of the backward pass
   const int lane2 = t & 63, jt2 = (t >> 6) * 16, li2 = lane2 & 15;
   adam_slot<T> s2[4][4], s3, sb1, sb2, sb3;
   // ---- Q_target(s') ---------------------------------------------------------------------------
-  param_regs<T> P;
-  params_load<T>(P, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
-  params_store<T>(L, P, tw1, D, t);
+  // Both networks' parameters are requested at once (the online network's stay in registers until
+  // the target network's forward pass has released the LDS buffer): twice the bytes in flight while
+  // the workgroup has nothing to compute.
+  param_regs<T> P, PT;
+  params_load<T>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
+  params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);
+  params_store<T>(L, PT, tw1, D, t);
   load_rows<T>(L.x, xn, L.slot, D, t);
   lds_barrier();
-  params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);   // in flight during the target forward pass
   // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
   // end (the other, small tensors are read again with their moments in the backward pass)
 #pragma unroll
@@ -643,13 +637,6 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   if (r.n == 0) return COBEL_OK;
   mlp_args A;
   A.r = r;
-  // Workgroups that start together stay in step: all load, then all compute.  The ones resident
-  // at the start of a launch that needs several rounds begin at delays spread over 20 us (float64;
-  // 10 us float32), so that the memory phases of the workgroups sharing a CU fall into each
-  // other's compute phases (8 192 instances: 900 -> 770 us per launch in float64).
-  static const char* const stag = getenv("COBEL_DEBUG_MLP_STAGGER_US");   // experiments
-  A.stagger_first = 256 * (r.is_float64 ? 2 : COBEL_MLP_WAVES_F32);
-  A.stagger_ticks = stag ? atoi(stag) * 100 : (r.n > 2 * A.stagger_first ? (r.is_float64 ? 2000 : 1000) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
     // (raised once per device: the call is not free and this entry point runs every step)
