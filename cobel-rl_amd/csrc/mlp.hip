@@ -25,10 +25,11 @@
 // HBM traffic per instance and step: 8 streams over the parameters (online read + write, two
 // moments read + write, target read + write) = 8 x 39 KB (float64).
 //
-// Arithmetic: products are accumulated with fused multiply-adds in the network's dtype, one
-// accumulator per output in index order — not torch's GEMM order, so results agree with the
-// PyTorch path to rounding (1e-12 relative in float64 on single steps; tests bound it), not bit for
-// bit.  The optimizer update is k_adam's (adam.hip), operation for operation.
+// Arithmetic: the three 64 x 64 products are 16 x 16 x 4 MFMAs in the network's dtype (see
+// mfma_acc below), the thin layers fused multiply-adds with one accumulator per output in index
+// order — not torch's GEMM order, so results agree with the PyTorch path to rounding (1e-10
+// relative in float64 after ten steps; tests bound it), not bit for bit.  The optimizer update is
+// k_adam's (adam.hip), operation for operation.
 #include <stdlib.h>
 
 #include "cobel_common.h"

@@ -1,6 +1,4 @@
-"""Scratch: launch time of cobel_dqn_replay alone (C5 shapes, gathered batches) for several spans of
-the staggered workgroup starts (COBEL_DEBUG_MLP_STAGGER_US; read once per process, so one span per
-run: `COBEL_DEBUG_MLP_STAGGER_US=20 python scripts/exp_mlp.py`)."""
+"""Scratch: launch time of cobel_dqn_replay alone (C5 shapes, gathered batches)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
@@ -16,7 +14,7 @@ for dt_name in ('f64', 'f32'):
     s = torch.rand((n, B, 6), device=dev, dtype=dt); ns = torch.rand((n, B, 6), device=dev, dtype=dt)
     a = torch.randint(0, 4, (n, B), device=dev); r = torch.rand((n, B), device=dev, dtype=dt)
     nt = torch.ones((n, B), device=dev, dtype=dt)
-    for skip, stag in [(0, int(os.environ.get('COBEL_DEBUG_MLP_STAGGER_US', '-1')))]:
+    for _ in (0,):
         for _ in range(2):
             assert net.dqn_replay_fused(tgt, s, a, r, ns, nt, 0.8, False, 0.01, None)
         torch.cuda.synchronize()
@@ -24,4 +22,4 @@ for dt_name in ('f64', 'f32'):
         for _ in range(10):
             net.dqn_replay_fused(tgt, s, a, r, ns, nt, 0.8, False, 0.01, None)
         torch.cuda.synchronize()
-        print('%s skip %3d stagger %2d us: %.1f us per launch' % (dt_name, skip, stag, (time.perf_counter() - t0) / 10 * 1e6), flush=True)
+        print('%s: %.1f us per launch' % (dt_name, (time.perf_counter() - t0) / 10 * 1e6), flush=True)
