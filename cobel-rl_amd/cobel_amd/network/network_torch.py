@@ -334,20 +334,43 @@ class StackedTorchNetwork:
     fused_mlp = True       # False keeps the PyTorch forward / backward (tests compare the two)
 
     def _mlp3_names(self):
-        """Names of the three Linear layers if the architecture is [Flatten -] Linear - ReLU -
-        Linear - ReLU - Linear with every parameter trainable, else None (cached)."""
-        if not hasattr(self, '_mlp3'):
-            self._mlp3 = None
-            kids = list(self.base.named_children()) if isinstance(self.base, nn.Sequential) else []
-            if kids and type(kids[0][1]) is nn.Flatten:
-                kids = kids[1:]
-            kinds = [type(m) for _, m in kids]
-            if kinds == [nn.Linear, nn.ReLU, nn.Linear, nn.ReLU, nn.Linear] and not self.buffers:
-                names = [kids[0][0], kids[2][0], kids[4][0]]
-                want = [n + s for n in names for s in ('.weight', '.bias')]
-                if sorted(want) == sorted(self.params) and \
-                        all(p.requires_grad for p in self.params.values()):
+        """Names of the three Linear layers if the model computes Linear - ReLU - Linear - ReLU -
+        Linear on a (flattened) input, else None (cached).  Recognised by behaviour, not by class:
+        the reference's demo and test models are custom ``Module``s that call
+        ``torch.nn.functional.relu`` in ``forward`` (demo/topology/demo_dqn.py:36-60), others are
+        ``nn.Sequential``s — so the model must own exactly three Linear layers (all trainable,
+        nothing else with parameters or buffers) whose shapes chain, and instance 0 must agree
+        with the explicit formula on random probes."""
+        if hasattr(self, '_mlp3'):
+            return self._mlp3
+        self._mlp3 = None
+        lin = [(k, m) for k, m in self.base.named_modules() if type(m) is nn.Linear]
+        want = [k + s for k, _ in lin for s in ('.weight', '.bias')]
+        if len(lin) != 3 or self.buffers or sorted(want) != sorted(self.params) or \
+                not all(p.requires_grad for p in self.params.values()):
+            return None
+        names = [k for k, _ in lin]
+        w = [self.params[k + '.weight'] for k in names]
+        if w[1].shape[2] != w[0].shape[1] or w[2].shape[2] != w[1].shape[1]:
+            return None
+        try:
+            with torch.no_grad():
+                p0 = {k: v[0] for k, v in self.params.items()}
+                gen = torch.Generator(device='cpu').manual_seed(1234)
+                x = (torch.rand((16, w[0].shape[2]), generator=gen, dtype=torch.float64) * 4 - 2
+                     ).to(device=self.device, dtype=w[0].dtype)
+                got = functional_call(self.base, (p0, {}), (x,))
+                h = x
+                for k in names[:2]:
+                    h = torch.relu(torch.nn.functional.linear(h, p0[k + '.weight'], p0[k + '.bias']))
+                ref = torch.nn.functional.linear(h, p0[names[2] + '.weight'], p0[names[2] + '.bias'])
+                tol = 1e-11 if w[0].dtype == torch.float64 else 1e-5
+                hidden_used = bool((h == 0).any()) and bool((h > 0).any())   # the probe saw both
+                if got.shape == ref.shape and hidden_used and \
+                        torch.allclose(got, ref, rtol=tol, atol=tol):      # sides of the ReLUs
                     self._mlp3 = names
+        except Exception:      # a forward that does not take one [B, D] batch: not this shape
+            self._mlp3 = None
         return self._mlp3
 
     def dqn_replay_fused(self, target: 'StackedTorchNetwork', states, actions, rewards, next_states,

@@ -823,6 +823,31 @@ def _mlp(torch, init):
     return net
 
 
+def _module_mlp(torch, init):
+    """The same network written the way the reference's demos write it
+    (demo/topology/demo_dqn.py:36-60): a custom Module calling functional relu in forward."""
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer_dense_1 = torch.nn.Linear(6, 64)
+            self.layer_dense_2 = torch.nn.Linear(64, 64)
+            self.layer_output = torch.nn.Linear(64, 4)
+            self.double()
+
+        def forward(self, layer_input):
+            x = torch.reshape(layer_input, (len(layer_input), -1))
+            x = torch.nn.functional.relu(self.layer_dense_1(x))
+            x = torch.nn.functional.relu(self.layer_dense_2(x))
+            return self.layer_output(x)
+
+    net = Model()
+    state = net.state_dict()
+    for key, w in zip(state, init):
+        state[key] = torch.as_tensor(w)
+    net.load_state_dict(state)
+    return net
+
+
 @pytest.mark.parametrize('name', ['dqn_i0', 'dqn_i2'])
 def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     """DQN on linear_track(10, 2), float64 6-64-64-4 MLP on PyTorch-ROCm, against the reference run
@@ -1563,6 +1588,15 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn):
     o = other.replicate(3)
     assert not o.dqn_replay_fused(o.clone(), s[:3], a[:3], r[:3], ns[:3], nt[:3], gamma, False,
                                   tau, None)
+    if n_in == 6:   # right shapes, wrong activation: recognised by behaviour, so refused as well
+        tanh = TorchNetwork(torch.nn.Sequential(
+            torch.nn.Linear(6, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+            torch.nn.Linear(64, 4)).to(dt))
+        tanh.set_device(torch.device('cuda', 0))
+        o = tanh.replicate(3)
+        assert o._mlp3_names() is None
+        assert not o.dqn_replay_fused(o.clone(), s[:3], a[:3], r[:3], ns[:3], nt[:3], gamma, False,
+                                      tau, None)
 
 
 @pytest.mark.parametrize('dtype_name', ['f64', 'f32'])
@@ -1584,8 +1618,8 @@ def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, dtype_name):
 
     def run(fused):
         env = Topology(nodes, starts, n_envs=48, seed=4242, instance_base=9)
-        net = _mlp(torch, init)
-        net = net.double() if dtype_name == 'f64' else net.float()
+        # float64: the reference's way of writing the model (a custom Module); float32: Sequential
+        net = _module_mlp(torch, init) if dtype_name == 'f64' else _mlp(torch, init).float()
         ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.4), TorchNetwork(net),
                  gamma=0.8, memory=DQNMemory(capacity=40))
         ag.fused_loop = None if fused else False
