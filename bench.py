@@ -71,7 +71,7 @@ CONFIGS = {
 SEED = 0xC0BE1
 
 
-def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=None):
+def run_c5(device, dtype_name, n=8192, iters=256, warm=8, graph=None):
     """C5: 8192 linear_track(10, 2) Topology envs, DQN 6-64-64-4 (gamma .8, eps .3, Adam 1e-3, MSE,
     tau .01, batch 32, 100 steps/trial), one network and one replay ring per instance.  graph =
     None: the two-kernel loop (cobel_dqn_act + cobel_dqn_replay); True: the PyTorch loop with one
@@ -95,7 +95,11 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=4, graph=None):
                 TorchNetwork(net, optimizer_params={'lr': 1e-3}), gamma=0.8,
                 memory=DQNMemory(capacity=256))
     agent.use_graph = graph
+    # warm-up: a short run, then one of the timed length (rings at their final size, and — after
+    # the host-only CPU-baseline legs before this one — the GPU back at its working clocks: the
+    # first 0.3 s after an idle phase run 1.3-1.6x slower)
     agent._run(env, 4096, 100, 32, True, budget=warm)
+    agent._run(env, 4096, 100, 32, True, budget=iters)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     agent._run(env, 4096, 100, 32, True, budget=iters)
@@ -496,6 +500,8 @@ def main():
             try:
                 others.update(run_next_rows(device))
             except Exception as e:
+                import traceback
+                traceback.print_exc()      # (stderr: the JSON line on stdout stays one line)
                 others['next_rows'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:

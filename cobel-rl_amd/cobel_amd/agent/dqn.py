@@ -17,12 +17,31 @@ Requires array observations (``interface.observe()`` -> ``[N, D]``), e.g. ``Topo
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import numpy as np
 import torch
 
 from .. import _lib
 from ..memory.dqn import DQNMemory
 from .agent import Agent, DeviceMonitors
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """``torch.cuda.graph`` with the garbage collector switched off for the duration: a collection
+    in the middle of a capture can free tensors of earlier runs, and the allocator's event
+    bookkeeping for them is not capturable (seen once as hipErrorStreamCaptureInvalidated in a
+    bench run that had several agents behind it)."""
+    was_enabled = gc.isenabled()      # (torch.cuda.graph itself collects once on entry)
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class DQN(Agent):
@@ -343,7 +362,7 @@ class DQN(Agent):
             iteration()
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 iteration()
             for _ in range(budget - 4):
                 graph.replay()
@@ -367,7 +386,7 @@ class DQN(Agent):
                             k -= 1
                             torch.cuda.synchronize(dev)
                             graph = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(graph):
+                            with _capture(graph):
                                 iteration()
                         for _ in range(k):
                             graph.replay()
