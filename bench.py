@@ -178,10 +178,13 @@ def run_next_rows(device):
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 4)), gamma=0.8)
-    agent.use_graph = True
+    timed(agent, env, n, 128)          # (warm-up of the timed length, as for C5)
     r = timed(agent, env, n, 128)
     r['config'] = {'workload': 'Dyna-DQN: %d x 5x5 open field, MLP 25-64-64-4 f64 per instance, '
-                               'model-sampled batches of 32, one step replayed from a HIP graph' % n,
+                               'model-sampled batches of 32, %s' % (
+                                   n, 'two launches per lockstep step: cobel_dqn_act (world-model '
+                                   'mode) + cobel_dqn_replay' if agent.fused_steps else
+                                   'PyTorch-ROCm loop'),
                    'instances_per_gpu': n, 'lockstep_iterations': 128}
     out['dyna_dqn'] = r
     del agent, env

@@ -57,6 +57,7 @@ class DQNReplay(C.Structure):
         ('eps', C.c_double), ('weight_decay', C.c_double), ('tau', C.c_double),
         ('batch_slots', C.c_void_p), ('ring_slots', C.c_int32), ('reserved_', C.c_int32),
         ('obs_index', C.c_void_p), ('obs_table', C.c_void_p), ('q_out', C.c_void_p),
+        ('state_index', C.c_void_p), ('next_index', C.c_void_p),
     ]
 
 
@@ -78,6 +79,12 @@ class DQNAct(C.Structure):
         ('steps_per_trial', C.c_int32), ('trials_target', C.c_int32), ('trial_cap', C.c_int32),
         ('mon_stripes', C.c_int32),
         ('instance_base', C.c_uint32), ('reserved_', C.c_uint32), ('seed', C.c_uint64),
+        ('model_rewards', C.c_void_p), ('model_states', C.c_void_p),
+        ('model_nonterminal', C.c_void_p), ('model_lr', C.c_double),
+        ('n_states', C.c_int32), ('reserved2_', C.c_int32),
+        ('batch_state_index', C.c_void_p), ('batch_next_index', C.c_void_p),
+        ('batch_actions', C.c_void_p), ('batch_rewards', C.c_void_p),
+        ('batch_nonterminal', C.c_void_p),
     ]
 
 

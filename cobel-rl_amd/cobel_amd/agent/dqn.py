@@ -185,8 +185,8 @@ class DQN(Agent):
         from ..interface.topology import Topology
         from ..policy.greedy import EpsilonGreedy
         net = self._online
-        if type(self) is not DQN or self.fused_loop is False or self.use_graph is True \
-                or not isinstance(interface, Topology) or type(self.M) is not DQNMemory \
+        if not self._fused_setting_ok(interface) or self.fused_loop is False \
+                or self.use_graph is True \
                 or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \
                 or getattr(self, '_no_replay', False) or not net.fused_mlp:
             return False
@@ -203,6 +203,31 @@ class DQN(Agent):
             w[0].shape[2], w[0].shape[1], w[1].shape[1], w[2].shape[1], batch_size,
             int(self.dtype == torch.float64), None) == _lib.OK
 
+    def _fused_setting_ok(self, interface) -> bool:
+        """Agent class, environment and memory are the ones ``_fused_wire`` knows how to hand to
+        the kernels."""
+        from ..interface.topology import Topology
+        return type(self) is DQN and isinstance(interface, Topology) and type(self.M) is DQNMemory
+
+    def _fused_wire(self, interface, act, rep, batch_size: int):
+        """Environment and memory side of the two launch descriptors; returns (world handle,
+        env state tensor, observation table, tensors to keep alive)."""
+        M, n, dev = self.M, self.n_envs, self.device
+        slots = torch.zeros((n, batch_size), dtype=torch.int32, device=dev)
+        for run in (act, rep):
+            prefix = 'ring_' if run is act else ''
+            setattr(run, prefix + 'states', _lib.ptr(M.states))
+            setattr(run, prefix + 'next_states', _lib.ptr(M.next_states))
+            setattr(run, prefix + 'actions', _lib.ptr(M.actions))
+            setattr(run, prefix + 'rewards', _lib.ptr(M.rewards))
+            setattr(run, prefix + 'nonterminal', _lib.ptr(M.terminals))
+        act.ring_size, act.ring_head = _lib.ptr(M.size), _lib.ptr(M.head)
+        act.memory_ctr, act.slots = _lib.ptr(M.counter), M.slots
+        act.batch_slots = rep.batch_slots = _lib.ptr(slots)
+        rep.ring_slots = M.slots
+        act.env_ctr = _lib.ptr(interface.env_ctr)
+        return interface.handle.ptr, interface.state, interface._pose_dev, [slots]
+
     def _run_fused(self, interface, pol, trials: int, steps: int, batch_size: int,
                    budget: int) -> None:
         """Two launches per lockstep step and nothing else: cobel_dqn_act (select, env.step,
@@ -214,13 +239,13 @@ class DQN(Agent):
         n, dev, net, M, mon = self.n_envs, self.device, self._online, self.M, self.monitors
         first = self.current_trial
         f64 = self.dtype == torch.float64
-        table = interface._pose_dev
+        rep, act = _lib.DQNReplay(), _lib.DQNAct()
+        world, state, table, keep = self._fused_wire(interface, act, rep, batch_size)
         q = self._q_values(interface.observe().to(self.dtype)).contiguous()
         step = torch.zeros(n, dtype=torch.int32, device=dev)
         trew = torch.zeros(n, dtype=torch.float64, device=dev)
         active = torch.ones(n, dtype=torch.uint8, device=dev)
         stepped = torch.zeros(n, dtype=torch.uint8, device=dev)
-        slots = torch.zeros((n, batch_size), dtype=torch.int32, device=dev)
         # Adam step counts per instance (shared with the PyTorch path's fused optimizer kernel)
         net._diverged = True
         opt = net.optimizer
@@ -231,7 +256,6 @@ class DQN(Agent):
             counts = net._steps = torch.full((n,), max(seen, default=0.0), dtype=torch.float64,
                                              device=dev)
         names = net._mlp3_names()
-        rep = _lib.DQNReplay()
         for k, name in enumerate(names):
             for kind, dp, dt_, dm, dv in (('.weight', rep.w, rep.w_target, rep.m_w, rep.v_w),
                                           ('.bias', rep.b, rep.b_target, rep.m_b, rep.v_b)):
@@ -247,9 +271,6 @@ class DQN(Agent):
         w = [net.params[k + '.weight'] for k in names]
         group = opt.param_groups[0]
         rep.steps, rep.active = _lib.ptr(counts), _lib.ptr(stepped)
-        rep.states, rep.next_states = _lib.ptr(M.states), _lib.ptr(M.next_states)
-        rep.actions, rep.rewards = _lib.ptr(M.actions), _lib.ptr(M.rewards)
-        rep.nonterminal = _lib.ptr(M.terminals)
         rep.n, rep.batch = n, batch_size
         rep.n_inputs, rep.n_hidden1 = w[0].shape[2], w[0].shape[1]
         rep.n_hidden2, rep.n_actions = w[1].shape[1], w[2].shape[1]
@@ -258,28 +279,21 @@ class DQN(Agent):
         rep.beta1, rep.beta2 = (float(b) for b in group['betas'])
         rep.eps, rep.weight_decay = float(group['eps']), float(group['weight_decay'])
         rep.tau = float(self.target_update)
-        rep.batch_slots, rep.ring_slots = _lib.ptr(slots), M.slots
-        rep.obs_index, rep.obs_table, rep.q_out = _lib.ptr(interface.state), _lib.ptr(table), _lib.ptr(q)
-        act = _lib.DQNAct()
-        act.state, act.env_ctr = _lib.ptr(interface.state), _lib.ptr(interface.env_ctr)
+        rep.obs_index, rep.obs_table, rep.q_out = _lib.ptr(state), _lib.ptr(table), _lib.ptr(q)
+        act.state = _lib.ptr(state)
         act.obs_table, act.q = _lib.ptr(table), _lib.ptr(q)
         act.policy_ctr, act.policy_stream = _lib.ptr(pol.counter), pol.stream
         act.is_float64, act.epsilon = int(f64), float(pol.epsilon)
-        act.ring_states, act.ring_next_states = _lib.ptr(M.states), _lib.ptr(M.next_states)
-        act.ring_actions, act.ring_rewards = _lib.ptr(M.actions), _lib.ptr(M.rewards)
-        act.ring_nonterminal = _lib.ptr(M.terminals)
-        act.ring_size, act.ring_head = _lib.ptr(M.size), _lib.ptr(M.head)
-        act.memory_ctr = _lib.ptr(M.counter)
         act.trial, act.step, act.trial_reward = _lib.ptr(self.trial), _lib.ptr(step), _lib.ptr(trew)
         act.active, act.adam_steps = _lib.ptr(active), _lib.ptr(counts)
         act.lat_sum, act.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
         act.reward_sum = _lib.ptr(mon.raw('reward_sum'))
-        act.stepped, act.batch_slots = _lib.ptr(stepped), _lib.ptr(slots)
-        act.n, act.n_obs, act.slots, act.batch = n, table.shape[1], M.slots, batch_size
+        act.stepped = _lib.ptr(stepped)
+        act.n, act.n_obs, act.batch = n, table.shape[1], batch_size
         act.steps_per_trial, act.trials_target = steps, first + trials
         act.trial_cap, act.mon_stripes = mon.cap, mon.stripes
         act.instance_base, act.seed = interface.instance_base, interface.seed
-        lib, world, stream = _lib.lib(), interface.handle.ptr, _lib.current_stream(dev)
+        lib, stream = _lib.lib(), _lib.current_stream(dev)
         done = 0
         while True:
             chunk = (budget - done) if budget else min(steps, 64)

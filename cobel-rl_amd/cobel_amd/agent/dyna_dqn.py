@@ -144,6 +144,36 @@ class DynaDQN(DQN):
             self._target.copy_from(self._online, active)
             self.last_update = 0
 
+    # -- two-kernel training step (see DQN._run_fused) -------------------------------------------
+    def _fused_setting_ok(self, interface) -> bool:
+        from ..interface.gridworld import Gridworld
+        return type(self) is DynaDQN and isinstance(interface, DynaDQN._ObsView) \
+            and isinstance(interface.env, Gridworld) and type(self.M) is _ModelMemory \
+            and self.M.A == 4 and interface.table.dtype == torch.float64 \
+            and interface.table.dim() == 2 and not self.mask_actions and not self.episodic_replay
+
+    def _fused_wire(self, interface, act, rep, batch_size: int):
+        """cobel_dqn_act in world-model mode: it updates the model tables in place and writes the
+        drawn batch out as state indices (rows of the observation table) + gathered action /
+        reward / non-terminal arrays, which cobel_dqn_replay reads in its index mode."""
+        M, n, dev, env = self.M, self.n_envs, self.device, interface.env
+        si = torch.zeros((n, batch_size), dtype=torch.int32, device=dev)
+        ni = torch.zeros_like(si)
+        ba = torch.zeros((n, batch_size), dtype=torch.int64, device=dev)
+        br = torch.zeros((n, batch_size), dtype=self.dtype, device=dev)
+        bt = torch.zeros_like(br)
+        act.model_rewards, act.model_states = _lib.ptr(M.rewards), _lib.ptr(M.states)
+        act.model_nonterminal, act.model_lr = _lib.ptr(M.terminals), float(M.learning_rate)
+        act.n_states, act.memory_ctr = M.S, _lib.ptr(M.counter)
+        act.batch_state_index = rep.state_index = _lib.ptr(si)
+        act.batch_next_index = rep.next_index = _lib.ptr(ni)
+        act.batch_actions = rep.actions = _lib.ptr(ba)
+        act.batch_rewards = rep.rewards = _lib.ptr(br)
+        act.batch_nonterminal = rep.nonterminal = _lib.ptr(bt)
+        act.env_ctr = _lib.ptr(env.env_ctr)
+        table = interface.table.contiguous()
+        return env.handle.ptr, env.state, table, [si, ni, ba, br, bt, table]
+
     def _run(self, interface, trials, steps, batch_size, learn, budget: int = 0) -> None:
         view = self._view(interface)
         self._table = view.table

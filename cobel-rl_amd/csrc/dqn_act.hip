@@ -29,7 +29,8 @@ struct act_args {
   cobel_eps_consts eps;
 };
 
-template <typename T>
+// DYNA: the memory is DynaDQN's tabular world model instead of a replay ring.
+template <typename T, bool DYNA>
 __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   const cobel_dqn_act_t& R = A.r;
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -57,13 +58,24 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   const float reward = entered.reward;
   const bool done = entered.terminal != 0u;
 
-  // ---- store (memory/dqn.py:103-119): FIFO ring, the oldest entry goes once it is full --------------
+  // ---- store ----------------------------------------------------------------------------------------
   const int slots = R.slots;
-  int size = R.ring_size[i];
-  long long head = R.ring_head[i];
-  const bool full = size >= slots;
-  const int slot = (int)((head + (long long)size) % slots);
-  {
+  int size = 0;
+  long long head = 0;
+  if (DYNA) {
+    // memory/dyna_q.py:92-96 in float64: rewards[s, a] += lr * (r - rewards[s, a]); states[s, a] =
+    // ns; terminals[s, a] = 1 - end_trial
+    const size_t e = (size_t)i * R.n_states * 4 + (size_t)s * 4 + (a & 3);
+    const double old = R.model_rewards[e];
+    R.model_rewards[e] = old + R.model_lr * ((double)reward - old);
+    R.model_states[e] = (int64_t)ns;
+    R.model_nonterminal[e] = done ? 0.0 : 1.0;
+  } else {
+    // memory/dqn.py:103-119: FIFO ring, the oldest entry goes once it is full
+    size = R.ring_size[i];
+    head = R.ring_head[i];
+    const bool full = size >= slots;
+    const int slot = (int)((head + (long long)size) % slots);
     const size_t row = (size_t)i * slots + slot;
     T* const ds = (T*)R.ring_states + row * D;
     T* const dn = (T*)R.ring_next_states + row * D;
@@ -76,11 +88,11 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
     R.ring_actions[row] = (int64_t)a;
     ((T*)R.ring_rewards)[row] = (T)reward;
     ((T*)R.ring_nonterminal)[row] = done ? (T)0 : (T)1;
+    if (full) head = (head + 1) % slots;
+    else size += 1;
+    R.ring_size[i] = size;
+    R.ring_head[i] = head;
   }
-  if (full) head = (head + 1) % slots;
-  else size += 1;
-  R.ring_size[i] = size;
-  R.ring_head[i] = head;
 
   // ---- trial bookkeeping (agent/dqn.py:186-212) -------------------------------------------------------
   int trial = R.trial[i];
@@ -119,7 +131,21 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   // ---- replay batch (memory/dqn.py:137): `batch` indices below the number of stored entries --------
   R.stepped[i] = 1;
   if (R.adam_steps) R.adam_steps[i] += 1.0;
-  if (R.batch_slots) {
+  if (DYNA) {
+    // memory/dyna_q.py:137-155: `batch` pairs drawn uniformly from all n_states x 4 pairs
+    const uint32_t mc = R.memory_ctr[i];
+    const uint32_t pairs = (uint32_t)R.n_states * 4u;
+    const size_t base = (size_t)i * pairs, out = (size_t)i * R.batch;
+    for (int j = 0; j < R.batch; ++j) {
+      const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed, pairs);
+      R.batch_state_index[out + j] = (int32_t)(idx >> 2);
+      R.batch_next_index[out + j] = (int32_t)R.model_states[base + idx];
+      R.batch_actions[out + j] = (int64_t)(idx & 3u);
+      ((T*)R.batch_rewards)[out + j] = (T)R.model_rewards[base + idx];
+      ((T*)R.batch_nonterminal)[out + j] = (T)R.model_nonterminal[base + idx];
+    }
+    R.memory_ctr[i] = mc + 1u;
+  } else if (R.batch_slots) {
     const uint32_t mc = R.memory_ctr[i];
     for (int j = 0; j < R.batch; ++j) {
       const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed,
@@ -138,15 +164,22 @@ extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* 
   const cobel_dqn_act_t& r = *run;
   COBEL_REQUIRE(r.state && r.env_ctr && r.obs_table && r.q && r.policy_ctr, COBEL_E_ARG,
                 "cobel_dqn_act: NULL env / policy argument");
-  COBEL_REQUIRE(r.ring_states && r.ring_next_states && r.ring_actions && r.ring_rewards &&
-                    r.ring_nonterminal && r.ring_size && r.ring_head,
-                COBEL_E_ARG, "cobel_dqn_act: NULL replay ring argument");
+  const bool dyna = r.model_rewards != nullptr;
+  if (dyna)
+    COBEL_REQUIRE(r.model_states && r.model_nonterminal && r.memory_ctr && r.batch_state_index &&
+                      r.batch_next_index && r.batch_actions && r.batch_rewards &&
+                      r.batch_nonterminal && r.n_states == world->n_states,
+                  COBEL_E_ARG, "cobel_dqn_act: incomplete world-model arguments");
+  else
+    COBEL_REQUIRE(r.ring_states && r.ring_next_states && r.ring_actions && r.ring_rewards &&
+                      r.ring_nonterminal && r.ring_size && r.ring_head,
+                  COBEL_E_ARG, "cobel_dqn_act: NULL replay ring argument");
   COBEL_REQUIRE(r.trial && r.step && r.trial_reward && r.active && r.stepped, COBEL_E_ARG,
                 "cobel_dqn_act: NULL bookkeeping argument");
   COBEL_REQUIRE(!r.batch_slots || r.memory_ctr, COBEL_E_ARG,
                 "cobel_dqn_act: batch_slots given without memory_ctr");
-  COBEL_REQUIRE(r.n >= 0 && r.n_obs > 0 && r.slots > 0 && r.batch >= 0 && r.steps_per_trial > 0 &&
-                    r.trial_cap >= 0,
+  COBEL_REQUIRE(r.n >= 0 && r.n_obs > 0 && (dyna || r.slots > 0) && r.batch >= 0 &&
+                    r.steps_per_trial > 0 && r.trial_cap >= 0,
                 COBEL_E_RANGE, "cobel_dqn_act: bad sizes");
   COBEL_REQUIRE(r.epsilon >= 0.0 && r.epsilon <= 1.0, COBEL_E_ARG,
                 "cobel_dqn_act: epsilon %g outside [0, 1]", r.epsilon);
@@ -160,10 +193,11 @@ extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* 
   A.r = r;
   A.eps = cobel_make_eps_consts(r.epsilon);
   const dim3 grid((unsigned)((r.n + 63) / 64));
-  if (r.is_float64)
-    hipLaunchKernelGGL(k_dqn_act<double>, grid, dim3(64), 0, (hipStream_t)stream, A);
-  else
-    hipLaunchKernelGGL(k_dqn_act<float>, grid, dim3(64), 0, (hipStream_t)stream, A);
+  hipStream_t st = (hipStream_t)stream;
+  if (r.is_float64 && dyna) hipLaunchKernelGGL((k_dqn_act<double, true>), grid, dim3(64), 0, st, A);
+  else if (r.is_float64) hipLaunchKernelGGL((k_dqn_act<double, false>), grid, dim3(64), 0, st, A);
+  else if (dyna) hipLaunchKernelGGL((k_dqn_act<float, true>), grid, dim3(64), 0, st, A);
+  else hipLaunchKernelGGL((k_dqn_act<float, false>), grid, dim3(64), 0, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }

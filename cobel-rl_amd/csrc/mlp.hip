@@ -76,11 +76,6 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T>
-struct alignas(4 * sizeof(T)) vec4 {
-  T x[4];
-};
-
 // The three 64 x 64 products of a step (second-layer forward, its weight gradient, the delta of
 // the first layer: 85 % of the arithmetic) run on the matrix cores as 16 x 16 x 4 MFMAs in the
 // network's dtype.  Operand layout of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (probed on
@@ -262,6 +257,14 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
 }
 
 template <typename T>
+__device__ void load_rows_table(T* dst, const double* table, const int32_t* index, int D, int t) {
+  for (int e = t; e < kB * D; e += 256) {
+    const int s = e / D, d = e - s * D;
+    dst[e] = (T)table[(size_t)index[s] * D + d];
+  }
+}
+
+template <typename T>
 __device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
   for (int e = t; e < kB * D; e += 256) {
     const int s = e / D, d = e - s * D;
@@ -339,7 +342,8 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   params_load<T>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
   params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);
   params_store<T>(L, PT, tw1, D, t);
-  load_rows<T>(L.x, xn, L.slot, D, t);
+  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, R.next_index + (size_t)i * kB, D, t);
+  else load_rows<T>(L.x, xn, L.slot, D, t);
   lds_barrier();
   // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
   // end (the other, small tensors are read again with their moments in the backward pass)
@@ -367,7 +371,8 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
     lds_barrier();
   }
-  load_rows<T>(L.x, xs, L.slot, D, t);
+  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, R.state_index + (size_t)i * kB, D, t);
+  else load_rows<T>(L.x, xs, L.slot, D, t);
   lds_barrier();
   forward<T>(L, L.q, D, t);
 
@@ -628,8 +633,12 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
     COBEL_REQUIRE(r.w[l] && r.b[l] && r.w_target[l] && r.b_target[l] && r.m_w[l] && r.m_b[l] &&
                       r.v_w[l] && r.v_b[l],
                   COBEL_E_ARG, "cobel_dqn_replay: NULL parameter / moment tensor (layer %d)", l);
-  COBEL_REQUIRE(r.states && r.next_states && r.actions && r.rewards && r.nonterminal && r.steps,
-                COBEL_E_ARG, "cobel_dqn_replay: NULL batch tensor or step counts");
+  COBEL_REQUIRE(r.actions && r.rewards && r.nonterminal && r.steps, COBEL_E_ARG,
+                "cobel_dqn_replay: NULL batch tensor or step counts");
+  COBEL_REQUIRE(r.state_index ? (r.next_index && r.obs_table && !r.batch_slots)
+                              : (r.states && r.next_states),
+                COBEL_E_ARG, "cobel_dqn_replay: the batch's observations are missing (states + "
+                "next_states, or state_index + next_index + obs_table without batch_slots)");
   COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_dqn_replay: n = %d", r.n);
   COBEL_REQUIRE(!r.batch_slots || r.ring_slots > 0, COBEL_E_RANGE,
                 "cobel_dqn_replay: batch_slots given with ring_slots = %d", r.ring_slots);
@@ -640,7 +649,8 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   A.r = r;
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
-    // (raised once per device: the call is not free and this entry point runs every step)
+    // (raised once per device: the call is not free and this entry point runs every step; a race
+    //  between two host threads at worst raises the limit twice)
     static int raised_to[64] = {0};
     int dev = 0;
     COBEL_HIP_TRY(hipGetDevice(&dev));

@@ -511,6 +511,11 @@ typedef struct {
   const int32_t* obs_index;   /* [N]                                                            */
   const double* obs_table;    /* [rows][n_inputs] float64                                       */
   void* q_out;                /* [N][n_actions] network dtype, or NULL                          */
+  /* optional: the batch's observations as rows of obs_table (DynaDQN: the model is indexed by
+     integer states, agent/dyna_q.py:333-708).  With state_index != NULL states / next_states are
+     not read; actions / rewards / nonterminal are the gathered [N][batch] arrays. */
+  const int32_t* state_index; /* [N][batch] or NULL                                             */
+  const int32_t* next_index;  /* [N][batch]                                                     */
 } cobel_dqn_replay_t;
 /* 0 = the fused step covers this network / batch shape; fills *lds_bytes (per instance). */
 COBEL_API int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
@@ -568,6 +573,21 @@ typedef struct {
   uint32_t instance_base;
   uint32_t reserved_;
   uint64_t seed;
+  /* optional, instead of the replay ring (ring_* may then be NULL): the tabular world model of
+     DynaDQN (memory/dyna_q.py:62-157 in float64, as the reference keeps it): store = running
+     reward estimate + successor + non-terminal flag of (state, action); the batch = `batch` pairs
+     drawn uniformly from ALL n_states x 4 pairs, written out gathered. */
+  double* model_rewards;        /* [N][n_states * 4]                                            */
+  int64_t* model_states;        /* [N][n_states * 4]                                            */
+  double* model_nonterminal;    /* [N][n_states * 4]                                            */
+  double model_lr;
+  int32_t n_states;
+  int32_t reserved2_;
+  int32_t* batch_state_index;   /* [N][batch] out: state of each drawn pair                     */
+  int32_t* batch_next_index;    /* [N][batch] out: its modelled successor                       */
+  int64_t* batch_actions;       /* [N][batch] out                                               */
+  void* batch_rewards;          /* [N][batch] out, network dtype                                */
+  void* batch_nonterminal;      /* [N][batch] out, network dtype                                */
 } cobel_dqn_act_t;
 COBEL_API int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* run, void* stream);
 

@@ -1647,3 +1647,45 @@ def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, dtype_name):
         for x, y in zip(a._target.get_weights(i), b._target.get_weights(i)):
             assert np.allclose(x, y, **tol)
     assert a.current_trial == b.current_trial == 8
+
+
+def test_dyna_dqn_two_kernel_loop_equals_torch_loop(torch_cuda):
+    """DynaDQN.train through cobel_dqn_act in world-model mode + cobel_dqn_replay reading the
+    batch as rows of the observation table, against the PyTorch loop: identical model tables,
+    stream counters, trial counts and monitors; weights to float64 round-off."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd.agent import DynaDQN
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    world = make_gridworld(4, 5, terminals=[3], rewards=np.array([[3, 1.0]]), goals=[3],
+                           invalid_transitions=[(6, 7), (7, 6)])
+
+    def run(fused):
+        torch.manual_seed(5)
+        env = Gridworld(world, n_envs=40, seed=991, instance_base=3)
+        ag = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                     TorchNetwork(bench._mlp(20, 4)), gamma=0.9)
+        ag.fused_loop = None if fused else False
+        ag.use_graph = None if fused else False
+        ag.train(env, 4, 12, 32)
+        ag.train(env, 2, 12, 32)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (a, ea), (b, eb) = run(True), run(False)
+    assert a.fused_steps > 0 and b.fused_steps == 0
+    assert torch.equal(a.M.rewards, b.M.rewards) and torch.equal(a.M.states, b.M.states)
+    assert torch.equal(a.M.terminals, b.M.terminals) and torch.equal(a.M.counter, b.M.counter)
+    assert torch.equal(a.policy.counter, b.policy.counter) and torch.equal(ea.env_ctr, eb.env_ctr)
+    assert torch.equal(a.trial, b.trial) and int(a.trial.min()) == 6
+    for k in ('lat_sum', 'lat_cnt', 'reward_sum'):
+        assert torch.equal(getattr(a.monitors, k), getattr(b.monitors, k)), k
+    assert float(a.M.rewards.abs().max()) > 0.0
+    for i in (0, 11, 39):
+        for x, y in zip(a._online.get_weights(i), b._online.get_weights(i)):
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-12), float(np.abs(x - y).max())
+        for x, y in zip(a._target.get_weights(i), b._target.get_weights(i)):
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-12)
