@@ -169,7 +169,7 @@ __device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restric
                                             const T* __restrict__ b2, const T* __restrict__ w3,
                                             const T* __restrict__ b3, int D, int t) {
 #pragma unroll
-  for (int u = 0; u < 16; ++u) P.w2[u] = w2[t + 256 * u];   // coalesced along k
+  for (int u = 0; u < 16; ++u) P.w2[u] = __builtin_nontemporal_load(w2 + t + 256 * u);   // coalesced along k
   P.w3 = w3[t];   // 4 * 64 = 256 elements
   P.b1 = t < kH ? b1[t] : (T)0;
   P.b2 = t < kH ? b2[t] : (T)0;
@@ -425,8 +425,8 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const size_t e = (size_t)(jt2 + mfma_acc<T>::row(lane2, b)) * kH + 16 * a + li2;
-      s2[a][b].m = m_w2[e];
-      s2[a][b].v = v_w2[e];
+      s2[a][b].m = __builtin_nontemporal_load(m_w2 + e);
+      s2[a][b].v = __builtin_nontemporal_load(v_w2 + e);
     }
   s3.m = m_w3[t];
   s3.v = v_w3[t];
@@ -495,10 +495,10 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
         adam_update<T>(L.wt2[k * kRow + j], g2[kt][v], s2[kt][v], c, pn, mn, vn, tn);
         new_w2[kt][v] = pn;
         const size_t e = (size_t)j * kH + k;
-        m_w2[e] = mn;
-        v_w2[e] = vn;
-        w2[e] = pn;
-        if (c.blend) tw2[e] = tn;
+        __builtin_nontemporal_store(mn, m_w2 + e);
+        __builtin_nontemporal_store(vn, v_w2 + e);
+        __builtin_nontemporal_store(pn, w2 + e);
+        if (c.blend) __builtin_nontemporal_store(tn, tw2 + e);
       }
     if (t < kH) {
       T gb = (T)0;
