@@ -1164,6 +1164,29 @@ def test_edge_empty_and_zero_work(torch_cuda):
     what = (C.c_int32 * 4)(9, 9, 9, 9)
     _lib.check(lib.cobel_tab_describe(env.handle.ptr, C.byref(run), what))
     assert list(what) == [0, 0, 0, 0]
+    # ... also for the two kernels of the DQN step
+    z64 = torch.zeros(8, dtype=torch.float64, device='cuda')
+    rep = _lib.DQNReplay()
+    for k in range(3):
+        for arr in (rep.w, rep.b, rep.w_target, rep.b_target, rep.m_w, rep.m_b, rep.v_w, rep.v_b):
+            arr[k] = _lib.ptr(z64)
+    rep.steps = rep.states = rep.next_states = rep.rewards = rep.nonterminal = _lib.ptr(z64)
+    rep.actions = _lib.ptr(z64)
+    rep.n, rep.n_inputs, rep.n_hidden1, rep.n_hidden2, rep.n_actions, rep.batch = 0, 6, 64, 64, 4, 32
+    rep.is_float64 = 1
+    _lib.check(lib.cobel_dqn_replay(C.byref(rep), None))
+    act = _lib.DQNAct()
+    for name in ('state', 'env_ctr', 'obs_table', 'q', 'policy_ctr', 'ring_states',
+                 'ring_next_states', 'ring_actions', 'ring_rewards', 'ring_nonterminal',
+                 'ring_size', 'ring_head', 'trial', 'step', 'trial_reward', 'active', 'stepped'):
+        setattr(act, name, _lib.ptr(z64))
+    act.n, act.n_obs, act.slots, act.batch, act.steps_per_trial = 0, 6, 4, 32, 10
+    act.epsilon, act.is_float64 = 0.1, 1
+    _lib.check(lib.cobel_dqn_act(env.handle.ptr, C.byref(act), None))
+    act.n, act.epsilon = 1, 1.5
+    with pytest.raises(AssertionError):     # refused before any launch
+        _lib.check(lib.cobel_dqn_act(env.handle.ptr, C.byref(act), None))
+    assert float(z64.abs().sum()) == 0.0
     # zero trials: nothing moves, nothing is drawn
     agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
     before = env.state.clone()
