@@ -530,3 +530,48 @@ def test_device_monitors_stripes_on_cpu():
     assert one.raw('lat_sum').tolist() == [[1, 2, 3]] and one.lat_sum.data_ptr() == one.raw('lat_sum').data_ptr()
     one.lat_sum = None
     assert one.raw('lat_sum') is None and one.lat_sum is None
+
+
+def test_fused_dqn_path_recognises_models_by_behaviour():
+    """StackedTorchNetwork._mlp3_names (host logic of the fused DQN step): Linear-ReLU-Linear-ReLU-
+    Linear is recognised whether written as nn.Sequential or, like the reference's demos
+    (demo/topology/demo_dqn.py:36-60), as a custom Module calling functional relu; look-alikes
+    (another activation, another depth, a frozen layer, extra parameters) are left to PyTorch."""
+    import torch
+    from torch import nn
+    from cobel_amd.network import TorchNetwork
+
+    class Demo(nn.Module):
+        def __init__(self, act=torch.relu, extra=False):
+            super().__init__()
+            self.layer_dense_1 = nn.Linear(6, 64)
+            self.layer_dense_2 = nn.Linear(64, 64)
+            self.layer_output = nn.Linear(64, 4)
+            self.act = act
+            if extra:
+                self.scale = nn.Parameter(torch.ones(1))
+            self.double()
+
+        def forward(self, x):
+            x = torch.reshape(x, (len(x), -1))
+            x = self.act(self.layer_dense_1(x))
+            x = self.act(self.layer_dense_2(x))
+            return self.layer_output(x)
+
+    def names(model):
+        torch.manual_seed(0)
+        return TorchNetwork(model).replicate(2)._mlp3_names()
+
+    assert names(Demo()) == ['layer_dense_1', 'layer_dense_2', 'layer_output']
+    seq = nn.Sequential(nn.Flatten(), nn.Linear(6, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(),
+                        nn.Linear(64, 4)).double()
+    assert names(seq) == ['1', '3', '5']
+    assert names(Demo(act=torch.tanh)) is None
+    assert names(Demo(act=lambda v: torch.nn.functional.leaky_relu(v, 0.1))) is None
+    assert names(Demo(extra=True)) is None
+    assert names(nn.Sequential(nn.Linear(6, 32), nn.ReLU(), nn.Linear(32, 4)).double()) is None
+    frozen = Demo()
+    frozen.layer_dense_1.weight.requires_grad = False
+    net = TorchNetwork(frozen).replicate(2)
+    net.params['layer_dense_1.weight'].requires_grad_(False)
+    assert net._mlp3_names() is None
