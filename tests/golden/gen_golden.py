@@ -27,6 +27,13 @@ import typing_extensions as te
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+# Where the fixtures are written: this directory, or a scratch directory for the test that
+# re-generates them and compares with the committed files (tests/test_golden_regen.py).
+OUT = os.environ.get('COBEL_GOLDEN_OUT', HERE)
+
+
+def _out(name: str) -> str:
+    return os.path.join(OUT, name)
 
 
 def load_reference():
@@ -181,14 +188,14 @@ def gen_worlds():
     for name, w in worlds.items():
         for k, v in compact(w).items():
             out['%s/%s' % (name, k)] = v
-    np.savez_compressed(os.path.join(HERE, 'worlds.npz'), **out)
+    np.savez_compressed(_out('worlds.npz'), **out)
     # a WorldDict as the reference's gridworld editor pickles it (misc/gridworld_gui.py:225)
     import pickle
-    with open(os.path.join(HERE, 'double_t_maze_2_1.pkl'), 'wb') as fh:
+    with open(_out('double_t_maze_2_1.pkl'), 'wb') as fh:
         pickle.dump(dict(gt.make_double_t_maze(2, 1)), fh, protocol=4)
     for k, v in compact(gt.make_double_t_maze(2, 1)).items():
         out['double_t_maze_2_1/%s' % k] = v
-    np.savez_compressed(os.path.join(HERE, 'worlds.npz'), **out)
+    np.savez_compressed(_out('worlds.npz'), **out)
     return worlds
 
 
@@ -205,7 +212,7 @@ def gen_gridworld_kat():
     assert states == [23, 22, 21, 20, 20, 15, 10, 5, 0]
     assert rewards == [0] * 8 + [10.] and terms == [False] * 8 + [True]
     np.savez_compressed(
-        os.path.join(HERE, 'gridworld_kat.npz'), start=np.int64(state),
+        _out('gridworld_kat.npz'), start=np.int64(state),
         actions=np.array(actions), states=np.array(states),
         rewards=np.array(rewards, dtype=np.float64), terminals=np.array(terms),
         n_obs=np.int64(env.observation_space.n), n_act=np.int64(env.action_space.n))
@@ -231,13 +238,13 @@ def gen_eps_greedy():
                     mm = None if m is None else np.array(m, dtype=bool)
                     p = pol.get_action_probs(v, mm)
                     for u in us:
-                        pol.rng.random = lambda u=u: u
+                        pol.rng.random = lambda size=None, u=u: u
                         a = int(pol.select_action(v, mm))
                         rows.append((dt == np.float32, eps, *[float(x) for x in v],
                                      0xF if m is None else sum(b << i for i, b in enumerate(m)),
                                      u, a, *p))
     rows = np.array(rows, dtype=np.float64)
-    np.savez_compressed(os.path.join(HERE, 'eps_greedy_kat.npz'), rows=rows, columns=np.array(
+    np.savez_compressed(_out('eps_greedy_kat.npz'), rows=rows, columns=np.array(
         ['is_f32', 'eps', 'v0', 'v1', 'v2', 'v3', 'mask', 'u', 'action', 'p0', 'p1', 'p2', 'p3']))
 
 
@@ -342,7 +349,7 @@ def gen_dynaq(worlds):
         out['%s/world' % name] = np.array(wname)
     out['cfg_columns'] = np.array(['instance', 'f32', 'trials', 'steps', 'B', 'no_replay',
                                    'episodic', 'mask', 'test_trials', 'n_train_steps'])
-    np.savez_compressed(os.path.join(HERE, 'dynaq_traces.npz'), **out)
+    np.savez_compressed(_out('dynaq_traces.npz'), **out)
 
 
 def gen_qagent(worlds):
@@ -378,7 +385,7 @@ def gen_qagent(worlds):
         for k, v in d.items():
             out['%s/%s' % (name, k)] = v
         out['%s/world' % name] = np.array(wname)
-    np.savez_compressed(os.path.join(HERE, 'qagent_traces.npz'), **out)
+    np.savez_compressed(_out('qagent_traces.npz'), **out)
 
 
 def gen_qagent_topology():
@@ -433,7 +440,7 @@ def gen_qagent_topology():
                  probe=probe, probe_q=np.array(ag.predict_on_batch(probe), dtype=np.float64))
         for k, v in d.items():
             out['%s/%s' % (name, k)] = v
-    np.savez_compressed(os.path.join(HERE, 'qagent_topology_traces.npz'), **out)
+    np.savez_compressed(_out('qagent_topology_traces.npz'), **out)
 
 
 def gen_sr(worlds):
@@ -481,7 +488,7 @@ def gen_sr(worlds):
         for k, v in d.items():
             out['%s/%s' % (name, k)] = v
         out['%s/world' % name] = np.array(wname)
-    np.savez_compressed(os.path.join(HERE, 'sr_traces.npz'), **out)
+    np.savez_compressed(_out('sr_traces.npz'), **out)
 
 
 MODES = ['default', 'reverse', 'forward', 'blend_forward', 'blend_reverse', 'interpolate',
@@ -642,7 +649,7 @@ def gen_sfma():
             d['action_mask'] = ag.action_mask
         for k, v in d.items():
             out['%s/%s' % (name, k)] = v
-    np.savez_compressed(os.path.join(HERE, 'sfma_traces.npz'), **out)
+    np.savez_compressed(_out('sfma_traces.npz'), **out)
 
 
 def gen_monitor(worlds):
@@ -670,7 +677,7 @@ def gen_monitor(worlds):
         resp_a.update({'trial': t, 'trial_reward': float(rewards[t])})
         resp_b.update({'trial': t, 'trial_reward': float(rewards[t]), 'response': int(responses[t])})
     np.savez_compressed(
-        os.path.join(HERE, 'monitor_kat.npz'), steps=steps, order=np.array(order),
+        _out('monitor_kat.npz'), steps=steps, order=np.array(order),
         rewards=rewards, responses=responses, reward_trace=rew_mon.reward_trace,
         reward_avg=rew_mon.reward_trace_avg, resp_default=resp_a.responses, crc_default=resp_a.CRC,
         resp_given=resp_b.responses, crc_given=resp_b.CRC,
@@ -730,7 +737,7 @@ def gen_topology():
     out.update(walk_first=np.int64(first), walk_actions=np.array(walk_a), walk_states=np.array(walk_s),
                walk_obs=np.array(walk_obs), walk_rewards=np.array(walk_r),
                walk_terminals=np.array(walk_t))
-    np.savez_compressed(os.path.join(HERE, 'topology_kat.npz'), **out)
+    np.savez_compressed(_out('topology_kat.npz'), **out)
 
 
 def gen_dqn():
@@ -779,7 +786,7 @@ def gen_dqn():
         out[name + '/steps'] = np.array(tr.steps)
         out[name + '/q_all'] = agent.predict_on_batch(poses)
         out[name + '/cfg'] = np.array([inst, trials, steps, 32, ddqn])
-    np.savez_compressed(os.path.join(HERE, 'dqn_trace.npz'), **out)
+    np.savez_compressed(_out('dqn_trace.npz'), **out)
 
 
 def gen_dyna_dqn():
@@ -823,7 +830,7 @@ def gen_dyna_dqn():
         out[name + '/M_terminals'] = agent.M.terminals
         out[name + '/q_all'] = agent.predict_on_batch(np.arange(16))
         out[name + '/cfg'] = np.array([inst, trials, steps, B])
-    np.savez_compressed(os.path.join(HERE, 'dyna_dqn_trace.npz'), **out)
+    np.savez_compressed(_out('dyna_dqn_trace.npz'), **out)
 
 
 def gen_dyna_dsr():
@@ -879,7 +886,7 @@ def gen_dyna_dsr():
         out[name + '/steps'] = d['steps']
         out[name + '/q_all'] = agent.predict_on_batch(np.arange(16))
         out[name + '/cfg'] = np.array([inst, trials, steps, B])
-    np.savez_compressed(os.path.join(HERE, 'dyna_dsr_trace.npz'), **out)
+    np.savez_compressed(_out('dyna_dsr_trace.npz'), **out)
 
 
 def _opt_sim(task, params):
@@ -914,7 +921,7 @@ def gen_optimizer():
         out['fit_keys'] = np.array(list(fit), dtype=np.float64)
         out['fit_values'] = np.array([fit[k] for k in fit], dtype=np.float64)
         out['fit_files'] = np.array(sorted(os.listdir(tmp)))
-    np.savez_compressed(os.path.join(HERE, 'optimizer_kat.npz'), **out)
+    np.savez_compressed(_out('optimizer_kat.npz'), **out)
 
 
 def main():
@@ -932,9 +939,9 @@ def main():
     gen_monitor(worlds)
     gen_sfma()
     gen_qagent_topology()
-    for f in sorted(os.listdir(HERE)):
+    for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
-            print('%-24s %8d B' % (f, os.path.getsize(os.path.join(HERE, f))))
+            print('%-24s %8d B' % (f, os.path.getsize(_out(f))))
 
 
 if __name__ == '__main__':
