@@ -17,7 +17,7 @@ STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST, STREAM_AGENT = 0, 
 SUB_DOUBLE = 1
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
-F_FORCE_LDS_MODEL, F_NO_PREFETCH = 64, 128
+F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS = 64, 128, 256
 TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX = range(4)
 MAX_BATCH = 62
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
@@ -161,6 +161,7 @@ class SRRun(C.Structure):
         ('seed', C.c_uint64),
         ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
         ('mon_stripes', C.c_int32),
+        ('traffic', C.c_void_p),
     ]
 
 

@@ -99,6 +99,7 @@ class DeviceMonitors:
                           if occupancy else None)
         self.steps_done = torch.zeros(1, dtype=torch.int64, device=device)
         self.lat_trace = None
+        self.collectives = 0          # all-gathers issued by all_reduce() (one per call)
 
     def raw(self, name: str):
         """The striped tensor ``[stripes, cap]`` handed to the kernels (or None)."""
@@ -143,40 +144,117 @@ class DeviceMonitors:
             self.lat_trace = torch.full((n_envs, self.cap), -1, dtype=torch.int32,
                                         device=self.device)
 
-    def all_reduce(self) -> None:
-        """Sum the monitor buffers over all ranks (the only collective of the path; RCCL)."""
+    def snapshot(self) -> 'MonitorSums':
+        """This rank's sums on the host (stripes folded)."""
+        return MonitorSums.unpack(self._pack().cpu().numpy()[None, :], self._layout())
+
+    def _layout(self):
+        """(name, elements) of the fused buffer, in order; every rank must agree on it."""
+        lay = [('header', 2)]
+        for name in ('lat_sum', 'lat_cnt', 'resp_cnt', 'reward_sum'):
+            if self._raw[name] is not None:
+                lay.append((name, self.cap))
+        if self.occupancy is not None:
+            lay.append(('occupancy', self.occupancy.numel()))
+        lay.append(('steps_done', 1))
+        return lay
+
+    def _pack(self):
+        """ONE int64 buffer holding every monitor of this rank: a header (capacity, layout
+        digest), the per-trial arrays with their stripes folded, the float64 reward sums as
+        their bit patterns, the visit counts and the step counter."""
+        lay = self._layout()
+        digest = sum((k + 1) * n for k, (_, n) in enumerate(lay)) + 1000003 * len(lay)
+        parts = [torch.tensor([self.cap, digest], dtype=torch.int64, device=self.device)]
+        for name, _ in lay[1:]:
+            if name == 'occupancy':
+                parts.append(self.occupancy.reshape(-1))
+            elif name == 'steps_done':
+                parts.append(self.steps_done.reshape(-1))
+            elif name == 'reward_sum':
+                parts.append(self._raw[name].sum(dim=0).view(torch.int64))
+            else:
+                parts.append(self._raw[name].sum(dim=0))
+        return torch.cat(parts)
+
+    def all_reduce(self) -> 'MonitorSums':
+        """Sums of the monitor buffers over all ranks — the only collective of the path (RCCL on
+        GPUs): ONE all-gather of the fused buffer per call, summed in rank order on every rank
+        (integers exactly, the float64 reward sums in a fixed order, so all ranks hold the same
+        bits).  The rank-local accumulators the kernels add into are left untouched: calling
+        this again — a second monitor, a second reporting interval — counts nothing twice."""
         import torch.distributed as dist
+        flat = self._pack()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        bufs = [b for b in (self._raw['lat_sum'], self._raw['lat_cnt'], self._raw['resp_cnt'],
-                            self.occupancy, self.steps_done)
-                if b is not None]
-        flat = torch.cat([b.reshape(-1) for b in bufs])
-        dist.all_reduce(flat)
-        off = 0
-        for b in bufs:
-            b.copy_(flat[off: off + b.numel()].reshape(b.shape))
-            off += b.numel()
-        if self._raw['reward_sum'] is not None:
-            dist.all_reduce(self._raw['reward_sum'])
+            return MonitorSums.unpack(flat.cpu().numpy()[None, :], self._layout())
+        world = dist.get_world_size()
+        gathered = torch.empty(world * flat.numel(), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(gathered, flat)
+        self.collectives += 1
+        g = gathered.cpu().numpy().reshape(world, flat.numel())
+        assert (g[:, :2] == g[0, :2]).all(), \
+            'ranks disagree on the monitor layout (trial capacity / tracked monitors)'
+        return MonitorSums.unpack(g, self._layout())
 
     def mean_latency(self) -> np.ndarray:
-        s, c = self.lat_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
-        with np.errstate(invalid='ignore', divide='ignore'):
-            return np.where(c > 0, s / np.maximum(c, 1), np.nan)
+        return self.snapshot().mean_latency()
 
     def mean_response(self) -> np.ndarray:
         """Fraction of instances rewarded in each trial (ResponseMonitor's default response,
         monitor/behavior.py:286-289, averaged over instances)."""
         assert self.resp_cnt is not None, 'set agent.track_responses = True before training'
-        s, c = self.resp_cnt.cpu().numpy(), self.lat_cnt.cpu().numpy()
+        return self.snapshot().mean_response()
+
+    def mean_reward(self) -> np.ndarray:
+        return self.snapshot().mean_reward()
+
+
+class MonitorSums:
+    """Monitor sums on the host — one rank's (``DeviceMonitors.snapshot``) or all ranks'
+    (``DeviceMonitors.all_reduce``) — with the per-trial means the monitors report."""
+
+    def __init__(self) -> None:
+        self.lat_sum = self.lat_cnt = self.resp_cnt = self.reward_sum = self.occupancy = None
+        self.steps_done = 0
+        self.ranks = 1
+
+    @classmethod
+    def unpack(cls, rows: np.ndarray, layout) -> 'MonitorSums':
+        """rows: int64 [ranks, elements] of fused buffers laid out as ``layout``."""
+        out = cls()
+        out.ranks = rows.shape[0]
+        off = 0
+        for name, n in layout:
+            part = rows[:, off: off + n]
+            off += n
+            if name == 'header':
+                continue
+            if name == 'reward_sum':
+                vals = np.ascontiguousarray(part).view(np.float64)
+                acc = np.zeros(n, dtype=np.float64)
+                for r in range(vals.shape[0]):        # fixed (rank) order
+                    acc = acc + vals[r]
+                out.reward_sum = acc
+            elif name == 'steps_done':
+                out.steps_done = int(part.sum())
+            else:
+                setattr(out, name, part.sum(axis=0))
+        return out
+
+    def _mean(self, s):
+        c = self.lat_cnt
         with np.errstate(invalid='ignore', divide='ignore'):
             return np.where(c > 0, s / np.maximum(c, 1), np.nan)
 
+    def mean_latency(self) -> np.ndarray:
+        return self._mean(self.lat_sum)
+
     def mean_reward(self) -> np.ndarray:
-        s, c = self.reward_sum.cpu().numpy(), self.lat_cnt.cpu().numpy()
-        with np.errstate(invalid='ignore', divide='ignore'):
-            return np.where(c > 0, s / np.maximum(c, 1), np.nan)
+        return self._mean(self.reward_sum)
+
+    def mean_response(self) -> np.ndarray:
+        assert self.resp_cnt is not None, 'set agent.track_responses = True before training'
+        return self._mean(self.resp_cnt)
 
 
 class FusedAgent(Agent):

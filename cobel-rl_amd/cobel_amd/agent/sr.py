@@ -27,6 +27,8 @@ class SR(FusedAgent):
         self.learning_rate = learning_rate
         self.gamma = gamma
         self._sr = self._T = self._rw = None
+        self.stream_rows = False   # True: always the row-streaming kernel (A/B measurements)
+        self.traffic = None        # [4] device counters of the sparse-reward kernel (cobel_hip.h)
 
     def _alloc_tables(self) -> None:
         S, N = self.n_states, self.n_envs
@@ -77,9 +79,13 @@ class SR(FusedAgent):
         run.occupancy, run.steps_done = _lib.ptr(mon.occupancy), _lib.ptr(mon.steps_done)
         run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
-        run.instance_base, run.flags = interface.instance_base, flags
+        run.instance_base = interface.instance_base
+        run.flags = flags | (_lib.F_SR_STREAM_ROWS if self.stream_rows else 0)
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
         run.seed = interface.seed
+        if self.traffic is None:
+            self.traffic = torch.zeros(4, dtype=torch.int64, device=self.device)
+        run.traffic = _lib.ptr(self.traffic)
         self._hyper(run, self.learning_rate, self.gamma, pol.epsilon)
         _lib.check(_lib.lib().cobel_sr_run(interface.handle.ptr, C.byref(run),
                                            _lib.current_stream(self.device)))

@@ -4,8 +4,10 @@
 ``update(logs)`` has the reference's semantics (``latency_trace[trial] = logs['steps']`` and the
 11-trial running nan-mean, behavior.py:82-85), so it can be registered under ``on_trial_end``
 unchanged.  With vectorised agents the kernels reduce ``logs['steps']`` over instances on device
-(``agent.monitors``); ``update_from_device`` ingests those sums — after an all-reduce over ranks
-when running on several GPUs — and fills the traces with per-trial means.
+(``agent.monitors``); ``update_from_device`` ingests those sums — summed over ranks when running
+on several GPUs (``DeviceMonitors.all_reduce`` returns the global sums and leaves the rank-local
+accumulators alone, so any number of monitors and reporting intervals may ask) — and fills the
+traces with per-trial means.
 """
 from __future__ import annotations
 
@@ -38,9 +40,8 @@ class EscapeLatencyMonitor(Monitor):
 
     def update_from_device(self, monitors, reduce: bool = True) -> None:
         """Fill the traces from an agent's device-side reductions (mean over instances)."""
-        if reduce:
-            monitors.all_reduce()
-        lat = monitors.mean_latency()
+        sums = monitors.all_reduce() if reduce else monitors
+        lat = sums.mean_latency()
         for trial in range(min(len(lat), len(self.latency_trace))):
             if not np.isnan(lat[trial]):
                 self.update({'trial': trial, 'steps': lat[trial]})
@@ -63,9 +64,8 @@ class RewardMonitor(Monitor):
         self.reward_trace_avg[trial] = self.reward_range[0] if np.isnan(avg) else avg
 
     def update_from_device(self, monitors, reduce: bool = True) -> None:
-        if reduce:
-            monitors.all_reduce()
-        rew = monitors.mean_reward()
+        sums = monitors.all_reduce() if reduce else monitors
+        rew = sums.mean_reward()
         for trial in range(min(len(rew), len(self.reward_trace))):
             if not np.isnan(rew[trial]):
                 self.update({'trial': trial, 'trial_reward': rew[trial]})
@@ -95,9 +95,8 @@ class ResponseMonitor(Monitor):
     def update_from_device(self, monitors, reduce: bool = True) -> None:
         """Vectorised runs: the response of a trial is the FRACTION of instances rewarded in it
         (mean of the per-instance default responses)."""
-        if reduce:
-            monitors.all_reduce()
-        rate = monitors.mean_response()
+        sums = monitors.all_reduce() if reduce else monitors
+        rate = sums.mean_response()
         for trial in range(min(len(rate), len(self.responses))):
             if not np.isnan(rate[trial]):
                 self.update({'trial': trial, 'response': rate[trial]})

@@ -23,7 +23,12 @@ struct cobel_world {
   uint16_t* starts;      // [dev] concatenated
   int32_t* start_off;    // [dev] [n_worlds + 1]
   int32_t* h_start_off;  // [host] copy for argument checks
+  int32_t max_rewarded_states;  // max over worlds of #{s : reward[s] != 0}
 };
+
+// sr_wave.hip: the sparse-reward form of the SR agent (one wavefront per instance)
+bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);
+int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipStream_t st);
 
 int cobel_fail(int code, const char* fmt, ...);
 

@@ -1,0 +1,535 @@
+// Successor-representation agent, sparse-reward form — ONE WAVEFRONT per agent-env instance.
+//
+// retrieve_q (sr.py:302-306) evaluates V[j] = sum_k SR[j][k] * R[k] for the four rows
+// j = T[s][a].  R[k], the agent's reward estimate, is non-zero only for states the agent has
+// been rewarded in, and a product with a zero factor is +-0 and leaves every partial sum of
+// NumPy's pairwise summation unchanged.  With at most two non-zero estimates
+//     V[j] = SR[j][e0] * R[e0]  (+ SR[j][e1] * R[e1])            one product, at most one addition
+// is therefore bit for bit what the reference's full row sum returns (up to the sign of an exact
+// zero, which no comparison of the epsilon-greedy selection can see), and a step needs FOUR OR
+// EIGHT FLOATS of the four value rows instead of 4 x S.  What remains is the row update
+// (sr.py:276-284): read SR[ns], write SR[s] — and SR[s] is the row the previous step read as
+// SR[ns], so it is carried in registers (S / 64 floats per lane).  Per step: one row read, one row
+// written, a handful of 4-byte gathers.  No LDS staging, no workgroup barriers; eight instances
+// per SIMD hide the latency of the one row read each of them waits for.
+//
+// Instances whose reward estimate holds more than two non-zeros (possible only if the caller
+// edited `rewards`, since cobel_sr_run sends worlds with more than two rewarded states to the
+// row-streaming kernel k_sr in sr.hip) evaluate the full pairwise sum straight from memory —
+// slow, exact, and tested.
+//
+// Reference behaviour restated (paths relative to /root/reference/src/cobel):
+//   agent/sr.py:155-197 (train loop), :267-284 (update), :302-308 (retrieve_q)
+// Numerics as in sr.hip: row TD error in float64 rounded once on store, gamma * SR[ns] in
+// float32, reward estimate in float32.
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+namespace {
+
+struct srw_args {
+  const cobel_wrec* rec;
+  const uint16_t* starts;
+  const int32_t* start_off;
+  int32_t S, n_worlds;
+  cobel_sr_run_t r;
+  cobel_eps_consts eps;
+  float alpha_f, gamma_f;
+};
+
+__device__ __forceinline__ int t_of(uint64_t row, int k) { return (int)((row >> (16 * k)) & 0xffffu); }
+__device__ __forceinline__ uint64_t t_set(uint64_t row, int k, uint32_t v) {
+  return (row & ~(0xffffull << (16 * k))) | ((uint64_t)v << (16 * k));
+}
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ float rlf(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float rflf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
+  const uint32_t w = (a & 2) ? w1 : w0;
+  return (a & 1) ? (w >> 16) : (w & 0xffffu);
+}
+// A load that is served by L2, never by this CU's L1: single elements of rows that OTHER lanes
+// of the wave wrote in an earlier step.
+__device__ __forceinline__ float ld_l2(const float* p) {
+  return __builtin_bit_cast(
+      float, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Lane l holds elements (j * 64 + l) * 4 .. + 3 of a row in c[j]: every load / store instruction
+// of a row moves 1 KiB of consecutive addresses, and an element is owned by the same lane in
+// every row — a row load after a row store is ordered by the program order of one thread.
+template <int NV>
+struct row_regs {
+  float4 c[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane) {
+  const float4* const p = reinterpret_cast<const float4*>(src) + lane;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) d.c[j] = p[j * 64];
+}
+
+// Element e of a row held in registers, as a wave-uniform value (e wave-uniform).
+template <int NV>
+__device__ __forceinline__ float row_element(const row_regs<NV>& r, int e) {
+  const int j = e >> 8, comp = e & 3, owner = (e >> 2) & 63;
+  float v = 0.0f;
+#pragma unroll
+  for (int jj = 0; jj < NV; ++jj) {
+    const float4 c = r.c[jj];
+    const float x = comp == 0 ? c.x : (comp == 1 ? c.y : (comp == 2 ? c.z : c.w));
+    v = jj == j ? x : v;
+  }
+  return rlf(v, owner);
+}
+
+// The kernel arguments as they lie in the kernarg segment, through a pointer the optimizer cannot
+// see through: what is read through it is loaded where it is used (trial ends, masked selection,
+// the final save) instead of being held in scalar registers across the step loop, which is short
+// of them (about sixty wave-uniform values are live in it).
+__device__ __forceinline__ const srw_args* rare_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* p = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return static_cast<const srw_args*>(p);
+#else
+  return nullptr;
+#endif
+}
+
+// NV = S / 256 float4 per lane (S = 256, 512, 1024).  OCC: visit counts in LDS.  PSETS: per-
+// instance hyper-parameters.  Six waves per SIMD (80 registers): 24 rows of 4 KiB in flight per
+// CU, more than the ~64 KB per CU that 8 TB/s at 2 us of latency take.
+template <int NV, bool OCC, bool PSETS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
+    const srw_args A) {
+  __shared__ uint64_t thr[48];
+  extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
+  constexpr int S = NV * 256;
+  constexpr int NL = S / 128;   // leaves of NumPy's pairwise sum, all 128 long
+  const int lane = (int)threadIdx.x;
+  const int i = (int)blockIdx.x;
+  const uint32_t g = A.r.instance_base + (uint32_t)i;
+  const int world = (int)(g % (uint32_t)A.n_worlds);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
+  float* const SRg = A.r.sr + (size_t)i * S * S;
+  uint16_t* const Tg = A.r.trans + (size_t)i * S * 4;
+  const uint64_t* const T8 = reinterpret_cast<const uint64_t*>(Tg);
+  float* const Rg = A.r.rewards + (size_t)i * S;
+
+  const cobel_param_set_t* P = nullptr;
+  if (PSETS) {
+    const int k = (int)A.r.param_index[i];
+    P = A.r.param_sets + (k < A.r.n_param_sets ? k : A.r.n_param_sets - 1);
+  }
+  if (lane < 48) thr[lane] = PSETS ? P->eps_thr[lane / 3][lane % 3] : A.eps.thr[lane / 3][lane % 3];
+  if (OCC)
+    for (int e = lane; e < S; e += 64) occ[e] = 0u;
+
+  // ---- the non-zero reward estimates of this instance --------------------------------------
+  int nz = 0, e0 = 0, e1 = 0;
+  float r0 = 0.0f, r1 = 0.0f;
+  bool dense = false;
+  {
+    const float4* const R4 = reinterpret_cast<const float4*>(Rg) + lane;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float4 v = R4[j * 64];
+#pragma unroll
+      for (int comp = 0; comp < 4; ++comp) {
+        const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
+        unsigned long long m = __ballot(x != 0.0f);
+        while (m) {
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const int e = (j * 64 + l) * 4 + comp;
+          const float val = rlf(x, l);
+          if (nz == 0) { e0 = e; r0 = val; }
+          else if (nz == 1) { e1 = e; r1 = val; }
+          else dense = true;
+          nz += 1;
+        }
+      }
+    }
+    if (dense) nz = 2;
+  }
+  __syncthreads();   // (one wave: orders the LDS writes above)
+
+  int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
+  int state = (int)rfl((uint32_t)inst[COBEL_I_STATE]);
+  int step = (int)rfl((uint32_t)inst[COBEL_I_STEP]);
+  int trial = (int)rfl((uint32_t)inst[COBEL_I_TRIAL]);
+  uint32_t ce = rfl((uint32_t)inst[COBEL_I_CTR_ENV]);
+  uint32_t cp = rfl((uint32_t)inst[COBEL_I_CTR_POLICY]);
+  uint32_t iflags = rfl((uint32_t)inst[COBEL_I_FLAGS]);
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
+
+  const uint32_t flags = A.r.flags;
+  const bool learn = flags & COBEL_F_LEARN;
+  const uint32_t pol_stream =
+      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
+  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const uint64_t seed = A.r.seed;
+  const int start_lo = A.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
+  const double alpha = PSETS ? P->alpha : A.r.alpha, gamma = PSETS ? P->gamma : A.r.gamma;
+  const float alpha_f = PSETS ? P->alpha_f : A.alpha_f, gamma_f = PSETS ? P->gamma_f : A.gamma_f;
+
+  uint32_t cw0 = 0, cw1 = 0;
+  uint4 cand = {0, 0, 0, 0};
+  uint32_t mask_cur = 15u;
+  uint64_t tcur = 0;     // T[state][0..3], carried from step to step
+  uint64_t tleft = 0;    // the row of the state just left, after that step's write
+  int left_state = -1;
+  int stored_state = -1; // the row whose store may still be in flight (written in the last step)
+  row_regs<NV> cur;      // SR[state] (learning runs)
+#pragma unroll
+  for (int j = 0; j < NV; ++j) cur.c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;   // V[T[state][a]]
+  cobel_u4 pblk = {0, 0, 0, 0};
+  uint32_t pb_idx = ~0u;
+  uint32_t rows_read = 0, gathers = 0;
+
+  auto load_trow = [&](int s) -> uint64_t {
+    const uint64_t v = __hip_atomic_load(T8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | (uint64_t)rfl((uint32_t)v);
+  };
+
+  // The value gathers of the rows tq = T[.][0..3]: lane 2a + n reads element e_n of row tq[a],
+  // unless that row is `fresh` (being rewritten in this step: its values come from registers).
+  auto issue_gathers = [&](uint64_t tq, int fresh) -> float {
+    float gv = 0.0f;
+    if (stored_state >= 0 && (t_of(tq, 0) == stored_state || t_of(tq, 1) == stored_state ||
+                              t_of(tq, 2) == stored_state || t_of(tq, 3) == stored_state)) {
+      wait_vm0();   // last step's row store has to be in L2 before single elements are read back
+      stored_state = -1;
+    }
+    if (lane < 8) {
+      const int n = lane & 1;
+      const int j = t_of(tq, lane >> 1);
+      if (n < nz && j != fresh) gv = ld_l2(SRg + (size_t)j * S + (n ? e1 : e0));
+    }
+    gathers += (uint32_t)(4 * nz);
+    return gv;
+  };
+  auto assemble = [&](uint64_t tq, int fresh, float f0, float f1, float gv) {
+    float qv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bool is_fresh = t_of(tq, a) == fresh;
+      const float s0 = is_fresh ? f0 : rlf(gv, 2 * a);
+      const float s1 = is_fresh ? f1 : rlf(gv, 2 * a + 1);
+      const float p0 = s0 * r0;
+      const float p1 = s1 * r1;
+      const float two = p0 + p1;
+      qv[a] = nz == 0 ? 0.0f : (nz == 1 ? p0 : two);
+    }
+    q0 = qv[0]; q1 = qv[1]; q2 = qv[2]; q3 = qv[3];
+  };
+  // Full pairwise sums from memory (more than two non-zero reward estimates): lane (l, k) runs
+  // accumulator k of leaf l, then the butterflies of NumPy's combine order (as k_sr does in LDS).
+  auto dense_values = [&](uint64_t tq) {
+    wait_vm0();
+    stored_state = -1;
+    float qv[4];
+    const int l = lane >> 3, k = lane & 7;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float* const row = SRg + (size_t)t_of(tq, a) * S;
+      float acc = 0.0f;
+      if (l < NL) {
+        const int base = 128 * l + k;
+        acc = ld_l2(row + base) * ld_l2(Rg + base);
+        for (int o = 8; o < 128; o += 8) {
+          const float prod = ld_l2(row + base + o) * ld_l2(Rg + base + o);
+          acc = acc + prod;
+        }
+      }
+      acc = acc + __shfl_xor(acc, 1);
+      acc = acc + __shfl_xor(acc, 2);
+      acc = acc + __shfl_xor(acc, 4);
+#pragma unroll
+      for (int o = 8; o < 8 * NL; o <<= 1) acc = acc + __shfl_xor(acc, o);
+      qv[a] = rflf(acc);
+    }
+    rows_read += 4u;
+    q0 = qv[0]; q1 = qv[1]; q2 = qv[2]; q3 = qv[3];
+  };
+  auto enter_state = [&](int s) {
+    const uint4 c = W4[s];
+    cw0 = rfl(c.x);
+    cw1 = rfl(c.y);
+    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
+    tcur = load_trow(s);
+    left_state = -1;
+    if (learn) {
+      load_row<NV>(cur, SRg + (size_t)s * S, lane);
+      rows_read += 1u;
+    }
+    if (dense) {
+      dense_values(tcur);
+    } else {
+      const float gv = issue_gathers(tcur, -1);
+      assemble(tcur, -1, 0.0f, 0.0f, gv);
+    }
+  };
+  if (iflags & 1u) enter_state(state);
+
+  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  uint32_t executed = 0;
+
+  while (true) {
+    if (!(iflags & 1u)) {
+      if (trial >= A.r.trials_target) break;
+      state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                               start_cnt)];
+      state = (int)rfl((uint32_t)state);
+      ce += 1u;
+      step = 0;
+      trew = 0.0;
+      iflags |= 1u;
+      enter_state(state);
+    }
+    if (budget == 0) break;
+    budget -= 1;
+
+    // ---- select (greedy.py:40-88) + env.step (gridworld.py:115-126) -------------------------
+    if ((cp >> 1) != pb_idx) {
+      pb_idx = cp >> 1;
+      pblk = cobel_philox(pb_idx, 0u, g, pol_stream, seed);
+    }
+    const uint32_t w0 = (cp & 1u) ? pblk.z : pblk.x;
+    const uint32_t w1 = (cp & 1u) ? pblk.w : pblk.y;
+    cp += 1u;
+    int a;
+    if (mask_cur == 15u) {
+      a = (int)rfl((uint32_t)cobel_eps_greedy_select_thr(q0, q1, q2, q3, cobel_u53(w0, w1), thr,
+                                                          lane));
+    } else {
+      cobel_eps_bb ebb;
+      const srw_args* const R = rare_args();
+      ebb.base[0] = ebb.bonus[0] = 0.0;
+#pragma unroll
+      for (int n = 1; n <= 4; ++n) {
+        ebb.base[n] = PSETS ? P->eps_base[n] : R->eps.base[n];
+        ebb.bonus[n] = PSETS ? P->eps_bonus[n] : R->eps.bonus[n];
+      }
+      a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q0, q1, q2, q3, mask_cur,
+                                                           cobel_u01(w0, w1), ebb, lane));
+    }
+    const int ns = (int)next_of(cw0, cw1, a);
+    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
+    const float r = __builtin_bit_cast(float, rl(cand.z, a));
+    const uint32_t end = rl(cand.w, a);
+    const uint32_t nt = 1u - end;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    // T[ns][.] as it stands before this step's write
+    uint64_t tnxt = tcur;
+    if (!trial_over && ns != state) tnxt = ns == left_state ? tleft : load_trow(ns);
+
+    float f0 = 0.0f, f1 = 0.0f, gv = 0.0f;
+    uint64_t tq = tnxt;   // the rows whose values the next step needs
+    if (learn) {
+      // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
+      float old;
+      if (dense) old = rflf(ld_l2(Rg + ns));
+      else old = (nz > 0 && ns == e0) ? r0 : ((nz > 1 && ns == e1) ? r1 : 0.0f);
+      const float d = r - old;
+      const float upd = old + d * alpha_f;
+      if (lane == 0) {
+        Rg[ns] = upd;
+        Tg[state * 4 + a] = (uint16_t)ns;
+      }
+      if (!dense) {
+        if (nz > 0 && ns == e0) r0 = upd;
+        else if (nz > 1 && ns == e1) r1 = upd;
+        else if (upd != 0.0f) {
+          if (nz == 0) { e0 = ns; r0 = upd; nz = 1; }
+          else if (nz == 1) { e1 = ns; r1 = upd; nz = 2; }
+          else dense = true;
+        }
+      }
+      tcur = t_set(tcur, a, (uint32_t)ns);
+      if (ns == state) tq = tcur;
+    }
+    const int fresh = learn ? state : -1;
+    if (!trial_over && !dense) gv = issue_gathers(tq, fresh);
+
+    if (learn) {
+      // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
+      const bool need_ns = nt != 0u;
+      // SR[ns]: loaded, or — after a bump (ns == state) — the row in hand
+      row_regs<NV> nxt = cur;
+      if (need_ns && ns != state) {
+        load_row<NV>(nxt, SRg + (size_t)ns * S, lane);
+        rows_read += 1u;
+      }
+      // Everything issued before this point has landed: the gathers, the row of ns, and the row
+      // store of the previous step.
+      wait_vm0();
+      float4* const out = reinterpret_cast<float4*>(SRg + (size_t)state * S) + lane;
+      const bool want_fresh =
+          !trial_over && !dense && (t_of(tq, 0) == state || t_of(tq, 1) == state ||
+                                    t_of(tq, 2) == state || t_of(tq, 3) == state);
+      auto upd1 = [&](int e, float cs, float cn) -> float {
+        double td = (e == state) ? 1.0 : 0.0;
+        if (need_ns) {
+          const float gs = gamma_f * cn;
+          td = td + (double)gs;
+        } else {
+          td = td + gamma * ((e == ns) ? 1.0 : 0.0);
+        }
+        td = td - (double)cs;
+        return (float)((double)cs + alpha * td);
+      };
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float4 cs4 = cur.c[j];
+        const float4 cn4 = nxt.c[j];
+        const int e = (j * 64 + lane) * 4;
+        float4 o4;
+        o4.x = upd1(e + 0, cs4.x, cn4.x);
+        o4.y = upd1(e + 1, cs4.y, cn4.y);
+        o4.z = upd1(e + 2, cs4.z, cn4.z);
+        o4.w = upd1(e + 3, cs4.w, cn4.w);
+        out[j * 64] = o4;
+        if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
+          if (nz > 0 && (e0 >> 8) == j) {
+            const int comp = e0 & 3;
+            f0 = rlf(comp == 0 ? o4.x : (comp == 1 ? o4.y : (comp == 2 ? o4.z : o4.w)),
+                     (e0 >> 2) & 63);
+          }
+          if (nz > 1 && (e1 >> 8) == j) {
+            const int comp = e1 & 3;
+            f1 = rlf(comp == 0 ? o4.x : (comp == 1 ? o4.y : (comp == 2 ? o4.z : o4.w)),
+                     (e1 >> 2) & 63);
+          }
+        }
+        // the row the next step starts from: SR[ns], or the row just written after a bump
+        cur.c[j] = (ns == state) ? o4 : cn4;
+      }
+      stored_state = state;
+    }
+
+    if (A.r.step_budget == 1 && rare_args()->r.last_exp && lane == 0) {
+      int32_t* const e = rare_args()->r.last_exp + (size_t)i * 6;
+      e[0] = state;
+      e[1] = a;
+      e[2] = ns;
+      e[3] = (int32_t)nt;
+      e[4] = __builtin_bit_cast(int32_t, r);
+      e[5] = 0;
+    }
+    trew += (double)r;
+    executed += 1u;
+    if (OCC && lane == 0) occ[ns] += 1u;
+    if (ns != state) {   // (a bumping move stays in the row just updated)
+      tleft = tcur;
+      left_state = state;
+      tcur = tnxt;
+    }
+    state = ns;
+    cw0 = nw0;
+    cw1 = nw1;
+    if (!trial_over) {
+      if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+      mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
+      step += 1;
+      if (dense) dense_values(tq);
+      else assemble(tq, fresh, f0, f1, gv);
+    } else {
+      const cobel_sr_run_t& rr = rare_args()->r;
+      if (lane == 0 && trial >= 0 && trial < rr.trial_cap) {
+        const size_t m = cobel_mon_offset(rr.mon_stripes, rr.trial_cap) + (size_t)trial;
+        if (rr.lat_sum) atomicAdd(rr.lat_sum + m, (unsigned long long)step);
+        if (rr.lat_cnt) atomicAdd(rr.lat_cnt + m, 1ull);
+        if (rr.reward_sum) atomicAdd(rr.reward_sum + m, trew);
+        if (rr.resp_cnt && trew > 0.0) atomicAdd(rr.resp_cnt + m, 1ull);
+        if (rr.lat_trace) rr.lat_trace[(size_t)i * rr.trial_cap + trial] = step;
+      }
+      trial += 1;
+      iflags &= ~1u;
+    }
+  }
+
+  const cobel_sr_run_t& rr = rare_args()->r;
+  if (OCC) {
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+      const uint32_t c = occ[e];
+      if (c && rr.occupancy) atomicAdd(rr.occupancy + (size_t)world * S + e, (unsigned long long)c);
+    }
+  }
+  if (lane == 0) {
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += (unsigned long long)executed;
+    if (rr.steps_done && executed) atomicAdd(rr.steps_done, (unsigned long long)executed);
+    if (rr.traffic) {
+      atomicAdd(rr.traffic + 0, (unsigned long long)rows_read);
+      if (learn) atomicAdd(rr.traffic + 1, (unsigned long long)executed);   // one row per step
+      atomicAdd(rr.traffic + 2, (unsigned long long)gathers);
+      if (dense) atomicAdd(rr.traffic + 3, 1ull);
+    }
+  }
+}
+
+template <int NV, bool OCC, bool PSETS>
+int launch(const srw_args& A, hipStream_t st) {
+  const size_t lds = OCC ? (size_t)NV * 256 * 4 : 0;
+  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS>), dim3(A.r.n), dim3(64), lds, st, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+template <int NV>
+int launch_nv(const srw_args& A, bool occ, bool psets, hipStream_t st) {
+  if (psets) return occ ? launch<NV, true, true>(A, st) : launch<NV, false, true>(A, st);
+  return occ ? launch<NV, true, false>(A, st) : launch<NV, false, false>(A, st);
+}
+
+}  // namespace
+
+bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
+  const int S = world->n_states;
+  return (S == 256 || S == 512 || S == 1024) && world->max_rewarded_states <= 2 &&
+         !(r.flags & COBEL_F_SR_STREAM_ROWS);
+}
+
+// Arguments already checked by cobel_sr_run.
+int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipStream_t st) {
+  srw_args A;
+  A.rec = world->rec;
+  A.starts = world->starts;
+  A.start_off = world->start_off;
+  A.S = world->n_states;
+  A.n_worlds = world->n_worlds;
+  A.r = r;
+  A.eps = cobel_make_eps_consts(r.epsilon);
+  A.alpha_f = (float)r.alpha;
+  A.gamma_f = (float)r.gamma;
+  const bool occ = r.occupancy != nullptr, psets = r.param_index != nullptr;
+  switch (world->n_states) {
+    case 256: return launch_nv<1>(A, occ, psets, st);
+    case 512: return launch_nv<2>(A, occ, psets, st);
+    default: return launch_nv<4>(A, occ, psets, st);
+  }
+}

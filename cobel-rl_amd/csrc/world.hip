@@ -23,7 +23,7 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1006; }
+extern "C" int cobel_abi_version(void) { return 1007; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {
@@ -97,6 +97,11 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   w->n_states = n_states;
   w->n_worlds = n_worlds;
   w->device = device;
+  for (int k = 0; k < n_worlds; ++k) {
+    int32_t rewarded = 0;
+    for (int32_t s = 0; s < n_states; ++s) rewarded += reward[(size_t)k * n_states + s] != 0.0f;
+    if (rewarded > w->max_rewarded_states) w->max_rewarded_states = rewarded;
+  }
   w->h_start_off = (int32_t*)malloc(sizeof(int32_t) * (n_worlds + 1));
   memcpy(w->h_start_off, start_offsets, sizeof(int32_t) * (n_worlds + 1));
   hipError_t e = hipMalloc((void**)&w->rec, total * sizeof(cobel_wrec));

@@ -195,6 +195,8 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
                                      use the general kernel instead of a specialised one      */
 #define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 #define COBEL_F_NO_PREFETCH 128u   /* SR: load value rows at the top of each step (testing)        */
+#define COBEL_F_SR_STREAM_ROWS 256u /* SR: always take the row-streaming kernel, also where the
+                                      sparse-reward kernel applies (testing, A/B measurements)    */
 
 /* Per-instance hyper-parameters.  The reference explores hyper-parameters by running one
  * simulation per combination (optimizer/grid_search.py:173-262: `simulation(task, parameters)`
@@ -326,6 +328,10 @@ typedef struct {
   const uint16_t* param_index;
   int32_t n_param_sets;
   int32_t mon_stripes;   /* as in cobel_tab_run_t                                             */
+  /* optional [dev] [4] counters the sparse-reward kernel adds to: SR rows read, SR rows
+     written, 4-byte value gathers, instances that fell back to full row sums (NULL: not counted;
+     untouched by the row-streaming kernel) */
+  unsigned long long* traffic;
 } cobel_sr_run_t;
 
 COBEL_API int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n, int32_t n_states,

@@ -1,0 +1,233 @@
+"""k_sr_wave (csrc/sr_wave.hip) — the sparse-reward form of the successor-representation step, one
+wavefront per instance — against the C oracle (the reference's full row sums, sr.py:302-306) and
+against the row-streaming kernel k_sr on the same seeded inputs: SR matrices, transition tables,
+reward estimates, counters and monitors bit for bit.
+
+Covered: the three state counts the kernel serves (16x16, 16x32, 32x32), worlds with one and two
+rewarded states (also a negative reward), goals that ARE reached (reward estimates become non-zero
+in the middle of a launch and the values stop being all-tie), runs cut into launches at odd
+budgets, action masks, Agent.test(), per-instance hyper-parameters, occupancy, and the fallback
+for hand-edited reward estimates with more than two non-zeros."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch
+
+
+def _worlds():
+    from cobel_amd.misc.gridworld_tools import make_gridworld, make_open_field
+    two = make_gridworld(16, 32, terminals=[0, 511], rewards=np.array([[0, 1.0], [511, -0.5]]),
+                         goals=[0], starting_states=[17, 40, 250, 300, 480],
+                         invalid_states=[100, 101, 102, 200, 232, 264],
+                         invalid_transitions=[(33, 34), (34, 33)])
+    near = make_gridworld(16, 16, terminals=[0], rewards=np.array([[0, 2.0], [20, 0.25]]),
+                          goals=[0], starting_states=[17, 18, 34, 50])
+    return {'open_32x32': make_open_field(32, 32, 0, 1),
+            'two_rewards_16x32': two,
+            'near_goal_16x16': near,     # a rewarded NON-terminal state beside the goal
+            'open_16x16': make_open_field(16, 16, 5, 1)}
+
+
+def _oracle_world(world):
+    from oracle import c_oracle
+    return c_oracle.OracleWorld([dict(next=world['next'], reward=world['rewards'],
+                                      terminal=world['terminals'],
+                                      starts=world['starting_states'])])
+
+
+def _agent(torch, world, n, seed, eps=0.2, stream_rows=False, base=0, mask=None, alpha=0.1,
+           gamma=0.99):
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld(world, n_envs=n, seed=seed, instance_base=base)
+    ag = SR(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha,
+            gamma=gamma)
+    ag.stream_rows = stream_rows
+    ag.track_occupancy = True
+    ag.track_responses = True
+    ag.track_instances = True
+    if mask is not None:
+        ag.mask_actions = True
+        ag.action_mask = mask
+    return env, ag
+
+
+def _launches(torch, env, ag, budgets, steps_per_trial, learn=True, trial_cap=64):
+    from cobel_amd import _lib
+    ag._bind(env)
+    ag._env_in(env)
+    pol = ag.policy if learn else ag.policy_test
+    flags = (_lib.F_LEARN if learn else 0) | ag._policy_in(pol, env, not learn)
+    if ag.mask_actions:
+        flags |= _lib.F_MASK_ACTIONS
+    ag.monitors.reserve(trial_cap, ag.n_envs, True)
+    for b in budgets:
+        ag._launch(env, pol, flags, 0x7fffffff, steps_per_trial, b, 0)
+    torch.cuda.synchronize()
+
+
+def _same(torch, a, b):
+    assert torch.equal(a._sr, b._sr), 'SR matrices differ'
+    assert torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
+    assert torch.equal(a.inst, b.inst)
+    for name in ('lat_sum', 'lat_cnt', 'resp_cnt', 'reward_sum'):
+        assert torch.equal(getattr(a.monitors, name), getattr(b.monitors, name)), name
+    assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
+    assert torch.equal(a.monitors.occupancy, b.monitors.occupancy)
+    assert a.env_steps() == b.env_steps()
+
+
+@pytest.mark.parametrize('name,n,budgets,spt', [
+    ('open_32x32', 10, (150, 1, 77), 200),
+    ('two_rewards_16x32', 16, (97, 160, 3, 140), 60),
+    ('near_goal_16x16', 24, (211, 190), 25),
+    ('open_16x16', 12, (64, 64, 64, 64, 64), 40),
+])
+def test_wave_kernel_vs_oracle_and_row_streaming(torch_cuda, name, n, budgets, spt):
+    torch = torch_cuda
+    from oracle import c_oracle
+    world = _worlds()[name]
+    env, ag = _agent(torch, world, n, 31337, base=7)
+    _launches(torch, env, ag, budgets, spt)
+    env2, ref = _agent(torch, world, n, 31337, base=7, stream_rows=True)
+    _launches(torch, env2, ref, budgets, spt)
+    _same(torch, ag, ref)
+    traffic = ag.traffic.cpu().numpy()
+    steps = n * sum(budgets)
+    assert traffic[1] == steps, 'one SR row written per env step'
+    assert 0 < traffic[0] <= steps + int(ag.inst[:, 2].sum().item()) + n * len(budgets)
+    assert traffic[3] == 0 and ref.traffic.sum().item() == 0
+    # the goals were reached: the value gathers did real work for part of the run
+    rw = ag._rw.cpu().numpy()
+    found = int((rw != 0).any(axis=1).sum())
+    need = {'near_goal_16x16': n // 2, 'two_rewards_16x32': 2, 'open_16x16': 2}.get(name, 1)
+    assert found >= need, 'rewards were estimated by %d instances only' % found
+    assert traffic[2] > 0
+
+    o = c_oracle.SROracle(_oracle_world(world), n, env.seed, True, instance_base=7, epsilon=0.2,
+                          trial_cap=64, occupancy=True)
+    for b in budgets:
+        o.run(0x7fffffff, spt, step_budget=b)
+    assert np.array_equal(ag._T.cpu().numpy().astype(np.int64), o.T)
+    assert np.array_equal(ag._rw.cpu().numpy().astype(np.float64), o.RW)
+    assert np.array_equal(ag._sr.cpu().numpy().astype(np.float64), o.SR)
+    inst = ag.inst.cpu().numpy()
+    for col, key in ((0, 'state'), (1, 'step'), (2, 'trial'), (3, 'ctr_env'), (4, 'ctr_policy')):
+        assert np.array_equal(inst[:, col], o.inst[key].astype(np.int32)), key
+    assert np.array_equal(ag.monitors.lat_trace.cpu().numpy(), o.lat_trace)
+    assert np.array_equal(ag.monitors.occupancy.cpu().numpy(), o.occupancy.astype(np.int64))
+    assert np.array_equal(ag.monitors.lat_cnt.cpu().numpy(), o.lat_cnt.astype(np.int64))
+    assert np.allclose(ag.monitors.reward_sum.cpu().numpy(), o.reward_sum, rtol=0, atol=1e-9)
+
+
+def test_wave_kernel_masks_and_test_runs(torch_cuda):
+    """Action masks (float64 selection path) while learning, then Agent.test() on the learned
+    tables (no row traffic at all: values are gathers), both equal to the row-streaming kernel."""
+    torch = torch_cuda
+    world = _worlds()['near_goal_16x16']
+    nxt = np.asarray(world['next'])
+    mask = nxt != np.arange(256)[:, None]          # forbid moves that bump into the border
+    mask[~mask.any(axis=1)] = True
+    runs = []
+    for stream_rows in (False, True):
+        env, ag = _agent(torch, world, 20, 99, eps=0.3, stream_rows=stream_rows, mask=mask)
+        _launches(torch, env, ag, (120, 120), 30)
+        before = ag.traffic.clone()
+        ag._env_out(env)
+        ag._policy_out(ag.policy)
+        ag.test(env, 5, 30)
+        torch.cuda.synchronize()
+        runs.append((ag, before))
+    (a, before), (b, _) = runs
+    _same(torch, a, b)
+    moved = (a.traffic - before).cpu().numpy()
+    assert moved[0] == 0 and moved[1] == 0 and moved[2] > 0, 'test runs read values only'
+    occ = a.monitors.occupancy.cpu().numpy()[0]
+    assert occ.sum() == a.env_steps()
+
+
+def test_wave_kernel_hand_edited_rewards_take_full_row_sums(torch_cuda):
+    """More than two non-zero reward estimates (only a caller's edit can produce them in a world
+    with two rewarded states): the kernel evaluates NumPy's pairwise sums from memory; results
+    equal the row-streaming kernel and the oracle started from the same estimates."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    world = _worlds()['two_rewards_16x32']
+    n, budgets, spt = 9, (50, 41), 45
+    rng = np.random.default_rng(5)
+    edit = np.zeros((n, 512), dtype=np.float32)
+    for i in range(n):
+        k = rng.choice(512, size=3 + i, replace=False)
+        edit[i, k] = rng.standard_normal(3 + i).astype(np.float32)
+    edit[0] = 0
+    edit[0, [3, 77]] = [0.5, -0.25]               # instance 0 stays on the sparse path
+    out = []
+    for stream_rows in (False, True):
+        env, ag = _agent(torch, world, n, 2024, eps=0.1, stream_rows=stream_rows)
+        ag._bind(env)
+        ag._rw.copy_(torch.as_tensor(edit, device='cuda'))
+        _launches(torch, env, ag, budgets, spt)
+        out.append(ag)
+    _same(torch, out[0], out[1])
+    assert out[0].traffic[3].item() >= (n - 1) * len(budgets)
+    o = c_oracle.SROracle(_oracle_world(world), n, 2024, True, epsilon=0.1, trial_cap=64)
+    o.RW[:] = edit
+    for b in budgets:
+        o.run(0x7fffffff, spt, step_budget=b)
+    assert np.array_equal(out[0]._sr.cpu().numpy().astype(np.float64), o.SR)
+    assert np.array_equal(out[0]._rw.cpu().numpy().astype(np.float64), o.RW)
+    assert np.array_equal(out[0]._T.cpu().numpy().astype(np.int64), o.T)
+
+
+def test_wave_kernel_third_estimate_mid_launch(torch_cuda):
+    """An instance that starts with two non-zero estimates and earns a third one during the launch
+    switches to full row sums in the same step (no value may be computed from a stale set)."""
+    torch = torch_cuda
+    world = _worlds()['near_goal_16x16']          # rewards at 0 (terminal) and 20
+    n = 16
+    edit = np.zeros((n, 256), dtype=np.float32)
+    edit[:, 200] = 0.75                            # a state that is NOT rewarded in the world
+    out = []
+    for stream_rows in (False, True):
+        env, ag = _agent(torch, world, n, 4, eps=0.2, stream_rows=stream_rows)
+        ag._bind(env)
+        ag._rw.copy_(torch.as_tensor(edit, device='cuda'))
+        _launches(torch, env, ag, (400,), 25)
+        out.append(ag)
+    _same(torch, out[0], out[1])
+    nonzeros = (out[0]._rw != 0).sum(dim=1)
+    assert int((nonzeros >= 3).sum().item()) >= n // 2
+    assert out[0].traffic[3].item() > 0
+
+
+def test_wave_kernel_param_sets(torch_cuda):
+    """Per-instance learning rate / gamma / epsilon: instance i of a mixed launch equals instance
+    i of a launch in which every instance uses i's combination (and the row-streaming kernel)."""
+    torch = torch_cuda
+    world = _worlds()['open_16x16']
+    n = 24
+    combos = [(0.1, 0.99, 0.1), (0.5, 0.9, 0.3), (0.05, 0.5, 0.0)]
+    which = np.arange(n) % 3
+    alpha = np.array([combos[k][0] for k in which])
+    gamma = np.array([combos[k][1] for k in which])
+    eps = np.array([combos[k][2] for k in which])
+    env, mixed = _agent(torch, world, n, 8, eps=eps, alpha=alpha, gamma=gamma)
+    _launches(torch, env, mixed, (90, 90), 40)
+    env, mixed_rows = _agent(torch, world, n, 8, eps=eps, alpha=alpha, gamma=gamma,
+                             stream_rows=True)
+    _launches(torch, env, mixed_rows, (90, 90), 40)
+    _same(torch, mixed, mixed_rows)
+    for k, (a, g, e) in enumerate(combos):
+        env, uni = _agent(torch, world, n, 8, eps=e, alpha=a, gamma=g)
+        _launches(torch, env, uni, (90, 90), 40)
+        sel = torch.as_tensor(np.flatnonzero(which == k), device='cuda')
+        assert torch.equal(mixed._sr[sel], uni._sr[sel]), k
+        assert torch.equal(mixed._T[sel], uni._T[sel]) and torch.equal(mixed.inst[sel], uni.inst[sel])

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1006
+    assert lib.cobel_abi_version() == 1007
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -206,7 +206,7 @@ def test_world_builders_match_reference_tables(golden_worlds):
 
 
 def test_monitors_match_reference(golden):
-    from cobel_amd.monitor import EscapeLatencyMonitor
+    from cobel_amd.monitor import EscapeLatencyMonitor, RewardMonitor
     k = golden('monitor_kat')
     mon = EscapeLatencyMonitor(len(k['steps']), int(k['max_steps']))
     for t in k['order']:
@@ -286,7 +286,7 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'cobel-rl_amd'))
 import numpy as np, torch, torch.distributed as dist
 from cobel_amd.agent.agent import DeviceMonitors
-from cobel_amd.monitor import EscapeLatencyMonitor
+from cobel_amd.monitor import EscapeLatencyMonitor, RewardMonitor
 rank = int(os.environ['RANK'])
 dist.init_process_group('gloo')
 # each rank owns half of 8 instances: per-trial latencies are rank-local partial sums
@@ -296,11 +296,36 @@ mon = DeviceMonitors(torch.device('cpu'), 1, 4, occupancy=True)
 mon.reserve(3)
 mon.lat_sum += torch.as_tensor(mine.sum(axis=0)); mon.lat_cnt += 4
 mon.reward_sum += float(rank + 1); mon.occupancy += rank + 1; mon.steps_done += 100 * (rank + 1)
-el = EscapeLatencyMonitor(3, 10)
-el.update_from_device(mon)            # all-reduces, then fills the trace with per-trial means
-assert np.allclose(el.latency_trace, lat.mean(axis=0)), el.latency_trace
-assert int(mon.steps_done.item()) == 300 and int(mon.occupancy.sum().item()) == 12
-assert np.allclose(mon.reward_sum.numpy(), 3.0)
+# first reporting interval, TWO monitors: each asks for the global sums; the rank-local
+# accumulators must stay rank-local, every call is one collective
+el, rw = EscapeLatencyMonitor(6, 10), RewardMonitor(6)
+el.update_from_device(mon)
+rw.update_from_device(mon)
+assert mon.collectives == 2
+assert np.allclose(el.latency_trace[:3], lat.mean(axis=0)), el.latency_trace
+assert np.allclose(rw.reward_trace[:3], 3.0 / 8.0), rw.reward_trace
+assert int(mon.steps_done.item()) == 100 * (rank + 1), 'local accumulator was overwritten'
+assert np.array_equal(mon.lat_sum.numpy(), mine.sum(axis=0))
+g = mon.all_reduce()
+assert g.ranks == 2 and g.steps_done == 300 and int(g.occupancy.sum()) == 12
+assert np.allclose(g.reward_sum, 3.0) and np.array_equal(g.lat_cnt, [8, 8, 8])
+# second interval: three more trials on every rank (the kernels keep adding into the same buffers)
+mon.reserve(6)
+more = (lat + 1)[rank * 4:(rank + 1) * 4]
+mon._raw['lat_sum'][0, 3:6] += torch.as_tensor(more.sum(axis=0)); mon._raw['lat_cnt'][0, 3:6] += 4
+mon._raw['reward_sum'][0, 3:6] += 0.5 * (rank + 1); mon.steps_done += 7
+el.update_from_device(mon)
+rw.update_from_device(mon)
+assert np.allclose(el.latency_trace, np.concatenate([lat.mean(axis=0), (lat + 1).mean(axis=0)]))
+assert np.allclose(rw.reward_trace, [3 / 8.] * 3 + [1.5 / 8.] * 3), rw.reward_trace
+g2 = mon.all_reduce()
+assert g2.steps_done == 314 and np.array_equal(g2.lat_cnt, [8] * 6)
+assert np.array_equal(g2.lat_sum[:3], lat.sum(axis=0))        # earlier trials counted once
+# the float64 sums are bit-identical on all ranks (fixed summation order)
+bits = torch.as_tensor(np.ascontiguousarray(g2.reward_sum).view(np.int64))
+both = [torch.zeros_like(bits) for _ in range(2)]
+dist.all_gather(both, bits)
+assert torch.equal(both[0], both[1])
 dist.destroy_process_group()
 print('rank', rank, 'ok')
 '''
@@ -316,6 +341,22 @@ def test_monitor_allreduce_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+def test_instance_shards_are_disjoint_and_complete():
+    """Global instance ids of the ranks of a node: contiguous, disjoint, complete, balanced —
+    for the BASELINE split of C3's 65 536 instances over 1/2/4/8 GPUs and for ragged totals."""
+    from cobel_amd.misc.sharding import shard_instances
+    for total in (65536, 16384, 8192, 1000, 7, 0):
+        for world in (1, 2, 4, 8):
+            ids, sizes = [], []
+            for rank in range(world):
+                base, count = shard_instances(total, world, rank)
+                ids.extend(range(base, base + count))
+                sizes.append(count)
+            assert ids == list(range(total)), (total, world)
+            assert max(sizes) - min(sizes) <= 1
+    assert [shard_instances(65536, 8, r) for r in (0, 7)] == [(0, 8192), (57344, 8192)]
 
 
 def test_topology_builders_match_reference(golden):
