@@ -9,9 +9,12 @@ One bench "step" = ONE launch of the fused agent kernel that advances every inst
 by `env_steps_per_launch` env steps (select -> env.step -> learn -> B planning updates, with
 per-instance auto-reset).  W untimed warm-up launches, then exactly K launches timed between
 barrier + torch.cuda.synchronize() pairs; the max over ranks is used and rank 0 prints one JSON
-line.  Instances are independent, so each rank runs its own `instances` (weak scaling; global
-instance ids keep the random streams disjoint) and the only collective is the all-reduce of the
-monitor buffers after the last launch (inside the timed region).
+line.  Instances are independent: with --gpus N the configuration's instances are SPLIT evenly over
+the ranks (BASELINE config 3: "batch split 1 -> 8 MI355X"; contiguous ranges of global instance
+ids, cobel_amd.misc.sharding) — strong scaling — or, with --weak, every rank runs the full
+instance count.  Global instance ids key the random streams and the world of an instance, so the
+results do not depend on N.  The only collective is the reduction of the monitor buffers after
+the last launch (one all-gather, inside the timed region).
 
 Workloads, all synthetic, tables zero-initialised as the reference does:
   C3 (default, the configuration the metric is quoted on): 65 536 instances over 64 distinct
@@ -22,10 +25,15 @@ Workloads, all synthetic, tables zero-initialised as the refere
   C6: 65 536 x the 5x5 walled world of demo/gridworld/demo_sfma.py, SFMA with the DR metric in
       reverse mode, 32 reactivations per trial (reported beside the headline).
 
-`roofline.achieved` = algorithmic bytes per env step (C2 67 B, C3 1 628 B,
-C4 32 817 B) x env steps per launch / mean launch duration, the latter measured with HIP events
-on the launch stream.  `cpu_baseline` = the NumPy restatement of the reference's single-instance
-loop (oracle/ref_loop.py), one core, on a bounded sample of the same workload (rank 0, N = 1).
+`roofline.achieved` = algorithmic bytes per env step (C2 67 B, C3 1 628 B; C4: the
+SR rows and value elements the sparse-reward kernel actually asks for, counted by the kernel —
+DESIGN.md §4.2; §8d's eight-row figure of 32 817 B is reported beside it as `sec8d_*`) x env steps
+per launch / mean launch duration, the latter measured with HIP events on the launch stream.
+`roofline.traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes and
+`roofline.frac_measured` = traffic / launch duration / peak — the PHYSICAL HBM utilisation;
+`roofline.limiter` names what bounds the kernel.  `cpu_baseline` = the NumPy
+restatement of the reference's single-instance loop (oracle/ref_loop.py), one core, on a bounded
+sample of the same workload (rank 0, N = 1).
 """
 from __future__ import annotations
 
@@ -47,23 +55,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 CONFIGS = {
     'C2': dict(instances=65536, env_steps_per_launch=1024, steps_per_trial=50, batch=0,
-               bytes_per_step=67, agent='q',
+               bytes_per_step=67, agent='q', limiter='issue',
                desc='65536 x 5x5 open gridworld, tabular Q-learning (alpha .9, gamma .8, eps .1, '
                     'no replay), 50 steps/trial'),
     # (512 steps per launch: loading and storing the 16 KiB Q table of an instance once per launch
     #  is 2 GB of traffic for 65 536 instances; at 256 steps per launch C3 runs 3 % slower)
     'C3': dict(instances=65536, env_steps_per_launch=512, steps_per_trial=200, batch=50,
-               bytes_per_step=1628, agent='dynaq',
+               bytes_per_step=1628, agent='dynaq', limiter='issue',
                desc='65536 instances over 64 32x32 obstacle mazes (p_wall .20, seeds 1234..1297), '
                     'Dyna-Q (alpha .99, gamma .99, eps .1, model lr .9), 50 planning updates/step, '
                     '200 steps/trial'),
     'C4': dict(instances=16384, env_steps_per_launch=128, steps_per_trial=200, batch=0,
-               bytes_per_step=32817, agent='sr',
+               bytes_per_step=32817, agent='sr', limiter='hbm',
                desc='16384 x 32x32 open gridworld, successor representation (alpha .1, gamma .99, '
                     'eps .1), 200 steps/trial'),
     # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's SFMA demo, vectorised
     'C6': dict(instances=65536, env_steps_per_launch=200, steps_per_trial=50, batch=32,
                bytes_per_step=98, bytes_per_reactivation=20 * 100 + 16 * 25 + 32, agent='sfma',
+               limiter='issue',
                desc='65536 x 5x5 walled gridworld of demo/gridworld/demo_sfma.py, SFMA (alpha .99, '
                     'gamma .99, eps .1, DR metric gamma .9, reverse mode, action mask on), 32 '
                     'reactivations per trial, 50 steps/trial'),
@@ -256,12 +265,13 @@ def make_worlds(cfg_name):
     return [make_open_field(32, 32, 0, 1)]
 
 
-def build_agent(cfg_name, cfg, n, rank, device):
+def build_agent(cfg_name, cfg, n, base, device):
+    """Environment + agent for `n` instances whose global ids start at `base`."""
     from cobel_amd.agent import SR, DynaQ, QAgent
     from cobel_amd.interface import Gridworld
     from cobel_amd.policy import EpsilonGreedy
     env = Gridworld(make_worlds(cfg_name), n_envs=n, seed=SEED, device=device,
-                    instance_base=rank * n)
+                    instance_base=base)
     pol = EpsilonGreedy(0.1)
     if cfg['agent'] == 'sfma':
         from cobel_amd.agent import SFMA
@@ -356,7 +366,7 @@ def cpu_baseline(cfg_name, cfg, seconds=12.0):
                       '%.1f s on 1 of %d host cores' % (steps, dt, os.cpu_count() or 1)}
 
 
-def pmc_traffic(cfg_name, cfg):
+def pmc_traffic(cfg_name, cfg, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
     script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only reported for
@@ -369,24 +379,31 @@ def pmc_traffic(cfg_name, cfg):
     if any(cfg[k] != ref[k] for k in ('instances', 'env_steps_per_launch', 'batch')):
         return None
     entry = json.load(open(files[-1])).get(cfg_name)
-    return None if entry is None else entry['hbm_bytes_per_launch']
+    if entry is None or (kernel is not None and not entry['kernel'].startswith(kernel.split('<')[0])):
+        return None       # counters of another kernel than the one that ran
+    return entry['hbm_bytes_per_launch']
 
 
 def run_config(cfg_name, args, rank, world_size, device, dist):
+    from cobel_amd.misc.sharding import shard_instances
     cfg = dict(CONFIGS[cfg_name])
     if args.instances:
         cfg['instances'] = args.instances
     if args.env_steps:
         cfg['env_steps_per_launch'] = args.env_steps
-    n = cfg['instances']
-    env, agent = build_agent(cfg_name, cfg, n, rank, device)
+    if args.weak:      # every rank runs the whole configuration
+        base, n, n_global = rank * cfg['instances'], cfg['instances'], cfg['instances'] * world_size
+    else:              # the configuration's instances split over the ranks
+        (base, n), n_global = shard_instances(cfg['instances'], world_size, rank), cfg['instances']
+    env, agent = build_agent(cfg_name, cfg, n, base, device)
     runner = Runner(cfg, env, agent)
     for _ in range(args.warmup):
         runner.launch()
     torch.cuda.synchronize(device)
-    before = agent.env_steps()
+    before = agent.monitors.all_reduce().steps_done       # (global; untimed)
     sfma = cfg['agent'] == 'sfma'
     replays_before = int(agent.replays_done.item()) if sfma else 0
+    sr_before = agent.traffic.clone() if cfg['agent'] == 'sr' else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
@@ -396,51 +413,83 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
     for k in range(args.steps):
         runner.launch()
         ev[k + 1].record()
-    agent.monitors.all_reduce()          # the path's only collective: monitor buffers
+    sums = agent.monitors.all_reduce()   # the path's only collective: monitor buffers, one gather
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     launch_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
-    steps_rank = (agent.env_steps() - before) if dist is None else None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if dist.get_backend() == 'gloo' else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # steps_done was summed over ranks by monitors.all_reduce()
-        total_steps = agent.env_steps() - before * world_size
-    else:
-        total_steps = steps_rank
-    expect = n * cfg['env_steps_per_launch'] * args.steps * world_size
+    total_steps = sums.steps_done - before
+    expect = n_global * cfg['env_steps_per_launch'] * args.steps
     assert total_steps == expect, 'kernel executed %d env steps, expected %d' % (total_steps, expect)
     mean_launch_s = float(np.mean(launch_ms)) * 1e-3
-    alg_bytes_per_launch = cfg['bytes_per_step'] * n * cfg['env_steps_per_launch']
+    steps_per_launch = n * cfg['env_steps_per_launch']           # this rank's launches
+    sec8d_bytes_per_launch = cfg['bytes_per_step'] * steps_per_launch
+    alg_bytes_per_launch, extra = sec8d_bytes_per_launch, {}
     if sfma:   # reactivations per launch depend on the trial lengths: count them (this rank)
         replays = int(agent.replays_done.item()) - replays_before
         alg_bytes_per_launch += cfg['bytes_per_reactivation'] * replays // args.steps
+    kernel = {'q': 'k_tab_lpi', 'dynaq': 'k_tab_wpi<DYNAQ>', 'sr': 'k_sr', 'sfma': 'k_sfma'}[cfg['agent']]
+    limiter = cfg['limiter']
+    if cfg['agent'] == 'sr':
+        moved = (agent.traffic - sr_before).cpu().numpy().astype(np.int64)
+        if moved[1] > 0:     # the sparse-reward kernel ran and counted what it asked for
+            S = int(env.observation_space.n)
+            asked = int((moved[0] + moved[1]) * 4 * S + moved[2] * 4) // args.steps + 49 * steps_per_launch
+            kernel = 'k_sr_wave'
+            extra = {'sec8d_bytes_per_env_step': cfg['bytes_per_step'],
+                     'sec8d_achieved': sec8d_bytes_per_launch / mean_launch_s / 1e9,
+                     'rows_read_per_env_step': float(moved[0]) / (steps_per_launch * args.steps),
+                     'rows_written_per_env_step': float(moved[1]) / (steps_per_launch * args.steps),
+                     'value_gathers_per_env_step': float(moved[2]) / (steps_per_launch * args.steps),
+                     'note': 'algorithmic bytes = SR rows read + written and 4-byte value elements '
+                             'requested by k_sr_wave (counted in the kernel) + 49 B of scalars per '
+                             'step; SURVEY 8d counts eight row streams per step (sec8d_*), of which '
+                             'the sparse-reward form needs two'}
+            alg_bytes_per_launch = asked
+        else:
+            limiter = 'latency'
     achieved = alg_bytes_per_launch / mean_launch_s / 1e9
+    traffic = pmc_traffic(cfg_name, cfg, kernel) if (n == cfg['instances']) else None
     res = {
         'metric': 'gridworld env-steps/sec (whole job)',
         'value': total_steps / elapsed,
         'unit': 'env-steps/s',
         'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': cfg_name + ': ' + cfg['desc'], 'instances_per_gpu': n,
+        'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg_name + ': ' + cfg['desc'], 'instances_total': n_global,
+                   'instances_per_gpu': n,
                    'env_steps_per_launch': cfg['env_steps_per_launch'],
-                   'parallelism': 'instances sharded x%d, no data-path collective' % world_size},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(cfg_name, cfg),
+                   'parallelism': ('%d instances per GPU x%d (weak)' % (n, world_size) if args.weak
+                                   else '%d instances split x%d (strong)' % (n_global, world_size))
+                   + ', contiguous global instance ids, no data-path collective, one all-gather '
+                     'of the monitor buffers'},
+        'roofline': {'bound': 'hbm', 'limiter': limiter, 'achieved': achieved,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'frac_measured': (None if traffic is None
+                                       else traffic / mean_launch_s / 1e9 / HBM_PEAK_GBS),
                      'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
                      'algorithmic_bytes_per_launch': alg_bytes_per_launch,
-                     'kernel': {'q': 'k_tab_lpi', 'dynaq': 'k_tab_wpi<DYNAQ>',
-                                'sr': 'k_sr', 'sfma': 'k_sfma'}[cfg['agent']],
-                     'algorithmic_bytes_per_env_step': cfg['bytes_per_step'],
+                     'kernel': kernel,
+                     'algorithmic_bytes_per_env_step': alg_bytes_per_launch / steps_per_launch,
                      'launch_ms_mean': mean_launch_s * 1e3,
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
+    res['roofline'].update(extra)
+    # global monitor sums (after the one collective): identical for any split of the instances
+    res['monitors'] = {'trials_finished': int(sums.lat_cnt.sum()),
+                       'escape_latency_sum': int(sums.lat_sum.sum()),
+                       'trial_reward_sum': float(sums.reward_sum.sum()),
+                       'collectives_in_timed_region': 1 if dist is not None else 0}
     what = runner.describe()
     if what is not None:
         res['roofline']['lds_bytes_per_workgroup'] = what['lds_bytes']
@@ -460,6 +509,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='C3', choices=sorted(CONFIGS))
     ap.add_argument('--also', default='C2,C4,C6', help='extra configs reported under "other_configs"')
+    ap.add_argument('--weak', action='store_true',
+                    help='every rank runs the full instance count (default: the instances of the '
+                         'configuration are split over the ranks, BASELINE config 3)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo: rehearse several ranks on one GPU (LOCAL_RANK is ignored)')
     ap.add_argument('--instances', type=int, default=0)
     ap.add_argument('--env-steps', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -470,13 +524,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', 0 if args.backend == 'gloo' else local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+        else:   # rehearsal of the N > 1 path with several ranks on ONE GPU (tests)
+            dist.init_process_group(args.backend)
     assert args.gpus == world_size, '--gpus must equal the number of launched ranks'
 
     res, cfg = run_config(args.config, args, rank, world_size, device, dist)

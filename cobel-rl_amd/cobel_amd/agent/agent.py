@@ -188,7 +188,9 @@ class DeviceMonitors:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return MonitorSums.unpack(flat.cpu().numpy()[None, :], self._layout())
         world = dist.get_world_size()
-        gathered = torch.empty(world * flat.numel(), dtype=torch.int64, device=self.device)
+        if dist.get_backend() == 'gloo':      # CPU rehearsals of the multi-GPU path
+            flat = flat.cpu()
+        gathered = torch.empty(world * flat.numel(), dtype=torch.int64, device=flat.device)
         dist.all_gather_into_tensor(gathered, flat)
         self.collectives += 1
         g = gathered.cpu().numpy().reshape(world, flat.numel())

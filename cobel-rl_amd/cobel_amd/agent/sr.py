@@ -35,6 +35,7 @@ class SR(FusedAgent):
         self._sr = torch.empty((N, S, S), dtype=torch.float32, device=self.device)
         self._T = torch.empty((N, S, 4), dtype=torch.int16, device=self.device)
         self._rw = torch.empty((N, S), dtype=torch.float32, device=self.device)
+        self.traffic = torch.zeros(4, dtype=torch.int64, device=self.device)
         _lib.check(_lib.lib().cobel_sr_init(_lib.ptr(self._sr), _lib.ptr(self._T),
                                             _lib.ptr(self._rw), N, S,
                                             _lib.current_stream(self.device)))
@@ -83,8 +84,6 @@ class SR(FusedAgent):
         run.flags = flags | (_lib.F_SR_STREAM_ROWS if self.stream_rows else 0)
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
         run.seed = interface.seed
-        if self.traffic is None:
-            self.traffic = torch.zeros(4, dtype=torch.int64, device=self.device)
         run.traffic = _lib.ptr(self.traffic)
         self._hyper(run, self.learning_rate, self.gamma, pol.epsilon)
         _lib.check(_lib.lib().cobel_sr_run(interface.handle.ptr, C.byref(run),

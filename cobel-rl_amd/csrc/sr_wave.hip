@@ -22,6 +22,8 @@
 //   agent/sr.py:155-197 (train loop), :267-284 (update), :302-308 (retrieve_q)
 // Numerics as in sr.hip: row TD error in float64 rounded once on store, gamma * SR[ns] in
 // float32, reward estimate in float32.
+#include <stdlib.h>
+
 #include "cobel_common.h"
 #include "cobel_policy.h"
 
@@ -494,7 +496,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 
 template <int NV, bool OCC, bool PSETS>
 int launch(const srw_args& A, hipStream_t st) {
-  const size_t lds = OCC ? (size_t)NV * 256 * 4 : 0;
+  size_t lds = OCC ? (size_t)NV * 256 * 4 : 0;
+  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) {   // occupancy experiments
+    lds += (size_t)atoi(pad);
+    if (lds > 64 * 1024)
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
