@@ -335,6 +335,7 @@ class FusedAgent(Agent):
                 'an agent stays bound to the instance count / device it first trained on'
             return
         self.n_envs, self.device = interface.n_envs, interface.device
+        self._seed, self._instance_base = interface.seed, interface.instance_base
         if self.n_states is None:
             self.n_states = interface.handle.n_states
             self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)

@@ -11,7 +11,9 @@ agent–environment pairs run in lockstep, each with its own copy of the network
     optimizer step on the online copies -> target blend w_t += tau (w_o - w_t)
 
 with every tensor resident on the GPU (the reference crosses the host boundary at least five
-times per step and blends the target on the host, dqn.py:346-371).  Instances whose trial ends
+times per step and blends the target on the host, dqn.py:346-371).  After every run
+``model_online`` / ``model_target`` hold instance 0's trained weights; weights assigned to them
+between runs are adopted by all instances.  Instances whose trial ends
 reset immediately and stop once they have run ``trials`` trials, like the tabular kernels.
 Requires array observations (``interface.observe()`` -> ``[N, D]``), e.g. ``Topology``.
 """
@@ -308,7 +310,14 @@ class DQN(Agent):
     def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool,
              budget: int = 0) -> None:
         """``budget`` > 0 stops after that many lockstep iterations (benchmarking)."""
-        self._bind(interface, min(trials * steps, budget or trials * steps))
+        # the ring keeps everything up to `capacity` (memory/dqn.py:113-119): room for what is
+        # stored already plus what this run can add
+        bound = self.n_envs is not None
+        stored = getattr(self.M, 'size', None)
+        have = int(stored.max().item()) if torch.is_tensor(stored) else 0
+        self._bind(interface, have + min(trials * steps, budget or trials * steps))
+        if bound:
+            self._adopt_user_weights()
         pol = self.policy if learn else self.policy_test
         self._policy_bind(pol, interface, not learn)
         n, dev = self.n_envs, self.device
@@ -418,8 +427,21 @@ class DQN(Agent):
                     all_active = left == n
         self._finish_run(first, trials)
 
+    def _stacks(self):
+        """(stacked network, single network the user holds, instance) triples kept in step."""
+        return [(self._online, self.model_online, 0), (self._target, self.model_target, 0)]
+
+    def _adopt_user_weights(self) -> None:
+        """Weights the user assigned to ``model_online`` / ``model_target`` since the last run
+        (``set_weights``, an edited module) replace those of every instance."""
+        for stack, single, inst in self._stacks():
+            if not stack.matches(single, inst):
+                stack.load_from(single)
+
     def _finish_run(self, first: int, trials: int) -> None:
         self.current_trial = first + trials
+        for stack, single, inst in self._stacks():      # the trained networks, as attributes
+            stack.write_back(single, inst)
         if self.callbacks.has('on_trial_end'):
             lat, rew = self.monitors.mean_latency(), self.monitors.mean_reward()
             cnt = self.monitors.lat_cnt.cpu().numpy()

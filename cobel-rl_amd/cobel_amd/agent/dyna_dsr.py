@@ -68,6 +68,15 @@ class DynaDSR(DynaDQN):
             self.trial = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._bind_memory(interface, slots)
 
+    def _stacks(self):
+        A = self.n_actions
+        return ([(self._online, self.models_online[a], a) for a in range(A)]
+                + [(self._target, self.models_target[a], a) for a in range(A)]
+                + [(self._reward_net, self.model_reward, 0)])
+
+    def _adopt_user_weights(self) -> None:
+        pass    # (per-action views: edits of the single networks between runs are not tracked)
+
     # -- values ---------------------------------------------------------------------------------
     def _make_capturable(self) -> None:
         self._online.make_capturable()

@@ -29,7 +29,7 @@ class DynaQ(TabularAgent):
 
     def _alloc_tables(self) -> None:
         super()._alloc_tables()
-        self.M._bind(self.n_envs, self.device)
+        self.M._bind(self.n_envs, self.device, self._seed, self._instance_base)
 
     def _extra(self, run) -> None:
         run.model = _lib.ptr(self.M.table)

@@ -529,3 +529,29 @@ class StackedTorchNetwork:
     def get_weights(self, instance: int = 0):
         return [v[instance].detach().cpu().numpy().copy()
                 for v in list(self.params.values()) + list(self.buffers.values())]
+
+    def write_back(self, net: 'TorchNetwork', instance: int = 0) -> None:
+        """Copy one instance's parameters and buffers into a single network's module — after a
+        run the user's ``model_online`` / ``model_target`` hold what was trained (instance 0), as
+        the reference's attributes do (agent/dqn.py:108-110)."""
+        with torch.no_grad():
+            state = dict(net.model.named_parameters())
+            state.update(dict(net.model.named_buffers()))
+            for k, v in list(self.params.items()) + list(self.buffers.items()):
+                state[k].copy_(v[instance].to(state[k].device))
+
+    def matches(self, net: 'TorchNetwork', instance: int = 0) -> bool:
+        """Whether a single network still holds this instance's values (False after the user
+        assigned new weights to it)."""
+        state = dict(net.model.named_parameters())
+        state.update(dict(net.model.named_buffers()))
+        return all(torch.equal(v[instance], state[k].detach().to(v.device))
+                   for k, v in list(self.params.items()) + list(self.buffers.items()))
+
+    def load_from(self, net: 'TorchNetwork') -> None:
+        """Every instance takes the single network's current values."""
+        with torch.no_grad():
+            state = dict(net.model.named_parameters())
+            state.update(dict(net.model.named_buffers()))
+            for k, v in list(self.params.items()) + list(self.buffers.items()):
+                v.copy_(state[k].detach().to(v.device).expand_as(v))

@@ -352,6 +352,43 @@ def gen_dynaq(worlds):
     np.savez_compressed(_out('dynaq_traces.npz'), **out)
 
 
+def gen_dynaq_memory():
+    """memory/dyna_q.py:62-157 on its own: stores interleaved with retrieve_batch, the memory's
+    generator fed from the build's memory stream (one vector draw per batch)."""
+    from cobel.memory.dyna_q import DynaQMemory
+    out = {}
+    for name, f32, inst in (('f32', True, 3), ('f64', False, 11)):
+        M = DynaQMemory(25, 4, rng=TapeRNG(SEED, inst, STREAM_MEMORY))
+        if f32:
+            M.rewards = M.rewards.astype(np.float32)
+        src = np.random.default_rng(77)
+        ops, stores, batches = [], [], []
+        for k in range(60):
+            if k % 5 == 4:
+                B = [1, 8, 32, 50][(k // 5) % 4]
+                batch = M.retrieve_batch(B)
+                ops.append(B)
+                batches.append(np.array([[e['state'], e['action'], e['reward'], e['next_state'],
+                                          e['terminal']] for e in batch], dtype=np.float64))
+            else:
+                exp = {'state': int(src.integers(25)), 'action': int(src.integers(4)),
+                       'reward': float(src.choice([0.0, 1.0, -0.5, 0.3])),
+                       'next_state': int(src.integers(25)), 'terminal': int(src.integers(2))}
+                M.store(exp)
+                ops.append(0)
+                stores.append([exp['state'], exp['action'], exp['reward'], exp['next_state'],
+                               exp['terminal']])
+        one = M.retrieve(int(stores[-1][0]), int(stores[-1][1]))
+        out.update({name + '/ops': np.array(ops), name + '/stores': np.array(stores),
+                    name + '/batches': np.concatenate(batches), name + '/instance': np.int64(inst),
+                    name + '/rewards': np.array(M.rewards, dtype=np.float64),
+                    name + '/states': M.states.astype(np.int64),
+                    name + '/terminals': M.terminals.astype(np.int64),
+                    name + '/retrieve_last': np.array([one['reward'], one['next_state'],
+                                                       one['terminal']], dtype=np.float64)})
+    np.savez_compressed(_out('dynaq_memory_kat.npz'), **out)
+
+
 def gen_qagent(worlds):
     cases = {
         'open5_b0_f32': ('open_5x5', 0, True, 40, 50, 0),
@@ -751,7 +788,12 @@ def gen_dqn():
     from cobel.misc.topology_tools import linear_track
     from cobel.network import TorchNetwork
     out = {}
-    for name, inst, trials, steps, ddqn in (('dqn_i0', 0, 3, 25, False), ('dqn_i2', 2, 2, 30, False)):
+    for name, inst, trials, steps, ddqn, sessions, cap in (
+            ('dqn_i0', 0, 3, 25, False, (3,), 100000), ('dqn_i2', 2, 2, 30, False, (2,), 100000),
+            # two train() calls on one agent: the memory keeps the first session's experiences
+            ('dqn_two_sessions', 1, 4, 25, False, (2, 2), 100000),
+            # ... and a memory smaller than the run: FIFO eviction (memory/dqn.py:113-119)
+            ('dqn_two_sessions_cap40', 3, 4, 25, False, (2, 2), 40)):
         torch.manual_seed(1234 + inst)
         layers = [('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
                   ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
@@ -763,7 +805,7 @@ def gen_dqn():
         env = Topology(nodes, starts, rng=TapeRNG(SEED, inst, STREAM_ENV))
         pol = EpsilonGreedy(0.3, rng=TapeRNG(SEED, inst, STREAM_POLICY))
         agent = DQN(env.observation_space, env.action_space, pol, model, gamma=0.8,
-                    memory=DQNMemory(100000, rng=TapeRNG(SEED, inst, STREAM_MEMORY)))
+                    memory=DQNMemory(cap, rng=TapeRNG(SEED, inst, STREAM_MEMORY)))
         agent.DDQN = ddqn
         tr = Tracer(None)
         nodes_seen = []
@@ -772,7 +814,10 @@ def gen_dqn():
                             lambda logs, t=tr: t.td.append(0.0)],
             'on_trial_end': [tr.on_trial_end], 'on_trial_begin': [], 'on_step_begin': []}
         torch.set_num_threads(1)
-        agent.train(env, trials, steps, 32)
+        for part in sessions:
+            agent.train(env, part, steps, 32)
+        out[name + '/sessions'] = np.array(sessions)
+        out[name + '/capacity'] = np.int64(cap)
         poses = np.array([nodes[k]['pose'] for k in nodes])
         for i, w in enumerate(init):
             out['%s/init_%d' % (name, i)] = w
@@ -797,11 +842,19 @@ def gen_dyna_dqn():
     from cobel.agent.dyna_q import DynaDQN
     from cobel.network import TorchNetwork
     out = {}
-    for name, inst, trials, steps, B in (('ddqn_i0', 0, 3, 20, 16), ('ddqn_i1', 1, 2, 25, 8)):
+    for name, inst, trials, steps, B in (('ddqn_i0', 0, 3, 20, 16), ('ddqn_i1', 1, 2, 25, 8),
+                                         # the network shape and batch the fused DQN step covers
+                                         ('ddqn_mlp64', 2, 3, 20, 32)):
         torch.manual_seed(99 + inst)
-        net = torch.nn.Sequential(OrderedDict([
-            ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
-            ('output', torch.nn.Linear(32, 4))])).double()
+        if name == 'ddqn_mlp64':
+            net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 64)), ('relu_1', torch.nn.ReLU()),
+                ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(64, 4))])).double()
+        else:
+            net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(32, 4))])).double()
         model = TorchNetwork(net)
         init = model.get_weights()
         world = gt.make_open_field(4, 4, 0, 1)
@@ -934,6 +987,7 @@ def main():
     gen_gridworld_kat()
     gen_eps_greedy()
     gen_dynaq(worlds)
+    gen_dynaq_memory()
     gen_qagent(worlds)
     gen_sr(worlds)
     gen_monitor(worlds)

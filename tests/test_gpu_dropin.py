@@ -289,3 +289,62 @@ def test_network_demo_flows(cobel):
     agent.train(interface, 6, 30)
     agent.test(interface, 3, 30)
     assert np.isfinite(el_monitor.get_trace()).all()
+
+
+def test_dynaq_memory_store_and_retrieve_batch_match_reference(cobel):
+    """DynaQMemory.store / retrieve / retrieve_batch as host calls (memory/dyna_q.py:77-157): the
+    reference's own sequence of stores and batch draws (float32 tables, the generator fed from the
+    memory stream of instance 3) reproduced through the device table — and interleaved with a
+    kernel launch, which continues the same stream and sees the stored records."""
+    import os
+    import torch
+    from conftest import SEED
+    from cobel.agent import DynaQ
+    from cobel.interface import Gridworld
+    from cobel.memory.dyna_q import DynaQMemory
+    from cobel.misc.gridworld_tools import make_open_field
+    from cobel.policy import EpsilonGreedy
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                             'dynaq_memory_kat.npz'))
+    inst = int(k['f32/instance'])
+    M = DynaQMemory(25, 4)
+    M._bind(1, None, SEED, inst)          # the stream the fixture was generated with
+    stores, batches, row = iter(k['f32/stores']), k['f32/batches'], 0
+    for op in k['f32/ops']:
+        if op == 0:
+            s, a, r, ns, nt = next(stores)
+            M.store({'state': int(s), 'action': int(a), 'reward': float(r), 'next_state': int(ns),
+                     'terminal': int(nt)})
+        else:
+            batch = M.retrieve_batch(int(op))
+            assert isinstance(batch, list) and len(batch) == op
+            got = np.array([[e['state'], e['action'], e['reward'], e['next_state'], e['terminal']]
+                            for e in batch], dtype=np.float64)
+            assert np.array_equal(got, batches[row: row + op])
+            row += int(op)
+    assert row == len(batches)
+    assert np.array_equal(M.rewards.astype(np.float64), k['f32/rewards'])
+    assert np.array_equal(M.states, k['f32/states'])
+    assert np.array_equal(M.terminals, k['f32/terminals'])
+    last = k['f32/stores'][-1]
+    one = M.retrieve(int(last[0]), int(last[1]))
+    assert [float(one['reward']), one['next_state'], one['terminal']] == list(k['f32/retrieve_last'])
+    # the digest the planning kernel reads stayed in step with the table
+    fresh = torch.empty_like(M.index)
+    from cobel_amd import _lib
+    _lib.check(_lib.lib().cobel_model_index_build(_lib.ptr(M.table), _lib.ptr(fresh), 1, 25, None))
+    assert torch.equal(fresh, M.index)
+
+    # host calls between launches: the agent's planning continues the stream after the host draw
+    def run(host_draw):
+        env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=1, seed=SEED)
+        ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        ag.train(env, 2, 20, 8)
+        if host_draw:
+            b = ag.M.retrieve_batch(8)
+            assert len(b) == 8 and all(0 <= e['state'] < 25 for e in b)
+        ag.train(env, 2, 20, 8)
+        return ag
+    a, b = run(False), run(True)
+    assert int(b.M.counter[0].item()) == int(a.M.counter[0].item()) + 1
+    assert not np.array_equal(a.Q, b.Q)       # the host draw consumed one batch of the stream

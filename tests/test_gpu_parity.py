@@ -848,7 +848,7 @@ def _module_mlp(torch, init):
     return net
 
 
-@pytest.mark.parametrize('name', ['dqn_i0', 'dqn_i2'])
+@pytest.mark.parametrize('name', ['dqn_i0', 'dqn_i2', 'dqn_two_sessions', 'dqn_two_sessions_cap40'])
 def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     """DQN on linear_track(10, 2), float64 6-64-64-4 MLP on PyTorch-ROCm, against the reference run
     on the CPU with the same initial weights and the same injected draws: identical node /
@@ -865,17 +865,24 @@ def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     init = [D['%s/init_%d' % (name, i)] for i in range(6)]
     nodes, starts = linear_track(10, 2, 1., 20., 'right')
     env = Topology(nodes, starts, seed=SEED, instance_base=inst)
-    agent = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
-                TorchNetwork(_mlp(torch, init)), gamma=0.8)
-    agent.train(env, trials, steps, batch)
+    from cobel_amd.memory import DQNMemory
+    user_model = TorchNetwork(_mlp(torch, init))
+    agent = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3), user_model, gamma=0.8,
+                memory=DQNMemory(int(D[name + '/capacity'])))
+    # (two train() calls on one agent: the ring has to keep the first session's experiences up to
+    #  the memory's capacity, as the reference's growing arrays do)
+    for part in D[name + '/sessions']:
+        agent.train(env, int(part), steps, batch)
+    assert agent.fused_steps > 0, 'the golden must exercise the two-kernel DQN step'
     m = agent.M
     size = int(m.size[0].item())
     assert size == len(D[name + '/actions'])
-    assert np.array_equal(m.actions[0, :size].cpu().numpy(), D[name + '/actions'])
-    assert np.array_equal(m.rewards[0, :size].cpu().numpy(), D[name + '/rewards'])
+    order = ((int(m.head[0].item()) + np.arange(size)) % m.slots)      # oldest first
+    assert np.array_equal(m.actions[0].cpu().numpy()[order], D[name + '/actions'])
+    assert np.array_equal(m.rewards[0].cpu().numpy()[order], D[name + '/rewards'])
     pose = np.array([nodes[k]['pose'] for k in nodes])
-    seen = m.next_states[0, :size].cpu().numpy()
-    assert np.array_equal(seen, pose[D[name + '/nodes']])
+    seen = m.next_states[0].cpu().numpy()[order]
+    assert np.array_equal(seen, pose[D[name + '/nodes'][-size:]])
     lat = agent.monitors.lat_sum.cpu().numpy()
     assert np.array_equal(lat[:trials], D[name + '/steps'])
     for i, w in enumerate(agent._online.get_weights(0)):
@@ -883,6 +890,21 @@ def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     for i, w in enumerate(agent._target.get_weights(0)):
         assert np.allclose(w, D['%s/target_%d' % (name, i)], rtol=1e-9, atol=1e-12), i
     assert np.allclose(agent.predict_on_batch(pose), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
+    # the attributes the reference's users read hold the trained networks (agent/dqn.py:108-110):
+    # model_online / model_target, and the module the user passed in (the target network)
+    for i, w in enumerate(agent.model_online.get_weights()):
+        assert np.array_equal(w, agent._online.get_weights(0)[i]), i
+    for i, w in enumerate(user_model.get_weights()):
+        assert np.array_equal(w, agent._target.get_weights(0)[i]), i
+    assert np.allclose(agent.model_online.predict_on_batch(pose), D[name + '/q_all'], rtol=1e-9,
+                       atol=1e-12)
+    # weights assigned to the user-facing networks between runs are adopted by every instance
+    agent.model_online.set_weights(init)
+    assert not agent._online.matches(agent.model_online)
+    agent._adopt_user_weights()
+    for i, w in enumerate(agent._online.get_weights(0)):
+        assert np.array_equal(w, init[i]), i
+    assert agent._target.matches(agent.model_target)
 
 
 def test_dqn_graph_replay_equals_eager_steps(torch_cuda, golden):
@@ -1323,7 +1345,7 @@ def test_dqn_idle_instances_are_frozen(torch_cuda, golden):
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12), np.abs(a - b).max()
 
 
-@pytest.mark.parametrize('name', ['ddqn_i0', 'ddqn_i1'])
+@pytest.mark.parametrize('name', ['ddqn_i0', 'ddqn_i1', 'ddqn_mlp64'])
 def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     """DynaDQN (DQN fed by the tabular Dyna-Q model) on a 4x4 open field, float64, against the
     reference with the same initial weights and injected draws: identical state / action
@@ -1337,9 +1359,15 @@ def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     from cobel_amd.policy import EpsilonGreedy
     D = golden('dyna_dqn_trace')
     inst, trials, steps, B = [int(x) for x in D[name + '/cfg']]
-    net = torch.nn.Sequential(OrderedDict([
-        ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
-        ('output', torch.nn.Linear(32, 4))])).double()
+    if name == 'ddqn_mlp64':       # 64-64 ReLU, batch 32: the two-kernel step in world-model mode
+        net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(16, 64)), ('relu_1', torch.nn.ReLU()),
+            ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(64, 4))])).double()
+    else:
+        net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(16, 32)), ('relu_1', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(32, 4))])).double()
     state = net.state_dict()
     for i, key in enumerate(state):
         state[key] = torch.as_tensor(D['%s/init_%d' % (name, i)])
@@ -1348,6 +1376,8 @@ def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.2), TorchNetwork(net),
                     gamma=0.9)
     agent.train(env, trials, steps, B)
+    assert (agent.fused_steps > 0) == (name == 'ddqn_mlp64'), \
+        'the 64-64 golden has to run on the fused kernels (and only that one can)'
     m = agent.M
     assert np.array_equal(m.states[0].cpu().numpy().reshape(16, 4), D[name + '/M_states'])
     assert np.array_equal(m.terminals[0].cpu().numpy().reshape(16, 4), D[name + '/M_terminals'])

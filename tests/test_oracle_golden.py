@@ -243,3 +243,26 @@ def test_many_instances_are_independent_of_batching(golden_worlds):
         one = c_oracle.TabOracle(w, 1, c_oracle.AG_DYNAQ, 7, True, instance_base=i, trial_cap=5)
         one.run(5, 40, 12)
         assert np.array_equal(one.Q[0], whole.Q[i])
+
+
+@pytest.mark.parametrize('name', ['f32', 'f64'])
+def test_dynaq_memory_kat(golden, name):
+    """oracle RefDynaQMemory == the reference's DynaQMemory (memory/dyna_q.py:62-157) over a
+    sequence of stores interleaved with retrieve_batch draws, float32 and float64 tables."""
+    from oracle import philox, ref_loop
+    k = golden('dynaq_memory_kat')
+    inst = int(k[name + '/instance'])
+    M = ref_loop.RefDynaQMemory(25, 4, philox.TapeRNG(SEED, inst, philox.STREAM_MEMORY),
+                                dtype=np.float32 if name == 'f32' else np.float64)
+    stores, batches = iter(k[name + '/stores']), k[name + '/batches']
+    got = []
+    for op in k[name + '/ops']:
+        if op == 0:
+            s, a, r, ns, nt = next(stores)
+            M.store(int(s), int(a), float(r), int(ns), int(nt))
+        else:
+            got.extend(M.sample(int(op))[0])
+    assert np.array_equal(np.array(got, dtype=np.float64), batches)
+    assert np.array_equal(M.rewards.astype(np.float64), k[name + '/rewards'])
+    assert np.array_equal(M.states, k[name + '/states'])
+    assert np.array_equal(M.terminals, k[name + '/terminals'])
