@@ -17,9 +17,10 @@ STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST, STREAM_AGENT = 0, 
 SUB_DOUBLE = 1
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
-F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS = 64, 128, 256
-TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX = range(4)
-MAX_BATCH = 62
+F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS, F_TAB_GENERAL = 64, 128, 256, 512
+TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX, TAB_KERNEL_GENERAL = range(5)
+MAX_BATCH = 62       # largest batch of the wavefront kernels; larger ones run on the general kernel
+MAX_ACTIONS = 8
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
  I_REWARD_LO, I_REWARD_HI, I_STEPS_LO, I_STEPS_HI, I_WORDS) = range(13)
 
@@ -178,6 +179,9 @@ _SIGNATURES = {
     'cobel_eps_greedy_f64': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),
     'cobel_world_create': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(_P)]),
+    'cobel_world_create_n': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.POINTER(_P)]),
+    'cobel_world_actions': (C.c_int, [_P, C.POINTER(C.c_int32)]),
     'cobel_world_destroy': (C.c_int, [_P]),
     'cobel_world_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
@@ -185,6 +189,9 @@ _SIGNATURES = {
     'cobel_env_reset': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_uint32, _P]),
     'cobel_gather_rows': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'cobel_eps_greedy': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),
+    'cobel_eps_greedy_n': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, C.c_int32, _P]),
+    'cobel_eps_greedy_n_f64': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, C.c_int32,
+                                         _P]),
     'cobel_param_set_fill': (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.POINTER(ParamSet)]),
     'cobel_tab_query': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),

@@ -262,6 +262,8 @@ class MonitorSums:
 class FusedAgent(Agent):
     """Plumbing common to the agents whose whole loop runs in one kernel."""
 
+    general_actions = False    # True: the agent also runs on action counts other than four
+
     def __init__(self, observation_space, action_space, policy, policy_test, custom_callbacks):
         super().__init__(observation_space, action_space, custom_callbacks)
         self.policy = policy
@@ -270,7 +272,9 @@ class FusedAgent(Agent):
         # environment the agent is first trained on
         self.n_states = int(observation_space.n) if hasattr(observation_space, 'n') else None
         self.n_actions = int(action_space.n)
-        assert self.n_actions == 4, 'the fused kernels cover 4-action worlds'
+        assert self.n_actions == 4 or self.general_actions, \
+            'this agent\'s kernels cover 4-action worlds'
+        assert 1 <= self.n_actions <= _lib.MAX_ACTIONS
         self.action_mask = (np.ones((self.n_states, self.n_actions), dtype=bool)
                             if self.n_states is not None else None)
         self.mask_actions = False
@@ -359,9 +363,9 @@ class FusedAgent(Agent):
         ...
 
     def _mask_bits(self):
-        m = np.asarray(self.action_mask, dtype=bool).reshape(self.n_states, 4)
+        m = np.asarray(self.action_mask, dtype=bool).reshape(self.n_states, self.n_actions)
         assert m.any(axis=1).all(), 'The action mask masks all actions!'
-        bits = (m * np.array([1, 2, 4, 8])).sum(axis=1).astype(np.uint8)
+        bits = (m * (1 << np.arange(self.n_actions))).sum(axis=1).astype(np.uint8)
         return torch.as_tensor(bits, device=self.device)
 
     def _policy_in(self, pol, interface, test: bool) -> int:

@@ -50,7 +50,8 @@ class DQN(Agent):
     def __init__(self, observation_space, action_space, policy, model, gamma: float = 0.8,
                  memory=None, policy_test=None, custom_callbacks=None) -> None:
         super().__init__(observation_space, action_space, custom_callbacks)
-        assert int(action_space.n) == 4, 'the epsilon-greedy kernel covers 4-action spaces'
+        assert 1 <= int(action_space.n) <= _lib.MAX_ACTIONS
+        self.n_actions = int(action_space.n)
         self.policy = policy
         self.policy_test = policy if policy_test is None else policy_test
         self.model_target = model
@@ -111,12 +112,19 @@ class DQN(Agent):
                                                 _lib.ptr(u), n, 1, st))
         act = torch.empty(n, dtype=torch.uint8, device=self.device)
         q = q.contiguous()
-        fn = (_lib.lib().cobel_eps_greedy_f64 if q.dtype == torch.float64
-              else _lib.lib().cobel_eps_greedy)
         if q.dtype not in (torch.float64, torch.float32):
             q = q.float()
-        _lib.check(fn(_lib.ptr(q), None, _lib.ptr(u), float(pol.epsilon), _lib.ptr(act), None, n,
-                      st))
+        A = int(q.shape[1])
+        if A == 4:
+            fn = (_lib.lib().cobel_eps_greedy_f64 if q.dtype == torch.float64
+                  else _lib.lib().cobel_eps_greedy)
+            _lib.check(fn(_lib.ptr(q), None, _lib.ptr(u), float(pol.epsilon), _lib.ptr(act), None,
+                          n, st))
+        else:       # e.g. the six neighbours of a hexagonal Topology
+            fn = (_lib.lib().cobel_eps_greedy_n_f64 if q.dtype == torch.float64
+                  else _lib.lib().cobel_eps_greedy_n)
+            _lib.check(fn(_lib.ptr(q), None, _lib.ptr(u), float(pol.epsilon), _lib.ptr(act), None,
+                          n, A, st))
         if idle is not None:        # instances that are done do not consume their streams
             pol.counter -= idle.to(torch.int32)
         return act
@@ -188,6 +196,7 @@ class DQN(Agent):
         from ..policy.greedy import EpsilonGreedy
         net = self._online
         if not self._fused_setting_ok(interface) or self.fused_loop is False \
+                or self.n_actions != 4 \
                 or self.use_graph is True \
                 or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \
                 or getattr(self, '_no_replay', False) or not net.fused_mlp:

@@ -4,7 +4,8 @@ Same constructor, ``train(interface, trials, steps, batch_size=32, no_replay=Fal
 ``test``, ``predict_on_batch`` and attributes (``Q``, ``M``, ``learning_rate``, ``gamma``,
 ``action_mask``, ``mask_actions``, ``episodic_replay``, ``current_trial``, ``stop``).  Tables are
 float32; see include/cobel_hip.h for the exact arithmetic (bit-exact against the reference run
-with float32 tables).  ``batch_size`` is limited to 62 (one wavefront plans one batch).
+with float32 tables).  Up to 62 planning updates per step one wavefront plans a batch; larger
+``batch_size`` values (the reference has no limit) run on the general kernel of ``cobel_tab_run``.
 """
 from __future__ import annotations
 
@@ -45,8 +46,7 @@ class DynaQ(TabularAgent):
 
     def train(self, interface, trials: int, steps: int, batch_size: int = 32,
               no_replay: bool = False) -> None:
-        assert 0 <= batch_size <= _lib.MAX_BATCH, \
-            'batch_size above %d is not supported by the planning kernel' % _lib.MAX_BATCH
+        assert batch_size >= 0
         extra = (_lib.F_NO_REPLAY if no_replay else 0) | \
                 (_lib.F_EPISODIC if self.episodic_replay else 0)
         self._session(interface, trials, steps, batch_size, True, extra)

@@ -5,6 +5,8 @@ reference keys Q by ``tuple(pose)``, here the key is the node index and ``predic
 ``Q_dict`` translate): the reference's lazily created dict rows are a dense zero table.  The replay memory is the per-instance log of experienced transitions
 (q.py:143,213), kept on device; its capacity must be announced with ``reserve_replay`` (or is
 sized from the first ``train`` call).  ``batch_size=0`` disables replay (demo/topology/demo.py:76).
+Any action count up to 8 (a hexagonal ``Topology`` has six) and any ``batch_size``: runs outside
+what the wavefront kernels cover take the general kernel of ``cobel_tab_run``, same results.
 """
 from __future__ import annotations
 
@@ -49,8 +51,10 @@ class QAgent(TabularAgent):
         raw = self._log[0, :n].cpu().numpy()
         lo = (raw & 0xFFFFFFFF).astype('uint32').view('float32')
         hi = (raw >> 32) & 0xFFFFFFFF
-        return [{'state': (int(h & 0x3FFF),), 'action': int((h >> 28) & 3), 'reward': float(r),
-                 'next_state': (int((h >> 14) & 0x3FFF),), 'terminal': int((h >> 30) & 1)}
+        # (more than four actions: three action bits, the flag moves up — cobel_hip.h)
+        a_mask, t_shift = (3, 30) if self.n_actions <= 4 else (7, 31)
+        return [{'state': (int(h & 0x3FFF),), 'action': int((h >> 28) & a_mask), 'reward': float(r),
+                 'next_state': (int((h >> 14) & 0x3FFF),), 'terminal': int((h >> t_shift) & 1)}
                 for r, h in zip(lo, hi)]
 
     @property
@@ -66,8 +70,7 @@ class QAgent(TabularAgent):
         run.log_cap = self._log_cap
 
     def train(self, interface, trials: int, steps: int = 32, batch_size: int = 32) -> None:
-        assert 0 <= batch_size <= _lib.MAX_BATCH, \
-            'batch_size above %d is not supported by the replay kernel' % _lib.MAX_BATCH
+        assert batch_size >= 0     # (above _lib.MAX_BATCH: the general kernel, any size)
         self._bind(interface)
         if batch_size > 0:
             used = int(self.inst[:, _lib.I_LOG_LEN].max().item())

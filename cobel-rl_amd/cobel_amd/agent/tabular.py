@@ -11,9 +11,12 @@ from .agent import FusedAgent
 
 
 class TabularAgent(FusedAgent):
-    """Q table [N, S, 4] float32 on device + launch plumbing for ``cobel_tab_run``."""
+    """Q table [N, S, A] float32 on device (A = 4 but for the general kernel) + launch plumbing
+    for ``cobel_tab_run``."""
 
     agent_kind = _lib.AGENT_Q
+    general_actions = True     # cobel_tab_run's general kernel takes any action count
+    force_general = False      # True: always the general kernel (tests, A/B comparisons)
 
     def __init__(self, observation_space, action_space, policy, policy_test, learning_rate,
                  gamma, custom_callbacks) -> None:
@@ -27,10 +30,7 @@ class TabularAgent(FusedAgent):
 
     # -- tables -----------------------------------------------------------------------------
     def _alloc_tables(self) -> None:
-        lds, per_block = C.c_int32(), C.c_int32()
-        _lib.check(_lib.lib().cobel_tab_query(self.n_states, self.agent_kind, 0, C.byref(lds),
-                                              C.byref(per_block)))
-        self._q = torch.zeros((self.n_envs, self.n_states, 4), dtype=torch.float32,
+        self._q = torch.zeros((self.n_envs, self.n_states, self.n_actions), dtype=torch.float32,
                               device=self.device)
         if self._q_host is not None:
             self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
@@ -46,7 +46,7 @@ class TabularAgent(FusedAgent):
     @Q.setter
     def Q(self, value) -> None:
         if self._q is None:
-            self._q_host = np.array(value, dtype=np.float32).reshape(self.n_states, 4)
+            self._q_host = np.array(value, dtype=np.float32).reshape(self.n_states, self.n_actions)
         else:
             v = torch.as_tensor(np.asarray(value, dtype=np.float32) if not torch.is_tensor(value)
                                 else value, device=self.device).to(torch.float32)
@@ -98,7 +98,8 @@ class TabularAgent(FusedAgent):
         run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base = interface.instance_base
-        run.agent, run.flags = self.agent_kind, flags
+        run.agent = self.agent_kind
+        run.flags = flags | (_lib.F_TAB_GENERAL if self.force_general else 0)
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
         run.batch = batch
         run.seed = interface.seed

@@ -48,12 +48,13 @@ class WorldHandle:
         starts = np.ascontiguousarray(np.concatenate([t['starts'] for t in tabs]), dtype=np.uint16)
         off = np.zeros(len(tabs) + 1, dtype=np.int32)
         off[1:] = np.cumsum([len(t['starts']) for t in tabs])
-        assert nxt.shape == (len(tabs), S, 4)
+        assert nxt.ndim == 3 and nxt.shape[:2] == (len(tabs), S)
         self.n_states, self.n_worlds, self.device = S, len(tabs), device
+        self.n_actions = int(nxt.shape[2])      # 4: gridworlds and 4-neighbour graphs
         self.ptr = C.c_void_p()
-        _lib.check(_lib.lib().cobel_world_create(
+        _lib.check(_lib.lib().cobel_world_create_n(
             nxt.ctypes.data, rew.ctypes.data, term.ctypes.data, starts.ctypes.data,
-            off.ctypes.data, S, len(tabs), device.index or 0, C.byref(self.ptr)))
+            off.ctypes.data, S, len(tabs), self.n_actions, device.index or 0, C.byref(self.ptr)))
 
     def __del__(self) -> None:
         try:
@@ -108,10 +109,13 @@ class Gridworld(Interface):
 
     @current_state.setter
     def current_state(self, value) -> None:
+        v = torch.as_tensor(value, dtype=torch.int32)
+        if v.numel() and (int(v.min()) < 0 or int(v.max()) >= self.handle.n_states):
+            raise IndexError('state outside the world (%d states)' % self.handle.n_states)
         if self.n_envs == 1 and not torch.is_tensor(value):
             self.state.fill_(int(value))
         else:
-            self.state.copy_(torch.as_tensor(value, dtype=torch.int32, device=self.device))
+            self.state.copy_(v.to(self.device))
 
     @property
     def current_coordinates(self):

@@ -34,9 +34,12 @@ class Topology(Interface):
         if starting_nodes is None:
             starting_nodes = [k for k, nd in nodes.items() if not nd['terminal']]
         self.starting_nodes = starting_nodes
-        for nd in nodes.values():
-            assert len(nd['neighbors']) == 4, \
-                'the env kernels serve 4-neighbour topologies (hexagonal graphs have 6 actions)'
+        # the action space is the neighbour count of the start node (topology.py:110-112): four
+        # on track / grid / maze graphs, six on hexagonal ones
+        n_act = len(nodes[starting_nodes[0]]['neighbors'])
+        assert 1 <= n_act <= _lib.MAX_ACTIONS and \
+            all(len(nd['neighbors']) == n_act for nd in nodes.values()), \
+            'every node needs the same number of neighbours (at most %d)' % _lib.MAX_ACTIONS
         S = len(self.ids)
         self.pose = np.array([nodes[k]['pose'] for k in self.ids], dtype=np.float64).reshape(S, 6)
         world = dict(
@@ -58,7 +61,7 @@ class Topology(Interface):
         self.observation_space = Box(low=np.array([-np.inf, -np.inf, -np.inf, 0.0, 0.0, 0.0]),
                                      high=np.array([np.inf, np.inf, np.inf, 360.0, 360.0, 360.0]),
                                      dtype=np.float64)
-        self.action_space = Discrete(4)
+        self.action_space = Discrete(n_act)
         self.state = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
         self.env_ctr = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
         self._reward = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
@@ -103,7 +106,7 @@ class Topology(Interface):
     def step(self, action):
         if self.n_envs == 1 and not torch.is_tensor(action):
             a = int(action)
-            assert 0 <= a < 4, 'Invalid action type!'
+            assert 0 <= a < int(self.action_space.n), 'Invalid action type!'
             act = torch.full((1,), a, dtype=torch.uint8, device=self.device)
         else:
             act = torch.as_tensor(action, device=self.device).to(torch.uint8).contiguous()

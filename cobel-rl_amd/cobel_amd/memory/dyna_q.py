@@ -19,7 +19,6 @@ from .. import _lib
 
 class DynaQMemory:
     def __init__(self, states: int, actions: int, learning_rate: float = 0.9, rng=None) -> None:
-        assert actions == 4, 'the model record layout covers 4-action worlds'
         self.rng = rng
         self.number_of_states = states
         self.number_of_actions = actions
@@ -37,6 +36,7 @@ class DynaQMemory:
             from ..interface.gridworld import _as_seed
             seed = _as_seed(self.rng)
         self.seed, self.base = int(seed), int(base)
+        assert self.number_of_actions == 4, 'the model records are laid out for 4-action worlds'
         self.table = torch.empty((n_envs, self.number_of_states, 4), dtype=torch.int64,
                                  device=device)
         _lib.check(_lib.lib().cobel_model_init(_lib.ptr(self.table), n_envs,

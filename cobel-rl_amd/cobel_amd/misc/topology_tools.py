@@ -1,12 +1,13 @@
-"""Topology-graph builders for the 4-neighbour environments the HIP env kernels serve.
+"""Topology-graph builders for the environments the HIP env kernels serve.
 
 Call surface of the reference's ``cobel.misc.topology_tools`` (misc/topology_tools.py:14-373) for
 ``linear_track``, ``grid``, ``t_maze`` and ``cross``: same arguments, same ``(nodes, starting_nodes)`` result
 with ``nodes[id] = {'id', 'pose', 'terminal', 'reward', 'neighbors'}``; ids are ``str(n)`` in
 construction order, neighbours are ordered [left, up, right, down] and point back at the node
 itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` builds the six-neighbour
-graph as the reference does, but the env kernels cover four actions, so ``Topology`` refuses it;
-the shapely-based obstacle pruning is outside the accelerated path.
+graph as the reference does: a ``Topology`` over it has six actions and runs through the general
+entry points (``cobel_world_create_n``, ``cobel_eps_greedy_n``, the general tabular kernel); the
+shapely-based obstacle pruning is outside the accelerated path.
 """
 from __future__ import annotations
 
@@ -140,7 +141,7 @@ def hexagonal(nb_nodes: int, limits=(0.0, 1.0), reward: float = 1.0, location=No
     """Hexagonal lattice (topology_tools.py:175-272): every other row is shifted by half a
     spacing and loses the node that leaves the range; neighbours are the nodes closer than 1.5
     spacings, sorted into six 60-degree sectors and listed clockwise starting at the left; a
-    missing neighbour is the node itself.  Six actions: not served by the 4-action kernels."""
+    missing neighbour is the node itself.  Six actions (``Topology`` takes the general kernels)."""
     assert nb_nodes > 1, 'Invalid number of nodes!'
     assert limits[1] > limits[0], 'Invalid coordinate range!'
     spacing = (limits[1] - limits[0]) / (nb_nodes - 1)

@@ -353,21 +353,35 @@ class StackedTorchNetwork:
         w = [self.params[k + '.weight'] for k in names]
         if w[1].shape[2] != w[0].shape[1] or w[2].shape[2] != w[1].shape[1]:
             return None
+        # structure: besides the three Linear layers only modules that cannot change the function
+        # (a saturating activation module such as ReLU6 / Hardtanh is refused outright)
+        leaves = [m for m in self.base.modules() if not list(m.children())]
+        if not all(type(m) in (nn.Linear, nn.ReLU, nn.Flatten, nn.Identity) for m in leaves
+                   if m is not self.base or type(m) is nn.Linear):
+            return None
         try:
             with torch.no_grad():
-                p0 = {k: v[0] for k, v in self.params.items()}
                 gen = torch.Generator(device='cpu').manual_seed(1234)
-                x = (torch.rand((16, w[0].shape[2]), generator=gen, dtype=torch.float64) * 4 - 2
-                     ).to(device=self.device, dtype=w[0].dtype)
-                got = functional_call(self.base, (p0, {}), (x,))
-                h = x
-                for k in names[:2]:
-                    h = torch.relu(torch.nn.functional.linear(h, p0[k + '.weight'], p0[k + '.bias']))
-                ref = torch.nn.functional.linear(h, p0[names[2] + '.weight'], p0[names[2] + '.bias'])
-                tol = 1e-11 if w[0].dtype == torch.float64 else 1e-5
-                hidden_used = bool((h == 0).any()) and bool((h > 0).any())   # the probe saw both
-                if got.shape == ref.shape and hidden_used and \
-                        torch.allclose(got, ref, rtol=tol, atol=tol):      # sides of the ReLUs
+                ok = True
+                # behaviour: at the weights as they are, and with inputs and weights scaled up so
+                # that hidden pre-activations reach ~1e5 — a clamp, ReLU6 or Hardtanh written
+                # inside a custom forward() equals ReLU on small activations only
+                for x_scale, w_scale in ((1.0, 1.0), (1e3, 30.0)):
+                    p0 = {k: v[0] * w_scale for k, v in self.params.items()}
+                    x = ((torch.rand((16, w[0].shape[2]), generator=gen, dtype=torch.float64) * 4
+                          - 2) * x_scale).to(device=self.device, dtype=w[0].dtype)
+                    got = functional_call(self.base, (p0, {}), (x,))
+                    h = x
+                    for k in names[:2]:
+                        h = torch.relu(torch.nn.functional.linear(h, p0[k + '.weight'],
+                                                                  p0[k + '.bias']))
+                    ref = torch.nn.functional.linear(h, p0[names[2] + '.weight'],
+                                                     p0[names[2] + '.bias'])
+                    tol = 1e-11 if w[0].dtype == torch.float64 else 1e-5
+                    hidden_used = bool((h == 0).any()) and bool((h > 0).any())  # both sides of
+                    ok = ok and got.shape == ref.shape and hidden_used and \
+                        torch.allclose(got, ref, rtol=tol, atol=tol * float(ref.abs().max() + 1))
+                if ok:                                                          # the ReLUs seen
                     self._mlp3 = names
         except Exception:      # a forward that does not take one [B, D] batch: not this shape
             self._mlp3 = None

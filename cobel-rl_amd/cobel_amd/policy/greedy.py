@@ -3,8 +3,8 @@
 ``get_action_probs`` / ``select_action`` evaluate on the GPU through ``cobel_eps_greedy``: the
 probabilities are float64, ties are exact equality on the float32 values, and the action is
 ``searchsorted(cumsum(p) / cumsum(p)[-1], u, 'right')`` exactly like ``Generator.choice``.
-Inputs may be one row ``v[4]`` (returns an int / ``p[4]``, as the reference) or a batch
-``v[N, 4]``.  Four actions only — the gridworld / 4-neighbour topology case this build covers.
+Inputs may be one row ``v[A]`` (returns an int / ``p[A]``, as the reference) or a batch
+``v[N, A]``; A = 4 takes ``cobel_eps_greedy``, any other count up to 8 ``cobel_eps_greedy_n``.
 """
 from __future__ import annotations
 
@@ -15,12 +15,12 @@ from .. import _lib
 from .policy import Policy
 
 
-def _mask_bits(mask, n: int, device):
+def _mask_bits(mask, n: int, device, actions: int = 4):
     if mask is None:
         return None
-    m = torch.as_tensor(np.asarray(mask), device=device).reshape(n, 4).to(torch.uint8)
+    m = torch.as_tensor(np.asarray(mask), device=device).reshape(n, actions).to(torch.int32)
     assert bool((m.sum(dim=1) > 0).all()), 'The action mask masks all actions!'
-    w = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=device)
+    w = (1 << torch.arange(actions, dtype=torch.int32, device=device))
     return (m * w).sum(dim=1).to(torch.uint8).contiguous()
 
 
@@ -44,9 +44,11 @@ class EpsilonGreedy(Policy):
         device = torch.device('cuda', torch.cuda.current_device())
         vals = torch.as_tensor(np.asarray(v, dtype=np.float32) if not torch.is_tensor(v) else v)
         single = vals.dim() == 1
-        vals = vals.reshape(-1, 4).to(device=device, dtype=torch.float32).contiguous()
+        A = int(vals.shape[-1])
+        assert 1 <= A <= _lib.MAX_ACTIONS, 'up to %d actions' % _lib.MAX_ACTIONS
+        vals = vals.reshape(-1, A).to(device=device, dtype=torch.float32).contiguous()
         n = vals.shape[0]
-        bits = _mask_bits(mask, n, device)
+        bits = _mask_bits(mask, n, device, A)
         if u is None:
             self._bind(n, device)
             u = torch.empty(n, dtype=torch.float64, device=device)
@@ -56,10 +58,15 @@ class EpsilonGreedy(Policy):
         else:
             u = torch.as_tensor(u, dtype=torch.float64, device=device).reshape(n).contiguous()
         act = torch.empty(n, dtype=torch.uint8, device=device)
-        probs = torch.empty((n, 4), dtype=torch.float64, device=device)
-        _lib.check(_lib.lib().cobel_eps_greedy(
-            _lib.ptr(vals), _lib.ptr(bits), _lib.ptr(u), float(self.epsilon), _lib.ptr(act),
-            _lib.ptr(probs), n, _lib.current_stream(device)))
+        probs = torch.empty((n, A), dtype=torch.float64, device=device)
+        if A == 4:
+            _lib.check(_lib.lib().cobel_eps_greedy(
+                _lib.ptr(vals), _lib.ptr(bits), _lib.ptr(u), float(self.epsilon), _lib.ptr(act),
+                _lib.ptr(probs), n, _lib.current_stream(device)))
+        else:
+            _lib.check(_lib.lib().cobel_eps_greedy_n(
+                _lib.ptr(vals), _lib.ptr(bits), _lib.ptr(u), float(self.epsilon), _lib.ptr(act),
+                _lib.ptr(probs), n, A, _lib.current_stream(device)))
         return single, act, probs
 
     # -- reference surface ------------------------------------------------------------------

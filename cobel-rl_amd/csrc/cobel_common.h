@@ -24,13 +24,26 @@ struct cobel_world {
   int32_t* start_off;    // [dev] [n_worlds + 1]
   int32_t* h_start_off;  // [host] copy for argument checks
   int32_t max_rewarded_states;  // max over worlds of #{s : reward[s] != 0}
+  // action counts other than four (cobel_world_create_n): `rec` is NULL and these hold the world
+  int32_t n_actions;
+  uint16_t* next_n;     // [dev] [n_worlds][S][n_actions]
+  float* reward_s;      // [dev] [n_worlds][S]
+  uint8_t* terminal_s;  // [dev] [n_worlds][S]
 };
+
+// general.hip: any action count / batch size / state count (one lane per instance)
+int cobel_env_step_general(const cobel_world* world, int32_t* state, const uint8_t* action,
+                           float* reward_out, uint8_t* done_out, int32_t n,
+                           uint32_t instance_base, hipStream_t st);
+int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
 
 // sr_wave.hip: the sparse-reward form of the SR agent (one wavefront per instance)
 bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);
 int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipStream_t st);
 
 int cobel_fail(int code, const char* fmt, ...);
+int cobel_world_check(const cobel_world* w, const char* who);   // non-NULL, on the current device
+int cobel_world_check4(const cobel_world* w, const char* who);  // ... and a four-action world
 
 #define COBEL_HIP_TRY(expr)                                                                  \
   do {                                                                                       \

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
 
 extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* run,
                              void* stream) {
+  if (int rc = cobel_world_check4(world, "cobel_dqn_act")) return rc;
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_dqn_act: NULL world/run");
   const cobel_dqn_act_t& r = *run;
   COBEL_REQUIRE(r.state && r.env_ctr && r.obs_table && r.q && r.policy_ctr, COBEL_E_ARG,

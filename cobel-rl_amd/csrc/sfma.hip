@@ -918,6 +918,7 @@ extern "C" int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes) {
 
 extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run,
                               void* stream) {
+  if (int rc = cobel_world_check4(world, "cobel_sfma_run")) return rc;
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sfma_run: NULL world/run");
   const cobel_sfma_run_t& r = *run;
   COBEL_REQUIRE(r.q && r.model && r.strength && r.stamp && r.inst && r.sfma_inst && r.metric,

@@ -636,6 +636,7 @@ extern "C" int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t
 }
 
 extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* run, void* stream) {
+  if (int rc = cobel_world_check4(world, "cobel_sr_run")) return rc;
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sr_run: NULL world/run");
   const cobel_sr_run_t& r = *run;
   COBEL_REQUIRE(r.sr && r.trans && r.rewards && r.inst, COBEL_E_ARG,

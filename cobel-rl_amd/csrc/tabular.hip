@@ -1064,17 +1064,18 @@ extern "C" int cobel_model_index_build(const uint64_t* model, uint16_t* index, i
 static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream,
                         int32_t* describe) {
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_tab_run: NULL world/run");
+  if (int rc = cobel_world_check(world, "cobel_tab_run")) return rc;
   const cobel_tab_run_t& r = *run;
   COBEL_REQUIRE(r.q && r.inst, COBEL_E_ARG, "cobel_tab_run: q and inst are required");
-  COBEL_REQUIRE(((uintptr_t)r.q & 15u) == 0 && ((uintptr_t)r.inst & 7u) == 0, COBEL_E_ARG,
+  COBEL_REQUIRE(((uintptr_t)r.q & (world->n_actions == 4 ? 15u : 3u)) == 0 &&
+                    ((uintptr_t)r.inst & 7u) == 0, COBEL_E_ARG,
                 "cobel_tab_run: q must be 16-byte and inst 8-byte aligned");
   COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_tab_run: n = %d", r.n);
   COBEL_REQUIRE(r.agent == COBEL_AGENT_Q || r.agent == COBEL_AGENT_DYNAQ, COBEL_E_ARG,
                 "cobel_tab_run: unknown agent %d", r.agent);
   COBEL_REQUIRE(r.agent != COBEL_AGENT_DYNAQ || r.model, COBEL_E_ARG,
                 "cobel_tab_run: Dyna-Q needs the model table");
-  COBEL_REQUIRE(r.batch >= 0 && r.batch <= COBEL_MAX_BATCH, COBEL_E_UNSUPPORTED,
-                "cobel_tab_run: batch %d outside 0..%d", r.batch, COBEL_MAX_BATCH);
+  COBEL_REQUIRE(r.batch >= 0, COBEL_E_RANGE, "cobel_tab_run: batch %d", r.batch);
   COBEL_REQUIRE(r.steps_per_trial > 0, COBEL_E_RANGE, "cobel_tab_run: steps_per_trial = %d",
                 r.steps_per_trial);
   COBEL_REQUIRE(r.epsilon >= 0.0 && r.epsilon <= 1.0, COBEL_E_ARG,
@@ -1086,8 +1087,26 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                 "cobel_tab_run: param_index given without parameter sets");
   COBEL_REQUIRE(r.agent != COBEL_AGENT_Q || world->n_states <= 16384, COBEL_E_UNSUPPORTED,
                 "cobel_tab_run: replay records address at most 16384 states");
+  // Runs outside what the wavefront kernels are built for — an action count other than four
+  // (hexagonal topologies), more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take
+  // the general kernel (general.hip: one lane per instance, every update in sequence).
   int32_t lds_max = 0;
-  if (int rc = cobel_tab_query(world->n_states, r.agent, r.batch, &lds_max, nullptr)) return rc;
+  const bool general = world->n_actions != 4 || r.batch > COBEL_MAX_BATCH ||
+                       (r.flags & COBEL_F_TAB_GENERAL) ||
+                       cobel_tab_query(world->n_states, r.agent, r.batch, &lds_max, nullptr) != COBEL_OK;
+  if (general) {
+    COBEL_REQUIRE(world->n_actions == 4 || !r.model_index, COBEL_E_ARG,
+                  "cobel_tab_run: the model digest exists for four-action worlds only");
+    if (describe) {
+      describe[0] = r.n ? COBEL_TAB_KERNEL_GENERAL : 0;
+      describe[1] = 0;
+      describe[2] = 0;
+      describe[3] = r.n ? 64 : 0;
+      return COBEL_OK;
+    }
+    if (r.n == 0) return COBEL_OK;
+    return cobel_tab_general_launch(world, r, (hipStream_t)stream);
+  }
   if (r.n == 0) return COBEL_OK;
 
   tab_args A;

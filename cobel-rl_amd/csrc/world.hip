@@ -23,7 +23,7 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1007; }
+extern "C" int cobel_abi_version(void) { return 1008; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {
@@ -97,6 +97,7 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   w->n_states = n_states;
   w->n_worlds = n_worlds;
   w->device = device;
+  w->n_actions = 4;
   for (int k = 0; k < n_worlds; ++k) {
     int32_t rewarded = 0;
     for (int32_t s = 0; s < n_states; ++s) rewarded += reward[(size_t)k * n_states + s] != 0.0f;
@@ -127,6 +128,9 @@ extern "C" int cobel_world_destroy(cobel_world_t* w) {
   if (w->rec) (void)hipFree(w->rec);
   if (w->starts) (void)hipFree(w->starts);
   if (w->start_off) (void)hipFree(w->start_off);
+  if (w->next_n) (void)hipFree(w->next_n);
+  if (w->reward_s) (void)hipFree(w->reward_s);
+  if (w->terminal_s) (void)hipFree(w->terminal_s);
   free(w->h_start_off);
   free(w);
   return COBEL_OK;
@@ -153,7 +157,9 @@ __global__ __launch_bounds__(256) void k_env_step(const cobel_wrec* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const cobel_wrec* w = rec + (size_t)((base + (uint32_t)i) % (uint32_t)n_worlds) * S;
-  const int s = state[i];
+  // (the host setters refuse states outside the world; the clamp only keeps a buffer the caller
+  //  filled by other means from reading outside the tables)
+  const int s = min(max(state[i], 0), S - 1);
   const int a = action[i] & 3;
   const int ns = w[s].next[a];
   const cobel_wrec r = w[ns];
@@ -179,9 +185,24 @@ __global__ __launch_bounds__(256) void k_env_reset(const uint16_t* __restrict__ 
   env_ctr[i] = idx + 1u;
 }
 
-static int check_states_dev(const cobel_world_t* w, const char* who) {
+// A world handle may only be used on the device it was created on (its tables live there).
+int cobel_world_check(const cobel_world_t* w, const char* who) {
   COBEL_REQUIRE(w, COBEL_E_ARG, "%s: NULL world", who);
+  int dev = -1;
+  COBEL_HIP_TRY(hipGetDevice(&dev));
+  COBEL_REQUIRE(dev == w->device, COBEL_E_ARG,
+                "%s: the world lives on device %d, the current device is %d", who, w->device, dev);
   return COBEL_OK;
+}
+int cobel_world_check4(const cobel_world_t* w, const char* who) {
+  if (int rc = cobel_world_check(w, who)) return rc;
+  COBEL_REQUIRE(w->n_actions == 4, COBEL_E_UNSUPPORTED,
+                "%s: the world has %d actions, this entry point serves four-action worlds", who,
+                w->n_actions);
+  return COBEL_OK;
+}
+static int check_states_dev(const cobel_world_t* w, const char* who) {
+  return cobel_world_check(w, who);
 }
 
 extern "C" int cobel_env_step(const cobel_world_t* world, int32_t* state, const uint8_t* action,
@@ -191,6 +212,9 @@ extern "C" int cobel_env_step(const cobel_world_t* world, int32_t* state, const 
   COBEL_REQUIRE(state && action, COBEL_E_ARG, "cobel_env_step: NULL state/action");
   COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_env_step: n = %d", n);
   if (n == 0) return COBEL_OK;
+  if (world->n_actions != 4)
+    return cobel_env_step_general(world, state, action, reward_out, done_out, n, instance_base,
+                                  (hipStream_t)stream);
   hipLaunchKernelGGL(k_env_step, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      world->rec, world->n_states, world->n_worlds, state, action, reward_out,
                      done_out, n, instance_base);

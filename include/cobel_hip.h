@@ -38,6 +38,7 @@ extern "C" {
 #define COBEL_E_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. table exceeds LDS)   */
 
 #define COBEL_ACTIONS 4 /* gridworld / 4-neighbour topology action count (gridworld.py:86) */
+#define COBEL_MAX_ACTIONS 8 /* largest action count of cobel_world_create_n (hexagonal topology: 6) */
 
 /* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (block, sub, instance, stream).
  * Each stream is consumed through a per-instance draw counter c:
@@ -93,6 +94,20 @@ COBEL_API int cobel_world_create(const uint16_t* next /* [host] [n_worlds][S][4]
                        const uint16_t* starts /* [host] concatenated start lists */,
                        const int32_t* start_offsets /* [host] [n_worlds + 1] into starts */,
                        int32_t n_states, int32_t n_worlds, int32_t device, cobel_world_t** out);
+/* Worlds whose action count is not four: a Topology's action space is the neighbour count of its
+ * start node (interface/topology.py:110-112), six on the hexagonal graphs of
+ * misc/topology_tools.py:175-272.  next is [n_worlds][S][n_actions]; n_actions = 4 is
+ * cobel_world_create.  Such a world is served by cobel_env_step / cobel_env_reset, and by
+ * cobel_tab_run through its general kernel (Q rows of n_actions entries); the entry points built
+ * around four actions (cobel_sr_run, cobel_sfma_run, cobel_dqn_act) refuse it with
+ * COBEL_E_UNSUPPORTED. */
+COBEL_API int cobel_world_create_n(const uint16_t* next /* [host] [n_worlds][S][n_actions] */,
+                       const float* reward /* [host] [n_worlds][S] */,
+                       const uint8_t* terminal /* [host] [n_worlds][S] */,
+                       const uint16_t* starts, const int32_t* start_offsets, int32_t n_states,
+                       int32_t n_worlds, int32_t n_actions /* 1..COBEL_MAX_ACTIONS */,
+                       int32_t device, cobel_world_t** out);
+COBEL_API int cobel_world_actions(const cobel_world_t* world, int32_t* n_actions);
 COBEL_API int cobel_world_destroy(cobel_world_t* world);
 COBEL_API int cobel_world_info(const cobel_world_t* world, int32_t* n_states, int32_t* n_worlds,
                      int32_t* device);
@@ -150,6 +165,19 @@ COBEL_API int cobel_eps_greedy_f64(const double* values /* [dev] [N][4] */,
                                    double* probs_out /* [dev] [N][4] or NULL */, int32_t n,
                                    void* stream);
 
+/* The same selection over rows of n_actions values (1..COBEL_MAX_ACTIONS; mask bit a = action a
+ * allowed): action spaces other than four, e.g. the six neighbours of a hexagonal Topology. */
+COBEL_API int cobel_eps_greedy_n(const float* values /* [dev] [N][n_actions] */,
+                                 const uint8_t* mask /* [dev] [N] or NULL */,
+                                 const double* u /* [dev] [N] */, double epsilon,
+                                 uint8_t* action_out /* [dev] [N] */,
+                                 double* probs_out /* [dev] [N][n_actions] or NULL */, int32_t n,
+                                 int32_t n_actions, void* stream);
+COBEL_API int cobel_eps_greedy_n_f64(const double* values /* [dev] [N][n_actions] */,
+                                     const uint8_t* mask, const double* u, double epsilon,
+                                     uint8_t* action_out, double* probs_out, int32_t n,
+                                     int32_t n_actions, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused tabular agents.  One call advances every instance through
  *   select -> env.step -> [model store] -> TD update -> [B planning / replay TD updates]
@@ -195,6 +223,7 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
                                      use the general kernel instead of a specialised one      */
 #define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 #define COBEL_F_NO_PREFETCH 128u   /* SR: load value rows at the top of each step (testing)        */
+#define COBEL_F_TAB_GENERAL 512u   /* cobel_tab_run: always take the general kernel (testing)          */
 #define COBEL_F_SR_STREAM_ROWS 256u /* SR: always take the row-streaming kernel, also where the
                                       sparse-reward kernel applies (testing, A/B measurements)    */
 
@@ -265,6 +294,12 @@ typedef struct {
                             sums the copies.  0 or 1: one copy.                                 */
 } cobel_tab_run_t;
 
+/* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —
+ * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — run on the general
+ * kernel: one lane per instance, every update in the reference's sequential order, tables in
+ * HBM / L2; also taken for worlds with an action count other than four (Q is then
+ * [N][S][n_actions], replay records carry the action in bits 28-30 and the nonterminal flag in bit
+ * 31 of the high word) and for state counts whose tables exceed the LDS. */
 #define COBEL_MAX_BATCH 62
 
 /* 0 = this (S, agent, batch) combination is supported; fills *lds_bytes with the LDS per instance. */
@@ -279,7 +314,9 @@ enum {
   COBEL_TAB_KERNEL_LPI = 0,       /* one lane per instance (runs without planning)              */
   COBEL_TAB_KERNEL_WPI = 1,       /* one wavefront per instance, every run-time switch          */
   COBEL_TAB_KERNEL_WPI_FAST = 2,  /* ... plain Dyna-Q training, model digest in LDS             */
-  COBEL_TAB_KERNEL_WPI_INDEX = 3  /* ... plain Dyna-Q training, model digest in HBM (model_index) */
+  COBEL_TAB_KERNEL_WPI_INDEX = 3, /* ... plain Dyna-Q training, model digest in HBM (model_index) */
+  COBEL_TAB_KERNEL_GENERAL = 4    /* one lane per instance, tables in HBM: any action count, batch
+                                     size and state count                                        */
 };
 COBEL_API int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run_t* run,
                                  int32_t* out /* [host] [4] */);

@@ -244,8 +244,30 @@ def gen_eps_greedy():
                                      0xF if m is None else sum(b << i for i, b in enumerate(m)),
                                      u, a, *p))
     rows = np.array(rows, dtype=np.float64)
+    # six values per row (hexagonal Topology: action space = 6 neighbours, topology.py:110-112)
+    rows6 = []
+    vs6 = [[0] * 6, [0, 0, 1, 0, 0, 0], [2, 1, 2, 0, 2, -1], [0.5, 0.25, 0.5, 0.5, 0.125, 0.5],
+           [-1, -2, -3, -1, -1, -4], [1e-8, 0, 0, 1e-8, 0, 0], [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]]
+    masks6 = [None, [1] * 6, [1, 0, 1, 0, 1, 0], [0, 0, 0, 0, 0, 1], [0, 1, 1, 1, 1, 0]]
+    us6 = [0.0, 0.016, 1 / 60., 0.0167, 0.05, 1 / 6., 0.1667, 0.25, 1 / 3., 0.5, 0.65, 2 / 3.,
+           0.8, 5 / 6., 0.834, 0.95, 0.999999999, 1.0 - 2.0 ** -53]
+    for eps in (0.0, 0.1, 0.3, 1.0):
+        pol = EpsilonGreedy(eps, rng=TapeRNG(SEED, 0, STREAM_POLICY))
+        for v in vs6:
+            v = np.array(v, dtype=np.float32)
+            for m in masks6:
+                mm = None if m is None else np.array(m, dtype=bool)
+                p = pol.get_action_probs(v, mm)
+                for u in us6:
+                    pol.rng.random = lambda size=None, u=u: u
+                    a = int(pol.select_action(v, mm))
+                    rows6.append((eps, *[float(x) for x in v],
+                                  0x3F if m is None else sum(b << i for i, b in enumerate(m)),
+                                  u, a, *p))
     np.savez_compressed(_out('eps_greedy_kat.npz'), rows=rows, columns=np.array(
-        ['is_f32', 'eps', 'v0', 'v1', 'v2', 'v3', 'mask', 'u', 'action', 'p0', 'p1', 'p2', 'p3']))
+        ['is_f32', 'eps', 'v0', 'v1', 'v2', 'v3', 'mask', 'u', 'action', 'p0', 'p1', 'p2', 'p3']),
+        rows6=np.array(rows6, dtype=np.float64), columns6=np.array(
+        ['eps'] + ['v%d' % i for i in range(6)] + ['mask', 'u', 'action'] + ['p%d' % i for i in range(6)]))
 
 
 class Tracer:
@@ -436,10 +458,19 @@ def gen_qagent_topology():
         'track_b8_f32': ((10, 2, 1., 20., 'right'), 1, True, 20, 100, 8),
         'track_b8_f64': ((10, 2, 1., 20., 'right'), 1, False, 20, 100, 8),
         'track5_b4_f32': ((5, 1, 0.5, 2., 'left'), 2, True, 25, 12, 4),
+        # six actions: hexagonal(5) (misc/topology_tools.py:175-272), goal at node 7
+        'hex5_b0_f32': (('hex', 5, (0.0, 2.0), 3.0, '7'), 4, True, 30, 40, 0),
+        'hex5_b8_f32': (('hex', 5, (0.0, 2.0), 3.0, '7'), 5, True, 30, 40, 8),
+        'hex4_b70_f32': (('hex', 4, (0.0, 1.0), 1.0, None), 6, True, 12, 30, 70),
     }
     out = {}
     for name, (args, inst, f32, trials, steps, B) in cases.items():
-        nodes, starts = tt.linear_track(*args)
+        if args[0] == 'hex':
+            nodes, starts = tt.hexagonal(*args[1:])
+            args = (float(args[1]), 0.0, 0.0, 0.0, 'hex')
+        else:
+            nodes, starts = tt.linear_track(*args)
+        n_act = len(nodes[starts[0]]['neighbors'])
         env = Topology(nodes, starts, rng=TapeRNG(SEED, inst, STREAM_ENV))
         pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
         ag = QAgent(env.observation_space, env.action_space, pol,
@@ -448,7 +479,7 @@ def gen_qagent_topology():
         key = {tuple(np.array(nodes[k]['pose']).flatten()): i for i, k in enumerate(ids)}
         if f32:
             for k in key:
-                ag.Q[k] = np.zeros(4, dtype=np.float32)
+                ag.Q[k] = np.zeros(n_act, dtype=np.float32)
         sarsn, tds, steps_log, rewards = [], [], [], []
 
         def on_step_end(logs, sarsn=sarsn, tds=tds, key=key):
@@ -464,7 +495,7 @@ def gen_qagent_topology():
                                          'on_trial_begin': [], 'on_step_begin': []}
         ag.train(env, trials, steps, B)
         a = np.array(sarsn, dtype=np.float64).reshape(-1, 5)
-        Q = np.zeros((len(ids), 4))
+        Q = np.zeros((len(ids), n_act))
         for k, row in ag.Q.items():
             Q[key[k]] = row
         probe = np.array([nodes[k]['pose'] for k in ids[:5]], dtype=np.float64)

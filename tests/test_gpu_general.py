@@ -1,0 +1,261 @@
+"""The general tabular path (csrc/general.hip): action counts other than four, batches beyond what
+one wavefront plans, state counts beyond the LDS — against the reference's rows (epsilon-greedy
+over six values), the C oracle, and the wavefront kernels on runs both can serve."""
+import numpy as np
+import pytest
+
+from conftest import SEED, as_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch
+
+
+def test_eps_greedy_six_actions_kat(torch_cuda, golden):
+    """cobel_eps_greedy_n on the reference's six-value rows: every action exact, probabilities
+    bit for bit; and on four-value rows it equals cobel_eps_greedy."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    rows = golden('eps_greedy_kat')['rows6']
+    n = len(rows)
+    d = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), device='cuda').to(dt).contiguous()  # noqa: E731
+    v, bits, u = d(rows[:, 1:7], torch.float32), d(rows[:, 7], torch.uint8), d(rows[:, 8], torch.float64)
+    act = torch.empty(n, dtype=torch.uint8, device='cuda')
+    probs = torch.empty((n, 6), dtype=torch.float64, device='cuda')
+    for eps in np.unique(rows[:, 0]):
+        sel = torch.as_tensor(np.flatnonzero(rows[:, 0] == eps), device='cuda')
+        vv, bb, uu = v[sel].contiguous(), bits[sel].contiguous(), u[sel].contiguous()
+        a_out = torch.empty(len(sel), dtype=torch.uint8, device='cuda')
+        p_out = torch.empty((len(sel), 6), dtype=torch.float64, device='cuda')
+        _lib.check(_lib.lib().cobel_eps_greedy_n(_lib.ptr(vv), _lib.ptr(bb), _lib.ptr(uu), float(eps),
+                                                 _lib.ptr(a_out), _lib.ptr(p_out), len(sel), 6, None))
+        act[sel], probs[sel] = a_out, p_out
+    assert np.array_equal(act.cpu().numpy(), rows[:, 9].astype(np.uint8))
+    assert np.array_equal(probs.cpu().numpy(), rows[:, 10:16])
+    # four values: the general entry equals the four-action one (float32 and float64 rows)
+    r4 = golden('eps_greedy_kat')['rows']
+    r4 = r4[r4[:, 1] == 0.3]
+    v4, b4, u4 = d(r4[:, 2:6], torch.float32), d(r4[:, 6], torch.uint8), d(r4[:, 7], torch.float64)
+    outs = []
+    for fn, extra in ((_lib.lib().cobel_eps_greedy, ()), (_lib.lib().cobel_eps_greedy_n, (4,))):
+        a_out = torch.empty(len(r4), dtype=torch.uint8, device='cuda')
+        p_out = torch.empty((len(r4), 4), dtype=torch.float64, device='cuda')
+        _lib.check(fn(_lib.ptr(v4), _lib.ptr(b4), _lib.ptr(u4), 0.3, _lib.ptr(a_out),
+                      _lib.ptr(p_out), len(r4), *extra, None))
+        outs.append((a_out, p_out))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    v8 = d(r4[:, 2:6], torch.float64)
+    a64 = torch.empty(len(r4), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().cobel_eps_greedy_n_f64(_lib.ptr(v8), _lib.ptr(b4), _lib.ptr(u4), 0.3,
+                                                 _lib.ptr(a64), None, len(r4), 4, None))
+    b64 = torch.empty_like(a64)
+    _lib.check(_lib.lib().cobel_eps_greedy_f64(_lib.ptr(v8), _lib.ptr(b4), _lib.ptr(u4), 0.3,
+                                               _lib.ptr(b64), None, len(r4), None))
+    assert torch.equal(a64, b64)
+
+
+def test_hexagonal_topology_env_and_policy_surface(torch_cuda, golden):
+    """Topology over hexagonal(5): six actions, steps follow the reference's neighbour table,
+    the policy facade selects among six values, the four-action entry points refuse the world."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import hexagonal
+    from cobel_amd.policy import EpsilonGreedy
+    from cobel_amd.spaces import Discrete
+    K = golden('topology_kat')
+    nodes, starts = hexagonal(5, (0.0, 2.0), 3.0, '7')
+    env = Topology(nodes, starts, n_envs=64, seed=SEED)
+    assert int(env.action_space.n) == 6 and env.handle.n_actions == 6
+    nbr, rew, term = K['hex_5_goal7/nbr'], K['hex_5_goal7/reward'], K['hex_5_goal7/terminal']
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        before = env.state.cpu().numpy()
+        act = rng.integers(0, 6, 64).astype(np.uint8)
+        _, r, done, trunc, _ = env.step(torch.as_tensor(act, device='cuda'))
+        after = env.state.cpu().numpy()
+        assert np.array_equal(after, nbr[before, act])
+        assert np.array_equal(r.cpu().numpy(), rew[after].astype(np.float32))
+        assert np.array_equal(done.cpu().numpy(), term[after].astype(bool))
+        env.reset(done)
+    pol = EpsilonGreedy(0.0)
+    assert pol.select_action(np.array([0., 0., 0., 2., 0., 1.], dtype=np.float32), u=0.5) == 3
+    p = pol.get_action_probs(np.array([1., 0., 1., 0., 0., 1.], dtype=np.float32),
+                             np.array([1, 1, 0, 1, 1, 1], dtype=bool))
+    assert np.array_equal(p, [0.5, 0, 0, 0, 0, 0.5])
+    with pytest.raises(AssertionError):      # the SR kernels are four-action kernels
+        SR(Discrete(23), env.action_space, EpsilonGreedy(0.1))
+    run = _lib.SRRun()
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.lib().cobel_sr_run(env.handle.ptr, run, None))
+
+
+def _dynaq(torch, world, n, seed, general, eps=0.1, base=0):
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld(world, n_envs=n, seed=seed, instance_base=base)
+    ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(eps))
+    ag.force_general = general
+    ag.track_instances = True
+    ag.track_occupancy = True
+    ag.track_responses = True
+    return env, ag
+
+
+def _same_tab(torch, a, b):
+    assert torch.equal(a._q, b._q), 'Q tables differ'
+    assert torch.equal(a.inst, b.inst)
+    if hasattr(a.M, 'table'):
+        assert torch.equal(a.M.table, b.M.table) and torch.equal(a.M.index, b.M.index)
+        assert torch.equal(a.M.counter, b.M.counter)
+    for name in ('lat_sum', 'lat_cnt', 'resp_cnt', 'reward_sum'):
+        assert torch.equal(getattr(a.monitors, name), getattr(b.monitors, name)), name
+    assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
+    assert torch.equal(a.monitors.occupancy, b.monitors.occupancy)
+
+
+def test_general_kernel_equals_wavefront_kernels(torch_cuda, golden_worlds):
+    """Four actions, batch <= 62: the lane-per-instance kernel and the wavefront kernels leave
+    identical Q tables, model tables + digests, counters and monitors — Dyna-Q (plain, masked,
+    episodic, without replay, train then test) and QAgent (online, with its replay log)."""
+    torch = torch_cuda
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    world = as_world(golden_worlds('walls_8x8'))
+    nxt = np.asarray(world['next'])
+    bump = nxt != np.arange(64)[:, None]
+    bump[~bump.any(axis=1)] = True
+    for kind in ('plain', 'mask', 'episodic', 'no_replay', 'train_test'):
+        out = []
+        for general in (False, True):
+            env, ag = _dynaq(torch, world, 96, 17, general, eps=0.2, base=3)
+            if kind == 'mask':
+                ag.mask_actions, ag.action_mask = True, bump
+            ag.episodic_replay = kind == 'episodic'
+            ag.train(env, 7, 30, 24, no_replay=(kind == 'no_replay'))
+            if kind == 'train_test':
+                ag.test(env, 4, 30)
+            torch.cuda.synchronize()
+            out.append(ag)
+        _same_tab(torch, out[0], out[1])
+    for B in (0, 24):
+        out = []
+        for general in (False, True):
+            env = Gridworld(world, n_envs=80, seed=23)
+            ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.15))
+            ag.force_general = general
+            ag.track_instances = ag.track_occupancy = ag.track_responses = True
+            ag.train(env, 6, 25, B)
+            ag.train(env, 3, 25, B)
+            torch.cuda.synchronize()
+            out.append(ag)
+        _same_tab(torch, out[0], out[1])
+        if B:
+            assert torch.equal(out[0]._log, out[1]._log)
+            assert out[0].M[:5] == out[1].M[:5]
+
+
+@pytest.mark.parametrize('agent_name', ['dynaq', 'q'])
+def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
+    """batch_size = 100 (the reference has no limit; one wavefront plans at most 62): the general
+    kernel against the C oracle — Q, model tables, replay counters, latencies."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    tab = golden_worlds('walls_8x8')
+    world = as_world(tab)
+    n, trials, steps, B = 20, 5, 30, 100
+    w = c_oracle.OracleWorld([tab])
+    if agent_name == 'dynaq':
+        env, ag = _dynaq(torch, world, n, SEED, False)
+        ag.train(env, trials, steps, B)
+        assert ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)['kernel'] == \
+            _lib.TAB_KERNEL_GENERAL
+        o = c_oracle.TabOracle(w, n, c_oracle.AG_DYNAQ, SEED, True, trial_cap=trials)
+        o.run(trials, steps, B)
+        assert np.array_equal(ag.M.rewards.astype(np.float64), o.MR)
+        assert np.array_equal(ag.M.states, o.MS) and np.array_equal(ag.M.terminals, o.MT)
+        assert np.array_equal(ag.M.counter.cpu().numpy(), o.inst['ctr_memory'].astype(np.int32))
+    else:
+        env = Gridworld(world, n_envs=n, seed=SEED)
+        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        ag.track_instances = True
+        ag.train(env, trials, steps, B)
+        o = c_oracle.TabOracle(w, n, c_oracle.AG_Q, SEED, True, alpha=0.9, gamma=0.8,
+                               trial_cap=trials, log_cap=trials * steps)
+        o.run(trials, steps, B)
+        assert np.array_equal(ag.inst[:, _lib.I_LOG_LEN].cpu().numpy(), o.inst['log_len'].astype(np.int32))
+    torch.cuda.synchronize()
+    assert np.array_equal(ag._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(ag.monitors.lat_trace.cpu().numpy()[:, :trials], o.lat_trace)
+    assert np.array_equal(ag.inst[:, _lib.I_CTR_POLICY].cpu().numpy(),
+                          o.inst['ctr_policy'].astype(np.int32))
+
+
+def test_state_count_beyond_lds_runs_on_the_general_kernel(torch_cuda):
+    """90 x 90 = 8 100 states: Q + model digest of one instance exceed 160 KiB of LDS, the run
+    takes the general kernel and matches the C oracle."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    from cobel_amd import _lib
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    world = make_open_field(90, 90, 4000, 1)
+    world['starting_states'] = np.array([3999, 4001, 3910, 4090, 3820])
+    n, trials, steps, B = 6, 4, 40, 16
+    env, ag = _dynaq(torch, world, n, 5, False)
+    ag.train(env, trials, steps, B)
+    torch.cuda.synchronize()
+    assert ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)['kernel'] == \
+        _lib.TAB_KERNEL_GENERAL
+    w = c_oracle.OracleWorld([dict(next=world['next'], reward=world['rewards'],
+                                   terminal=world['terminals'], starts=world['starting_states'])])
+    o = c_oracle.TabOracle(w, n, c_oracle.AG_DYNAQ, 5, True, trial_cap=trials)
+    o.run(trials, steps, B)
+    assert np.array_equal(ag._q.cpu().numpy().astype(np.float64), o.Q)
+    assert np.array_equal(ag.monitors.lat_trace.cpu().numpy()[:, :trials], o.lat_trace)
+    assert (ag.monitors.lat_trace.cpu().numpy()[:, :trials] < steps - 1).any(), 'goal never reached'
+
+
+def test_dqn_on_hexagonal_topology(torch_cuda):
+    """DQN over six actions (PyTorch-ROCm loop; the fused step is a four-action kernel): runs,
+    selects all six actions, and instance i of a batch equals the same instance run alone."""
+    torch = torch_cuda
+    from collections import OrderedDict
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.misc.topology_tools import hexagonal
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    nodes, starts = hexagonal(4)
+
+    def run(n, base):
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+            ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(64, 6))])).double()
+        env = Topology(nodes, starts, n_envs=n, seed=SEED, instance_base=base)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3), TorchNetwork(net),
+                 gamma=0.8)
+        ag.train(env, 3, 15, 32)
+        torch.cuda.synchronize()
+        return ag
+    vec, one = run(4, 0), run(1, 2)
+    assert vec.fused_steps == 0
+    size = int(one.M.size[0].item())
+    assert size == int(vec.M.size[2].item()) and size > 0
+    assert torch.equal(vec.M.actions[2, :size], one.M.actions[0, :size])
+    assert int(vec.M.actions.max().item()) == 5
+    for a, b in zip(vec._online.get_weights(2), one._online.get_weights(0)):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12)

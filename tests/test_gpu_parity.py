@@ -1219,9 +1219,13 @@ def test_edge_empty_and_zero_work(torch_cuda):
     run.n, run.steps_per_trial = 3, 0
     with pytest.raises(IndexError):
         _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
-    run.steps_per_trial, run.batch = 5, 63
-    with pytest.raises(NotImplementedError):
+    run.steps_per_trial, run.batch = 5, -1
+    with pytest.raises(IndexError):
         _lib.check(lib.cobel_tab_run(env.handle.ptr, C.byref(run), None))
+    # (a batch above COBEL_MAX_BATCH is no longer refused: it takes the general kernel,
+    #  tests/test_gpu_general.py; cobel_tab_query still answers for the wavefront kernels)
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.cobel_tab_query(25, 1, 63, None, None))
     with pytest.raises(IndexError):   # next state out of range
         bad = make_open_field(3, 3, 0, 1)
         bad['next'] = bad['next'].copy()

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1007
+    assert lib.cobel_abi_version() == 1008
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -609,6 +609,15 @@ def test_fused_dqn_path_recognises_models_by_behaviour():
     assert names(seq) == ['1', '3', '5']
     assert names(Demo(act=torch.tanh)) is None
     assert names(Demo(act=lambda v: torch.nn.functional.leaky_relu(v, 0.1))) is None
+    # activations that EQUAL ReLU on the small activations of a freshly initialised network
+    assert names(Demo(act=torch.nn.functional.relu6)) is None
+    assert names(Demo(act=lambda v: torch.clamp(v, 0.0, 50.0))) is None
+    assert names(Demo(act=lambda v: torch.nn.functional.hardtanh(v, 0.0, 1e3))) is None
+    for act in (nn.ReLU6(), nn.Hardtanh(0.0, 20.0)):
+        assert names(nn.Sequential(nn.Linear(6, 64), act, nn.Linear(64, 64), nn.ReLU(),
+                                   nn.Linear(64, 4)).double()) is None
+    f32 = nn.Sequential(nn.Linear(6, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 4))
+    assert names(f32.float()) == ['0', '2', '4']
     assert names(Demo(extra=True)) is None
     assert names(nn.Sequential(nn.Linear(6, 32), nn.ReLU(), nn.Linear(32, 4)).double()) is None
     frozen = Demo()

@@ -266,3 +266,46 @@ def test_dynaq_memory_kat(golden, name):
     assert np.array_equal(M.rewards.astype(np.float64), k[name + '/rewards'])
     assert np.array_equal(M.states, k[name + '/states'])
     assert np.array_equal(M.terminals, k[name + '/terminals'])
+
+
+def test_eps_greedy_six_actions_kat(golden):
+    """policy/greedy.py:40-88 over six values (a hexagonal Topology's action space), masks and
+    draws at the CDF edges: the NumPy restatement against the reference's rows."""
+    rows = golden('eps_greedy_kat')['rows6']
+    assert len(rows) > 2000
+    for r in rows[::7]:
+        eps, v, bits, u, act, p = r[0], r[1:7].astype(np.float32), int(r[7]), r[8], int(r[9]), r[10:16]
+        mask = np.array([(bits >> i) & 1 for i in range(6)], dtype=bool)
+
+        class _U:
+            def random(self, size=None, u=u):
+                return u
+        pol = ref_loop.RefEpsilonGreedy(eps, _U())
+        assert np.array_equal(pol.get_action_probs(v, mask), p)
+        assert pol.select_action(v, mask) == act
+
+
+@pytest.mark.parametrize('name', ['hex5_b0_f32', 'hex5_b8_f32', 'hex4_b70_f32'])
+def test_qagent_on_hexagonal_topology_golden(golden, name):
+    """QAgent on the six-action hexagonal graphs (misc/topology_tools.py:175-272; the action space
+    is the neighbour count, interface/topology.py:110-112): the NumPy restatement against the
+    reference's float32 run — trajectory, escape latencies, Q table, replay log length; one case
+    with a replay batch (70) beyond what one wavefront plans."""
+    D, K = golden('qagent_topology_traces'), golden('topology_kat')
+    inst, f32, trials, steps, B = [int(x) for x in D[name + '/cfg']]
+    graph = {'hex5': 'hex_5_goal7', 'hex4': 'hex_4'}[name[:4]]
+    tab = dict(next=K[graph + '/nbr'], reward=K[graph + '/reward'],
+               terminal=K[graph + '/terminal'], starts=K[graph + '/starts'])
+    assert tab['next'].shape[1] == 6
+    env = ref_loop.RefGridworld(tab, TapeRNG(SEED, inst, STREAM_ENV))
+    pol = ref_loop.RefEpsilonGreedy(0.1, TapeRNG(SEED, inst, STREAM_POLICY))
+    ag = ref_loop.RefQAgent(tab['next'].shape[0], 6, pol, TapeRNG(SEED, inst, STREAM_MEMORY),
+                            dtype=np.float32 if f32 else np.float64)
+    tr = ref_loop.new_trace()
+    ag.train(env, trials, steps, B, trace=tr)
+    got = np.array(tr['sarsn'], dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(got[:, col], D['%s/%s' % (name, key)]), key
+    assert np.array_equal(tr['steps'], D[name + '/steps'])
+    assert np.array_equal(ag.Q.astype(np.float64), D[name + '/Q'])
+    assert len(ag.M) == int(D[name + '/log_len'])
