@@ -72,7 +72,7 @@ CONFIGS = {
     # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's SFMA demo, vectorised
     'C6': dict(instances=65536, env_steps_per_launch=200, steps_per_trial=50, batch=32,
                bytes_per_step=98, bytes_per_reactivation=20 * 100 + 16 * 25 + 32, agent='sfma',
-               limiter='issue',
+               limiter='issue', min_warmup=40,
                desc='65536 x 5x5 walled gridworld of demo/gridworld/demo_sfma.py, SFMA (alpha .99, '
                     'gamma .99, eps .1, DR metric gamma .9, reverse mode, action mask on), 32 '
                     'reactivations per trial, 50 steps/trial'),
@@ -114,7 +114,8 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=8, graph=None):
     agent._run(env, 4096, 100, 32, True, budget=iters)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    how = ('two launches per lockstep step: cobel_dqn_act + cobel_dqn_replay' if agent.fused_steps
+    how = ('two launches per lockstep step (cobel_dqn_act + cobel_dqn_replay), 16 steps per HIP graph'
+           if agent.fused_steps
            else 'PyTorch-ROCm loop' + (', one step captured as a HIP graph and replayed' if graph
                                        else ''))
     # cobel_dqn_replay moves 8 streams over an instance's parameters (online, two Adam moments,
@@ -397,8 +398,22 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
         (base, n), n_global = shard_instances(cfg['instances'], world_size, rank), cfg['instances']
     env, agent = build_agent(cfg_name, cfg, n, base, device)
     runner = Runner(cfg, env, agent)
-    for _ in range(args.warmup):
-        runner.launch()
+    # C6: the work per launch grows while the agents learn (trials get shorter, so more of them
+    # end — each with its 32 reactivations — inside a launch of 200 env steps): 9.8e6 reactivations
+    # and 12 ms in the first launch, 4.66e7 and 28.7 ms from the ~30th on
+    # (scripts/exp_c6_trend.py).  The timed window starts in that steady state.
+    warm = max(args.warmup, cfg.get('min_warmup', 0))
+    first_ms = None
+    for k in range(warm):
+        if k == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            runner.launch()
+            e1.record()
+            torch.cuda.synchronize(device)
+            first_ms = e0.elapsed_time(e1)
+        else:
+            runner.launch()
     torch.cuda.synchronize(device)
     before = agent.monitors.all_reduce().steps_done       # (global; untimed)
     sfma = cfg['agent'] == 'sfma'
@@ -461,7 +476,7 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
         'metric': 'gridworld env-steps/sec (whole job)',
         'value': total_steps / elapsed,
         'unit': 'env-steps/s',
-        'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world_size, 'steps': args.steps, 'warmup': warm,
         'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -497,6 +512,10 @@ def run_config(cfg_name, args, rank, world_size, device, dist):
     if sfma:
         res['reactivations_per_s'] = replays * world_size / elapsed
         res['roofline']['algorithmic_bytes_per_reactivation'] = cfg['bytes_per_reactivation']
+        res['roofline']['reactivations_per_launch'] = replays // args.steps
+        res['transient'] = {'first_launch_ms': first_ms, 'warmup_launches': warm,
+                            'note': 'launch time grows with the reactivations per launch while the '
+                                    'agents learn; the timed window is the steady state'}
     return res, cfg
 
 
@@ -544,7 +563,9 @@ def main():
                 r, _ = run_config(name, args, rank, world_size, device, dist)
                 others[name] = {'value': r['value'], 'unit': r['unit'],
                                 'ms_per_step': r['ms_per_step'], 'config': r['config'],
-                                'roofline': r['roofline']}
+                                'warmup': r['warmup'], 'roofline': r['roofline']}
+                if 'transient' in r:
+                    others[name]['transient'] = r['transient']
                 if 'reactivations_per_s' in r:
                     others[name]['reactivations_per_s'] = r['reactivations_per_s']
                     if rank == 0 and not args.no_cpu_baseline:

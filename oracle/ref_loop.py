@@ -91,12 +91,15 @@ class RefDynaQMemory:
 
     def sample(self, batch):
         flat = self.rng.integers(0, self.S * self.A, batch)
-        ss, aa = flat // self.A, flat % self.A
-        return [
-            (ss[i], aa[i], self.rewards[ss[i], aa[i]], self.states[ss[i], aa[i]],
-             self.terminals[ss[i], aa[i]])
-            for i in range(batch)
-        ], flat
+        pairs = np.array(np.unravel_index(flat, (self.S, self.A)))
+        out = []
+        for i in range(batch):       # one dictionary per experience, as the reference builds them
+            s, a = pairs[0, i], pairs[1, i]
+            exp = {'state': s, 'action': a, 'reward': self.rewards[s, a],
+                   'next_state': self.states[s, a], 'terminal': self.terminals[s, a]}
+            out.append((exp['state'], exp['action'], exp['reward'], exp['next_state'],
+                        exp['terminal']))
+        return out, flat
 
 
 class _Tabular:
@@ -218,6 +221,9 @@ class RefSR:
         self.S, self.A = n_states, n_actions
         self.SR = np.eye(n_states, dtype=dtype)
         self.T = np.repeat(np.arange(n_states), n_actions).reshape(n_states, n_actions)
+        # sr.py:131-135: the one-hot [S, A, S] tensor the reference keeps; T is its index form
+        self.transitions = np.zeros((n_states, n_actions, n_states))
+        self.transitions[np.arange(n_states), :, np.arange(n_states)] = 1.0
         self.rewards = np.zeros(n_states, dtype=dtype)
         self.action_mask = np.ones((n_states, n_actions), dtype=bool)
         self.mask_actions = False
@@ -227,12 +233,16 @@ class RefSR:
         # sr.py:302-306: V = sum(SR * rewards, axis=1) over ALL rows (the reference's S^2 cost
         # pattern is kept so that this loop is a faithful CPU baseline); q[a] = V[T[s, a]]
         v = np.sum(self.SR * self.rewards, axis=1)
-        return np.array([np.mean(v[self.T[state, a]:self.T[state, a] + 1]) for a in range(self.A)])
+        q = []
+        for a in range(self.A):      # sr.py:303-306: boolean lookup in the one-hot row
+            q.append(np.mean(v[self.transitions[state][a] == 1]))
+        return np.array(q)
 
     def update(self, s, a, r, ns, nt):
         d = r - self.rewards[ns]
         self.rewards[ns] += d * self.learning_rate
         self.T[s, a] = ns
+        self.transitions[s][a] = np.eye(self.S)[ns]  # sr.py:274 (an S x S identity per update)
         td = np.eye(self.S)[s]                       # float64 whatever the table dtype
         if nt > 0:
             td += self.gamma * np.copy(self.SR[ns])

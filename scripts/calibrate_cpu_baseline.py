@@ -15,11 +15,19 @@ from cobel.misc import gridworld_tools as gt
 from oracle import ref_loop
 from oracle.philox import TapeRNG, STREAM_ENV, STREAM_POLICY, STREAM_MEMORY
 
-def time_it(fn, count, budget=8.0):
-    t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < budget:
-        fn(); n = count()
-    return n / (time.perf_counter() - t0)
+def time_pair(fn_a, count_a, fn_b, count_b, slice_s=2.0, rounds=5):
+    """Rates of two loops measured in ALTERNATING slices (a, b, a, b, ...): load from other
+    tenants of the sandbox then hits both sides alike — a session that timed one side after the
+    other drifted to ratios of 1.2-1.4 for loops that do the same work."""
+    spent, done = [0.0, 0.0], [0, 0]
+    for _ in range(rounds):
+        for k, (fn, count) in enumerate(((fn_a, count_a), (fn_b, count_b))):
+            n0, t0 = count(), time.perf_counter()
+            while time.perf_counter() - t0 < slice_s:
+                fn()
+            spent[k] += time.perf_counter() - t0
+            done[k] += count() - n0
+    return done[0] / spent[0], done[1] / spent[1]
 
 rows = []
 for name, world, kind, B, steps in (('C1 5x5 Dyna-Q B=32', gt.make_open_field(5, 5, 0, 1), 'dynaq', 32, 50),
@@ -34,10 +42,10 @@ for name, world, kind, B, steps in (('C1 5x5 Dyna-Q B=32', gt.make_open_field(5,
     if kind == 'dynaq':
         ag = DynaQ(env.observation_space, env.action_space, pol, custom_callbacks=cb)
         ag.M.rng = np.random.default_rng(2)
-        ref = time_it(lambda: ag.train(env, 1, steps, B), lambda: cnt[0])
+        run_ref = lambda ag=ag, env=env, steps=steps, B=B: ag.train(env, 1, steps, B)
     else:
         ag = SR(env.observation_space, env.action_space, pol, custom_callbacks=cb)
-        ref = time_it(lambda: ag.train(env, 1, steps), lambda: cnt[0])
+        run_ref = lambda ag=ag, env=env, steps=steps: ag.train(env, 1, steps)
     tabs = dict(next=np.argmax(world['sas'], axis=2), reward=world['rewards'], terminal=world['terminals'],
                 starts=world['starting_states'])
     renv = ref_loop.RefGridworld(tabs, np.random.default_rng(0))
@@ -45,10 +53,11 @@ for name, world, kind, B, steps in (('C1 5x5 Dyna-Q B=32', gt.make_open_field(5,
     tr = ref_loop.new_trace()
     if kind == 'dynaq':
         rag = ref_loop.RefDynaQ(S, 4, rpol, np.random.default_rng(2))
-        port = time_it(lambda: rag.train(renv, 1, steps, B, trace=tr), lambda: len(tr['sarsn']))
+        run_port = lambda: rag.train(renv, 1, steps, B, trace=tr)
     else:
         rag = ref_loop.RefSR(S, 4, rpol)
-        port = time_it(lambda: rag.train(renv, 1, steps, trace=tr), lambda: len(tr['sarsn']))
+        run_port = lambda: rag.train(renv, 1, steps, trace=tr)
+    ref, port = time_pair(run_ref, lambda: cnt[0], run_port, lambda: len(tr['sarsn']))
     rows.append((name, ref, port, port / ref))
     print('%-32s reference %8.0f  port %8.0f  ratio %.2f' % rows[-1])
 
@@ -72,8 +81,6 @@ ag = SFMA(env.observation_space, env.action_space, EpsilonGreedy(0.1, rng=np.ran
           rng=np.random.default_rng(3))
 ag.M.mode = 'reverse'
 ag.mask_actions = True
-ref = time_it(lambda: ag.train(env, 1, 50, 32), lambda: cnt[0])
-ref_replays = cnt[1] / max(cnt[0], 1)
 tabs = dict(next=np.argmax(world['sas'], axis=2), reward=world['rewards'], terminal=world['terminals'],
             starts=world['starting_states'])
 renv = ref_loop.RefGridworld(tabs, np.random.default_rng(0))
@@ -82,7 +89,9 @@ mem.mode = 'reverse'
 rag = sfma_loop.RefSFMA(25, 4, ref_loop.RefEpsilonGreedy(0.1, np.random.default_rng(1)), mem,
                         rng=np.random.default_rng(3))
 rag.mask_actions = True
-port = time_it(lambda: rag.train(renv, 1, 50, 32), lambda: len(rag.sarsn))
+ref, port = time_pair(lambda: ag.train(env, 1, 50, 32), lambda: cnt[0],
+                      lambda: rag.train(renv, 1, 50, 32), lambda: len(rag.sarsn))
+ref_replays = cnt[1] / max(cnt[0], 1)
 print('%-32s reference %8.0f  port %8.0f  ratio %.2f   (reactivations per env step: %.2f vs %.2f)'
       % ('C6 5x5 SFMA DR reverse B=32', ref, port, port / ref, ref_replays,
          len(rag.replayed) / max(len(rag.sarsn), 1)))

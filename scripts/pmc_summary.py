@@ -7,7 +7,7 @@
     python scripts/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> NN
 
 Per launch of the dominant kernel of each config (mean over the TIMED launches, i.e. all but the
-first dispatch of that kernel, which is the warm-up launch).  Units and the gfx950 correction
+warm-up dispatches of that kernel: one, for C6 the 40 that take it to its steady state).  Units and the gfx950 correction
 follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE
 count KiB; FETCH_SIZE reports half the bytes of wide coalesced reads, so
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -17,7 +17,10 @@ import json
 import os
 import sys
 
-KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr<', 'C6': 'k_sfma'}
+KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma'}
+# untimed launches of each kernel at the head of a bench.py run (bench.py: warm-up; C6 warms up
+# into its steady state, CONFIGS['C6']['min_warmup'])
+WARMUP = {'C3': 1, 'C2': 1, 'C4': 1, 'C6': 40}
 
 
 def per_kernel(path, counter):
@@ -57,7 +60,7 @@ def main():
     for cfg, tag in KERNELS.items():
         names = [k for k in fetch if tag in k]
         assert len(names) == 1 and names[0] in write, (cfg, names)
-        f, w = fetch[names[0]][1:], write[names[0]][1:]   # bench.py's warm-up launch
+        f, w = fetch[names[0]][WARMUP[cfg]:], write[names[0]][WARMUP[cfg]:]   # bench.py's warm-up
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         start = names[0].index(tag.rstrip('<'))
         short = names[0][start:names[0].index('(', start)]

@@ -874,6 +874,7 @@ def test_dqn_matches_reference_float64(torch_cuda, golden, name):
     for part in D[name + '/sessions']:
         agent.train(env, int(part), steps, batch)
     assert agent.fused_steps > 0, 'the golden must exercise the two-kernel DQN step'
+    assert agent.fused_graph_steps > 0, '... replayed from the HIP graph of 16 steps'
     m = agent.M
     size = int(m.size[0].item())
     assert size == len(D[name + '/actions'])
@@ -1714,6 +1715,56 @@ def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, dtype_name):
         for x, y in zip(a._target.get_weights(int(i)), b._target.get_weights(int(i))):
             assert np.allclose(x, y, **tol)
     assert a.current_trial == b.current_trial == 8
+
+
+def test_full_size_c5_sample_and_conservation(torch_cuda, golden):
+    """C5 at its full size — 8 192 linear_track(10, 2) instances, float64 6-64-64-4 networks, the
+    two-kernel loop replayed from its HIP graph: eight instances spread over the range equal the
+    same global instances run alone through the PyTorch loop (transitions exactly, weights to
+    float64 round-off); over all instances every step was stored and counted once."""
+    torch = torch_cuda
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.memory import DQNMemory
+    from cobel_amd.misc.topology_tools import linear_track
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('dqn_trace')
+    init = [D['dqn_i0/init_%d' % i] for i in range(6)]
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+    n, budget = 8192, 40
+
+    def run(n_envs, base, fused):
+        env = Topology(nodes, starts, n_envs=n_envs, seed=SEED, instance_base=base)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(_mlp(torch, init)), gamma=0.8, memory=DQNMemory(capacity=256))
+        ag.fused_loop = None if fused else False
+        ag.use_graph = None if fused else False
+        ag._run(env, 10 ** 6, 100, 32, True, budget=budget)
+        torch.cuda.synchronize()
+        return ag, env
+
+    big, env = run(n, 0, True)
+    assert big.fused_steps == budget and big.fused_graph_steps == 32
+    size = big.M.size.cpu().numpy()
+    assert (size == budget).all(), 'every instance stores one experience per step'
+    trials = big.trial.cpu().numpy()
+    mon = big.monitors
+    assert int(mon.lat_cnt.sum().item()) == int(trials.sum())
+    # steps of finished trials + steps of the running ones = the budget, per instance and in total
+    lat_total = int(mon.lat_sum.sum().item()) + int(mon.lat_cnt.sum().item())   # logs['steps'] is 0-based
+    assert lat_total <= n * budget and lat_total >= n * budget - n * 100
+    assert int(big.policy.counter.min().item()) == int(big.policy.counter.max().item()) == budget
+    for g in (0, 1, 63, 64, 4097, 8190, 8191, 5000):
+        one, _ = run(1, g, False)
+        assert one.fused_steps == 0
+        assert torch.equal(big.M.actions[g, :budget], one.M.actions[0, :budget]), g
+        assert torch.equal(big.M.next_states[g, :budget], one.M.next_states[0, :budget]), g
+        assert int(big.trial[g]) == int(one.trial[0])
+        for x, y in zip(big._online.get_weights(g), one._online.get_weights(0)):
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-12), (g, float(np.abs(x - y).max()))
+        for x, y in zip(big._target.get_weights(g), one._target.get_weights(0)):
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-12), g
 
 
 def test_dyna_dqn_two_kernel_loop_equals_torch_loop(torch_cuda):
