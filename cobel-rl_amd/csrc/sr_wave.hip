@@ -339,8 +339,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const uint32_t nt = 1u - end;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     // T[ns][.] as it stands before this step's write
-    uint64_t tnxt = tcur;
-    if (!trial_over && ns != state) tnxt = ns == left_state ? tleft : load_trow(ns);
+    // (the 8-byte load is issued first and waited for only after the row of ns has been requested
+    //  behind it: loads return in order, so its latency hides in the row's)
+    uint64_t tnxt = tcur, traw = 0;
+    const bool t_load = !trial_over && ns != state && ns != left_state;
+    if (!trial_over && ns == left_state && ns != state) tnxt = tleft;
+    if (t_load) traw = __hip_atomic_load(T8 + ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // SR[ns] (sr.py:276-281): loaded, or — after a bump (ns == state) — the row in hand
+    row_regs<NV> nxt = cur;
+    if (learn && nt != 0u && ns != state) {
+      load_row<NV>(nxt, SRg + (size_t)ns * S, lane);
+      rows_read += 1u;
+    }
+    if (t_load) tnxt = ((uint64_t)rfl((uint32_t)(traw >> 32)) << 32) | (uint64_t)rfl((uint32_t)traw);
 
     float f0 = 0.0f, f1 = 0.0f, gv = 0.0f;
     uint64_t tq = tnxt;   // the rows whose values the next step needs
@@ -373,12 +384,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     if (learn) {
       // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
       const bool need_ns = nt != 0u;
-      // SR[ns]: loaded, or — after a bump (ns == state) — the row in hand
-      row_regs<NV> nxt = cur;
-      if (need_ns && ns != state) {
-        load_row<NV>(nxt, SRg + (size_t)ns * S, lane);
-        rows_read += 1u;
-      }
       // Everything issued before this point has landed: the gathers, the row of ns, and the row
       // store of the previous step.
       wait_vm0();
