@@ -346,7 +346,77 @@ class DQN(Agent):
 
     def _run(self, interface, trials: int, steps: int, batch_size: int, learn: bool,
              budget: int = 0) -> None:
-        """``budget`` > 0 stops after that many lockstep iterations (benchmarking)."""
+        """``budget`` > 0 stops after that many lockstep iterations (benchmarking).
+
+        One environment instance with host callbacks keeps the reference's contract
+        (agent/dqn.py:170-215): step hooks fire around every step with the reference's ``logs``
+        keys, trial hooks after every trial, and ``agent.stop`` ends the session at the next trial
+        boundary.  Vectorised runs fire the trial hooks once per ``train()`` call with per-trial
+        means (a device cannot call Python between steps of thousands of instances)."""
+        single = interface.n_envs == 1 and not budget
+        if single and self.callbacks.has('on_step_begin', 'on_step_end'):
+            self._run_hooks(interface, trials, steps, batch_size, learn)
+        elif single and self.callbacks.has('on_trial_begin', 'on_trial_end'):
+            for t in range(trials):          # one trial per run: same streams, same kernels
+                self._run_core(interface, 1, steps, batch_size, learn, 0, session0=t)
+                if self.stop:
+                    break
+        else:
+            self._run_core(interface, trials, steps, batch_size, learn, budget)
+
+    def _run_hooks(self, interface, trials: int, steps: int, batch_size: int, learn: bool) -> None:
+        """The reference's loop, step by step, for ONE instance with step hooks registered; the
+        same kernels, streams and counters as the lockstep loop (so the outcome is identical)."""
+        self._bind(interface, (int(self.M.size.max().item()) if torch.is_tensor(
+            getattr(self.M, 'size', None)) else 0) + trials * steps)
+        self._adopt_user_weights()
+        pol = self.policy if learn else self.policy_test
+        self._policy_bind(pol, interface, not learn)
+        dev, mon = self.device, self.monitors
+        for t in range(trials):
+            trial = self.current_trial
+            mon.reserve(trial + 1)
+            logs = self.callbacks.on_trial_begin({'trial_reward': 0.0, 'trial': trial,
+                                                  'trial_session': t})
+            interface.reset()
+            obs = interface.observe().to(self.dtype).clone()
+            step = 0
+            for step in range(steps):
+                logs['step'] = step
+                logs = self.callbacks.on_step_begin(logs)
+                action = self._select(pol, self._q_values(obs), interface.instance_base)
+                interface.step(action)
+                nxt = interface.observe().to(self.dtype).clone()
+                reward, done = float(interface._reward[0].item()), bool(interface._done[0].item())
+                if learn:
+                    self.M.store_batch(obs, action, interface._reward, nxt, ~interface._done.bool())
+                    if not getattr(self, '_no_replay', False):
+                        logs['replay'] = self.replay(batch_size)
+                logs['trial_reward'] += reward
+                if hasattr(interface, 'prev_state'):     # Dyna agents: integer gridworld states
+                    s_log, ns_log = int(interface.prev_state[0].item()), int(interface.env.state[0].item())
+                else:
+                    s_log, ns_log = obs[0].cpu().numpy(), nxt[0].cpu().numpy()
+                logs.update({'state': s_log, 'action': int(action[0].item()), 'reward': reward,
+                             'next_state': ns_log, 'terminal': 1 - int(done)})
+                logs = self.callbacks.on_step_end(logs)
+                obs = nxt
+                if done:
+                    break
+            mon.raw('lat_sum')[0, trial] += step
+            mon.raw('lat_cnt')[0, trial] += 1
+            mon.raw('reward_sum')[0, trial] += logs['trial_reward']
+            self.current_trial += 1
+            self.trial.fill_(self.current_trial)
+            logs['step'] = logs['steps'] = step
+            self.callbacks.on_trial_end(logs)
+            if self.stop:
+                break
+        for stack, single_net, inst in self._stacks():
+            stack.write_back(single_net, inst)
+
+    def _run_core(self, interface, trials: int, steps: int, batch_size: int, learn: bool,
+                  budget: int = 0, session0: int = 0) -> None:
         # the ring keeps everything up to `capacity` (memory/dqn.py:113-119): room for what is
         # stored already plus what this run can add
         bound = self.n_envs is not None
@@ -365,11 +435,11 @@ class DQN(Agent):
         trew = torch.zeros(n, dtype=torch.float64, device=dev)
         for t in range(trials):
             self.callbacks.on_trial_begin({'trial_reward': 0.0, 'trial': first + t,
-                                           'trial_session': t})
+                                           'trial_session': session0 + t})
         obs, _ = interface.reset()
         if learn and self._fused_loop_ok(interface, pol, batch_size):
             self._run_fused(interface, pol, trials, steps, batch_size, budget)
-            self._finish_run(first, trials)
+            self._finish_run(first, trials, session0)
             return
         obs = interface.observe().to(self.dtype).clone()
         active = torch.ones(n, dtype=torch.bool, device=dev)
@@ -462,7 +532,7 @@ class DQN(Agent):
                     if left == 0:
                         break
                     all_active = left == n
-        self._finish_run(first, trials)
+        self._finish_run(first, trials, session0)
 
     def _stacks(self):
         """(stacked network, single network the user holds, instance) triples kept in step."""
@@ -475,7 +545,7 @@ class DQN(Agent):
             if not stack.matches(single, inst):
                 stack.load_from(single)
 
-    def _finish_run(self, first: int, trials: int) -> None:
+    def _finish_run(self, first: int, trials: int, session0: int = 0) -> None:
         self.current_trial = first + trials
         for stack, single, inst in self._stacks():      # the trained networks, as attributes
             stack.write_back(single, inst)
@@ -484,7 +554,7 @@ class DQN(Agent):
             cnt = self.monitors.lat_cnt.cpu().numpy()
             for t in range(trials):
                 self.callbacks.on_trial_end({'trial_reward': float(rew[first + t]),
-                                             'trial': first + t, 'trial_session': t,
+                                             'trial': first + t, 'trial_session': session0 + t,
                                              'steps': float(lat[first + t]),
                                              'count': int(cnt[first + t])})
 

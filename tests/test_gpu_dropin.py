@@ -355,3 +355,60 @@ def test_dynaq_memory_store_and_retrieve_batch_match_reference(cobel):
     a, b = run(False), run(True)
     assert int(b.M.counter[0].item()) == int(a.M.counter[0].item()) + 1
     assert not np.array_equal(a.Q, b.Q)       # the host draw consumed one batch of the stream
+
+
+def test_dqn_single_instance_honours_hooks_and_stop(cobel, golden):
+    """agent/dqn.py:170-215 with one environment: step hooks fire around every step with the
+    reference's logs keys, trial hooks after every trial, `agent.stop` ends the session at the next
+    trial boundary — and neither mode changes the outcome (same transitions and weights as the
+    hook-free run, which takes the two fused kernels)."""
+    import torch
+    from conftest import SEED
+    from cobel.agent import DQN
+    from cobel.interface import Topology
+    from cobel.misc.topology_tools import linear_track
+    from cobel.network import TorchNetwork
+    from cobel.policy import EpsilonGreedy
+    nodes, starts = linear_track(10, 2, 1., 20., 'right')
+
+    def run(callbacks):
+        torch.manual_seed(11)
+        env = Topology(nodes, starts, seed=SEED, instance_base=4)
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(_Model(6, 4)), gamma=0.8, custom_callbacks=callbacks)
+        ag.train(env, 4, 20, 32)
+        torch.cuda.synchronize()
+        return ag
+
+    steps, begins, trials = [], [], []
+    plain = run(None)
+    hooked = run({'on_step_begin': [lambda l: begins.append(l['step'])],
+                  'on_step_end': [lambda l: steps.append(dict(l))],
+                  'on_trial_end': [lambda l: trials.append((l['trial'], l['steps'], l['trial_reward']))]})
+    per_trial = run({'on_trial_end': [lambda l: None]})
+    assert plain.fused_steps > 0 and hooked.fused_steps == 0 and per_trial.fused_steps > 0
+    n = int(plain.M.size[0].item())
+    for other in (hooked, per_trial):
+        assert int(other.M.size[0].item()) == n and other.current_trial == 4
+        assert torch.equal(other.M.actions[0, :n], plain.M.actions[0, :n])
+        assert torch.equal(other.M.next_states[0, :n], plain.M.next_states[0, :n])
+        assert torch.equal(other.monitors.lat_sum[:4], plain.monitors.lat_sum[:4])
+        for a, b in zip(other._online.get_weights(0), plain._online.get_weights(0)):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    assert len(steps) == n == len(begins) and [t[0] for t in trials] == [0, 1, 2, 3]
+    for key in ('trial', 'trial_session', 'step', 'state', 'action', 'reward', 'next_state',
+                'terminal', 'trial_reward', 'replay', 'agent'):
+        assert key in steps[0], key
+    assert steps[0]['state'].shape == (6,) and isinstance(steps[0]['action'], int)
+    assert [t[1] for t in trials] == plain.monitors.lat_sum[:4].cpu().numpy().tolist()
+    # agent.stop set by a trial hook ends the session after that trial
+    seen = []
+
+    def stop_after_two(logs):
+        seen.append(logs['trial'])
+        if logs['trial'] == 1:
+            logs['agent'].stop = True
+    stopped = run({'on_trial_end': [stop_after_two]})
+    assert seen == [0, 1] and stopped.current_trial == 2
+    stopped2 = run({'on_trial_end': [stop_after_two], 'on_step_end': [lambda l: None]})
+    assert stopped2.current_trial == 2
