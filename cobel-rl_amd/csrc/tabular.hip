@@ -79,6 +79,7 @@ struct tab_lds {
   uint32_t* occ;
 };
 constexpr int kThrBytes = 16 * 3 * 8;
+constexpr int kPassLanes = COBEL_MAX_BATCH;   // planning updates one wavefront takes per pass
 constexpr int kHashBuckets = 256;
 constexpr int kHashBucketsSmall = 128;   // with MIDX: keeps the footprint at 17 KiB (nine per CU)
 
@@ -204,6 +205,12 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
                             ? A.r.batch
                             : 0);
   const bool replay_each_step = FAST || (B > 0 && !episodic);
+  // Batches beyond one wavefront (the reference has no limit, dyna_q.py:319-330): the generic
+  // kernel plans them in passes of kPassLanes updates, one after the other — the passes are
+  // sequential, so later updates see earlier ones as the reference's loop does, and inside a pass
+  // the conflict analysis below applies unchanged.  BP = updates of the pass being planned.
+  int Bp = B > kPassLanes ? kPassLanes : B;
+#define BP (FAST ? B : Bp)
   const uint32_t pol_stream = (!FAST && (flags & COBEL_F_TEST_STREAM)) ? COBEL_STREAM_POLICY_TEST
                                                                        : COBEL_STREAM_POLICY;
   const uint8_t* const amask =
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // (inside == true: the caller already runs under `lane < B`; one predicated region instead of
   //  one per table access)
   auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r, bool inside = false) {
-    const bool on = inside || lane < B;
+    const bool on = inside || lane < BP;
     const uint32_t sj = idx >> 2;
 #if defined(COBEL_ABLATE) && COBEL_ABLATE == 3
     return;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     int first = 0;
     do {   // (B >= 1 here; most batches need one or two rounds)
       const unsigned long long blocked = __ballot(on && dep >= first);
-      const int stop = blocked ? (__ffsll((long long)blocked) - 1) : B;
+      const int stop = blocked ? (__ffsll((long long)blocked) - 1) : BP;
       if (lane >= first && lane < stop) {
         const float4 row = Qs[ns];
         const float q = Qf[idx];
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       }
       __builtin_amdgcn_wave_barrier();
       first = stop;
-    } while (first < B);
+    } while (first < BP);
     STAMP(4);
   };
   // Dyna-Q batch drawn with x: model entries from LDS, reward estimates from HBM where flagged.
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   auto plan_dynaq = [&](uint32_t x, uint32_t fresh_idx, float fresh_r) {
     uint32_t idx = 0, ns = 0, nt = 0;
     float r = 0.0f;
-    if (lane < B) {
+    if (lane < BP) {
       idx = cobel_bounded(x, SA);
       const uint32_t m = L.M16[idx];
       ns = m & 0x3fffu;
@@ -409,6 +416,19 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       if (idx == fresh_idx) r = fresh_r;
     }
     run_batch(idx, ns, nt, r);
+  };
+  // a whole batch: the first pass from the cached draw x, further passes (B > kPassLanes) from
+  // their own Philox blocks — element j of the vector draw comes from sub-stream j
+  auto plan_dynaq_batch = [&](uint32_t x, uint32_t fresh_idx, float fresh_r) {
+    plan_dynaq(x, fresh_idx, fresh_r);
+    if (!FAST && B > kPassLanes) {
+      for (int j0 = kPassLanes; j0 < B; j0 += kPassLanes) {
+        Bp = B - j0 < kPassLanes ? B - j0 : kPassLanes;
+        const cobel_u4 b = cobel_philox(cm >> 2, (uint32_t)(j0 + lane), g, COBEL_STREAM_MEMORY, seed);
+        plan_dynaq(cobel_word(b, cm & 3u), fresh_idx, fresh_r);
+      }
+      Bp = kPassLanes;
+    }
   };
   auto replay_log = [&](uint64_t rec) {
     const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
@@ -643,7 +663,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         mrec = mrec_next;
         cm += 1u;
       } else if (AGENT == COBEL_AGENT_DYNAQ) {
-        plan_dynaq(mdraw, fresh_idx, fresh_r);
+        plan_dynaq_batch(mdraw, fresh_idx, fresh_r);
         cm += 1u;
       } else {
         // experiences of the next batch are gathered now, behind this batch's updates
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       iflags &= ~1u;
       if (episodic && B > 0) {
         refresh_draws(cp >> 2);
-        plan_dynaq(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
+        plan_dynaq_batch(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
         cm += 1u;
       }
       if (!begin_trial()) break;
@@ -1091,9 +1111,13 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   // (hexagonal topologies), more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take
   // the general kernel (general.hip: one lane per instance, every update in sequence).
   int32_t lds_max = 0;
-  const bool general = world->n_actions != 4 || r.batch > COBEL_MAX_BATCH ||
+  // (Dyna-Q plans batches above COBEL_MAX_BATCH in several passes of the generic wavefront
+  //  kernel; QAgent's log replay gathers its records a step ahead, one lane each: general kernel)
+  const int32_t pass = r.batch > COBEL_MAX_BATCH ? COBEL_MAX_BATCH : r.batch;
+  const bool general = world->n_actions != 4 ||
+                       (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ) ||
                        (r.flags & COBEL_F_TAB_GENERAL) ||
-                       cobel_tab_query(world->n_states, r.agent, r.batch, &lds_max, nullptr) != COBEL_OK;
+                       cobel_tab_query(world->n_states, r.agent, pass, &lds_max, nullptr) != COBEL_OK;
   if (general) {
     COBEL_REQUIRE(world->n_actions == 4 || !r.model_index, COBEL_E_ARG,
                   "cobel_tab_run: the model digest exists for four-action worlds only");
@@ -1126,6 +1150,7 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
   A.use_hash = replay ? 1 : 0;
   const bool fast = r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
+                    r.batch <= COBEL_MAX_BATCH &&
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;

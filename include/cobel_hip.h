@@ -295,9 +295,11 @@ typedef struct {
 } cobel_tab_run_t;
 
 /* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —
- * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — run on the general
- * kernel: one lane per instance, every update in the reference's sequential order, tables in
- * HBM / L2; also taken for worlds with an action count other than four (Q is then
+ * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — are planned by
+ * Dyna-Q in ceil(batch / 62) passes per step (the passes run one after the other, so the
+ * sequential order of the reference's loop is kept); QAgent's log replay beyond 62 runs on the
+ * general kernel: one lane per instance, every update in the reference's sequential order, tables
+ * in HBM / L2; that kernel is also taken for worlds with an action count other than four (Q is then
  * [N][S][n_actions], replay records carry the action in bits 28-30 and the nonterminal flag in bit
  * 31 of the high word) and for state counts whose tables exceed the LDS. */
 #define COBEL_MAX_BATCH 62

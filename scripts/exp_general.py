@@ -40,4 +40,7 @@ if __name__ == '__main__':
     run(50, True)
     run(100, True)
     run(62, False)
+    run(63, False)
+    run(100, False)
+    run(124, False)
     run(63, True)

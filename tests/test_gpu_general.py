@@ -133,14 +133,16 @@ def test_general_kernel_equals_wavefront_kernels(torch_cuda, golden_worlds):
     nxt = np.asarray(world['next'])
     bump = nxt != np.arange(64)[:, None]
     bump[~bump.any(axis=1)] = True
-    for kind in ('plain', 'mask', 'episodic', 'no_replay', 'train_test'):
+    # (batch 24: one pass of the wavefront kernel; 70 and 130: two and three passes)
+    for kind, batch in (('plain', 24), ('mask', 24), ('episodic', 24), ('no_replay', 24),
+                        ('train_test', 24), ('plain', 70), ('mask', 130), ('episodic', 70)):
         out = []
         for general in (False, True):
             env, ag = _dynaq(torch, world, 96, 17, general, eps=0.2, base=3)
             if kind == 'mask':
                 ag.mask_actions, ag.action_mask = True, bump
             ag.episodic_replay = kind == 'episodic'
-            ag.train(env, 7, 30, 24, no_replay=(kind == 'no_replay'))
+            ag.train(env, 7, 30, batch, no_replay=(kind == 'no_replay'))
             if kind == 'train_test':
                 ag.test(env, 4, 30)
             torch.cuda.synchronize()
@@ -165,8 +167,9 @@ def test_general_kernel_equals_wavefront_kernels(torch_cuda, golden_worlds):
 
 @pytest.mark.parametrize('agent_name', ['dynaq', 'q'])
 def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
-    """batch_size = 100 (the reference has no limit; one wavefront plans at most 62): the general
-    kernel against the C oracle — Q, model tables, replay counters, latencies."""
+    """batch_size = 100 (the reference has no limit; one wavefront plans at most 62 per pass):
+    Dyna-Q in two passes of the wavefront kernel, QAgent on the general kernel, against the C
+    oracle — Q, model tables, replay counters, latencies."""
     torch = torch_cuda
     from oracle import c_oracle
     from cobel_amd import _lib
@@ -180,8 +183,13 @@ def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
     if agent_name == 'dynaq':
         env, ag = _dynaq(torch, world, n, SEED, False)
         ag.train(env, trials, steps, B)
+        # Dyna-Q: two passes (62 + 38 updates) of the generic wavefront kernel ...
         assert ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)['kernel'] == \
-            _lib.TAB_KERNEL_GENERAL
+            _lib.TAB_KERNEL_WPI
+        # ... which leave what the lane-per-instance kernel leaves
+        env2, ag2 = _dynaq(torch, world, n, SEED, True)
+        ag2.train(env2, trials, steps, B)
+        _same_tab(torch, ag, ag2)
         o = c_oracle.TabOracle(w, n, c_oracle.AG_DYNAQ, SEED, True, trial_cap=trials)
         o.run(trials, steps, B)
         assert np.array_equal(ag.M.rewards.astype(np.float64), o.MR)
