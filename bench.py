@@ -199,16 +199,32 @@ def run_next_rows(device):
     out['dyna_dqn'] = r
     del agent, env
 
-    n = 2048
+    n = 8192
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 25)), TorchNetwork(_mlp(25, 1)), gamma=0.8)
-    agent.use_graph = True
-    r = timed(agent, env, n, 64)
+    r = timed(agent, env, n, 48, warm=8)
+    fused = agent.fused_steps > 0
     r['config'] = {'workload': 'Dyna-DSR: %d x 5x5 open field, four online + four target successor '
                                'networks 25-64-64-25 and one reward network f64 per instance, batches '
-                               'of 32, one step replayed from a HIP graph' % n,
-                   'instances_per_gpu': n, 'lockstep_iterations': 64}
+                               'of 32, %s' % (n, 'five launches per lockstep step (cobel_dqn_act, 2 x '
+                                              'cobel_mlp_forward, 2 x cobel_mlp_fit) + elementwise '
+                                              'torch for the targets, 8 steps per HIP graph' if fused
+                                              else 'PyTorch-ROCm loop, one step per HIP graph'),
+                   'instances_per_gpu': n, 'lockstep_iterations': 48}
+    if fused:
+        # per instance and step: the four online successor networks move 8 streams over their
+        # parameters (p, m, v, target: read + write), the reward network 6 (no target), and the
+        # forward passes read the four target networks and the reward network once more
+        p_sr = sum(p.numel() for p in agent.models_online[0].model.parameters())
+        p_rw = sum(p.numel() for p in agent.model_reward.model.parameters())
+        bytes_per_step = (4 * 8 * p_sr + 6 * p_rw + 4 * p_sr + p_rw) * 8
+        gbs = bytes_per_step * r['value'] / 1e9
+        r['roofline'] = {'bound': 'hbm', 'limiter': 'latency', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'k_mlp_fit', 'algorithmic_bytes_per_env_step': bytes_per_step,
+                         'note': 'one workgroup per CU: a 25-64-64-25 float64 network needs 107 KB '
+                                 'of LDS (DESIGN.md section 4.4b)'}
     out['dyna_dsr'] = r
     del agent, env
 

@@ -89,6 +89,40 @@ class DQNAct(C.Structure):
     ]
 
 
+class MLPForward(C.Structure):
+    """``cobel_mlp_forward_t``."""
+    _fields_ = [
+        ('w', C.c_void_p * 3), ('b', C.c_void_p * 3), ('active', C.c_void_p),
+        ('in_table', C.c_void_p), ('in_index', C.c_void_p), ('in_dense', C.c_void_p),
+        ('out', C.c_void_p),
+        ('n', C.c_int32), ('n_inputs', C.c_int32), ('n_outputs', C.c_int32),
+        ('is_float64', C.c_int32),
+        ('net_div', C.c_int32), ('in_div', C.c_int32), ('act_div', C.c_int32),
+        ('reserved_', C.c_int32),
+    ]
+
+
+class MLPFit(C.Structure):
+    """``cobel_mlp_fit_t``."""
+    _fields_ = [
+        ('w', C.c_void_p * 3), ('b', C.c_void_p * 3),
+        ('w_target', C.c_void_p * 3), ('b_target', C.c_void_p * 3),
+        ('m_w', C.c_void_p * 3), ('m_b', C.c_void_p * 3),
+        ('v_w', C.c_void_p * 3), ('v_b', C.c_void_p * 3),
+        ('steps', C.c_void_p), ('train', C.c_void_p), ('active', C.c_void_p),
+        ('in_table', C.c_void_p), ('in_index', C.c_void_p), ('in_dense', C.c_void_p),
+        ('targets', C.c_void_p), ('sample_mask', C.c_void_p),
+        ('ep_table', C.c_void_p), ('ep_index', C.c_void_p), ('ep_dense', C.c_void_p),
+        ('ep_out', C.c_void_p),
+        ('n', C.c_int32), ('n_inputs', C.c_int32), ('n_outputs', C.c_int32),
+        ('is_float64', C.c_int32),
+        ('in_div', C.c_int32), ('tgt_div', C.c_int32), ('act_div', C.c_int32),
+        ('ep_div', C.c_int32), ('ep_rows', C.c_int32), ('reserved_', C.c_int32),
+        ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+        ('weight_decay', C.c_double), ('tau', C.c_double),
+    ]
+
+
 class TabRun(C.Structure):
     """``cobel_tab_run_t``."""
     _fields_ = [
@@ -215,6 +249,9 @@ _SIGNATURES = {
 _SIGNATURES['cobel_dqn_replay_query'] = (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)])
 _SIGNATURES['cobel_dqn_replay'] = (C.c_int, [C.POINTER(DQNReplay), _P])
 _SIGNATURES['cobel_dqn_act'] = (C.c_int, [_P, C.POINTER(DQNAct), _P])
+_SIGNATURES['cobel_mlp_query'] = (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)])
+_SIGNATURES['cobel_mlp_forward'] = (C.c_int, [C.POINTER(MLPForward), _P])
+_SIGNATURES['cobel_mlp_fit'] = (C.c_int, [C.POINTER(MLPFit), _P])
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

@@ -18,7 +18,11 @@ One replay (:1042-1150):
 Vectorised like ``DynaDQN``: ``n_envs`` independent agents in lockstep; the 4 x n online (and
 target) SR networks are one ``StackedTorchNetwork`` of 4 n instances (index ``4 i + a``), trained
 in one pass with per-instance sample masks and per-instance Adam step counts, so every network
-receives exactly the update it would compute alone.  Same constructor, attributes and methods as
+receives exactly the update it would compute alone.  With the 64-64 ReLU networks of the
+reference's demo (demo/gridworld/demo_dyna_dsr.py) a lockstep step is five kernel launches
+(``_run_fused``: cobel_dqn_act in world-model mode, two cobel_mlp_forward, two cobel_mlp_fit) and
+a handful of elementwise torch kernels for the targets, replayed from a HIP graph; any other
+network takes the PyTorch-ROCm loop (vmap + fused Adam), same results.  Same constructor, attributes and methods as
 the reference (``models_online`` / ``models_target`` are dictionaries of single-instance views).
 """
 from __future__ import annotations
@@ -26,9 +30,11 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .. import _lib
 from ..spaces import Discrete
 from .agent import DeviceMonitors
-from .dyna_dqn import DynaDQN
+from .dqn import _capture
+from .dyna_dqn import DynaDQN, _ModelMemory
 
 
 class DynaDSR(DynaDQN):
@@ -165,6 +171,227 @@ class DynaDSR(DynaDQN):
             'action masks / episodic replay are not part of the accelerated DynaDSR path'
         self._no_replay = no_replay
         self._run(interface, trials, steps, batch_size, True)
+
+    # -- fused lockstep step ----------------------------------------------------------------------
+    @staticmethod
+    def _mlp_ptrs(net, names):
+        """(weights, biases, exp_avg w/b, exp_avg_sq w/b) tensors of a stacked 3-layer network,
+        with Adam's state created where the optimizer has not run yet."""
+        opt, out = net.optimizer, {k: [] for k in ('w', 'b', 'mw', 'mb', 'vw', 'vb')}
+        for name in names:
+            for kind, kw, km, kv in (('.weight', 'w', 'mw', 'vw'), ('.bias', 'b', 'mb', 'vb')):
+                p = net.params[name + kind]
+                st = opt.state[p]
+                if 'exp_avg' not in st:
+                    st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
+                    st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+                out[kw].append(p)
+                out[km].append(st['exp_avg'])
+                out[kv].append(st['exp_avg_sq'])
+        return out
+
+    @staticmethod
+    def _step_counts(net):
+        """Per-network Adam step counts (shared with the PyTorch path's fused optimizer kernel)."""
+        net._diverged = True
+        counts = getattr(net, '_steps', None)
+        if counts is None:
+            seen = [float(st['steps'].max()) if 'steps' in st else float(st.get('step', 0.0))
+                    for st in net.optimizer.state.values()]
+            counts = net._steps = torch.full((net.n,), max(seen, default=0.0), dtype=torch.float64,
+                                             device=net.device)
+        for st in net.optimizer.state.values():
+            st['steps'] = counts
+        return counts
+
+    def _fused_loop_ok(self, interface, pol, batch_size: int) -> bool:
+        """The run is one the MLP kernels cover: three-layer 64-64 ReLU networks (successor
+        networks D -> D with D <= 32, reward network D -> 1), MSE, Adam, blended targets,
+        batches of 32, an epsilon-greedy policy on a Gridworld's one-hot observations."""
+        from ..interface.gridworld import Gridworld
+        from ..policy.greedy import EpsilonGreedy
+        if type(self) is not DynaDSR or self.fused_loop is False or self.use_graph is True \
+                or not isinstance(interface, DynaDQN._ObsView) \
+                or not isinstance(interface.env, Gridworld) or type(self.M) is not _ModelMemory \
+                or self.M.A != 4 or interface.table.dtype != torch.float64 \
+                or interface.table.dim() != 2 or self.mask_actions or self.episodic_replay \
+                or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \
+                or getattr(self, '_no_replay', False) or batch_size != 32 \
+                or self.dtype not in (torch.float64, torch.float32):
+            return False
+        shapes = []
+        for net in (self._online, self._target, self._reward_net):
+            names = net._mlp3_names() if net.fused_mlp else None
+            if names is None or type(net.criterion) is not torch.nn.MSELoss \
+                    or getattr(net.criterion, 'reduction', '') != 'none':
+                return False
+            w = [net.params[k + '.weight'] for k in names]
+            shapes.append((w[0].shape[2], w[0].shape[1], w[1].shape[1], w[2].shape[1]))
+        if not (self._online._fused_adam_ok() and self._reward_net._fused_adam_ok()):
+            return False
+        D = interface.table.shape[1]
+        (d0, h0, h1, o0), tgt, (dr, hr0, hr1, orr) = shapes
+        f64 = int(self.dtype == torch.float64)
+        return tgt == shapes[0] and d0 == D and dr == o0 and orr == 1 and \
+            _lib.lib().cobel_mlp_query(d0, h0, h1, o0, 32, f64, None) == _lib.OK and \
+            _lib.lib().cobel_mlp_query(dr, hr0, hr1, orr, 32, f64, None) == _lib.OK
+
+    def _run_fused(self, interface, pol, trials: int, steps: int, batch_size: int,
+                   budget: int) -> None:
+        """One lockstep step = cobel_dqn_act (select from Q, env.step, model store, trial
+        bookkeeping, batch draw) -> successor features of the sampled next states under the four
+        TARGET networks and their values under the reward network (two cobel_mlp_forward) -> the
+        targets (elementwise torch) -> one optimisation step of every online successor network on
+        the samples that took its action, target blend, and the successor features of the next
+        observation (cobel_mlp_fit) -> one step of the reward network and Q of the next
+        observation (cobel_mlp_fit).  Same streams, counters and arithmetic as ``replay``."""
+        import ctypes as C
+        n, A, dev, M, mon = self.n_envs, self.n_actions, self.device, self.M, self.monitors
+        first, f64, dt = self.current_trial, int(self.dtype == torch.float64), self.dtype
+        env, table = interface.env, interface.table.contiguous()
+        D = table.shape[1]
+        names_sr, names_r = self._online._mlp3_names(), self._reward_net._mlp3_names()
+        O = self._online.params[names_sr[2] + '.weight'].shape[1]
+        on, tg, rw = (self._mlp_ptrs(self._online, names_sr), self._mlp_ptrs(self._target, names_sr),
+                      self._mlp_ptrs(self._reward_net, names_r))
+        steps_sr, steps_r = self._step_counts(self._online), self._step_counts(self._reward_net)
+        q = self._q_values(interface.observe().to(dt)).contiguous()
+        step = torch.zeros(n, dtype=torch.int32, device=dev)
+        trew = torch.zeros(n, dtype=torch.float64, device=dev)
+        active = torch.ones(n, dtype=torch.uint8, device=dev)
+        stepped = torch.zeros(n, dtype=torch.uint8, device=dev)
+        unused_steps = torch.zeros(n, dtype=torch.float64, device=dev)
+        si = torch.zeros((n, 32), dtype=torch.int32, device=dev)
+        ni = torch.zeros_like(si)
+        ba = torch.zeros((n, 32), dtype=torch.int64, device=dev)
+        br = torch.zeros((n, 32), dtype=dt, device=dev)
+        bt = torch.zeros_like(br)
+        fsr = torch.zeros((n * A, 32, O), dtype=dt, device=dev)
+        val = torch.zeros((n * A, 32, 1), dtype=dt, device=dev)
+        y = torch.zeros((n, 32, O), dtype=dt, device=dev)
+        took = torch.zeros((n * A, 32), dtype=torch.uint8, device=dev)
+        train = torch.zeros(n * A, dtype=torch.uint8, device=dev)
+        sr_next = torch.zeros((n * A, 1, O), dtype=dt, device=dev)
+        arange_a = torch.arange(A, device=dev)[None, :, None]
+
+        act = _lib.DQNAct()
+        act.state, act.env_ctr = _lib.ptr(env.state), _lib.ptr(env.env_ctr)
+        act.obs_table, act.q = _lib.ptr(table), _lib.ptr(q)
+        act.policy_ctr, act.policy_stream = _lib.ptr(pol.counter), pol.stream
+        act.is_float64, act.epsilon = f64, float(pol.epsilon)
+        act.memory_ctr = _lib.ptr(M.counter)
+        act.trial, act.step, act.trial_reward = _lib.ptr(self.trial), _lib.ptr(step), _lib.ptr(trew)
+        act.active, act.adam_steps = _lib.ptr(active), _lib.ptr(unused_steps)
+        act.lat_sum, act.lat_cnt = _lib.ptr(mon.raw('lat_sum')), _lib.ptr(mon.raw('lat_cnt'))
+        act.reward_sum, act.stepped = _lib.ptr(mon.raw('reward_sum')), _lib.ptr(stepped)
+        act.n, act.n_obs, act.batch = n, D, 32
+        act.steps_per_trial, act.trials_target = steps, first + trials
+        act.trial_cap, act.mon_stripes = mon.cap, mon.stripes
+        act.instance_base, act.seed = interface.instance_base, interface.seed
+        act.model_rewards, act.model_states = _lib.ptr(M.rewards), _lib.ptr(M.states)
+        act.model_nonterminal, act.model_lr = _lib.ptr(M.terminals), float(M.learning_rate)
+        act.n_states = M.S
+        act.batch_state_index, act.batch_next_index = _lib.ptr(si), _lib.ptr(ni)
+        act.batch_actions, act.batch_rewards = _lib.ptr(ba), _lib.ptr(br)
+        act.batch_nonterminal = _lib.ptr(bt)
+
+        def fill(dst, tensors):
+            for k in range(3):
+                dst[k] = _lib.ptr(tensors[k])
+
+        fwd_t, fwd_r = _lib.MLPForward(), _lib.MLPForward()
+        fill(fwd_t.w, tg['w']); fill(fwd_t.b, tg['b'])           # noqa: E702
+        fwd_t.active, fwd_t.act_div = _lib.ptr(stepped), A
+        fwd_t.in_table, fwd_t.in_index, fwd_t.in_div = _lib.ptr(table), _lib.ptr(ni), A
+        fwd_t.out, fwd_t.n, fwd_t.net_div = _lib.ptr(fsr), n * A, 1
+        fwd_t.n_inputs, fwd_t.n_outputs, fwd_t.is_float64 = D, O, f64
+        fill(fwd_r.w, rw['w']); fill(fwd_r.b, rw['b'])           # noqa: E702
+        fwd_r.active, fwd_r.act_div = _lib.ptr(stepped), A
+        fwd_r.in_dense, fwd_r.in_div = _lib.ptr(fsr), 1
+        fwd_r.out, fwd_r.n, fwd_r.net_div = _lib.ptr(val), n * A, A
+        fwd_r.n_inputs, fwd_r.n_outputs, fwd_r.is_float64 = O, 1, f64
+
+        def optimiser(fit, net):
+            g = net.optimizer.param_groups[0]
+            fit.lr, (fit.beta1, fit.beta2) = float(g['lr']), (float(b) for b in g['betas'])
+            fit.eps, fit.weight_decay = float(g['eps']), float(g['weight_decay'])
+
+        fit_sr, fit_r = _lib.MLPFit(), _lib.MLPFit()
+        for dst, key in ((fit_sr.w, 'w'), (fit_sr.b, 'b'), (fit_sr.m_w, 'mw'), (fit_sr.m_b, 'mb'),
+                         (fit_sr.v_w, 'vw'), (fit_sr.v_b, 'vb')):
+            fill(dst, on[key])
+        fill(fit_sr.w_target, tg['w']); fill(fit_sr.b_target, tg['b'])   # noqa: E702
+        optimiser(fit_sr, self._online)
+        fit_sr.tau = float(self.target_update)
+        fit_sr.steps, fit_sr.train = _lib.ptr(steps_sr), _lib.ptr(train)
+        fit_sr.active, fit_sr.act_div = _lib.ptr(stepped), A
+        fit_sr.in_table, fit_sr.in_index, fit_sr.in_div = _lib.ptr(table), _lib.ptr(si), A
+        fit_sr.targets, fit_sr.tgt_div, fit_sr.sample_mask = _lib.ptr(y), A, _lib.ptr(took)
+        fit_sr.ep_table, fit_sr.ep_index, fit_sr.ep_div = _lib.ptr(table), _lib.ptr(env.state), A
+        fit_sr.ep_rows, fit_sr.ep_out = 1, _lib.ptr(sr_next)
+        fit_sr.n, fit_sr.n_inputs, fit_sr.n_outputs, fit_sr.is_float64 = n * A, D, O, f64
+        for dst, key in ((fit_r.w, 'w'), (fit_r.b, 'b'), (fit_r.m_w, 'mw'), (fit_r.m_b, 'mb'),
+                         (fit_r.v_w, 'vw'), (fit_r.v_b, 'vb')):
+            fill(dst, rw[key])
+        optimiser(fit_r, self._reward_net)
+        fit_r.tau = 0.0
+        fit_r.steps, fit_r.active, fit_r.act_div = _lib.ptr(steps_r), _lib.ptr(stepped), 1
+        fit_r.in_table, fit_r.in_index, fit_r.in_div = _lib.ptr(table), _lib.ptr(ni), 1
+        fit_r.targets, fit_r.tgt_div = _lib.ptr(br), 1
+        fit_r.ep_dense, fit_r.ep_div, fit_r.ep_rows = _lib.ptr(sr_next), 1, A
+        fit_r.ep_out = _lib.ptr(q)
+        fit_r.n, fit_r.n_inputs, fit_r.n_outputs, fit_r.is_float64 = n, O, 1, f64
+
+        follow, ignore = float(self.use_follow_up_state), float(self.ignore_terminality)
+        tab = table.to(dt)
+        lib, world = _lib.lib(), env.handle.ptr
+
+        def one_step() -> None:
+            st = _lib.current_stream(dev)
+            _lib.check(lib.cobel_dqn_act(world, C.byref(act), st))
+            _lib.check(lib.cobel_mlp_forward(C.byref(fwd_t), st))
+            _lib.check(lib.cobel_mlp_forward(C.byref(fwd_r), st))
+            # agent/dyna_q.py:1079-1118, for all instances at once (as in ``replay``)
+            future = fsr.view(n, A, 32, O)
+            if self.use_DR:
+                boot_sr = future.mean(dim=1)
+            else:
+                best = val.view(n, A, 32).argmax(dim=1)
+                boot_sr = torch.gather(future, 1, best[:, None, :, None].expand(n, 1, 32, O))[:, 0]
+            nxt, nonterminal = tab[ni.to(torch.int64)], (bt != 0).to(dt)
+            boot = nxt * ((1.0 - follow) * (1.0 - ignore)) * (1.0 - nonterminal)[..., None]
+            boot = boot + boot_sr * torch.clamp(nonterminal + ignore, max=1.0)[..., None]
+            y.copy_((nxt if self.use_follow_up_state else tab[si.to(torch.int64)]) + self.gamma * boot)
+            mine = (ba[:, None, :] == arange_a).reshape(n * A, 32)
+            took.copy_(mine.to(torch.uint8))
+            train.copy_(mine.any(dim=1).to(torch.uint8))
+            _lib.check(lib.cobel_mlp_fit(C.byref(fit_sr), st))
+            _lib.check(lib.cobel_mlp_fit(C.byref(fit_r), st))
+
+        graph, done = None, 0
+        per_graph = 8
+        if self.fused_graph and self.use_graph is not False and (budget or steps) >= per_graph:
+            one_step()
+            done = 1
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with _capture(graph):
+                for _ in range(per_graph):
+                    one_step()
+        while True:
+            chunk = (budget - done) if budget else min(steps, 64)
+            left = chunk
+            while graph is not None and left >= per_graph:
+                graph.replay()
+                left -= per_graph
+                self.fused_graph_steps += per_graph
+            for _ in range(left):
+                one_step()
+            done += chunk
+            if budget or int(active.sum().item()) == 0:
+                break
+        self.last_update += done
+        self.fused_steps += done
 
     # -- single-instance views of the stacked networks (reference attribute names) --------------
     def get_weights(self, action: int, target: bool = False, instance: int = 0):

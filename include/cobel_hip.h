@@ -569,6 +569,70 @@ COBEL_API int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_
 COBEL_API int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * TorchNetwork.train_on_batch / predict_on_batch for STACKS of small networks — Linear(D <= 32,
+ * 64)-ReLU-Linear(64, 64)-ReLU-Linear(64, O <= 32), batches of 32, float64 or float32 — one
+ * kernel each (network/network_torch.py:110-167).  They carry DynaDSR.replay
+ * (agent/dyna_q.py:1042-1150): per agent four online + four target successor networks
+ * (D -> 64 -> 64 -> D) and one reward network (D -> 64 -> 64 -> 1).
+ *
+ * cobel_mlp_forward: out[j] = net[j / net_div](inputs of instance j), 32 rows per instance; the
+ *   inputs are rows in_table[in_index[j / in_div][s]] of a float64 table or a dense block
+ *   in_dense[j][32][D] in the network's dtype.
+ * cobel_mlp_fit: network j takes ONE optimisation step towards targets[j / tgt_div][32][O] on its
+ *   32 input rows: loss = mean over the samples marked in sample_mask[j] (NULL: all) and the O
+ *   outputs of (out - target)^2, torch.optim.Adam with the network's own step count steps[j]
+ *   (incremented here), then w_target += tau * (w - w_target).  train[j] == 0: no optimiser step
+ *   (parameters, moments and step count untouched) but the blend still happens, as the reference
+ *   blends every network pair every step (agent/dyna_q.py:1134-1143).  active[j / act_div] == 0:
+ *   nothing at all.  Afterwards ep_out[j][ep_rows][O] receives the (updated) network's outputs
+ *   for ep_rows <= 4 extra rows — row ep_table[ep_index[j / ep_div]] or ep_dense[j][ep_rows][D] —
+ *   which is what the next action selection needs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* w[3];        /* [M][out][in], network dtype */
+  const void* b[3];        /* [M][out]                    */
+  const uint8_t* active;   /* [n / act_div] or NULL       */
+  const double* in_table;  /* [rows][D] float64, or NULL  */
+  const int32_t* in_index; /* [n / in_div][32]            */
+  const void* in_dense;    /* [n][32][D], network dtype   */
+  void* out;               /* [n][32][O]                  */
+  int32_t n, n_inputs, n_outputs, is_float64;
+  int32_t net_div, in_div, act_div, reserved_;
+} cobel_mlp_forward_t;
+
+typedef struct {
+  void* w[3];              /* [n][out][in] */
+  void* b[3];
+  void* w_target[3];       /* blend targets, or NULL with tau == 0 */
+  void* b_target[3];
+  void* m_w[3];            /* Adam exp_avg / exp_avg_sq */
+  void* m_b[3];
+  void* v_w[3];
+  void* v_b[3];
+  double* steps;           /* [n] Adam step counts, += 1 for every network that trains            */
+  const uint8_t* train;    /* [n] or NULL (= all)                                                 */
+  const uint8_t* active;   /* [n / act_div] or NULL                                               */
+  const double* in_table;  /* inputs as for cobel_mlp_forward                                     */
+  const int32_t* in_index;
+  const void* in_dense;
+  const void* targets;     /* [n / tgt_div][32][O], network dtype                                 */
+  const uint8_t* sample_mask; /* [n][32] or NULL                                                  */
+  const double* ep_table;  /* extra rows: one row of a float64 table ...                          */
+  const int32_t* ep_index; /* ... [n / ep_div]                                                    */
+  const void* ep_dense;    /* ... or [n][ep_rows][D], network dtype                               */
+  void* ep_out;            /* [n][ep_rows][O] or NULL                                             */
+  int32_t n, n_inputs, n_outputs, is_float64;
+  int32_t in_div, tgt_div, act_div, ep_div, ep_rows, reserved_;
+  double lr, beta1, beta2, eps, weight_decay, tau;
+} cobel_mlp_fit_t;
+/* 0 = this shape is covered; fills *lds_bytes (per workgroup). */
+COBEL_API int cobel_mlp_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
+                              int32_t n_outputs, int32_t batch, int32_t is_float64,
+                              int32_t* lds_bytes);
+COBEL_API int cobel_mlp_forward(const cobel_mlp_forward_t* run, void* stream);
+COBEL_API int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Everything of one lockstep DQN training step that is not the network: per instance
  *   epsilon-greedy on the given Q-values (policy/greedy.py:40-88) -> env.step
  *   (interface/topology.py:146-157, gridworld.py:115-126) -> append the experience to the replay

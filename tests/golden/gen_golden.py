@@ -929,15 +929,31 @@ def gen_dyna_dsr():
     out = {}
     runs = (('ddsr_default', 0, 3, 15, 12, dict()),
             ('ddsr_switches', 1, 2, 18, 10, dict(use_DR=True, use_follow_up_state=True,
-                                                 ignore_terminality=False, target_update=3)))
+                                                 ignore_terminality=False, target_update=3)),
+            # the networks of demo/gridworld/demo_dyna_dsr.py (64-64 ReLU) and its batch of 32:
+            # the shape the fused MLP kernels cover
+            ('ddsr_mlp64', 2, 3, 15, 32, dict()),
+            ('ddsr_mlp64_switches', 3, 2, 18, 32, dict(use_DR=True, use_follow_up_state=True,
+                                                       ignore_terminality=False,
+                                                       target_update=0.05)))
     for name, inst, trials, steps, B, switches in runs:
         torch.manual_seed(7 + inst)
-        sr_net = torch.nn.Sequential(OrderedDict([
-            ('dense_1', torch.nn.Linear(16, 24)), ('relu_1', torch.nn.ReLU()),
-            ('output', torch.nn.Linear(24, 16))])).double()
-        rw_net = torch.nn.Sequential(OrderedDict([
-            ('dense_1', torch.nn.Linear(16, 12)), ('relu_1', torch.nn.ReLU()),
-            ('output', torch.nn.Linear(12, 1))])).double()
+        if 'mlp64' in name:
+            sr_net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 64)), ('relu_1', torch.nn.ReLU()),
+                ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(64, 16))])).double()
+            rw_net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 64)), ('relu_1', torch.nn.ReLU()),
+                ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(64, 1))])).double()
+        else:
+            sr_net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 24)), ('relu_1', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(24, 16))])).double()
+            rw_net = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(16, 12)), ('relu_1', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(12, 1))])).double()
         model_sr, model_rw = TorchNetwork(sr_net), TorchNetwork(rw_net)
         init_sr, init_rw = model_sr.get_weights(), model_rw.get_weights()
         world = gt.make_open_field(4, 4, 0, 1)

@@ -1396,7 +1396,8 @@ def test_dyna_dqn_matches_reference(torch_cuda, golden, name):
     assert np.allclose(q[0].cpu().numpy(), D[name + '/q_all'], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize('name', ['ddsr_default', 'ddsr_switches'])
+@pytest.mark.parametrize('name', ['ddsr_default', 'ddsr_switches', 'ddsr_mlp64',
+                                  'ddsr_mlp64_switches'])
 def test_dyna_dsr_matches_reference(torch_cuda, golden, name):
     """DynaDSR (deep successor representation fed by the tabular Dyna-Q model) on a 4x4 open
     field, float64, against the reference with the same initial weights and injected draws:
@@ -1413,10 +1414,18 @@ def test_dyna_dsr_matches_reference(torch_cuda, golden, name):
     D = golden('dyna_dsr_trace')
     inst, trials, steps, B = [int(x) for x in D[name + '/cfg']]
 
+    mlp64 = 'mlp64' in name     # 64-64 ReLU networks, batch 32: the fused MLP kernels
+
     def net(sizes, tag):
-        m = torch.nn.Sequential(OrderedDict([
-            ('dense_1', torch.nn.Linear(sizes[0], sizes[1])), ('relu_1', torch.nn.ReLU()),
-            ('output', torch.nn.Linear(sizes[1], sizes[2]))])).double()
+        if mlp64:
+            m = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(sizes[0], 64)), ('relu_1', torch.nn.ReLU()),
+                ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(64, sizes[2]))])).double()
+        else:
+            m = torch.nn.Sequential(OrderedDict([
+                ('dense_1', torch.nn.Linear(sizes[0], sizes[1])), ('relu_1', torch.nn.ReLU()),
+                ('output', torch.nn.Linear(sizes[1], sizes[2]))])).double()
         state = m.state_dict()
         for i, key in enumerate(state):
             state[key] = torch.as_tensor(D['%s/init_%s_%d' % (name, tag, i)])
@@ -1429,10 +1438,14 @@ def test_dyna_dsr_matches_reference(torch_cuda, golden, name):
     if name == 'ddsr_switches':
         agent.use_DR, agent.use_follow_up_state = True, True
         agent.ignore_terminality, agent.target_update = False, 3
+    if name == 'ddsr_mlp64_switches':
+        agent.use_DR, agent.use_follow_up_state = True, True
+        agent.ignore_terminality, agent.target_update = False, 0.05
     seen = []
     agent.callbacks.custom_callbacks = {'on_trial_end': [lambda logs: seen.append(logs['steps'])]}
     agent.track_instances = True
     agent.train(env, trials, steps, B)
+    assert (agent.fused_steps > 0) == mlp64, 'the 64-64 goldens run on cobel_mlp_fit / _forward'
     for a in range(4):
         for i, w in enumerate(agent.get_weights(a)):
             assert np.allclose(w, D['%s/online_%d_%d' % (name, a, i)], rtol=1e-9, atol=1e-12), (a, i)
