@@ -64,3 +64,11 @@ def coinciding_trials(D, a, b):
             break
         same, oa, ob = same + 1, oa + na, ob + nb
     return same
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return int(sock.getsockname()[1])

@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +31,7 @@ def test_two_ranks_split_the_instances_and_report_the_same_monitors(config, inst
     assert one.returncode == 0, one.stderr[-3000:]
     two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
                           '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
-                          '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend',
+                          str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend',
                           'gloo'] + args, capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
     a, b = _line(one.stdout), _line(two.stdout)
@@ -49,7 +51,7 @@ def test_weak_scaling_option_runs_the_full_count_per_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
                           '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
-                          '29578', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                          str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
                           '--weak', '--config', 'C2', '--instances', '256', '--env-steps', '50']
                          + COMMON, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]

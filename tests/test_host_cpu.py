@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -335,7 +335,7 @@ def test_monitor_allreduce_two_ranks_gloo(tmp_path):
     """The N > 1 path's only collective (monitor reduction), world_size 2 on the gloo backend."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
