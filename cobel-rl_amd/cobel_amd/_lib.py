@@ -117,7 +117,7 @@ class MLPFit(C.Structure):
         ('n', C.c_int32), ('n_inputs', C.c_int32), ('n_outputs', C.c_int32),
         ('is_float64', C.c_int32),
         ('in_div', C.c_int32), ('tgt_div', C.c_int32), ('act_div', C.c_int32),
-        ('ep_div', C.c_int32), ('ep_rows', C.c_int32), ('reserved_', C.c_int32),
+        ('ep_div', C.c_int32), ('ep_rows', C.c_int32), ('debug_stage', C.c_int32),
         ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
         ('weight_decay', C.c_double), ('tau', C.c_double),
     ]

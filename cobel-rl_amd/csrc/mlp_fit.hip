@@ -31,6 +31,7 @@ constexpr int kRow = 66;
 constexpr int kMaxD = 32;
 constexpr int kMaxO = 32;
 constexpr int kMaxEp = 4;
+constexpr int kFitThreads = 512;   // threads of a training workgroup
 
 struct fit_args {
   cobel_mlp_fit_t r;
@@ -154,24 +155,25 @@ __device__ __forceinline__ net_lds<T> carve(unsigned char* raw, int D, int O) {
 }
 
 // One network's parameters (torch.nn.Linear layout [out][in]) into LDS.
-template <typename T>
+template <typename T, int NT>
 __device__ void stage_params(const net_lds<T>& L, const T* __restrict__ w1,
                              const T* __restrict__ b1, const T* __restrict__ w2,
                              const T* __restrict__ b2, const T* __restrict__ w3,
                              const T* __restrict__ b3, int D, int O, int t) {
-  T w2r[16];
+  constexpr int U = kH * kH / NT;
+  T w2r[U];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) w2r[u] = __builtin_nontemporal_load(w2 + t + 256 * u);
+  for (int u = 0; u < U; ++u) w2r[u] = __builtin_nontemporal_load(w2 + t + NT * u);
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {   // transposed write
-    const int e = t + 256 * u;
+  for (int u = 0; u < U; ++u) {   // transposed write
+    const int e = t + NT * u;
     L.wt2[(e & 63) * kRow + (e >> 6)] = w2r[u];
   }
-  for (int e = t; e < kH * D; e += 256) {
+  for (int e = t; e < kH * D; e += NT) {
     const int j = e / D, d = e - j * D;
     L.wt1[d * kH + j] = w1[e];
   }
-  for (int e = t; e < O * kH; e += 256) L.w3[e] = w3[e];
+  for (int e = t; e < O * kH; e += NT) L.w3[e] = w3[e];
   if (t < kH) {
     L.b1[t] = b1[t];
     L.b2[t] = b2[t];
@@ -179,54 +181,44 @@ __device__ void stage_params(const net_lds<T>& L, const T* __restrict__ w1,
   if (t < O) L.b3[t] = b3[t];
 }
 
-// h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), out[s][a] = W3 h2 + b3 for the 32 rows of L.x.
-template <typename T>
+// h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), out[s][a] = W3 h2 + b3 for the 32 rows of L.x, by a
+// workgroup of NT = 512 threads: first layer one sample x four neurons per thread, second layer one
+// 16 x 16 MFMA tile per wave (2 sample tiles x 4 neuron tiles = 8 waves).
+template <typename T, int NT>
 __device__ void forward32(const net_lds<T>& L, T* out, int D, int O, int t) {
-  const int jg = t & 15, sg = t >> 4;
-  const int j0 = jg * 4, s0 = sg * 2;
+  static_assert(NT == 512, "eight waves per workgroup");
   {
-    T acc[2][4];
+    const int j0 = (t & 15) * 4, s0 = t >> 4;
+    T acc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = L.b1[j0 + c];
+    for (int c = 0; c < 4; ++c) acc[c] = L.b1[j0 + c];
     for (int d = 0; d < D; ++d) {
-      const T x0 = L.x[s0 * D + d], x1 = L.x[(s0 + 1) * D + d];
+      const T x0 = L.x[s0 * D + d];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const T w = L.wt1[d * kH + j0 + c];
-        acc[0][c] = fma_t<T>(w, x0, acc[0][c]);
-        acc[1][c] = fma_t<T>(w, x1, acc[1][c]);
-      }
+      for (int c = 0; c < 4; ++c) acc[c] = fma_t<T>(L.wt1[d * kH + j0 + c], x0, acc[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      L.h1[s0 * kRow + j0 + c] = acc[0][c] > (T)0 ? acc[0][c] : (T)0;
-      L.h1[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
-    }
+    for (int c = 0; c < 4; ++c) L.h1[s0 * kRow + j0 + c] = acc[c] > (T)0 ? acc[c] : (T)0;
   }
   lds_barrier();
   {
     typedef typename mfma_acc<T>::type acc_t;
-    const int lane = t & 63, jt = (t >> 6) * 16;
+    const int lane = t & 63, wave = t >> 6;
+    const int jt = (wave & 3) * 16, st = (wave >> 2) * 16;
     const int li = lane & 15, lq = lane >> 4;
     const T bias = L.b2[jt + li];
-    acc_t acc0 = {bias, bias, bias, bias}, acc1 = acc0;
+    acc_t acc0 = {bias, bias, bias, bias};
 #pragma unroll 4
-    for (int k0 = 0; k0 < kH; k0 += 4) {
-      const T b = L.wt2[(k0 + lq) * kRow + jt + li];
-      const T a0 = L.h1[li * kRow + k0 + lq];
-      const T a1 = L.h1[(16 + li) * kRow + k0 + lq];
-      acc0 = mfma(a0, b, acc0);
-      acc1 = mfma(a1, b, acc1);
-    }
+    for (int k0 = 0; k0 < kH; k0 += 4)
+      acc0 = mfma(L.h1[(st + li) * kRow + k0 + lq], L.wt2[(k0 + lq) * kRow + jt + li], acc0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int r = mfma_acc<T>::row(lane, v);
-      L.h2[r * kRow + jt + li] = acc0[v] > (T)0 ? acc0[v] : (T)0;
-      L.h2[(16 + r) * kRow + jt + li] = acc1[v] > (T)0 ? acc1[v] : (T)0;
+      L.h2[(st + r) * kRow + jt + li] = acc0[v] > (T)0 ? acc0[v] : (T)0;
     }
   }
   lds_barrier();
-  for (int e = t; e < kB * O; e += 256) {
+  for (int e = t; e < kB * O; e += NT) {
     const int s = e / O, a = e - s * O;
     T acc = L.b3[a];
 #pragma unroll 8
@@ -237,10 +229,10 @@ __device__ void forward32(const net_lds<T>& L, T* out, int D, int O, int t) {
 }
 
 // the 32 input rows of an instance: rows of a float64 table by index, or a dense [32][D] block
-template <typename T>
+template <typename T, int NT>
 __device__ void load_inputs(T* dst, const double* table, const int32_t* index, const T* dense,
                             int D, int t) {
-  for (int e = t; e < kB * D; e += 256) {
+  for (int e = t; e < kB * D; e += NT) {
     const int s = e / D, d = e - s * D;
     dst[e] = table ? (T)table[(size_t)index[s] * D + d] : dense[e];
   }
@@ -361,6 +353,8 @@ __global__ __launch_bounds__(256) void k_mlp_forward(const fwd_args A) {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
+  constexpr int NT = kFitThreads;   // eight waves: the workgroup is alone on its CU (LDS), so the
+                                    // parallelism inside it is all there is to hide latency
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_mlp_fit_t& R = A.r;
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
@@ -383,7 +377,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   T* const tw3 = blend ? (T*)R.w_target[2] + (size_t)j * n3 : nullptr;
   T* const tb3 = blend ? (T*)R.b_target[2] + (size_t)j * O : nullptr;
 
-  stage_params<T>(L, w1, b1, w2, b2, w3, b3, D, O, t);
+  stage_params<T, NT>(L, w1, b1, w2, b2, w3, b3, D, O, t);
 
   if (!train) {
     // No samples for this network in this step: parameters and optimizer state stay as they are;
@@ -391,9 +385,9 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     // pair every step).
     if (blend) {
       const T tau = (T)R.tau;
-      for (size_t e = t; e < n1; e += 256) tw1[e] = tw1[e] + tau * (w1[e] - tw1[e]);
-      for (size_t e = t; e < n2; e += 256) tw2[e] = tw2[e] + tau * (w2[e] - tw2[e]);
-      for (size_t e = t; e < n3; e += 256) tw3[e] = tw3[e] + tau * (w3[e] - tw3[e]);
+      for (size_t e = t; e < n1; e += NT) tw1[e] = tw1[e] + tau * (w1[e] - tw1[e]);
+      for (size_t e = t; e < n2; e += NT) tw2[e] = tw2[e] + tau * (w2[e] - tw2[e]);
+      for (size_t e = t; e < n3; e += NT) tw3[e] = tw3[e] + tau * (w3[e] - tw3[e]);
       if (t < kH) {
         tb1[t] = tb1[t] + tau * (b1[t] - tb1[t]);
         tb2[t] = tb2[t] + tau * (b2[t] - tb2[t]);
@@ -407,24 +401,34 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     T* const m_b1 = (T*)R.m_b[0] + (size_t)j * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)j * kH;
     T* const m_b2 = (T*)R.m_b[1] + (size_t)j * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)j * kH;
     T* const m_b3 = (T*)R.m_b[2] + (size_t)j * O;  T* const v_b3 = (T*)R.v_b[2] + (size_t)j * O;
-    const int lane2 = t & 63, jt2 = (t >> 6) * 16, li2 = lane2 & 15;
-    constexpr int kU3 = (kMaxO * kH + 255) / 256, kU1 = (kMaxD * kH + 255) / 256;
-    adam_slot<T> s2[4][4], s3[kU3], s1[kU1], sb1, sb2, sb3;
+    // (the inputs are requested BEFORE the optimizer state: loads return in order, and the forward
+    //  pass must not queue behind 3 x 59 KB it does not need)
+    load_inputs<T, NT>(L.x, R.in_table,
+                   R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
+                   R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
+    // second layer: wave w owns the gradient tiles (rows j = 16 (w % 4) .., columns k = 16 kt ..
+    // for kt = 2 (w / 4), 2 (w / 4) + 1) and the delta tile (samples 16 (w / 4) .., columns k =
+    // 16 (w % 4) ..)
+    const int lane2 = t & 63, wave2 = t >> 6, jt2 = (wave2 & 3) * 16, li2 = lane2 & 15;
+    const int kt0 = (wave2 >> 2) * 2, st2 = (wave2 >> 2) * 16;
+    constexpr int kU3 = (kMaxO * kH + NT - 1) / NT, kU1 = (kMaxD * kH + NT - 1) / NT;
+    adam_slot<T> s2[2][4], s3[kU3], s1[kU1], sb1, sb2, sb3;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         s2[kt][v] = slot_load<T>(m_w2, v_w2, tw2,
-                                 (size_t)(jt2 + mfma_acc<T>::row(lane2, v)) * kH + 16 * kt + li2, blend);
+                                 (size_t)(jt2 + mfma_acc<T>::row(lane2, v)) * kH + 16 * (kt0 + kt) + li2,
+                                 blend);
 #pragma unroll
     for (int u = 0; u < kU3; ++u) {
-      const int e = t + 256 * u;
+      const int e = t + NT * u;
       s3[u].m = s3[u].v = s3[u].target = (T)0;
       if (e < O * kH) s3[u] = slot_load<T>(m_w3, v_w3, tw3, (size_t)e, blend);
     }
 #pragma unroll
     for (int u = 0; u < kU1; ++u) {
-      const int e = t + 256 * u;
+      const int e = t + NT * u;
       s1[u].m = s1[u].v = s1[u].target = (T)0;
       if (e < kH * D) s1[u] = slot_load<T>(m_w1, v_w1, tw1, (size_t)e, blend);
     }
@@ -435,11 +439,9 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     }
     if (t < O) sb3 = slot_load<T>(m_b3, v_b3, tb3, (size_t)t, blend);
 
-    load_inputs<T>(L.x, R.in_table,
-                   R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
-                   R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
     lds_barrier();
-    forward32<T>(L, L.q, D, O, t);
+    forward32<T, NT>(L, L.q, D, O, t);
+    if (R.debug_stage == 1) return;
 
     // ---- loss gradient at the output ----------------------------------------------------------
     // mean over the marked samples and the O outputs of (out - target)^2: 2 (out - y) / (count O)
@@ -452,7 +454,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     }
     const T scale = (T)1 / (T)(count * O);
     const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
-    for (int e = t; e < kB * O; e += 256) {
+    for (int e = t; e < kB * O; e += NT) {
       const int s = e / O;
       const T d = L.q[e] - y[e];
       L.q[e] = (!mask || mask[s]) ? ((T)2 * d) * scale : (T)0;   // delta3
@@ -478,10 +480,10 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
 
     // ---- output layer: dW3[a][k] = sum_s delta3[s][a] h2[s][k], db3[a] = sum_s delta3[s][a] ----
     // (the new weights go to memory now and into LDS once delta2 has used the old ones)
-    T new_w3[(kMaxO * kH + 255) / 256];
+    T new_w3[kU3];
 #pragma unroll
-    for (int u = 0; u < (kMaxO * kH + 255) / 256; ++u) {
-      const int e = t + 256 * u;
+    for (int u = 0; u < kU3; ++u) {
+      const int e = t + NT * u;
       new_w3[u] = (T)0;
       if (e < O * kH) {
         const int a = e >> 6, k = e & 63;
@@ -499,7 +501,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     }
     lds_barrier();
     // delta2[s][k] = (sum_a W3[a][k] delta3[s][a]) * (h2[s][k] > 0), in place over h2
-    for (int e = t; e < kB * kH; e += 256) {
+    for (int e = t; e < kB * kH; e += NT) {
       const int s = e >> 6, k = e & 63;
       T d = (T)0;
       for (int a = 0; a < O; ++a) d = fma_t<T>(L.w3[a * kH + k], L.q[s * O + a], d);
@@ -508,32 +510,33 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     }
     lds_barrier();
 #pragma unroll
-    for (int u = 0; u < (kMaxO * kH + 255) / 256; ++u) {
-      const int e = t + 256 * u;
+    for (int u = 0; u < kU3; ++u) {
+      const int e = t + NT * u;
       if (e < O * kH) L.w3[e] = new_w3[u];
     }
     if (t < O) L.b3[t] = new_b3;
+    if (R.debug_stage == 2) return;
 
     // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k] (MFMA) ---------------------------
-    T new_w2[4][4];
+    T new_w2[2][4];
     {
       typedef typename mfma_acc<T>::type acc_t;
       const int lq = lane2 >> 4;
-      acc_t g2[4];
+      acc_t g2[2];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) g2[a] = acc_t{(T)0, (T)0, (T)0, (T)0};
+      for (int a = 0; a < 2; ++a) g2[a] = acc_t{(T)0, (T)0, (T)0, (T)0};
 #pragma unroll 2
       for (int s0 = 0; s0 < kB; s0 += 4) {
         const T a = L.h2[(s0 + lq) * kRow + jt2 + li2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          g2[kt] = mfma(a, L.h1[(s0 + lq) * kRow + 16 * kt + li2], g2[kt]);
+        for (int kt = 0; kt < 2; ++kt)
+          g2[kt] = mfma(a, L.h1[(s0 + lq) * kRow + 16 * (kt0 + kt) + li2], g2[kt]);
       }
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int jj = jt2 + mfma_acc<T>::row(lane2, v), k = 16 * kt + li2;
+          const int jj = jt2 + mfma_acc<T>::row(lane2, v), k = 16 * (kt0 + kt) + li2;
           new_w2[kt][v] = adam_apply<T>(w2, m_w2, v_w2, tw2, (size_t)jj * kH + k,
                                         L.wt2[k * kRow + jj], g2[kt][v], s2[kt][v], c);
         }
@@ -543,38 +546,36 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
       }
     }
+    if (R.debug_stage == 3) return;
     lds_barrier();
     // delta1[s][k] = (sum_j delta2[s][j] W2[j][k]) * (h1[s][k] > 0), in place over h1, from the
     // weights this step started from (LDS still holds them)
     {
       typedef typename mfma_acc<T>::type acc_t;
       const int lq = lane2 >> 4;
-      acc_t d0 = {(T)0, (T)0, (T)0, (T)0}, d1 = d0;
+      acc_t d0 = {(T)0, (T)0, (T)0, (T)0};
 #pragma unroll 4
-      for (int j0 = 0; j0 < kH; j0 += 4) {
-        const T b = L.wt2[(jt2 + li2) * kRow + j0 + lq];
-        d0 = mfma(L.h2[li2 * kRow + j0 + lq], b, d0);
-        d1 = mfma(L.h2[(16 + li2) * kRow + j0 + lq], b, d1);
-      }
+      for (int j0 = 0; j0 < kH; j0 += 4)
+        d0 = mfma(L.h2[(st2 + li2) * kRow + j0 + lq], L.wt2[(jt2 + li2) * kRow + j0 + lq], d0);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int r = mfma_acc<T>::row(lane2, v), k = jt2 + li2;
-        const T h0 = L.h1[r * kRow + k], h1v = L.h1[(16 + r) * kRow + k];
+        const int r = st2 + mfma_acc<T>::row(lane2, v), k = jt2 + li2;
+        const T h0 = L.h1[r * kRow + k];
         L.h1[r * kRow + k] = h0 > (T)0 ? d0[v] : (T)0;
-        L.h1[(16 + r) * kRow + k] = h1v > (T)0 ? d1[v] : (T)0;
       }
     }
     lds_barrier();
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        L.wt2[(16 * kt + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
+        L.wt2[(16 * (kt0 + kt) + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
 
+    if (R.debug_stage == 4) return;
     // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] ------------------------------------
 #pragma unroll
     for (int u = 0; u < kU1; ++u) {
-      const int e = t + 256 * u;
+      const int e = t + NT * u;
       if (e < kH * D) {
         const int jj = e / D, d = e - jj * D;
         T g = (T)0;
@@ -596,14 +597,14 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   if (R.ep_out && R.ep_rows > 0) {
     lds_barrier();   // LDS holds the current parameters; x / h1 / h2 are free
     const int E = R.ep_rows;
-    for (int e = t; e < E * D; e += 256) {
+    for (int e = t; e < E * D; e += NT) {
       const int r = e / D, d = e - r * D;
       L.x[e] = R.ep_table ? (T)R.ep_table[(size_t)R.ep_index[j / R.ep_div] * D + d]
                           : ((const T*)R.ep_dense)[((size_t)j * E + r) * D + d];
     }
     lds_barrier();
     {
-      const int r = t >> 6, k = t & 63;   // 4 rows x 64 neurons = 256 threads
+      const int r = t >> 6, k = t & 63;   // rows x 64 neurons (waves beyond the rows idle)
       if (r < E) {
         T acc = L.b1[k];
         for (int d = 0; d < D; ++d) acc = fma_t<T>(L.wt1[d * kH + k], L.x[r * D + d], acc);
@@ -617,7 +618,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         L.h2[r * kRow + k] = acc > (T)0 ? acc : (T)0;
       }
       lds_barrier();
-      for (int e = t; e < E * O; e += 256) {
+      for (int e = t; e < E * O; e += NT) {
         const int rr = e / O, a = e - rr * O;
         T acc = L.b3[a];
 #pragma unroll 8
@@ -629,7 +630,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_mlp_fit(const fit_args A) {
+__global__ __launch_bounds__(kFitThreads) void k_mlp_fit(const fit_args A) {
   mlp_fit_body<T>(A);
 }
 
@@ -713,9 +714,9 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (r.is_float64) {
     if (int rc = raise_lds(&k_mlp_fit<double>, lds)) return rc;
-    hipLaunchKernelGGL(k_mlp_fit<double>, dim3(r.n), dim3(256), lds, st, A);
+    hipLaunchKernelGGL(k_mlp_fit<double>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   } else {
-    hipLaunchKernelGGL(k_mlp_fit<float>, dim3(r.n), dim3(256), lds, st, A);
+    hipLaunchKernelGGL(k_mlp_fit<float>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   }
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;

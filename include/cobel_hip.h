@@ -622,7 +622,9 @@ typedef struct {
   const void* ep_dense;    /* ... or [n][ep_rows][D], network dtype                               */
   void* ep_out;            /* [n][ep_rows][O] or NULL                                             */
   int32_t n, n_inputs, n_outputs, is_float64;
-  int32_t in_div, tgt_div, act_div, ep_div, ep_rows, reserved_;
+  int32_t in_div, tgt_div, act_div, ep_div, ep_rows;
+  int32_t debug_stage;     /* 0; k = 1..4: return after the forward pass / the output layer / the
+                              second layer's gradient / delta1 (phase timings, scripts/exp_mlp_fit.py) */
   double lr, beta1, beta2, eps, weight_decay, tau;
 } cobel_mlp_fit_t;
 /* 0 = this shape is covered; fills *lds_bytes (per workgroup). */
