@@ -38,6 +38,7 @@ sample of the same workload (rank 0, N = 1).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -576,6 +577,8 @@ def main():
     if world_size == 1 and not args.instances and args.also:
         for name in [c for c in args.also.split(',') if c and c != args.config]:
             try:
+                gc.collect()               # (the previous leg's tables: C4 alone holds 64 GiB)
+                torch.cuda.empty_cache()
                 r, _ = run_config(name, args, rank, world_size, device, dist)
                 others[name] = {'value': r['value'], 'unit': r['unit'],
                                 'ms_per_step': r['ms_per_step'], 'config': r['config'],
@@ -588,6 +591,8 @@ def main():
                         others[name]['cpu_baseline'] = cpu_baseline(name, CONFIGS[name], 8.0)
             except Exception as e:  # e.g. not enough HBM for C4 on a shared device
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        gc.collect()
+        torch.cuda.empty_cache()
         for dt_name in (() if args.no_c5 else ('f64', 'f32')):
             try:
                 others['C5_' + dt_name] = run_c5(device, dt_name)
