@@ -15,9 +15,9 @@ python3 bench.py > $O/r${R}_bench.json 2> $O/r${R}_bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d $O/r${R}_stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline > $O/r${R}_stats.log 2>&1
 echo "stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fetch -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $O/r${R}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fetch -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 --min-seconds 0 > $O/r${R}_pmc_fetch.log 2>&1
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_write -o w --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 > $O/r${R}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_write -o w --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 --min-seconds 0 > $O/r${R}_pmc_write.log 2>&1
 echo "write done"
 for dt in f64 f32; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_c5_fetch_$dt -o f --output-format csv -- python3 scripts/run_c5.py $dt 64 > $O/r${R}_pmc_c5_fetch_$dt.log 2>&1

@@ -13,7 +13,7 @@ from conftest import free_port
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--also', '']
+COMMON = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--also', '', '--min-seconds', '0']
 
 
 def _line(out: str) -> dict:
@@ -53,8 +53,13 @@ def test_weak_scaling_option_runs_the_full_count_per_rank():
                           '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
                           str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
                           '--weak', '--config', 'C2', '--instances', '256', '--env-steps', '50']
-                         + COMMON, capture_output=True, text=True, timeout=900, env=env)
+                         + COMMON[:-1] + ['0.2'], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     r = _line(out.stdout)
     assert r['scaling'] == 'weak' and r['config']['instances_total'] == 512
     assert r['config']['instances_per_gpu'] == 256
+    # --min-seconds: the same two-launch window again and again (both ranks agree when to stop);
+    # the headline stays the first window
+    rep = r['repeat_windows']
+    assert rep['count'] >= 1 and rep['seconds'] >= 0.2 and r['steps'] == 2
+    assert rep['ms_per_step_min'] <= rep['ms_per_step_median'] <= rep['ms_per_step_max']
