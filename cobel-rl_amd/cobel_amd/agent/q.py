@@ -4,7 +4,8 @@ Discrete observations (gridworlds) and the pose observations of a ``Topology`` (
 reference keys Q by ``tuple(pose)``, here the key is the node index and ``predict_on_batch`` /
 ``Q_dict`` translate): the reference's lazily created dict rows are a dense zero table.  The replay memory is the per-instance log of experienced transitions
 (q.py:143,213), kept on device; its capacity must be announced with ``reserve_replay`` (or is
-sized from the first ``train`` call).  ``batch_size=0`` disables replay (demo/topology/demo.py:76).
+sized by each ``train`` call).  ``batch_size=0`` disables replay (demo/topology/demo.py:76); the
+experiences are logged all the same, as in the reference (``log_experiences = False`` skips that).
 Any action count up to 8 (a hexagonal ``Topology`` has six) and any ``batch_size``: runs outside
 what the wavefront kernels cover take the general kernel of ``cobel_tab_run``, same results.
 """
@@ -32,6 +33,10 @@ class QAgent(TabularAgent):
         self.nb_actions = self.n_actions
         self._log = None
         self._log_cap = 0
+        # The reference appends every experience to ``M`` whether or not it replays (q.py:213), so
+        # a later session with batch_size > 0 samples from all of them.  False: sessions with
+        # batch_size 0 keep no log (8 B per instance and step saved).
+        self.log_experiences = True
 
     def reserve_replay(self, entries: int) -> None:
         """Make room for ``entries`` logged experiences per instance (8 B each)."""
@@ -66,13 +71,14 @@ class QAgent(TabularAgent):
         return {(i,): q[i] for i in range(q.shape[0])}
 
     def _extra(self, run) -> None:
-        run.replay_log = _lib.ptr(self._log)
-        run.log_cap = self._log_cap
+        keep = run.batch > 0 or self.log_experiences
+        run.replay_log = _lib.ptr(self._log) if keep else None
+        run.log_cap = self._log_cap if keep else 0
 
     def train(self, interface, trials: int, steps: int = 32, batch_size: int = 32) -> None:
         assert batch_size >= 0     # (above _lib.MAX_BATCH: the general kernel, any size)
         self._bind(interface)
-        if batch_size > 0:
+        if batch_size > 0 or self.log_experiences:
             used = int(self.inst[:, _lib.I_LOG_LEN].max().item())
             self.reserve_replay(used + trials * steps)
         self._session(interface, trials, steps, batch_size, True)

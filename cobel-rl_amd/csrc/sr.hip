@@ -598,13 +598,16 @@ __global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
                                                  uint16_t* __restrict__ trans,
                                                  float* __restrict__ rewards, size_t n, int S) {
   const size_t SS = (size_t)S * S;
-  const size_t total = n * SS;
+  // one index space for the three tables: per instance max(S * S, 4 * S) slots (worlds of fewer
+  // than four states have more transition entries than SR elements)
+  const size_t span = SS > (size_t)S * 4 ? SS : (size_t)S * 4;
+  const size_t total = n * span;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
-    const size_t within = e % SS;
-    sr[e] = (within / S == within % S) ? 1.0f : 0.0f;
-    if (within < (size_t)S * 4) trans[(e / SS) * S * 4 + within] = (uint16_t)(within >> 2);
-    if (within < (size_t)S) rewards[(e / SS) * S + within] = 0.0f;
+    const size_t inst = e / span, within = e % span;
+    if (within < SS) sr[inst * SS + within] = (within / S == within % S) ? 1.0f : 0.0f;
+    if (within < (size_t)S * 4) trans[inst * S * 4 + within] = (uint16_t)(within >> 2);
+    if (within < (size_t)S) rewards[inst * S + within] = 0.0f;
   }
 }
 

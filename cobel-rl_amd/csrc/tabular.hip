@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 constexpr int kMonSlots = 512;
 constexpr int kMonBytes = kMonSlots * 16;
 
-template <bool ONE_WORLD, bool MON>
+template <bool ONE_WORLD, bool MON, bool LOG>
 __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -832,6 +832,10 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
   double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
   unsigned long long nsteps = *reinterpret_cast<const unsigned long long*>(inst + COBEL_I_STEPS_LO);
+  // LOG: QAgent appends every experience to its memory even when nothing is replayed
+  // (agent/q.py:213) — one 8-byte record per step into the instance's row of the log
+  uint64_t* const rlog = LOG ? A.r.replay_log + (size_t)ii * A.r.log_cap : nullptr;
+  uint32_t loglen = LOG ? (uint32_t)inst[COBEL_I_LOG_LEN] : 0u;
 
   const uint32_t flags = A.r.flags;
   const bool learn = flags & COBEL_F_LEARN;
@@ -912,6 +916,10 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
         td = td - qsa;
         Qlf[cell] = qsa + alpha_f * td;
         td_online = td;
+        if (LOG && loglen < (uint32_t)A.r.log_cap) {
+          rlog[loglen] = cobel_log_pack(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
+          loglen += 1u;
+        }
       }
       if (A.r.last_exp) {
         int32_t* const e = A.r.last_exp + (size_t)ii * 6;
@@ -970,6 +978,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
     inst[COBEL_I_CTR_ENV] = (int32_t)ce;
     inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
     inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    if (LOG) inst[COBEL_I_LOG_LEN] = (int32_t)loglen;
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
     *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
   }
@@ -1194,18 +1203,26 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
       describe[3] = lpw;
       return COBEL_OK;
     }
-#define COBEL_LPI(ONE, MON)                                                                    \
+#define COBEL_LPI(ONE, MON, LOG)                                                               \
   do {                                                                                         \
     if (bytes > 64 * 1024)                                                                     \
-      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_lpi<ONE, MON>),   \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                        (int)bytes));                                          \
-    hipLaunchKernelGGL((k_tab_lpi<ONE, MON>), grid, dim3(64), bytes, st, A);                   \
+      COBEL_HIP_TRY(hipFuncSetAttribute(                                                       \
+          reinterpret_cast<const void*>(&k_tab_lpi<ONE, MON, LOG>),                            \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));                            \
+    hipLaunchKernelGGL((k_tab_lpi<ONE, MON, LOG>), grid, dim3(64), bytes, st, A);              \
   } while (0)
-    if (one && mon) COBEL_LPI(true, true);
-    else if (one) COBEL_LPI(true, false);
-    else if (mon) COBEL_LPI(false, true);
-    else COBEL_LPI(false, false);
+#define COBEL_LPI2(ONE, MON)                                                                   \
+  do {                                                                                         \
+    if (logs) COBEL_LPI(ONE, MON, true);                                                       \
+    else COBEL_LPI(ONE, MON, false);                                                           \
+  } while (0)
+    // (QAgent with a log but no replay in this call still appends its experiences)
+    const bool logs = r.agent == COBEL_AGENT_Q && learn && r.replay_log != nullptr && r.log_cap > 0;
+    if (one && mon) COBEL_LPI2(true, true);
+    else if (one) COBEL_LPI2(true, false);
+    else if (mon) COBEL_LPI2(false, true);
+    else COBEL_LPI2(false, false);
+#undef COBEL_LPI2
 #undef COBEL_LPI
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;

@@ -155,7 +155,11 @@ class TapeRNG:
         a = np.arange(a) if np.isscalar(a) else np.asarray(a)
         if p is None:
             return a[self.integers(0, len(a), size)]
-        # Generator.choice converts p to float64 before the cumulative sum
-        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        # Generator.choice converts p to float64 before the cumulative sum — and refuses NaN
+        # probabilities (numpy/random/_generator.pyx: "probabilities contain NaN")
+        p = np.asarray(p, dtype=np.float64)
+        if np.isnan(p).any():
+            raise ValueError('probabilities contain NaN')
+        cdf = np.cumsum(p)
         cdf /= cdf[-1]
         return a[cdf.searchsorted(self.random(size), side='right')]

@@ -119,6 +119,8 @@ class RefSFMAMemory:
 
     # memory/sfma.py:195-236 (error modulation needs experience['td'], which SFMA.train has not
     # computed yet when it calls store — the reference raises KeyError; not restated)
+    nan_ratings = 0
+
     def store(self, s, a, r, ns, nt):
         j = self.S * a + s
         self.rewards[s][a] += self.learning_rate * (r - self.rewards[s][a])
@@ -187,6 +189,12 @@ class RefSFMAMemory:
                 break
             if self.R_normalize:
                 R /= np.amax(R)
+            if np.isnan(R).any():
+                # 0 / 0 from C_normalize while every strength is still zero.  The reference goes on:
+                # argmax of NaNs is experience 0 (deterministic) or rng.choice raises ValueError.
+                # The build ends the replay here instead; the count lets
+                # the parity sweeps tell such runs apart.
+                self.nan_ratings += 1
             exp = np.argmax(R)
             if not self.deterministic:
                 probs = self.softmax(R, -1, self.beta)

@@ -276,8 +276,10 @@ def test_qagent_golden(torch_cuda, golden, golden_worlds, name):
     agent.train(env, trials, steps, B)
     assert np.array_equal(agent.monitors.lat_trace[inst].cpu().numpy(), D[name + '/steps'])
     assert np.array_equal(agent.Q[inst].cpu().numpy().astype(np.float64), D[name + '/Q'])
-    if B > 0:
-        assert int(agent.inst[inst, 6].item()) == int(D[name + '/log_len'])
+    # (the reference appends to M whether it replays or not: q.py:213 — also at batch_size 0)
+    assert int(agent.inst[inst, 6].item()) == int(D[name + '/log_len'])
+    if inst == 0:
+        assert len(agent.M) == int(D[name + '/log_len'])
 
 
 @pytest.mark.parametrize('name', ['open5_f32', 'walls8_f32', 'walls8_mask_f32'])
