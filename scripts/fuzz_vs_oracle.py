@@ -86,13 +86,18 @@ def draw_case(seed: int) -> dict:
                 stream_rows=bool(kind == 'sr' and r.random() < 0.3),
                 second=bool(r.random() < 0.4),
                 mask_seed=int(r.integers(0, 1 << 31)))
+    # (drawn last, so the fields above are what earlier versions of the sweep drew)
+    case['extra_worlds'] = int(r.choice([0, 0, 0, 1, 2]))       # instance i lives in world i % W
+    case['test_trials'] = int(r.choice([0, 0, 1, 3])) if kind != 'sr' else 0
+    case['world_seed'] = int(r.integers(0, 1 << 31))
     return case
 
 
 def describe(c: dict) -> str:
     return ('seed %(seed)d %(kind)s %(H)dx%(W)d n=%(n)d trials=%(trials)d steps=%(steps)d B=%(batch)d '
             'a=%(alpha)g g=%(gamma)g e=%(eps)g mlr=%(model_lr)g base=%(base)d epi=%(episodic)d '
-            'mask=%(mask)d general=%(general)d stream=%(stream_rows)d second=%(second)d' % c
+            'mask=%(mask)d general=%(general)d stream=%(stream_rows)d second=%(second)d '
+            'worlds=1+%(extra_worlds)d test=%(test_trials)d' % c
             + ' terminals=%s rewards=%s' % (c['terminals'], c['rewards'].tolist()))
 
 
@@ -111,14 +116,25 @@ def run_case(c: dict):
                            wind=c['wind'])
     if len(world['starting_states']) == 0:
         return []
+    worlds = [world]
+    wr = np.random.default_rng(c['world_seed'])
+    for _ in range(c['extra_worlds']):       # same size, other walls / goals / rewards
+        inv = sorted(set(int(x) for x in wr.integers(0, S, int(wr.integers(0, max(1, S // 5))))))
+        term = sorted(set(int(x) for x in wr.integers(0, S, int(wr.integers(0, 3)))) - set(inv))
+        rw = np.array([[int(wr.integers(0, S)), float(wr.choice([1.0, -0.5, 2.0]))]
+                       for _ in range(int(wr.integers(0, 3)))], dtype=np.float64).reshape(-1, 2)
+        w2 = make_gridworld(c['H'], c['W'], terminals=term, rewards=rw, goals=term, invalid_states=inv)
+        if len(w2['starting_states']):
+            worlds.append(w2)
     mask = None
     if c['mask']:
         m = np.random.default_rng(c['mask_seed']).random((S, 4)) < 0.8
         m[np.arange(S), np.random.default_rng(c['mask_seed'] + 1).integers(0, 4, S)] = True
         mask = m
-    env = Gridworld(world, n_envs=c['n'], seed=c['env_seed'], instance_base=c['base'])
-    ow = c_oracle.OracleWorld([dict(next=world['next'], reward=world['rewards'],
-                                    terminal=world['terminals'], starts=world['starting_states'])])
+    env = Gridworld(worlds if len(worlds) > 1 else world, n_envs=c['n'], seed=c['env_seed'],
+                    instance_base=c['base'])
+    ow = c_oracle.OracleWorld([dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'],
+                                    starts=w['starting_states']) for w in worlds])
     total = c['trials'] * (2 if c['second'] else 1)
     bad = []
 
@@ -134,9 +150,13 @@ def run_case(c: dict):
 
     if c['kind'] in ('dynaq', 'q'):
         cls = DynaQ if c['kind'] == 'dynaq' else QAgent
+        tt = c['test_trials']
+        test_eps = 0.0 if c['seed'] % 2 == 0 else 0.2
         ag = cls(env.observation_space, env.action_space, EpsilonGreedy(c['eps']),
+                 EpsilonGreedy(test_eps) if tt else None,
                  learning_rate=c['alpha'], gamma=c['gamma'])
         ag.track_instances = True
+        ag.track_responses = True
         ag.force_general = c['general']
         if c['kind'] == 'dynaq':
             ag.M.learning_rate = c['model_lr']
@@ -148,15 +168,33 @@ def run_case(c: dict):
         ag.train(env, c['trials'], c['steps'], c['batch'])
         if c['second']:
             ag.train(env, c['trials'], c['steps'], c['batch'])
+        if tt:
+            ag.test(env, tt, c['steps'])
         torch.cuda.synchronize()
         o = c_oracle.TabOracle(ow, c['n'], c_oracle.AG_DYNAQ if c['kind'] == 'dynaq' else c_oracle.AG_Q,
                                c['env_seed'], True, instance_base=c['base'], alpha=c['alpha'],
                                gamma=c['gamma'], epsilon=c['eps'], model_lr=c['model_lr'],
-                               trial_cap=total, log_cap=log_cap, action_mask=mask)
+                               trial_cap=total + tt, log_cap=log_cap, action_mask=mask)
         flags = c_oracle.F_LEARN | (c_oracle.F_EPISODIC if c['episodic'] else 0)
         o.run(c['trials'], c['steps'], c['batch'], flags=flags)
         if c['second']:
             o.run(total, c['steps'], c['batch'], flags=flags)
+        q_trained = o.Q.copy()
+        if tt:      # Agent.test: no learning, the test policy's own stream and counter
+            saved = o.inst['ctr_policy'].copy()
+            o.inst['ctr_policy'] = 0
+            o.run(total + tt, c['steps'], 0, flags=c_oracle.F_TEST_STREAM, epsilon=test_eps)
+            o.inst['ctr_policy'] = saved
+            cmp('Q after test', o.Q, q_trained)
+            cmp('test lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, total:total + tt],
+                o.lat_trace[:, total:total + tt])
+        cap = total + tt
+        cmp('lat_sum', ag.monitors.lat_sum.cpu().numpy()[:cap].astype(np.uint64), o.lat_sum[:cap])
+        cmp('lat_cnt', ag.monitors.lat_cnt.cpu().numpy()[:cap].astype(np.uint64), o.lat_cnt[:cap])
+        cmp('resp_cnt', ag.monitors.resp_cnt.cpu().numpy()[:cap].astype(np.uint64), o.resp_cnt[:cap])
+        if not np.allclose(ag.monitors.reward_sum.cpu().numpy()[:cap], o.reward_sum[:cap],
+                           rtol=1e-12, atol=1e-12):
+            bad.append('reward_sum')
         cmp('Q', ag._q.cpu().numpy().astype(np.float64).reshape(o.Q.shape), o.Q)
         if c['kind'] == 'dynaq':
             cmp('M.states', np.asarray(ag.M.states).reshape(o.MS.shape), o.MS)
@@ -169,7 +207,8 @@ def run_case(c: dict):
         cmp('state', got[:, 0], o.inst['state'])
         cmp('trial', got[:, 2], o.inst['trial'])
         cmp('ctr_env', got[:, 3], o.inst['ctr_env'].astype(np.int32))
-        cmp('ctr_policy', got[:, 4], o.inst['ctr_policy'].astype(np.int32))
+        cmp('ctr_policy', ag.policy.counter.cpu().numpy().astype(np.int64),
+            o.inst['ctr_policy'].astype(np.int64))
         if c['kind'] == 'dynaq':
             cmp('ctr_memory', got[:, 5], o.inst['ctr_memory'].astype(np.int32))
     else:

@@ -181,7 +181,7 @@ def test_qagent_on_topology_matches_reference(cobel, golden, name):
     assert np.array_equal(steps_log, g('steps'))
     assert np.array_equal(np.asarray(agent.Q, dtype=np.float64), g('Q'))
     assert np.array_equal(agent.predict_on_batch(g('probe')).astype(np.float64), g('probe_q'))
-    assert len(agent.M) == int(g('log_len')) if B else True
+    assert len(agent.M) == int(g('log_len'))     # (also at B = 0: q.py:213 appends regardless)
     qd = agent.Q_dict
     assert len(qd) == len(nodes) and all(len(k) == 6 for k in qd)
     with pytest.raises(KeyError):

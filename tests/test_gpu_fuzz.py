@@ -12,6 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('first', [0, 60, 120, 180])
@@ -41,6 +42,34 @@ def test_random_sfma_cases_match_the_restatement(first):
         if bad:
             failed.append((fz.describe(case), bad))
     assert not failed, failed[:3]
+
+
+def test_random_topologies_match_the_restatement():
+    """scripts/fuzz_topology.py: QAgent on random graphs with 1..8 actions (four: wavefront
+    kernels, otherwise the general kernel), replay batches 0..70, against oracle/ref_loop.py."""
+    import fuzz_topology as fz
+    failed = []
+    for seed in range(0, 120):
+        case = fz.draw_case(seed)
+        bad = fz.run_case(case)
+        if bad:
+            failed.append((fz.describe(case), bad))
+    assert not failed, failed[:3]
+
+
+def test_network_kernels_over_input_and_output_widths():
+    """A slice of scripts/fuzz_networks.py: cobel_dqn_replay at input widths the fixed tests do not
+    visit, cobel_mlp_forward / cobel_mlp_fit at random (inputs, outputs) pairs."""
+    import torch
+    import test_gpu_mlp
+    import test_gpu_parity
+    for n_in, dtype_name, ddqn in ((2, 'f64', True), (13, 'f64', False), (17, 'f32', True),
+                                   (31, 'f64', True), (32, 'f64', False), (12, 'f32', True)):
+        test_gpu_parity.test_fused_dqn_replay_equals_torch_path(torch, dtype_name, n_in, ddqn,
+                                                                f32_atol=1e-4)
+    for D, O, dtype_name in ((1, 1, 'f64'), (1, 32, 'f64'), (32, 1, 'f64'), (7, 29, 'f64'),
+                             (31, 18, 'f32'), (19, 5, 'f64'), (30, 31, 'f64')):
+        test_gpu_mlp.test_mlp_forward_and_fit_match_pytorch(torch, D, O, dtype_name, f32_atol=1e-4)
 
 
 def test_sweep_regressions():

@@ -41,12 +41,12 @@ def _ptrs(lib_mod, dst, tensors):
 
 @pytest.mark.parametrize('D,O,dtype_name', [(25, 25, 'f64'), (25, 1, 'f64'), (6, 4, 'f64'),
                                             (32, 32, 'f64'), (16, 16, 'f32'), (3, 7, 'f64')])
-def test_mlp_forward_and_fit_match_pytorch(torch_cuda, D, O, dtype_name):
+def test_mlp_forward_and_fit_match_pytorch(torch_cuda, D, O, dtype_name, f32_atol=2e-5):
     torch = torch_cuda
     from cobel_amd import _lib
     from cobel_amd.agent.dyna_dsr import DynaDSR
     dt = torch.float64 if dtype_name == 'f64' else torch.float32
-    tol = dict(rtol=1e-9, atol=1e-12) if dtype_name == 'f64' else dict(rtol=2e-4, atol=2e-5)
+    tol = dict(rtol=1e-9, atol=1e-12) if dtype_name == 'f64' else dict(rtol=2e-4, atol=f32_atol)
     n, rows = 12, 40
     gen = torch.Generator(device='cpu').manual_seed(D * 100 + O)
     table = torch.randn((rows, D), generator=gen, dtype=torch.float64).cuda()

@@ -1592,7 +1592,7 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
 # Fused DQN replay step (cobel_dqn_replay) against the PyTorch path it replaces
 @pytest.mark.parametrize('dtype_name,n_in,ddqn', [('f64', 6, False), ('f64', 25, True),
                                                   ('f32', 6, False), ('f64', 1, False)])
-def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn):
+def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, f32_atol=1e-6):
     """targets -> MSE backward -> Adam -> target blend in one kernel == the same step through
     vmap'ed forward passes, autograd and the optimizer kernel: online and target parameters and
     both Adam moments after every one of 10 steps fed with the same batches (duplicated samples,
@@ -1601,7 +1601,9 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn):
     import bench
     from cobel_amd.network import TorchNetwork
     dt = torch.float64 if dtype_name == 'f64' else torch.float32
-    tol = dict(rtol=1e-10, atol=1e-13) if dtype_name == 'f64' else dict(rtol=2e-4, atol=1e-6)
+    # (float32: Adam divides by |g| + 1e-8, so the rounding of gradient entries near 1e-8 shows
+    #  up at ~1e-3 of a step — scripts/exp_f32_adam.py; the shape sweep passes a wider f32_atol)
+    tol = dict(rtol=1e-10, atol=1e-13) if dtype_name == 'f64' else dict(rtol=2e-4, atol=f32_atol)
     n, B, gamma, tau = 23, 32, 0.8, 0.01
     gen = torch.Generator(device='cuda').manual_seed(7)
 
