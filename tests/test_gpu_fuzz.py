@@ -57,6 +57,20 @@ def test_random_topologies_match_the_restatement():
     assert not failed, failed[:3]
 
 
+def test_random_network_agent_runs_fused_equal_torch_loops():
+    """scripts/fuzz_network_agents.py: DQN on random tracks, Dyna-DQN and Dyna-DSR on random
+    gridworlds — the fused HIP loops against the PyTorch-ROCm loops of the same classes: rings /
+    model tables, counters and monitors exactly, every network to float64 round-off."""
+    import fuzz_network_agents as fz
+    failed = []
+    for seed in range(0, 40):
+        case = fz.draw_case(seed)
+        bad = fz.run_case(case)
+        if bad:
+            failed.append((fz.describe(case), bad))
+    assert not failed, failed[:3]
+
+
 def test_network_kernels_over_input_and_output_widths():
     """A slice of scripts/fuzz_networks.py: cobel_dqn_replay at input widths the fixed tests do not
     visit, cobel_mlp_forward / cobel_mlp_fit at random (inputs, outputs) pairs."""
