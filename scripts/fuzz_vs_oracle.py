@@ -90,6 +90,9 @@ def draw_case(seed: int) -> dict:
     case['extra_worlds'] = int(r.choice([0, 0, 0, 1, 2]))       # instance i lives in world i % W
     case['test_trials'] = int(r.choice([0, 0, 1, 3])) if kind != 'sr' else 0
     case['world_seed'] = int(r.integers(0, 1 << 31))
+    # sessions cut into launches of `chunk` steps per instance (0: one launch, what train() does);
+    # results may not depend on where the launches end (bench.py drives the kernels this way)
+    case['chunk'] = int(r.choice([0, 0, 0, 1, 7, 37]))
     return case
 
 
@@ -97,8 +100,37 @@ def describe(c: dict) -> str:
     return ('seed %(seed)d %(kind)s %(H)dx%(W)d n=%(n)d trials=%(trials)d steps=%(steps)d B=%(batch)d '
             'a=%(alpha)g g=%(gamma)g e=%(eps)g mlr=%(model_lr)g base=%(base)d epi=%(episodic)d '
             'mask=%(mask)d general=%(general)d stream=%(stream_rows)d second=%(second)d '
-            'worlds=1+%(extra_worlds)d test=%(test_trials)d' % c
+            'worlds=1+%(extra_worlds)d test=%(test_trials)d chunk=%(chunk)d' % c
             + ' terminals=%s rewards=%s' % (c['terminals'], c['rewards'].tolist()))
+
+
+def session(ag, env, c: dict, trials: int, steps: int, batch: int) -> None:
+    """agent.train(...), optionally as budgeted launches (the steps of Agent._session written out)"""
+    from cobel_amd import _lib
+    kind = c['kind']
+    if not c['chunk']:
+        ag.train(env, trials, steps, batch) if kind != 'sr' else ag.train(env, trials, steps)
+        return
+    ag._bind(env)
+    if kind == 'q':
+        used = int(ag.inst[:, _lib.I_LOG_LEN].max().item())
+        ag.reserve_replay(used + trials * steps)
+    flags = _lib.F_LEARN | (_lib.F_MASK_ACTIONS if ag.mask_actions else 0)
+    if kind == 'dynaq' and ag.episodic_replay:
+        flags |= _lib.F_EPISODIC
+    ag._env_in(env)
+    flags |= ag._policy_in(ag.policy, env, False)
+    target = ag.current_trial + trials
+    ag.monitors.reserve(target, ag.n_envs, ag.track_instances)
+    for _ in range(trials * steps + 1):
+        ag._launch(env, ag.policy, flags, target, steps, c['chunk'], batch)
+        if int(ag.inst[:, _lib.I_TRIAL].min().item()) >= target:
+            break
+    else:
+        raise AssertionError('budgeted launches did not finish the session')
+    ag.current_trial = target
+    ag._policy_out(ag.policy)
+    ag._env_out(env)
 
 
 def run_case(c: dict):
@@ -165,9 +197,9 @@ def run_case(c: dict):
             ag.mask_actions = True
             ag.action_mask = mask.copy()
         log_cap = total * c['steps'] if c['kind'] == 'q' else 0
-        ag.train(env, c['trials'], c['steps'], c['batch'])
+        session(ag, env, c, c['trials'], c['steps'], c['batch'])
         if c['second']:
-            ag.train(env, c['trials'], c['steps'], c['batch'])
+            session(ag, env, c, c['trials'], c['steps'], c['batch'])
         if tt:
             ag.test(env, tt, c['steps'])
         torch.cuda.synchronize()
@@ -219,9 +251,9 @@ def run_case(c: dict):
         if mask is not None:
             ag.mask_actions = True
             ag.action_mask = mask.copy()
-        ag.train(env, c['trials'], c['steps'])
+        session(ag, env, c, c['trials'], c['steps'], 0)
         if c['second']:
-            ag.train(env, c['trials'], c['steps'])
+            session(ag, env, c, c['trials'], c['steps'], 0)
         torch.cuda.synchronize()
         o = c_oracle.SROracle(ow, c['n'], c['env_seed'], True, instance_base=c['base'],
                               alpha=c['alpha'], gamma=c['gamma'], epsilon=c['eps'], trial_cap=total,
