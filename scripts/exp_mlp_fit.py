@@ -15,7 +15,8 @@ from cobel_amd import _lib  # noqa: E402
 from cobel_amd.agent.dyna_dsr import DynaDSR  # noqa: E402
 from test_gpu_mlp import _ptrs, _stack  # noqa: E402
 
-n, D, O = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 25, 25
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+D = O = int(sys.argv[2]) if len(sys.argv) > 2 else 25    # (6: 78 KB of LDS, two workgroups per CU)
 dt = torch.float64
 net, tgt = _stack(torch, n, D, O, dt, 1), _stack(torch, n, D, O, dt, 2)
 names = net._mlp3_names()
@@ -70,4 +71,5 @@ print(json.dumps({'full': timeit(make()), 'no_blend': timeit(make(tau=0.0)),
                   'no_training, no_blend (stage + epilogue)': timeit(make(tau=0.0, train_t=none)),
                   'until_forward': timeit(make(stage=1)), 'until_output_layer': timeit(make(stage=2)),
                   'until_second_layer_grad': timeit(make(stage=3)), 'until_delta1': timeit(make(stage=4)),
-                  'bytes_full_GB': n * 8 * 7449 * 8 / 1e9}))
+                  'bytes_full_GB': n * 8 * (64 * D + 64 + 4160 + 64 * O + O) * 8 / 1e9,
+                  'inputs_outputs': D, 'lds_pad': os.environ.get('COBEL_DEBUG_LDS_PAD')}))
