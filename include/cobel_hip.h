@@ -254,7 +254,10 @@ typedef struct {
                             kept in sync by the kernel.  When present the planning kernel reads
                             it from HBM/L2 instead of holding a copy in LDS: nine instances per
                             CU instead of six.                                                 */
-  uint64_t* replay_log;  /* Q with batch > 0: [N][log_cap] packed experiences (q.py:213), or NULL:
+  uint64_t* replay_log;  /* Q: [N][log_cap] packed experiences (q.py:213), or NULL (needed for
+                            batch > 0).  Every learning step appends one while there is room,
+                            also at batch 0 (the reference's memory grows whether it replays or
+                            not):
                             lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30 */
   int32_t* inst;         /* [N][COBEL_I_WORDS]                                               */
   const uint8_t* action_mask; /* [S] 4-bit masks shared by all instances, or NULL            */
