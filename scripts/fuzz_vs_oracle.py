@@ -93,6 +93,16 @@ def draw_case(seed: int) -> dict:
     # sessions cut into launches of `chunk` steps per instance (0: one launch, what train() does);
     # results may not depend on where the launches end (bench.py drives the kernels this way)
     case['chunk'] = int(r.choice([0, 0, 0, 1, 7, 37]))
+    # per-instance hyper-parameters (cobel_param_set_t): instance i runs combination which[i]; it
+    # must equal instance i of a run in which every instance uses that combination
+    case['psets'] = None
+    if r.random() < 0.2 and case['n'] > 1:
+        k = int(r.integers(2, 4))
+        case['psets'] = dict(
+            combos=[(float(r.choice([0.99, 0.5, 0.1])), float(r.choice([0.99, 0.9, 0.5])),
+                     float(r.choice([0.0, 0.1, 0.3, 1.0])), float(r.choice([0.9, 1.0, 0.25])))
+                    for _ in range(k)],
+            which=r.integers(0, k, case['n']))
     return case
 
 
@@ -101,6 +111,7 @@ def describe(c: dict) -> str:
             'a=%(alpha)g g=%(gamma)g e=%(eps)g mlr=%(model_lr)g base=%(base)d epi=%(episodic)d '
             'mask=%(mask)d general=%(general)d stream=%(stream_rows)d second=%(second)d '
             'worlds=1+%(extra_worlds)d test=%(test_trials)d chunk=%(chunk)d' % c
+            + (' psets=%s' % (c['psets']['combos'],) if c.get('psets') else '')
             + ' terminals=%s rewards=%s' % (c['terminals'], c['rewards'].tolist()))
 
 
@@ -170,8 +181,18 @@ def run_case(c: dict):
     total = c['trials'] * (2 if c['second'] else 1)
     bad = []
 
-    def cmp(name, got, want):
+    ps = c.get('psets')
+    combos = ps['combos'] if ps else [(c['alpha'], c['gamma'], c['eps'], c['model_lr'])]
+    which = np.asarray(ps['which']) if ps else np.zeros(c['n'], dtype=np.int64)
+    col = lambda j: np.array([combos[k][j] for k in which]) if ps else combos[0][j]   # noqa: E731
+    sel = [None]
+
+    def cmp(name, got, want, per_instance=True):
         got, want = np.asarray(got), np.asarray(want)
+        if ps and not per_instance:
+            return                     # sums over instances mix the combinations
+        if ps and got.shape == want.shape:
+            got, want = got[sel[0]], want[sel[0]]
         if got.shape != want.shape:
             bad.append('%s: shape %s vs %s' % (name, got.shape, want.shape))
         elif not np.array_equal(got, want):
@@ -184,14 +205,17 @@ def run_case(c: dict):
         cls = DynaQ if c['kind'] == 'dynaq' else QAgent
         tt = c['test_trials']
         test_eps = 0.0 if c['seed'] % 2 == 0 else 0.2
-        ag = cls(env.observation_space, env.action_space, EpsilonGreedy(c['eps']),
+        extra = {}
+        if c['kind'] == 'dynaq':
+            from cobel_amd.memory import DynaQMemory
+            extra['memory'] = DynaQMemory(S, 4, col(3))
+        ag = cls(env.observation_space, env.action_space, EpsilonGreedy(col(2)),
                  EpsilonGreedy(test_eps) if tt else None,
-                 learning_rate=c['alpha'], gamma=c['gamma'])
+                 learning_rate=col(0), gamma=col(1), **extra)
         ag.track_instances = True
         ag.track_responses = True
         ag.force_general = c['general']
         if c['kind'] == 'dynaq':
-            ag.M.learning_rate = c['model_lr']
             ag.episodic_replay = c['episodic']
         if mask is not None:
             ag.mask_actions = True
@@ -203,49 +227,51 @@ def run_case(c: dict):
         if tt:
             ag.test(env, tt, c['steps'])
         torch.cuda.synchronize()
-        o = c_oracle.TabOracle(ow, c['n'], c_oracle.AG_DYNAQ if c['kind'] == 'dynaq' else c_oracle.AG_Q,
-                               c['env_seed'], True, instance_base=c['base'], alpha=c['alpha'],
-                               gamma=c['gamma'], epsilon=c['eps'], model_lr=c['model_lr'],
-                               trial_cap=total + tt, log_cap=log_cap, action_mask=mask)
-        flags = c_oracle.F_LEARN | (c_oracle.F_EPISODIC if c['episodic'] else 0)
-        o.run(c['trials'], c['steps'], c['batch'], flags=flags)
-        if c['second']:
-            o.run(total, c['steps'], c['batch'], flags=flags)
-        q_trained = o.Q.copy()
-        if tt:      # Agent.test: no learning, the test policy's own stream and counter
-            saved = o.inst['ctr_policy'].copy()
-            o.inst['ctr_policy'] = 0
-            o.run(total + tt, c['steps'], 0, flags=c_oracle.F_TEST_STREAM, epsilon=test_eps)
-            o.inst['ctr_policy'] = saved
-            cmp('Q after test', o.Q, q_trained)
-            cmp('test lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, total:total + tt],
-                o.lat_trace[:, total:total + tt])
-        cap = total + tt
-        cmp('lat_sum', ag.monitors.lat_sum.cpu().numpy()[:cap].astype(np.uint64), o.lat_sum[:cap])
-        cmp('lat_cnt', ag.monitors.lat_cnt.cpu().numpy()[:cap].astype(np.uint64), o.lat_cnt[:cap])
-        cmp('resp_cnt', ag.monitors.resp_cnt.cpu().numpy()[:cap].astype(np.uint64), o.resp_cnt[:cap])
-        if not np.allclose(ag.monitors.reward_sum.cpu().numpy()[:cap], o.reward_sum[:cap],
-                           rtol=1e-12, atol=1e-12):
-            bad.append('reward_sum')
-        cmp('Q', ag._q.cpu().numpy().astype(np.float64).reshape(o.Q.shape), o.Q)
-        if c['kind'] == 'dynaq':
-            cmp('M.states', np.asarray(ag.M.states).reshape(o.MS.shape), o.MS)
-            cmp('M.terminals', np.asarray(ag.M.terminals).reshape(o.MT.shape), o.MT)
-            cmp('M.rewards', np.asarray(ag.M.rewards, dtype=np.float64).reshape(o.MR.shape), o.MR)
-        else:
-            cmp('log_len', ag.inst[:, 6].cpu().numpy(), o.inst['log_len'].astype(np.int32))
-        cmp('lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, :total], o.lat_trace[:, :total])
-        got = ag.inst.cpu().numpy()
-        cmp('state', got[:, 0], o.inst['state'])
-        cmp('trial', got[:, 2], o.inst['trial'])
-        cmp('ctr_env', got[:, 3], o.inst['ctr_env'].astype(np.int32))
-        cmp('ctr_policy', ag.policy.counter.cpu().numpy().astype(np.int64),
-            o.inst['ctr_policy'].astype(np.int64))
-        if c['kind'] == 'dynaq':
-            cmp('ctr_memory', got[:, 5], o.inst['ctr_memory'].astype(np.int32))
+        for k, (alpha, gamma, eps, mlr) in enumerate(combos):
+            sel[0] = np.flatnonzero(which == k)
+            o = c_oracle.TabOracle(ow, c['n'], c_oracle.AG_DYNAQ if c['kind'] == 'dynaq' else c_oracle.AG_Q,
+                                   c['env_seed'], True, instance_base=c['base'], alpha=alpha,
+                                   gamma=gamma, epsilon=eps, model_lr=mlr,
+                                   trial_cap=total + tt, log_cap=log_cap, action_mask=mask)
+            flags = c_oracle.F_LEARN | (c_oracle.F_EPISODIC if c['episodic'] else 0)
+            o.run(c['trials'], c['steps'], c['batch'], flags=flags)
+            if c['second']:
+                o.run(total, c['steps'], c['batch'], flags=flags)
+            q_trained = o.Q.copy()
+            if tt:      # Agent.test: no learning, the test policy's own stream and counter
+                saved = o.inst['ctr_policy'].copy()
+                o.inst['ctr_policy'] = 0
+                o.run(total + tt, c['steps'], 0, flags=c_oracle.F_TEST_STREAM, epsilon=test_eps)
+                o.inst['ctr_policy'] = saved
+                cmp('Q after test', o.Q, q_trained)
+                cmp('test lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, total:total + tt],
+                    o.lat_trace[:, total:total + tt])
+            cap = total + tt
+            cmp('lat_sum', ag.monitors.lat_sum.cpu().numpy()[:cap].astype(np.uint64), o.lat_sum[:cap], per_instance=False)
+            cmp('lat_cnt', ag.monitors.lat_cnt.cpu().numpy()[:cap].astype(np.uint64), o.lat_cnt[:cap], per_instance=False)
+            cmp('resp_cnt', ag.monitors.resp_cnt.cpu().numpy()[:cap].astype(np.uint64), o.resp_cnt[:cap], per_instance=False)
+            if not ps and not np.allclose(ag.monitors.reward_sum.cpu().numpy()[:cap], o.reward_sum[:cap],
+                               rtol=1e-12, atol=1e-12):
+                bad.append('reward_sum')
+            cmp('Q', ag._q.cpu().numpy().astype(np.float64).reshape(o.Q.shape), o.Q)
+            if c['kind'] == 'dynaq':
+                cmp('M.states', np.asarray(ag.M.states).reshape(o.MS.shape), o.MS)
+                cmp('M.terminals', np.asarray(ag.M.terminals).reshape(o.MT.shape), o.MT)
+                cmp('M.rewards', np.asarray(ag.M.rewards, dtype=np.float64).reshape(o.MR.shape), o.MR)
+            else:
+                cmp('log_len', ag.inst[:, 6].cpu().numpy(), o.inst['log_len'].astype(np.int32))
+            cmp('lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, :total], o.lat_trace[:, :total])
+            got = ag.inst.cpu().numpy()
+            cmp('state', got[:, 0], o.inst['state'])
+            cmp('trial', got[:, 2], o.inst['trial'])
+            cmp('ctr_env', got[:, 3], o.inst['ctr_env'].astype(np.int32))
+            cmp('ctr_policy', ag.policy.counter.cpu().numpy().astype(np.int64),
+                o.inst['ctr_policy'].astype(np.int64))
+            if c['kind'] == 'dynaq':
+                cmp('ctr_memory', got[:, 5], o.inst['ctr_memory'].astype(np.int32))
     else:
-        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(c['eps']),
-                learning_rate=c['alpha'], gamma=c['gamma'])
+        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(col(2)),
+                learning_rate=col(0), gamma=col(1))
         ag.track_instances = True
         ag.stream_rows = c['stream_rows']
         if mask is not None:
@@ -255,20 +281,22 @@ def run_case(c: dict):
         if c['second']:
             session(ag, env, c, c['trials'], c['steps'], 0)
         torch.cuda.synchronize()
-        o = c_oracle.SROracle(ow, c['n'], c['env_seed'], True, instance_base=c['base'],
-                              alpha=c['alpha'], gamma=c['gamma'], epsilon=c['eps'], trial_cap=total,
-                              action_mask=mask)
-        o.run(c['trials'], c['steps'])
-        if c['second']:
-            o.run(total, c['steps'])
-        cmp('SR', ag._sr.cpu().numpy().astype(np.float64), o.SR)
-        cmp('T', ag._T.cpu().numpy().astype(np.int64), o.T)
-        cmp('R', ag._rw.cpu().numpy().astype(np.float64), o.RW)
-        cmp('lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, :total], o.lat_trace[:, :total])
-        got = ag.inst.cpu().numpy()
-        cmp('state', got[:, 0], o.inst['state'])
-        cmp('ctr_env', got[:, 3], o.inst['ctr_env'].astype(np.int32))
-        cmp('ctr_policy', got[:, 4], o.inst['ctr_policy'].astype(np.int32))
+        for k, (alpha, gamma, eps, mlr) in enumerate(combos):
+            sel[0] = np.flatnonzero(which == k)
+            o = c_oracle.SROracle(ow, c['n'], c['env_seed'], True, instance_base=c['base'],
+                                  alpha=alpha, gamma=gamma, epsilon=eps, trial_cap=total,
+                                  action_mask=mask)
+            o.run(c['trials'], c['steps'])
+            if c['second']:
+                o.run(total, c['steps'])
+            cmp('SR', ag._sr.cpu().numpy().astype(np.float64), o.SR)
+            cmp('T', ag._T.cpu().numpy().astype(np.int64), o.T)
+            cmp('R', ag._rw.cpu().numpy().astype(np.float64), o.RW)
+            cmp('lat_trace', ag.monitors.lat_trace.cpu().numpy()[:, :total], o.lat_trace[:, :total])
+            got = ag.inst.cpu().numpy()
+            cmp('state', got[:, 0], o.inst['state'])
+            cmp('ctr_env', got[:, 3], o.inst['ctr_env'].astype(np.int32))
+            cmp('ctr_policy', got[:, 4], o.inst['ctr_policy'].astype(np.int32))
     return bad
 
 
