@@ -115,6 +115,9 @@ def describe(c: dict) -> str:
             + ' terminals=%s rewards=%s' % (c['terminals'], c['rewards'].tolist()))
 
 
+STATS = {}
+
+
 def session(ag, env, c: dict, trials: int, steps: int, batch: int) -> None:
     """agent.train(...), optionally as budgeted launches (the steps of Agent._session written out)"""
     from cobel_amd import _lib
@@ -206,6 +209,15 @@ def run_case(c: dict):
         tt = c['test_trials']
         test_eps = 0.0 if c['seed'] % 2 == 0 else 0.2
         extra = {}
+        # one instance: the reference's per-step callbacks (single-step launches, logs from the
+        # kernel's last-experience record) — compared with the oracle's per-step trace below
+        steplog, triallog = [], []
+        if c['n'] == 1 and not c['chunk']:
+            extra['custom_callbacks'] = {
+                'on_step_end': [lambda l: steplog.append((l['state'], l['action'], l['reward'],
+                                                          l['next_state'], l['terminal'],
+                                                          l.get('td', np.nan)))],
+                'on_trial_end': [lambda l: triallog.append((l['steps'], l['trial_reward']))]}
         if c['kind'] == 'dynaq':
             from cobel_amd.memory import DynaQMemory
             extra['memory'] = DynaQMemory(S, 4, col(3))
@@ -234,9 +246,18 @@ def run_case(c: dict):
                                    gamma=gamma, epsilon=eps, model_lr=mlr,
                                    trial_cap=total + tt, log_cap=log_cap, action_mask=mask)
             flags = c_oracle.F_LEARN | (c_oracle.F_EPISODIC if c['episodic'] else 0)
-            o.run(c['trials'], c['steps'], c['batch'], flags=flags)
+            tcap = total * c['steps'] if steplog else 0
+            tr = o.run(c['trials'], c['steps'], c['batch'], flags=flags, trace_inst=0, trace_cap=tcap)
             if c['second']:
-                o.run(total, c['steps'], c['batch'], flags=flags)
+                tr = np.concatenate([tr, o.run(total, c['steps'], c['batch'], flags=flags,
+                                               trace_inst=0, trace_cap=tcap)])
+            if steplog:
+                STATS['per-step callback runs'] = STATS.get('per-step callback runs', 0) + 1
+                STATS['per-step log rows'] = STATS.get('per-step log rows', 0) + len(tr)
+                mine = np.array(steplog, dtype=np.float64)[:len(tr)]
+                cmp('per-step logs', mine, tr, per_instance=False)
+                cmp('per-trial steps', np.array([t[0] for t in triallog][:total]), o.lat_trace[0, :total],
+                    per_instance=False)
             q_trained = o.Q.copy()
             if tt:      # Agent.test: no learning, the test policy's own stream and counter
                 saved = o.inst['ctr_policy'].copy()
@@ -308,6 +329,9 @@ def main() -> int:
     for seed in range(first, first + count):
         c = draw_case(seed)
         kinds[c['kind']] = kinds.get(c['kind'], 0) + 1
+        for key in ('psets', 'chunk', 'test_trials', 'extra_worlds', 'mask', 'general', 'episodic'):
+            if c.get(key) is not None and c.get(key) is not False and c.get(key) != 0:
+                STATS[key] = STATS.get(key, 0) + 1
         try:
             bad = run_case(c)
         except Exception as e:      # a refused configuration is a finding too
@@ -318,7 +342,7 @@ def main() -> int:
         if (seed - first) % 20 == 19:
             print('... %d cases, %d failing, %.0f s' % (seed - first + 1, len(failed), time.time() - t0),
                   flush=True)
-    print('cases %d (%s), failing %d: %s' % (count, kinds, len(failed), failed))
+    print('cases %d (%s), failing %d: %s; exercised: %s' % (count, kinds, len(failed), failed, STATS))
     return 1 if failed else 0
 
 
