@@ -67,7 +67,8 @@ class WorldHandle:
 
 def _compact(world: dict) -> dict:
     """Compact tables of a reference-style WorldDict that only carries the dense ``sas``."""
-    nxt = world['next'] if 'next' in world else np.argmax(world['sas'], axis=2)
+    from ..misc.gridworld_tools import successor_table
+    nxt = world['next'] if 'next' in world else successor_table(world['sas'])
     return dict(next=np.asarray(nxt, dtype=np.uint16),
                 reward=np.asarray(world['rewards'], dtype=np.float32),
                 terminal=(np.asarray(world['terminals']) != 0).astype(np.uint8),
@@ -79,8 +80,10 @@ class Gridworld(Interface):
                  device=None, instance_base: int = 0) -> None:
         super().__init__(widget)
         worlds = list(world) if isinstance(world, (list, tuple)) else [world]
-        for w in worlds:
-            assert w.get('deterministic', True), 'only deterministic worlds are supported'
+        # (world['deterministic'] = False makes the reference DRAW the successor from the row of
+        #  sas instead of taking its argmax, gridworld.py:115-123; with one-hot rows — all any
+        #  builder produces — that is the same step, so the flag is accepted; rows with several
+        #  successors are refused where the tables are compiled)
         self.worlds = worlds
         self.world = worlds[0]
         self.n_envs = int(n_envs)

@@ -20,6 +20,20 @@ from typing import Literal
 import numpy as np
 
 
+def successor_table(sas) -> np.ndarray:
+    """``next[S, A]`` of a dense ``sas[S, A, S]`` whose rows are one-hot — what every builder of the
+    reference produces.  Rows that spread their probability over
+    several successors are refused: the kernels step deterministic tables."""
+    sas = np.asarray(sas)
+    nxt = np.argmax(sas, axis=2)
+    peak = np.take_along_axis(sas, nxt[..., None], axis=2)[..., 0]
+    if not (np.count_nonzero(sas, axis=2) == 1).all() or not (peak > 0).all():
+        raise NotImplementedError(
+            'world["sas"] has rows with more than one possible successor; only one-hot transition '
+            'rows are accelerated (DESIGN.md section 7)')
+    return nxt.astype(np.uint16)
+
+
 class World(dict):
     """``WorldDict`` (interface/gridworld.py:17-30) plus ``'next'``; ``'sas'`` is lazy."""
 
@@ -34,6 +48,10 @@ class World(dict):
 
     def compact(self) -> dict:
         """Tables in the layout ``cobel_world_create`` takes."""
+        if dict.__contains__(self, 'sas'):
+            # somebody materialised (and may have edited) the dense tensor: it is the reference's
+            # source of truth, so the index table follows it — or the world is refused
+            self['next'] = successor_table(dict.__getitem__(self, 'sas'))
         return dict(
             next=np.ascontiguousarray(self['next'], dtype=np.uint16),
             reward=np.ascontiguousarray(self['rewards'], dtype=np.float32),
@@ -99,9 +117,10 @@ def make_gridworld(
                           dtype=bool, count=4 * n)
         stay |= hit.reshape(n, 4)
     world['next'] = np.where(stay, s[:, None], nxt).astype(np.uint16)
+    # The flag only selects how Gridworld.step reads a row of sas (argmax, or a draw from it:
+    # interface/gridworld.py:115-123); the rows this builder writes are one-hot either way
+    # (gridworld_tools.py:103-134), and a draw from a one-hot row is its only outcome.
     world['deterministic'] = deterministic
-    assert deterministic, ('only deterministic worlds are supported: no builder of the reference '
-                           'produces a non-one-hot sas (SURVEY.md §8a quirk 12)')
     return world
 
 
@@ -200,13 +219,12 @@ def load_world(path: str) -> World:
     import pickle
     with open(path, 'rb') as fh:
         raw = pickle.load(fh)
-    assert raw.get('deterministic', True), 'only deterministic worlds are supported'
     world = World()
     for key, value in raw.items():
         if key != 'sas':
             world[key] = value
     world['next'] = (np.asarray(raw['next'], dtype=np.uint16) if 'next' in raw
-                     else np.argmax(raw['sas'], axis=2).astype(np.uint16))
+                     else successor_table(raw['sas']))
     world.setdefault('deterministic', True)
     return world
 

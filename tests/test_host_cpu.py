@@ -625,3 +625,30 @@ def test_fused_dqn_path_recognises_models_by_behaviour():
     net = TorchNetwork(frozen).replicate(2)
     net.params['layer_dense_1.weight'].requires_grad_(False)
     assert net._mlp3_names() is None
+
+
+def test_deterministic_flag_and_stochastic_rows():
+    """world['deterministic'] = False only changes HOW the reference reads a row of sas (a draw
+    instead of argmax, interface/gridworld.py:115-123); all builders write one-hot rows
+    (misc/gridworld_tools.py:103-134), so the flag is accepted and the tables are the same.  Rows
+    with several successors are refused, also when a built world's sas was edited afterwards."""
+    from cobel_amd.misc import gridworld_tools as gt
+    a = gt.make_gridworld(3, 4, terminals=[0], rewards=np.array([[0, 1.0]]), goals=[0])
+    b = gt.make_gridworld(3, 4, terminals=[0], rewards=np.array([[0, 1.0]]), goals=[0],
+                          deterministic=False)
+    assert b['deterministic'] is False and np.array_equal(a['next'], b['next'])
+    assert np.array_equal(gt.successor_table(a['sas']), a['next'])
+    assert np.array_equal(b.compact()['next'], a['next'])
+    # an edited sas is followed ...
+    c = gt.make_gridworld(2, 2)
+    sas = c['sas']
+    sas[0, 2] = 0.0
+    sas[0, 2, 3] = 1.0                       # "right" from state 0 now jumps to state 3
+    assert c.compact()['next'][0, 2] == 3
+    # ... unless it is no longer a table
+    sas[0, 2, 1] = 0.5
+    sas[0, 2, 3] = 0.5
+    with pytest.raises(NotImplementedError):
+        c.compact()
+    with pytest.raises(NotImplementedError):
+        gt.successor_table(np.zeros((2, 4, 2)))       # rows without any successor
