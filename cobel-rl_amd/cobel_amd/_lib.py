@@ -219,7 +219,10 @@ _SIGNATURES = {
     'cobel_world_destroy': (C.c_int, [_P]),
     'cobel_world_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
+    'cobel_world_set_transitions': (C.c_int, [_P, _P, _P, _P, C.c_int64]),
     'cobel_env_step': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_uint32, _P]),
+    'cobel_env_step_draw': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_uint32,
+                                      _P]),
     'cobel_env_reset': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_uint32, _P]),
     'cobel_gather_rows': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'cobel_eps_greedy': (C.c_int, [_P, _P, _P, C.c_double, _P, _P, C.c_int32, _P]),

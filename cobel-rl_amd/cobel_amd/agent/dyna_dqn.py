@@ -148,7 +148,8 @@ class DynaDQN(DQN):
     def _fused_setting_ok(self, interface) -> bool:
         from ..interface.gridworld import Gridworld
         return type(self) is DynaDQN and isinstance(interface, DynaDQN._ObsView) \
-            and isinstance(interface.env, Gridworld) and type(self.M) is _ModelMemory \
+            and isinstance(interface.env, Gridworld) and not interface.env.handle.stochastic \
+            and type(self.M) is _ModelMemory \
             and self.M.A == 4 and interface.table.dtype == torch.float64 \
             and interface.table.dim() == 2 and not self.mask_actions and not self.episodic_replay
 

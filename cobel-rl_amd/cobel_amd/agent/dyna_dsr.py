@@ -212,7 +212,8 @@ class DynaDSR(DynaDQN):
         from ..policy.greedy import EpsilonGreedy
         if type(self) is not DynaDSR or self.fused_loop is False or self.use_graph is True \
                 or not isinstance(interface, DynaDQN._ObsView) \
-                or not isinstance(interface.env, Gridworld) or type(self.M) is not _ModelMemory \
+                or not isinstance(interface.env, Gridworld) or interface.env.handle.stochastic \
+                or type(self.M) is not _ModelMemory \
                 or self.M.A != 4 or interface.table.dtype != torch.float64 \
                 or interface.table.dim() != 2 or self.mask_actions or self.episodic_replay \
                 or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \

@@ -55,6 +55,27 @@ class WorldHandle:
         _lib.check(_lib.lib().cobel_world_create_n(
             nxt.ctypes.data, rew.ctypes.data, term.ctypes.data, starts.ctypes.data,
             off.ctypes.data, S, len(tabs), self.n_actions, device.index or 0, C.byref(self.ptr)))
+        # worlds whose transition rows are distributions: list form for all of them (a table row
+        # is a list of one successor with cumulative probability 1)
+        self.stochastic = any('transitions' in t for t in tabs)
+        if self.stochastic:
+            offs, sts, cdfs, base = [np.zeros(1, dtype=np.uint32)], [], [], 0
+            for t in tabs:
+                if 'transitions' in t:
+                    o, st, cd = t['transitions']
+                else:
+                    flat = np.asarray(t['next'], dtype=np.uint16).reshape(-1)
+                    o = np.arange(len(flat) + 1, dtype=np.uint32)
+                    st, cd = flat, np.ones(len(flat))
+                offs.append(o[1:].astype(np.uint64) + base)
+                sts.append(st)
+                cdfs.append(cd)
+                base += len(st)
+            o = np.ascontiguousarray(np.concatenate(offs), dtype=np.uint32)
+            st = np.ascontiguousarray(np.concatenate(sts), dtype=np.uint16)
+            cd = np.ascontiguousarray(np.concatenate(cdfs), dtype=np.float64)
+            _lib.check(_lib.lib().cobel_world_set_transitions(
+                self.ptr, o.ctypes.data, st.ctypes.data, cd.ctypes.data, len(st)))
 
     def __del__(self) -> None:
         try:
@@ -67,9 +88,12 @@ class WorldHandle:
 
 def _compact(world: dict) -> dict:
     """Compact tables of a reference-style WorldDict that only carries the dense ``sas``."""
-    from ..misc.gridworld_tools import successor_table
-    nxt = world['next'] if 'next' in world else successor_table(world['sas'])
-    return dict(next=np.asarray(nxt, dtype=np.uint16),
+    from ..misc.gridworld_tools import is_one_hot, successor_table, transition_lists
+    out = {}
+    if 'sas' in world and not world.get('deterministic', True) and not is_one_hot(world['sas']):
+        out['transitions'] = transition_lists(world['sas'])
+    nxt = successor_table(world['sas']) if 'sas' in world else world['next']
+    return dict(out, next=np.asarray(nxt, dtype=np.uint16),
                 reward=np.asarray(world['rewards'], dtype=np.float32),
                 terminal=(np.asarray(world['terminals']) != 0).astype(np.uint8),
                 starts=np.asarray(world['starting_states'], dtype=np.uint16))
@@ -81,9 +105,9 @@ class Gridworld(Interface):
         super().__init__(widget)
         worlds = list(world) if isinstance(world, (list, tuple)) else [world]
         # (world['deterministic'] = False makes the reference DRAW the successor from the row of
-        #  sas instead of taking its argmax, gridworld.py:115-123; with one-hot rows — all any
-        #  builder produces — that is the same step, so the flag is accepted; rows with several
-        #  successors are refused where the tables are compiled)
+        #  sas instead of taking its argmax, gridworld.py:115-123.  With one-hot rows — all any
+        #  builder produces — that is the same step; rows that are distributions travel to the
+        #  library as successor lists, WorldHandle below, and the draw happens on the device)
         self.worlds = worlds
         self.world = worlds[0]
         self.n_envs = int(n_envs)
@@ -136,9 +160,12 @@ class Gridworld(Interface):
         else:
             act = torch.as_tensor(action, device=self.device).to(torch.uint8).contiguous()
             assert act.shape == (self.n_envs,)
-        _lib.check(_lib.lib().cobel_env_step(
+        # (worlds whose rows are distributions draw the successor: one double of the env stream at
+        #  the counter the trial starts share; a world of tables steps as cobel_env_step does)
+        _lib.check(_lib.lib().cobel_env_step_draw(
             self.handle.ptr, _lib.ptr(self.state), _lib.ptr(act), _lib.ptr(self._reward),
-            _lib.ptr(self._done), self.n_envs, self.instance_base, self._stream()))
+            _lib.ptr(self._done), _lib.ptr(self.env_ctr), self.seed, self.n_envs,
+            self.instance_base, self._stream()))
         if self.n_envs == 1:
             out = torch.stack([self.state.to(torch.float64), self._reward.to(torch.float64),
                                self._done.to(torch.float64)]).cpu().numpy()[:, 0]

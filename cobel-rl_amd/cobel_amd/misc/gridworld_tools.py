@@ -21,17 +21,40 @@ import numpy as np
 
 
 def successor_table(sas) -> np.ndarray:
-    """``next[S, A]`` of a dense ``sas[S, A, S]`` whose rows are one-hot — what every builder of the
-    reference produces.  Rows that spread their probability over
-    several successors are refused: the kernels step deterministic tables."""
+    """``next[S, A]`` of a dense ``sas[S, A, S]``: the argmax of every row — what the reference's
+    ``Gridworld.step`` takes when ``world['deterministic']`` is set (interface/gridworld.py:115-117)
+    and, for the one-hot rows every builder writes, the only possible successor."""
     sas = np.asarray(sas)
-    nxt = np.argmax(sas, axis=2)
-    peak = np.take_along_axis(sas, nxt[..., None], axis=2)[..., 0]
-    if not (np.count_nonzero(sas, axis=2) == 1).all() or not (peak > 0).all():
-        raise NotImplementedError(
-            'world["sas"] has rows with more than one possible successor; only one-hot transition '
-            'rows are accelerated (DESIGN.md section 7)')
-    return nxt.astype(np.uint16)
+    if not (np.count_nonzero(sas, axis=2) >= 1).all():
+        raise ValueError('world["sas"] has rows without any successor')
+    return np.argmax(sas, axis=2).astype(np.uint16)
+
+
+def is_one_hot(sas) -> bool:
+    return bool((np.count_nonzero(np.asarray(sas), axis=2) == 1).all())
+
+
+def transition_lists(sas):
+    """List form of a dense ``sas[S, A, S]`` whose rows are distributions: offsets ``[S * A + 1]``,
+    the possible successors of every (state, action) in ascending state order, and the normalised
+    cumulative sum of their probabilities formed as ``Generator.choice`` forms it (float64 cumsum
+    over the row, divided by its last entry; entries of probability zero add nothing to a cumsum,
+    so leaving them out changes no value) — ``cobel_world_set_transitions`` (include/cobel_hip.h)."""
+    sas = np.asarray(sas, dtype=np.float64)
+    S, A, _ = sas.shape
+    if (sas < 0).any() or not (np.count_nonzero(sas, axis=2) >= 1).all():
+        raise ValueError('rows of world["sas"] must be probability vectors')
+    off = np.zeros(S * A + 1, dtype=np.uint32)
+    states, cdf = [], []
+    for p, row in enumerate(sas.reshape(S * A, S)):
+        c = np.cumsum(row)
+        c /= c[-1]
+        nz = np.flatnonzero(row)
+        states.append(nz.astype(np.uint16))
+        cdf.append(c[nz])
+        cdf[-1][-1] = 1.0
+        off[p + 1] = off[p] + len(nz)
+    return off, np.concatenate(states), np.concatenate(cdf)
 
 
 class World(dict):
@@ -48,11 +71,17 @@ class World(dict):
 
     def compact(self) -> dict:
         """Tables in the layout ``cobel_world_create`` takes."""
+        out = {}
         if dict.__contains__(self, 'sas'):
             # somebody materialised (and may have edited) the dense tensor: it is the reference's
-            # source of truth, so the index table follows it — or the world is refused
-            self['next'] = successor_table(dict.__getitem__(self, 'sas'))
-        return dict(
+            # source of truth.  The index table follows it (argmax, what the reference takes from a
+            # row while world['deterministic'] is set); rows that are distributions of a world with
+            # the flag off are DRAWN from (interface/gridworld.py:119-123) and travel as lists.
+            sas = dict.__getitem__(self, 'sas')
+            self['next'] = successor_table(sas)
+            if not self.get('deterministic', True) and not is_one_hot(sas):
+                out['transitions'] = transition_lists(sas)
+        return dict(out, 
             next=np.ascontiguousarray(self['next'], dtype=np.uint16),
             reward=np.ascontiguousarray(self['rewards'], dtype=np.float32),
             terminal=np.ascontiguousarray(self['terminals'] != 0, dtype=np.uint8),

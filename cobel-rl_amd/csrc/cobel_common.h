@@ -29,12 +29,30 @@ struct cobel_world {
   uint16_t* next_n;     // [dev] [n_worlds][S][n_actions]
   float* reward_s;      // [dev] [n_worlds][S]
   uint8_t* terminal_s;  // [dev] [n_worlds][S]
+  // transition rows that are distributions (cobel_world_set_transitions), else NULL: successors
+  // of pair p = (world * S + s) * n_actions + a are succ_state[succ_off[p] .. succ_off[p + 1]) with
+  // the normalised cumulative probabilities succ_cdf (last entry of a row = 1)
+  uint32_t* succ_off;   // [dev] [n_worlds * S * n_actions + 1]
+  uint16_t* succ_state; // [dev] [nnz]
+  double* succ_cdf;     // [dev] [nnz]
 };
+
+// the successor Generator.choice(arange(S), p=row) returns for the uniform u (interface/
+// gridworld.py:119-123): first entry whose cumulative probability exceeds u
+__device__ __forceinline__ int cobel_draw_successor(const uint32_t* __restrict__ off,
+                                                    const uint16_t* __restrict__ succ,
+                                                    const double* __restrict__ cdf, size_t pair,
+                                                    double u) {
+  const uint32_t lo = off[pair], hi = off[pair + 1];
+  uint32_t k = lo;
+  while (k + 1u < hi && !(cdf[k] > u)) ++k;
+  return (int)succ[k];
+}
 
 // general.hip: any action count / batch size / state count (one lane per instance)
 int cobel_env_step_general(const cobel_world* world, int32_t* state, const uint8_t* action,
-                           float* reward_out, uint8_t* done_out, int32_t n,
-                           uint32_t instance_base, hipStream_t st);
+                           float* reward_out, uint8_t* done_out, uint32_t* env_ctr, uint64_t seed,
+                           int32_t n, uint32_t instance_base, hipStream_t st);
 int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
 
 // sr_wave.hip: the sparse-reward form of the SR agent (one wavefront per instance)

@@ -30,6 +30,10 @@ struct gen_args {
   const uint8_t* terminal_s;    // [W][S]
   const uint16_t* starts;
   const int32_t* start_off;
+  // transition rows that are distributions (cobel_world_set_transitions), or NULL
+  const uint32_t* succ_off;
+  const uint16_t* succ_state;
+  const double* succ_cdf;
   int32_t S, n_worlds, A;
   cobel_tab_run_t r;
   float alpha_f, gamma_f, model_lr_f;
@@ -212,10 +216,15 @@ extern "C" int cobel_world_actions(const cobel_world_t* w, int32_t* n_actions) {
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_env_step_n(const uint16_t* __restrict__ next_n,
+__global__ __launch_bounds__(256) void k_env_step_n(const cobel_wrec* __restrict__ rec,
+                                                    const uint16_t* __restrict__ next_n,
                                                     const float* __restrict__ reward_s,
-                                                    const uint8_t* __restrict__ terminal_s, int S,
-                                                    int A, int n_worlds,
+                                                    const uint8_t* __restrict__ terminal_s,
+                                                    const uint32_t* __restrict__ succ_off,
+                                                    const uint16_t* __restrict__ succ_state,
+                                                    const double* __restrict__ succ_cdf,
+                                                    uint32_t* __restrict__ env_ctr, uint64_t seed,
+                                                    int S, int A, int n_worlds,
                                                     int32_t* __restrict__ state,
                                                     const uint8_t* __restrict__ action,
                                                     float* __restrict__ reward_out,
@@ -223,24 +232,36 @@ __global__ __launch_bounds__(256) void k_env_step_n(const uint16_t* __restrict__
                                                     uint32_t base) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const size_t w = (size_t)((base + (uint32_t)i) % (uint32_t)n_worlds) * S;
+  const uint32_t g = base + (uint32_t)i;
+  const size_t w = (size_t)(g % (uint32_t)n_worlds) * S;
   const int s = min(max(state[i], 0), S - 1);
   const int a = min((int)action[i], A - 1);
-  const int ns = next_n[(w + s) * A + a];
+  int ns;
+  if (succ_off) {   // interface/gridworld.py:119-123: the successor is drawn from the row
+    const uint32_t c = env_ctr[i];
+    const double u = cobel_draw_u01(c, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+    env_ctr[i] = c + 1u;
+    ns = cobel_draw_successor(succ_off, succ_state, succ_cdf, (w + s) * A + a, u);
+  } else {
+    ns = next_n[(w + s) * A + a];
+  }
   state[i] = ns;
-  if (reward_out) reward_out[i] = reward_s[w + ns];
-  if (done_out) done_out[i] = terminal_s[w + ns];
+  if (reward_out) reward_out[i] = rec ? rec[w + ns].reward : reward_s[w + ns];
+  if (done_out) done_out[i] = rec ? (uint8_t)rec[w + ns].terminal : terminal_s[w + ns];
 }
 
 }  // namespace
 
-// cobel_env_step for worlds created with an action count other than four.
+// cobel_env_step for worlds created with an action count other than four, and cobel_env_step_draw
+// for worlds whose transition rows are distributions (env_ctr / seed: their draws).
 int cobel_env_step_general(const cobel_world* world, int32_t* state, const uint8_t* action,
-                           float* reward_out, uint8_t* done_out, int32_t n,
-                           uint32_t instance_base, hipStream_t st) {
-  hipLaunchKernelGGL(k_env_step_n, dim3((n + 255) / 256), dim3(256), 0, st, world->next_n,
-                     world->reward_s, world->terminal_s, world->n_states, world->n_actions,
-                     world->n_worlds, state, action, reward_out, done_out, n, instance_base);
+                           float* reward_out, uint8_t* done_out, uint32_t* env_ctr, uint64_t seed,
+                           int32_t n, uint32_t instance_base, hipStream_t st) {
+  hipLaunchKernelGGL(k_env_step_n, dim3((n + 255) / 256), dim3(256), 0, st, world->rec,
+                     world->next_n, world->reward_s, world->terminal_s, world->succ_off,
+                     world->succ_state, world->succ_cdf, env_ctr, seed, world->n_states,
+                     world->n_actions, world->n_worlds, state, action, reward_out, done_out, n,
+                     instance_base);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -370,7 +391,16 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     cp += 1u;
     const int a = cobel_eps_greedy_select_n<float>(qv, A, amask ? (uint32_t)amask[state] : 0xffu,
                                                    u, eps, nullptr);
-    const int ns = next_of(state, a);
+    int ns;
+    if (G.succ_off) {   // the successor is drawn from the row of sas (gridworld.py:119-123): one
+                        // double of the env stream, at the counter the trial starts share
+      const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      ns = cobel_draw_successor(G.succ_off, G.succ_state, G.succ_cdf,
+                                (wbase + (size_t)state) * A + a, ue);
+    } else {
+      ns = next_of(state, a);
+    }
     const float r = reward_of(ns);
     const uint32_t end = terminal_of(ns), nt = 1u - end;
     float td_online = 0.0f;
@@ -476,6 +506,9 @@ int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r,
   G.terminal_s = world->terminal_s;
   G.starts = world->starts;
   G.start_off = world->start_off;
+  G.succ_off = world->succ_off;
+  G.succ_state = world->succ_state;
+  G.succ_cdf = world->succ_cdf;
   G.S = world->n_states;
   G.n_worlds = world->n_worlds;
   G.A = world->n_actions;

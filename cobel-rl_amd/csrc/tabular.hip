@@ -1117,13 +1117,14 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   COBEL_REQUIRE(r.agent != COBEL_AGENT_Q || world->n_states <= 16384, COBEL_E_UNSUPPORTED,
                 "cobel_tab_run: replay records address at most 16384 states");
   // Runs outside what the wavefront kernels are built for — an action count other than four
-  // (hexagonal topologies), more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take
+  // (hexagonal topologies), transition rows that are distributions (the successor is drawn),
+  // more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take
   // the general kernel (general.hip: one lane per instance, every update in sequence).
   int32_t lds_max = 0;
   // (Dyna-Q plans batches above COBEL_MAX_BATCH in several passes of the generic wavefront
   //  kernel; QAgent's log replay gathers its records a step ahead, one lane each: general kernel)
   const int32_t pass = r.batch > COBEL_MAX_BATCH ? COBEL_MAX_BATCH : r.batch;
-  const bool general = world->n_actions != 4 ||
+  const bool general = world->n_actions != 4 || world->succ_off != nullptr ||
                        (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ) ||
                        (r.flags & COBEL_F_TAB_GENERAL) ||
                        cobel_tab_query(world->n_states, r.agent, pass, &lds_max, nullptr) != COBEL_OK;

@@ -23,7 +23,7 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1009; }
+extern "C" int cobel_abi_version(void) { return 1010; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {
@@ -131,8 +131,61 @@ extern "C" int cobel_world_destroy(cobel_world_t* w) {
   if (w->next_n) (void)hipFree(w->next_n);
   if (w->reward_s) (void)hipFree(w->reward_s);
   if (w->terminal_s) (void)hipFree(w->terminal_s);
+  if (w->succ_off) (void)hipFree(w->succ_off);
+  if (w->succ_state) (void)hipFree(w->succ_state);
+  if (w->succ_cdf) (void)hipFree(w->succ_cdf);
   free(w->h_start_off);
   free(w);
+  return COBEL_OK;
+}
+
+extern "C" int cobel_world_set_transitions(cobel_world_t* w, const uint32_t* succ_off,
+                                           const uint16_t* succ_state, const double* succ_cdf,
+                                           int64_t nnz) {
+  if (int rc = cobel_world_check(w, "cobel_world_set_transitions")) return rc;
+  COBEL_REQUIRE(succ_off && succ_state && succ_cdf, COBEL_E_ARG,
+                "cobel_world_set_transitions: NULL table");
+  COBEL_REQUIRE(!w->succ_off, COBEL_E_ARG, "cobel_world_set_transitions: already set");
+  const size_t pairs = (size_t)w->n_worlds * w->n_states * w->n_actions;
+  COBEL_REQUIRE(nnz >= (int64_t)pairs && nnz < ((int64_t)1 << 32), COBEL_E_RANGE,
+                "cobel_world_set_transitions: %lld successors for %zu pairs", (long long)nnz, pairs);
+  COBEL_REQUIRE(succ_off[0] == 0 && succ_off[pairs] == (uint32_t)nnz, COBEL_E_ARG,
+                "cobel_world_set_transitions: offsets do not span the lists");
+  for (size_t p = 0; p < pairs; ++p) {
+    const uint32_t lo = succ_off[p], hi = succ_off[p + 1];
+    COBEL_REQUIRE(hi > lo && hi <= (uint32_t)nnz, COBEL_E_ARG,
+                  "cobel_world_set_transitions: pair %zu has no successor", p);
+    double prev = 0.0;
+    for (uint32_t k = lo; k < hi; ++k) {
+      COBEL_REQUIRE((int)succ_state[k] < w->n_states, COBEL_E_RANGE,
+                    "cobel_world_set_transitions: successor %u outside the world", succ_state[k]);
+      COBEL_REQUIRE(succ_cdf[k] > prev && succ_cdf[k] <= 1.0, COBEL_E_ARG,
+                    "cobel_world_set_transitions: pair %zu: cumulative probabilities must increase "
+                    "to 1", p);
+      prev = succ_cdf[k];
+    }
+    COBEL_REQUIRE(prev == 1.0, COBEL_E_ARG,
+                  "cobel_world_set_transitions: pair %zu: the last cumulative probability is %g, not 1",
+                  p, prev);
+  }
+  hipError_t e = hipMalloc((void**)&w->succ_off, (pairs + 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->succ_state, (size_t)nnz * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->succ_cdf, (size_t)nnz * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpy(w->succ_off, succ_off, (pairs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(w->succ_state, succ_state, (size_t)nnz * sizeof(uint16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(w->succ_cdf, succ_cdf, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (w->succ_off) (void)hipFree(w->succ_off);
+    if (w->succ_state) (void)hipFree(w->succ_state);
+    if (w->succ_cdf) (void)hipFree(w->succ_cdf);
+    w->succ_off = nullptr;
+    w->succ_state = nullptr;
+    w->succ_cdf = nullptr;
+    return cobel_fail(COBEL_E_HIP, "cobel_world_set_transitions: %s", hipGetErrorString(e));
+  }
   return COBEL_OK;
 }
 
@@ -199,6 +252,9 @@ int cobel_world_check4(const cobel_world_t* w, const char* who) {
   COBEL_REQUIRE(w->n_actions == 4, COBEL_E_UNSUPPORTED,
                 "%s: the world has %d actions, this entry point serves four-action worlds", who,
                 w->n_actions);
+  COBEL_REQUIRE(!w->succ_off, COBEL_E_UNSUPPORTED,
+                "%s: the world's transition rows are distributions (cobel_world_set_transitions); "
+                "this entry point steps transition tables", who);
   return COBEL_OK;
 }
 static int check_states_dev(const cobel_world_t* w, const char* who) {
@@ -211,15 +267,32 @@ extern "C" int cobel_env_step(const cobel_world_t* world, int32_t* state, const 
   if (int rc = check_states_dev(world, "cobel_env_step")) return rc;
   COBEL_REQUIRE(state && action, COBEL_E_ARG, "cobel_env_step: NULL state/action");
   COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_env_step: n = %d", n);
+  COBEL_REQUIRE(!world->succ_off, COBEL_E_UNSUPPORTED,
+                "cobel_env_step: the world's transition rows are distributions: "
+                "cobel_env_step_draw steps it (it needs the env counters and the seed)");
   if (n == 0) return COBEL_OK;
   if (world->n_actions != 4)
-    return cobel_env_step_general(world, state, action, reward_out, done_out, n, instance_base,
-                                  (hipStream_t)stream);
+    return cobel_env_step_general(world, state, action, reward_out, done_out, nullptr, 0, n,
+                                  instance_base, (hipStream_t)stream);
   hipLaunchKernelGGL(k_env_step, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      world->rec, world->n_states, world->n_worlds, state, action, reward_out,
                      done_out, n, instance_base);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
+}
+
+extern "C" int cobel_env_step_draw(const cobel_world_t* world, int32_t* state, const uint8_t* action,
+                                   float* reward_out, uint8_t* done_out, uint32_t* env_ctr,
+                                   uint64_t seed, int32_t n, uint32_t instance_base, void* stream) {
+  if (int rc = check_states_dev(world, "cobel_env_step_draw")) return rc;
+  if (!world->succ_off)
+    return cobel_env_step(world, state, action, reward_out, done_out, n, instance_base, stream);
+  COBEL_REQUIRE(state && action && env_ctr, COBEL_E_ARG,
+                "cobel_env_step_draw: NULL state / action / env_ctr");
+  COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "cobel_env_step_draw: n = %d", n);
+  if (n == 0) return COBEL_OK;
+  return cobel_env_step_general(world, state, action, reward_out, done_out, env_ctr, seed, n,
+                                instance_base, (hipStream_t)stream);
 }
 
 extern "C" int cobel_env_reset(const cobel_world_t* world, int32_t* state,

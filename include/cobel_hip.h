@@ -111,6 +111,22 @@ COBEL_API int cobel_world_actions(const cobel_world_t* world, int32_t* n_actions
 COBEL_API int cobel_world_destroy(cobel_world_t* world);
 COBEL_API int cobel_world_info(const cobel_world_t* world, int32_t* n_states, int32_t* n_worlds,
                      int32_t* device);
+/* Transition rows that are DISTRIBUTIONS.  The reference's Gridworld.step reads
+ * p = world['sas'][s][a] and, when world['deterministic'] is off, draws the successor with
+ * rng.choice(arange(S), p=p) (interface/gridworld.py:115-123).  Every builder writes one-hot rows;
+ * a world whose dense sas was edited (slippery floors, ...) is handed over here in list form: for
+ * pair p = (world * S + s) * n_actions + a the possible successors succ_state[succ_off[p] ..
+ * succ_off[p + 1]) in ascending state order and the normalised cumulative sum of their
+ * probabilities (cumsum(p) / cumsum(p)[-1], as Generator.choice forms it; the last entry of a row
+ * is 1).  Afterwards cobel_env_step_draw steps the world, and cobel_tab_run serves it through its
+ * general kernel: every step draws one double of COBEL_STREAM_ENV (sub-stream 1) at the instance's
+ * env counter, which trial starts share (they draw integers, sub-stream 0).  cobel_env_step,
+ * cobel_sr_run, cobel_sfma_run and cobel_dqn_act refuse such a world (COBEL_E_UNSUPPORTED); the
+ * table given to cobel_world_create (most likely successors) stays in place for them to see. */
+COBEL_API int cobel_world_set_transitions(cobel_world_t* world,
+                       const uint32_t* succ_off /* [host] [n_worlds * S * n_actions + 1] */,
+                       const uint16_t* succ_state /* [host] [nnz] */,
+                       const double* succ_cdf /* [host] [nnz] */, int64_t nnz);
 
 /* ------------------------------------------------------------------------------------------
  * Stand-alone vectorised environment.  Replaces Gridworld.step / Gridworld.reset
@@ -125,6 +141,14 @@ COBEL_API int cobel_env_step(const cobel_world_t* world, int32_t* state /* [dev]
                    const uint8_t* action /* [dev] [N] */, float* reward_out /* [dev] [N] */,
                    uint8_t* done_out /* [dev] [N] */, int32_t n, uint32_t instance_base,
                    void* stream);
+/* step of a world with distribution rows (cobel_world_set_transitions): u = double draw number
+ * env_ctr[i] of COBEL_STREAM_ENV, sub-stream 1; ns = first successor of (s, a) whose cumulative
+ * probability exceeds u; env_ctr[i] += 1.  Worlds without such rows step as cobel_env_step does
+ * and leave the counters alone. */
+COBEL_API int cobel_env_step_draw(const cobel_world_t* world, int32_t* state /* [dev] [N] in/out */,
+                   const uint8_t* action /* [dev] [N] */, float* reward_out /* [dev] [N] */,
+                   uint8_t* done_out /* [dev] [N] */, uint32_t* env_ctr /* [dev] [N] in/out */,
+                   uint64_t seed, int32_t n, uint32_t instance_base, void* stream);
 COBEL_API int cobel_env_reset(const cobel_world_t* world, int32_t* state /* [dev] [N] */,
                     const uint8_t* reset_mask /* [dev] [N] or NULL */,
                     uint32_t* env_ctr /* [dev] [N] in/out */, uint64_t seed, int32_t n,

@@ -29,13 +29,17 @@ import numpy as np
 
 
 class RefGridworld:
-    """Deterministic gridworld on compact tables (gridworld.py:76-145)."""
+    """Gridworld on compact tables (gridworld.py:76-145).  With ``world['sas']`` (dense
+    ``[S, A, S]`` rows that are distributions, ``world['deterministic']`` off) the successor is
+    DRAWN from the row as the reference does (gridworld.py:119-123): one double of the env stream
+    per step, next to the integer draws of the trial starts."""
 
     def __init__(self, world: dict, rng) -> None:
         self.next = np.asarray(world['next'])
         self.reward = np.asarray(world['reward'], dtype=np.float64)
         self.terminal = np.asarray(world['terminal'])
         self.starts = np.asarray(world['starts'])
+        self.sas = np.asarray(world['sas'], dtype=np.float64) if 'sas' in world else None
         self.rng = rng
         self.n_states, self.n_actions = self.next.shape
         self.current_state = 0
@@ -46,7 +50,11 @@ class RefGridworld:
         return self.current_state, {}
 
     def step(self, action):
-        self.current_state = int(self.next[self.current_state, int(action)])
+        if self.sas is None:
+            self.current_state = int(self.next[self.current_state, int(action)])
+        else:
+            self.current_state = int(self.rng.choice(
+                np.arange(self.n_states), p=self.sas[self.current_state][int(action)]))
         s = self.current_state
         return s, self.reward[s], bool(self.terminal[s]), False, {}
 

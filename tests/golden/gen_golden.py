@@ -374,6 +374,99 @@ def gen_dynaq(worlds):
     np.savez_compressed(_out('dynaq_traces.npz'), **out)
 
 
+def slippery(world, p_slip: float = 0.2):
+    """A reference world made stochastic the way a user would: rows of the dense ``sas`` edited in
+    place and ``deterministic`` switched off (interface/gridworld.py:115-123 then DRAWS the
+    successor).  The intended move keeps 1 - p_slip, each perpendicular move gets p_slip / 2."""
+    det = np.argmax(world['sas'], axis=2)
+    sas = np.zeros_like(world['sas'])
+    for s in range(world['states']):
+        for a in range(4):
+            sas[s, a, det[s, a]] += 1.0 - p_slip
+            sas[s, a, det[s, (a + 1) % 4]] += p_slip / 2
+            sas[s, a, det[s, (a + 3) % 4]] += p_slip / 2
+    world['sas'] = sas
+    world['deterministic'] = False
+    return world
+
+
+def gen_stochastic():
+    """Worlds whose transition rows are distributions: the env's own known answers (successor
+    for a given uniform) and Dyna-Q / Q-learning runs, the env stream now serving integer draws
+    (trial starts) and doubles (one per step) from one counter."""
+    out = {}
+    worlds = {
+        'slip_4x4': slippery(gt.make_gridworld(4, 4, terminals=[3], rewards=np.array([[3, 1.0]]),
+                                               goals=[3], invalid_transitions=[(5, 6), (6, 5)])),
+        'slip_5x6_wind': slippery(gt.make_gridworld(
+            5, 6, terminals=[5, 24], rewards=np.array([[5, 2.0], [24, -1.0], [14, 0.25]]),
+            goals=[5], invalid_states=[8, 9], wind=np.tile(np.array([[0, 0], [0, 1], [0, 0]]), (10, 1))),
+            0.35),
+    }
+    for wname, world in worlds.items():
+        for k, v in compact(world).items():
+            out['%s/%s' % (wname, k)] = v
+        out[wname + '/sas'] = np.asarray(world['sas'], dtype=np.float64)
+        # env known answers: (state, action, u) -> successor, through the reference's step()
+        rows = []
+        rng = np.random.default_rng(5)
+        for _ in range(400):
+            s, a, u = int(rng.integers(world['states'])), int(rng.integers(4)), float(rng.random())
+            if rng.random() < 0.1:       # uniforms on and next to the edges of the distribution
+                u = float(rng.choice([0.0, 0.8, 0.9, 0.65, 0.825, np.nextafter(0.8, 0), np.nextafter(1.0, 0)]))
+            env = Gridworld(world, rng=TapeRNG(SEED, 0, STREAM_ENV, double_sub=1))
+            env.current_state = s
+            env.rng.random = lambda size=None, u=u: u
+            ns, r, end, _, _ = env.step(a)
+            rows.append((s, a, u, ns, r, end))
+        out[wname + '/step_kat'] = np.array(rows, dtype=np.float64)
+    cases = {
+        # name: (world, agent, instance, trials, steps, B)
+        'slip4_dynaq_b8': ('slip_4x4', 'dynaq', 0, 30, 40, 8),
+        'slip4_q_b4': ('slip_4x4', 'q', 2, 30, 40, 4),
+        'slip4_q_b0': ('slip_4x4', 'q', 3, 20, 40, 0),
+        'slip56_dynaq_b70': ('slip_5x6_wind', 'dynaq', 1, 20, 60, 70),
+    }
+    for name, (wname, kind, inst, trials, steps, B) in cases.items():
+        world = worlds[wname]
+        env = Gridworld(world, rng=TapeRNG(SEED, inst, STREAM_ENV, double_sub=1))
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        if kind == 'dynaq':
+            ag = DynaQ(env.observation_space, env.action_space, pol)
+            ag.M.rng = TapeRNG(SEED, inst, STREAM_MEMORY)
+            ag.Q = ag.Q.astype(np.float32)
+            ag.M.rewards = ag.M.rewards.astype(np.float32)
+        else:
+            ag = QAgent(env.observation_space, env.action_space, pol,
+                        rng=TapeRNG(SEED, inst, STREAM_MEMORY))
+            for s_ in range(world['states']):     # float32 rows (created lazily as float64 otherwise)
+                ag.Q[(s_,)] = np.zeros(4, dtype=np.float32)
+        tr = Tracer(ag)
+        ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            ag.callbacks.custom_callbacks.setdefault(k, [])
+        ag.train(env, trials, steps, B)
+        d = tr.pack()
+        d.pop('Q_trial', None)
+        if kind == 'dynaq':
+            d.update(Q=np.array(ag.Q, dtype=np.float64),
+                     M_rewards=np.array(ag.M.rewards, dtype=np.float64),
+                     M_states=ag.M.states.astype(np.int16), M_terminals=ag.M.terminals.astype(np.int8))
+        else:
+            q = np.zeros((world['states'], 4))
+            for key, row in ag.Q.items():
+                q[key[0]] = np.asarray(row, dtype=np.float32)
+            d.update(Q=q, log_len=np.int64(len(ag.M)))
+        d['cfg'] = np.array([inst, trials, steps, B], dtype=np.int64)
+        d['env_draws'] = np.int64(env.rng.index)
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+        out[name + '/world'] = np.array(wname)
+        out[name + '/agent'] = np.array(kind)
+    np.savez_compressed(_out('stochastic_traces.npz'), **out)
+
+
+
 def gen_dynaq_memory():
     """memory/dyna_q.py:62-157 on its own: stores interleaved with retrieve_batch, the memory's
     generator fed from the build's memory stream (one vector draw per batch)."""
@@ -1034,6 +1127,7 @@ def main():
     gen_gridworld_kat()
     gen_eps_greedy()
     gen_dynaq(worlds)
+    gen_stochastic()
     gen_dynaq_memory()
     gen_qagent(worlds)
     gen_sr(worlds)

@@ -57,6 +57,20 @@ def test_random_topologies_match_the_restatement():
     assert not failed, failed[:3]
 
 
+def test_random_stochastic_worlds_match_the_restatement():
+    """scripts/fuzz_stochastic.py: gridworlds whose sas rows are edited into random distributions,
+    Dyna-Q / Q-learning through the general kernel against oracle/ref_loop.py drawing successors
+    the way the reference does."""
+    import fuzz_stochastic as fz
+    failed = []
+    for seed in range(0, 100):
+        case = fz.draw_case(seed)
+        bad = fz.run_case(case)
+        if bad:
+            failed.append((fz.describe(case), bad))
+    assert not failed, failed[:3]
+
+
 def test_random_network_agent_runs_fused_equal_torch_loops():
     """scripts/fuzz_network_agents.py: DQN on random tracks, Dyna-DQN and Dyna-DSR on random
     gridworlds — the fused HIP loops against the PyTorch-ROCm loops of the same classes: rings /

@@ -1,0 +1,157 @@
+"""Worlds whose transition rows are distributions — the reference's Gridworld.step then DRAWS the
+successor from sas[s][a] (interface/gridworld.py:119-123) — through cobel_world_set_transitions,
+cobel_env_step_draw and the general kernel of cobel_tab_run, against golden runs of the reference
+on slippery worlds (tests/golden/gen_golden.py gen_stochastic) and the Philox restatement."""
+import numpy as np
+import pytest
+
+from conftest import SEED, as_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def Z(golden):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return golden('stochastic_traces')
+
+
+def slippery_world(Z, wname):
+    tab = {k: Z['%s/%s' % (wname, k)] for k in ('height', 'width', 'next', 'reward', 'terminal',
+                                                'starts', 'coordinates')}
+    w = as_world(tab)
+    w['sas'] = np.array(Z[wname + '/sas'])
+    w['deterministic'] = False
+    return w
+
+
+@pytest.mark.parametrize('wname', ['slip_4x4', 'slip_5x6_wind'])
+def test_env_step_draws_the_successor(Z, wname):
+    """Gridworld.step on 4 096 instances: every successor is the one Generator.choice returns for
+    the uniform of the instance's env stream (oracle/philox.py), counters advance by one per step
+    and by one per reset, rewards / ends belong to the drawn state."""
+    import torch
+    from cobel_amd.interface import Gridworld
+    from oracle import philox
+    world = slippery_world(Z, wname)
+    sas = np.asarray(world['sas'])
+    n, base = 4096, 77
+    env = Gridworld(world, n_envs=n, seed=SEED, instance_base=base)
+    assert env.handle.stochastic
+    rng = np.random.default_rng(1)
+    inst = base + np.arange(n)
+    moved = 0
+    for it in range(6):
+        before, ctr = env.state.cpu().numpy(), env.env_ctr.cpu().numpy().astype(np.int64)
+        act = rng.integers(0, 4, n).astype(np.uint8)
+        _, r, done, _, _ = env.step(torch.as_tensor(act, device='cuda'))
+        after = env.state.cpu().numpy()
+        u = philox.draw_double(SEED, inst, ctr, 1, philox.STREAM_ENV)
+        cdf = np.cumsum(sas[before, act], axis=1)
+        cdf /= cdf[:, -1:]
+        want = (cdf <= u[:, None]).sum(axis=1)      # searchsorted(u, side='right') per row
+        assert np.array_equal(after, want)
+        assert np.array_equal(env.env_ctr.cpu().numpy(), ctr + 1)
+        assert np.array_equal(r.cpu().numpy(), np.asarray(world['rewards'], dtype=np.float32)[after])
+        assert np.array_equal(done.cpu().numpy(), np.asarray(world['terminals'])[after] != 0)
+        moved += int((after != np.asarray(world['next'])[before, act]).sum())
+        env.reset(done)
+    assert moved > 0.05 * 6 * n                      # the walk is not the one of the argmax table
+
+
+@pytest.mark.parametrize('name', ['slip4_dynaq_b8', 'slip4_q_b4', 'slip4_q_b0', 'slip56_dynaq_b70'])
+def test_stochastic_world_runs_match_reference(Z, name):
+    """Dyna-Q / Q-learning on the slippery worlds: per-step logs of a single instance, escape
+    latencies, tables and the env stream's draw count against the reference's float32 run; the same
+    instance inside a vectorised launch; cobel_tab_run takes its general kernel."""
+    import torch
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ, QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    inst, trials, steps, B = [int(x) for x in Z[name + '/cfg']]
+    world = slippery_world(Z, str(Z[name + '/world']))
+    dyna = str(Z[name + '/agent']) == 'dynaq'
+    cls = DynaQ if dyna else QAgent
+    g = lambda k: Z['%s/%s' % (name, k)]     # noqa: E731
+
+    def check_tables(ag, i):
+        q = ag._q[i].cpu().numpy().astype(np.float64)
+        assert np.array_equal(q, g('Q'))
+        if dyna:
+            M = ag.M
+            sq = (lambda a: np.asarray(a) if ag.n_envs == 1 else np.asarray(a)[i])
+            assert np.array_equal(sq(M.states), g('M_states'))
+            assert np.array_equal(sq(M.terminals), g('M_terminals'))
+            assert np.array_equal(np.asarray(sq(M.rewards), dtype=np.float64), g('M_rewards'))
+        else:
+            assert int(ag.inst[i, _lib.I_LOG_LEN].item()) == int(g('log_len'))
+
+    # one instance, the reference's callbacks
+    sarsn, tds, steps_log = [], [], []
+    cbs = {'on_step_end': [lambda l: (sarsn.append((l['state'], l['action'], l['reward'],
+                                                    l['next_state'], l['terminal'])),
+                                      tds.append(l['td']))],
+           'on_trial_end': [lambda l: steps_log.append(l['steps'])]}
+    env = Gridworld(world, seed=SEED, instance_base=inst)
+    ag = cls(env.observation_space, env.action_space, EpsilonGreedy(0.1), custom_callbacks=cbs)
+    ag.train(env, trials, steps, B)
+    arr = np.array(sarsn, dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(arr[:, col], g(key)), key
+    assert np.array_equal(steps_log, g('steps'))
+    if dyna or B == 0:
+        assert np.array_equal(np.array(tds, dtype=np.float64), g('td'))
+    check_tables(ag, 0)
+    assert int(env.env_ctr[0].item()) == int(g('env_draws'))
+    # vectorised: instance `inst` of one launch; the dispatcher names the general kernel
+    env = Gridworld(world, n_envs=inst + 70, seed=SEED)
+    ag = cls(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    ag.track_instances = True
+    ag.train(env, trials, steps, B)
+    torch.cuda.synchronize()
+    assert np.array_equal(ag.monitors.lat_trace[inst].cpu().numpy()[:trials], g('steps'))
+    check_tables(ag, inst)
+    assert int(env.env_ctr[inst].item()) == int(g('env_draws'))
+    what = ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)
+    assert what['kernel'] == _lib.TAB_KERNEL_GENERAL
+
+
+def test_stochastic_worlds_and_the_other_entry_points(Z):
+    """The kernels that step transition tables refuse a world of distributions loudly; the network
+    agents run it through their PyTorch loops (env.step draws); a world of the same rows with the
+    reference's `deterministic` flag SET is the argmax table again."""
+    import torch
+    import bench
+    from cobel_amd import _lib
+    from cobel_amd.agent import SR, DynaDQN, DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    world = slippery_world(Z, 'slip_4x4')
+    env = Gridworld(world, n_envs=8, seed=3)
+    sr = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    with pytest.raises(NotImplementedError):
+        sr.train(env, 1, 5)
+    state = torch.zeros(8, dtype=torch.int32, device='cuda')
+    act = torch.zeros(8, dtype=torch.uint8, device='cuda')
+    with pytest.raises(NotImplementedError):     # the counter-less entry cannot draw
+        _lib.check(_lib.lib().cobel_env_step(env.handle.ptr, _lib.ptr(state), _lib.ptr(act), None,
+                                             None, 8, 0, None))
+    torch.manual_seed(2)
+    env = Gridworld(world, n_envs=6, seed=4)
+    ag = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                 TorchNetwork(bench._mlp(16, 4)), gamma=0.9)
+    ag.train(env, 2, 8, 32)
+    assert ag.fused_steps == 0 and int(env.env_ctr.min().item()) > 2     # steps drew doubles
+    # flag set: the reference takes the argmax of every row, so does the build
+    det = slippery_world(Z, 'slip_4x4')
+    det['deterministic'] = True
+    env = Gridworld(det, n_envs=64, seed=5)
+    assert not env.handle.stochastic
+    ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(1.0))
+    ag.train(env, 2, 20, 8)
+    M = ag.M
+    seen = np.asarray(M.terminals) != 0
+    assert (np.asarray(M.states)[seen] == np.broadcast_to(np.asarray(det['next']), (64, 16, 4))[seen]).all()

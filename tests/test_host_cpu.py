@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1009
+    assert lib.cobel_abi_version() == 1010
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
@@ -628,27 +628,41 @@ def test_fused_dqn_path_recognises_models_by_behaviour():
 
 
 def test_deterministic_flag_and_stochastic_rows():
-    """world['deterministic'] = False only changes HOW the reference reads a row of sas (a draw
-    instead of argmax, interface/gridworld.py:115-123); all builders write one-hot rows
-    (misc/gridworld_tools.py:103-134), so the flag is accepted and the tables are the same.  Rows
-    with several successors are refused, also when a built world's sas was edited afterwards."""
+    """world['deterministic'] only selects HOW the reference reads a row of sas — argmax, or a draw
+    from it (interface/gridworld.py:115-123).  All builders write one-hot rows
+    (misc/gridworld_tools.py:103-134), for which both are the same step.  An edited sas is
+    followed: as a table (argmax) while the flag is set, as successor lists with cumulative
+    probabilities — what cobel_world_set_transitions takes — when it is off."""
     from cobel_amd.misc import gridworld_tools as gt
     a = gt.make_gridworld(3, 4, terminals=[0], rewards=np.array([[0, 1.0]]), goals=[0])
     b = gt.make_gridworld(3, 4, terminals=[0], rewards=np.array([[0, 1.0]]), goals=[0],
                           deterministic=False)
     assert b['deterministic'] is False and np.array_equal(a['next'], b['next'])
     assert np.array_equal(gt.successor_table(a['sas']), a['next'])
-    assert np.array_equal(b.compact()['next'], a['next'])
-    # an edited sas is followed ...
+    assert np.array_equal(b.compact()['next'], a['next']) and 'transitions' not in b.compact()
+    _ = b['sas']                                  # materialised, still one-hot: still a table
+    assert 'transitions' not in b.compact()
+    # an edited row of a deterministic world: argmax
     c = gt.make_gridworld(2, 2)
     sas = c['sas']
     sas[0, 2] = 0.0
-    sas[0, 2, 3] = 1.0                       # "right" from state 0 now jumps to state 3
+    sas[0, 2, 3] = 1.0                            # "right" from state 0 now jumps to state 3
     assert c.compact()['next'][0, 2] == 3
-    # ... unless it is no longer a table
-    sas[0, 2, 1] = 0.5
-    sas[0, 2, 3] = 0.5
-    with pytest.raises(NotImplementedError):
-        c.compact()
-    with pytest.raises(NotImplementedError):
-        gt.successor_table(np.zeros((2, 4, 2)))       # rows without any successor
+    sas[0, 2, 1], sas[0, 2, 3] = 0.25, 0.75
+    assert c.compact()['next'][0, 2] == 3 and 'transitions' not in c.compact()
+    # the same world with the flag off: lists (ascending states, normalised cumulative sums)
+    c['deterministic'] = False
+    sas[1, 0] = [2.0, 0.0, 1.0, 1.0]              # unnormalised rows are normalised like choice(p=)
+    t = c.compact()
+    off, succ, cdf = t['transitions']
+    assert len(off) == 17 and off[-1] == len(succ) == len(cdf) == 16 + 1 + 2
+    p = 0 * 4 + 2
+    assert list(succ[off[p]:off[p + 1]]) == [1, 3] and list(cdf[off[p]:off[p + 1]]) == [0.25, 1.0]
+    p = 1 * 4 + 0
+    assert list(succ[off[p]:off[p + 1]]) == [0, 2, 3]
+    assert list(cdf[off[p]:off[p + 1]]) == [0.5, 0.75, 1.0]
+    assert t['next'][1, 0] == 0
+    with pytest.raises(ValueError):
+        gt.successor_table(np.zeros((2, 4, 2)))   # rows without any successor
+    with pytest.raises(ValueError):
+        gt.transition_lists(-np.ones((2, 4, 2)))

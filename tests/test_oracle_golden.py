@@ -309,3 +309,63 @@ def test_qagent_on_hexagonal_topology_golden(golden, name):
     assert np.array_equal(tr['steps'], D[name + '/steps'])
     assert np.array_equal(ag.Q.astype(np.float64), D[name + '/Q'])
     assert len(ag.M) == int(D[name + '/log_len'])
+
+
+# ---------------------------------------------------------------------------------------------
+# Worlds whose transition rows are distributions (interface/gridworld.py:119-123: the successor is
+# drawn from sas[s][a]); fixtures from the reference with its sas edited, tests/golden/gen_golden.py
+# gen_stochastic.
+def stochastic_world(Z, wname):
+    return {'next': Z[wname + '/next'], 'reward': Z[wname + '/reward'],
+            'terminal': Z[wname + '/terminal'], 'starts': Z[wname + '/starts'],
+            'sas': Z[wname + '/sas']}
+
+
+@pytest.mark.parametrize('wname', ['slip_4x4', 'slip_5x6_wind'])
+def test_stochastic_step_known_answers(golden, wname):
+    """(state, action, uniform) -> successor, reward, end as the reference's step() returns them,
+    including uniforms on and next to the edges of the cumulative distribution."""
+    Z = golden('stochastic_traces')
+    tab = stochastic_world(Z, wname)
+    assert (np.count_nonzero(tab['sas'], axis=2) > 1).any()
+    env = ref_loop.RefGridworld(tab, TapeRNG(SEED, 0, STREAM_ENV, double_sub=1))
+    for s, a, u, ns, r, end in Z[wname + '/step_kat']:
+        env.current_state = int(s)
+        env.rng.random = lambda size=None, u=u: u
+        got = env.step(int(a))
+        assert (got[0], float(got[1]), got[2]) == (int(ns), float(r), bool(end))
+
+
+@pytest.mark.parametrize('name', ['slip4_dynaq_b8', 'slip4_q_b4', 'slip4_q_b0', 'slip56_dynaq_b70'])
+def test_stochastic_world_runs_golden(golden, name):
+    """Dyna-Q and Q-learning on the slippery worlds: the restatement against the reference's
+    float32 run — trajectory, TD errors, latencies, tables, and the number of draws the env stream
+    handed out (one integer per trial start, one double per step)."""
+    Z = golden('stochastic_traces')
+    inst, trials, steps, B = [int(x) for x in Z[name + '/cfg']]
+    tab = stochastic_world(Z, str(Z[name + '/world']))
+    S = tab['next'].shape[0]
+    erng = TapeRNG(SEED, inst, STREAM_ENV, double_sub=1)
+    env = ref_loop.RefGridworld(tab, erng)
+    pol = ref_loop.RefEpsilonGreedy(0.1, TapeRNG(SEED, inst, STREAM_POLICY))
+    tr = ref_loop.new_trace()
+    if str(Z[name + '/agent']) == 'dynaq':
+        ag = ref_loop.RefDynaQ(S, 4, pol, TapeRNG(SEED, inst, STREAM_MEMORY), dtype=np.float32)
+        ag.train(env, trials, steps, B, trace=tr)
+        assert np.array_equal(ag.M.rewards.astype(np.float64), Z[name + '/M_rewards'])
+        assert np.array_equal(ag.M.states, Z[name + '/M_states'])
+        assert np.array_equal(ag.M.terminals, Z[name + '/M_terminals'])
+    else:
+        ag = ref_loop.RefQAgent(S, 4, pol, TapeRNG(SEED, inst, STREAM_MEMORY), dtype=np.float32)
+        ag.train(env, trials, steps, B, trace=tr)
+        assert len(ag.M) == int(Z[name + '/log_len'])
+    got = np.array(tr['sarsn'], dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(got[:, col], Z['%s/%s' % (name, key)]), key
+    assert np.array_equal(tr['steps'], Z[name + '/steps'])
+    assert np.array_equal(ag.Q.astype(np.float64), Z[name + '/Q'])
+    assert erng.index == int(Z[name + '/env_draws'])
+    if B == 0 or str(Z[name + '/agent']) == 'dynaq':
+        assert np.array_equal(np.array(tr['td']), Z[name + '/td'])
+    # the walk is not the one of the argmax table
+    assert (got[:, 3] != tab['next'][got[:, 0].astype(int), got[:, 1].astype(int)]).any()
