@@ -16,8 +16,9 @@
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) and calls return without synchronising;
  *   - the library keeps no global mutable state besides the last-error string; a
- *     world handle is immutable after creation and may be shared by any number of
- *     runs on its device.
+ *     world handle is immutable after creation (cobel_world_create*, then at most one
+ *     cobel_world_set_transitions before its first use) and may be shared by any number
+ *     of runs on its device.
  */
 #ifndef COBEL_HIP_H
 #define COBEL_HIP_H
