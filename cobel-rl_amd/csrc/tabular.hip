@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     return;
 #endif
     int dep = -1;  // latest earlier lane this lane must wait for
+    unsigned long long conf = 0ull;   // exact lookup: ALL earlier lanes that write a cell I read
     if (__builtin_expect(A.hash_exact != 0, 1)) {
       // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
       // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         H2[h2] = 0ull;
       }
       STAMP(2);
-      if (cnd) dep = 63 - __clzll((long long)cnd);
+      conf = cnd;
       STAMP(3);
     } else {
     // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
@@ -374,6 +375,44 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     STAMP(3);
     }
     int first = 0;
+    if (__builtin_expect(A.hash_exact != 0, 1)) {
+      // With the exact conflict sets the rounds are speculative: every remaining lane computes its
+      // update from the table as it stands; a lane's result holds unless an earlier lane of this
+      // round that writes a cell it reads has CHANGED that cell — an update that leaves its cell
+      // as it was (all-zero regions of Q, converged entries) blocks nobody.  The lanes before the
+      // first one whose inputs moved are committed (only changed cells are written, so two lanes
+      // of one round never write the same cell), the rest goes again.  Same order of effects as
+      // the reference's loop; never fewer lanes per round than the conflict-free prefix.
+      do {
+        const bool act = on && lane >= first;
+        float q = 0.0f, qn = 0.0f;
+        if (act) {
+          const float4 row = Qs[ns];
+          q = Qf[idx];
+          const float m = max4(row);
+          if (AGENT == COBEL_AGENT_DYNAQ) {
+            const double gnt = gamma * (double)nt;
+            double td = (double)r + gnt * (double)m;
+            td = td - (double)q;
+            qn = (float)((double)q + alpha * td);
+          } else {
+            const float gnt = nt ? gamma_f : 0.0f;
+            float td = r + gnt * m;
+            td = td - q;
+            qn = q + alpha_f * td;
+          }
+        }
+        const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
+        const unsigned long long changed = __ballot(ch);
+        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
+        const int stop = blocked ? (__ffsll((long long)blocked) - 1) : BP;
+        if (ch && lane < stop) Qf[idx] = qn;
+        __builtin_amdgcn_wave_barrier();
+        first = stop;
+      } while (first < BP);
+      STAMP(4);
+      return;
+    }
     do {   // (B >= 1 here; most batches need one or two rounds)
       const unsigned long long blocked = __ballot(on && dep >= first);
       const int stop = blocked ? (__ffsll((long long)blocked) - 1) : BP;
