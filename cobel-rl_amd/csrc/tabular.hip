@@ -315,11 +315,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 #endif
     int dep = -1;  // latest earlier lane this lane must wait for
     unsigned long long conf = 0ull;   // exact lookup: ALL earlier lanes that write a cell I read
-    if (__builtin_expect(A.hash_exact != 0, 1)) {
-      // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
-      // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
-      // that write into row ns are those in one of the four H1 buckets of (ns & 15) and in the
-      // H2 bucket of ns >> 4.  No false candidates, nothing to verify.
+    // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
+    // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
+    // that write into row ns are those in one of the four H1 buckets of (ns & 15) and in the
+    // H2 bucket of ns >> 4.  No false candidates, nothing to verify.
+    auto conflict_sets = [&]() {
       unsigned long long* const H1 = L.H;
       unsigned long long* const H2 = L.H + 64;
       const uint32_t h1 = idx & 63u, h2 = idx >> 6;
@@ -345,10 +345,9 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         H1[h1] = 0ull;
         H2[h2] = 0ull;
       }
-      STAMP(2);
       conf = cnd;
-      STAMP(3);
-    } else {
+    };
+    if (__builtin_expect(A.hash_exact == 0, 0)) {
     // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
     const uint32_t bs = sj & hmask, bn = ns & hmask;
     if (on) atomicOr(&L.H[bs], 1ull << lane);
@@ -376,13 +375,15 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     }
     int first = 0;
     if (__builtin_expect(A.hash_exact != 0, 1)) {
-      // With the exact conflict sets the rounds are speculative: every remaining lane computes its
-      // update from the table as it stands; a lane's result holds unless an earlier lane of this
-      // round that writes a cell it reads has CHANGED that cell — an update that leaves its cell
-      // as it was (all-zero regions of Q, converged entries) blocks nobody.  The lanes before the
-      // first one whose inputs moved are committed (only changed cells are written, so two lanes
-      // of one round never write the same cell), the rest goes again.  Same order of effects as
-      // the reference's loop; never fewer lanes per round than the conflict-free prefix.
+      // The rounds are speculative: every remaining lane computes its update from the table as it
+      // stands; a lane's result holds unless an earlier lane of this round that writes a cell it
+      // reads has CHANGED that cell — an update that leaves its cell as it was (all-zero regions
+      // of Q, converged entries) blocks nobody.  The lanes before the first one whose inputs moved
+      // are committed (only changed cells are written, so two lanes of one round never write the
+      // same cell), the rest goes again.  Same order of effects as the reference's loop; never
+      // fewer lanes per round than the conflict-free prefix.  Who conflicts with whom is only
+      // looked up — once per batch — when something changes.
+      bool have_conf = false;
       do {
         const bool act = on && lane >= first;
         float q = 0.0f, qn = 0.0f;
@@ -404,10 +405,17 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         }
         const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
         const unsigned long long changed = __ballot(ch);
-        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
-        const int stop = blocked ? (__ffsll((long long)blocked) - 1) : BP;
-        if (ch && lane < stop) Qf[idx] = qn;
-        __builtin_amdgcn_wave_barrier();
+        int stop = BP;
+        if (changed) {
+          if (!have_conf) {
+            conflict_sets();
+            have_conf = true;
+          }
+          const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
+          if (blocked) stop = __ffsll((long long)blocked) - 1;
+          if (ch && lane < stop) Qf[idx] = qn;
+          __builtin_amdgcn_wave_barrier();
+        }
         first = stop;
       } while (first < BP);
       STAMP(4);
