@@ -543,8 +543,14 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
         res['repeat_windows'] = {'count': len(repeats), 'seconds': spent,
                                  'ms_per_step_median': float(np.median(repeats)),
                                  'ms_per_step_min': min(repeats), 'ms_per_step_max': max(repeats),
+                                 'ms_per_step_last': repeats[-1],
+                                 'value_last': total_steps / (repeats[-1] * 1e-3 * args.steps),
                                  'note': 'the timed window of exactly `steps` launches run again '
-                                         'until --min-seconds of GPU work; `value` is the first window'}
+                                         'until --min-seconds of GPU work; `value` is the first '
+                                         'window.  The instances keep learning through the repeats: '
+                                         'on C3 a launch takes longer once Q has filled and most '
+                                         'planning updates move their cell (DESIGN.md section 4.1), '
+                                         'so the last window is the rate of well-trained agents'}
     what = runner.describe()
     if what is not None:
         res['roofline']['lds_bytes_per_workgroup'] = what['lds_bytes']
