@@ -164,8 +164,14 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   const uint32_t hmask = (uint32_t)A.hash_buckets - 1u;
 
   // ---- stage the instance: Q, compact model, world records --------------------------------
+  // (nonzero: does anything that planning could propagate exist yet — a Q cell or a reward
+  //  estimate of the model that is not +0.0f?  See COBEL_IF_NONZERO below.)
+  uint32_t nonzero = 0u;
   for (int s = lane; s < S; s += 64) {
-    Qs[s] = Qg[s];
+    const float4 qv = Qg[s];
+    Qs[s] = qv;
+    nonzero |= __builtin_bit_cast(uint32_t, qv.x) | __builtin_bit_cast(uint32_t, qv.y) |
+               __builtin_bit_cast(uint32_t, qv.z) | __builtin_bit_cast(uint32_t, qv.w);
     if (WLDS) L.Wl[s] = W4[s];
     if (OCC) L.occ[s] = 0u;
   }
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       const uint64_t rec = model[e];
       const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
       L.M16[e] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
+      nonzero |= lo;
     }
   }
   if (A.use_hash)
@@ -191,6 +198,18 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
   uint32_t loglen = (uint32_t)inst[COBEL_I_LOG_LEN];
   uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  // COBEL_IF_NONZERO (bit 1 of the instance flags, Dyna-Q): the instance's Q table or its model's
+  // reward estimates hold something other than +0.0f.  Until then every planning update is
+  // 0 + alpha (0 + gamma nt 0 - 0) = 0: it leaves Q as it is, whatever pairs are drawn, so only the
+  // batch counter moves (in a maze with one rewarded goal that is every step before the agent
+  // first reaches it).  Derived here from the tables as the caller handed them over (the digest
+  // is only scanned while Q is all zero), set when a reward other than +0.0f arrives, not kept in
+  // `inst`.
+  if (AGENT == COBEL_AGENT_DYNAQ) {
+    if (MIDX && !__ballot(nonzero != 0u))
+      for (uint32_t e = (uint32_t)lane; e < SA; e += 64u) nonzero |= (uint32_t)Mg[e] & 0x8000u;
+    if (__ballot(nonzero != 0u)) iflags |= 2u;
+  }
   // trial reward: a per-lane (vector) register on purpose — it is only ever accumulated, and as a
   // wave-uniform value it would occupy scalar registers the step loop is short of
   double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO + (lane & 0));
@@ -588,7 +607,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // ---- env.step (interface/gridworld.py:115-126) ----------------------------------------------
     const int ns = (int)next_of(cw0, cw1, a);
     const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
-    const float r = __builtin_bit_cast(float, rl(cand.z, a));
+    const uint32_t r_bits = rl(cand.z, a);
+    const float r = __builtin_bit_cast(float, r_bits);
+    // COBEL_IF_NONZERO: while Q and the model's reward estimates are all +0.0f the only thing
+    // that can change that is a reward other than +0.0f (TD = r + gamma 0 - 0)
+    if (AGENT == COBEL_AGENT_DYNAQ && learn && r_bits != 0u) iflags |= 2u;
     const uint32_t end = rl(cand.w, a);
     const float ns_max = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, smax), a));
     const uint32_t nt = 1u - end;
@@ -699,10 +722,12 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
           float r = 0.0f;
           idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
           mg_next = (uint32_t)Mg[idx_next];
-          if (__builtin_expect((m & 0x8000u) != 0u, 0))
-            r = __builtin_bit_cast(float, model32[2u * idx_cur]);
-          if (idx_cur == fresh_idx) r = fresh_r;
-          run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r, true);
+          if (iflags & 2u) {   // (COBEL_IF_NONZERO: otherwise no update of the batch can move Q)
+            if (__builtin_expect((m & 0x8000u) != 0u, 0))
+              r = __builtin_bit_cast(float, model32[2u * idx_cur]);
+            if (idx_cur == fresh_idx) r = fresh_r;
+            run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r, true);
+          }
           if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
         }
         idx_cur = idx_next;
@@ -710,7 +735,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         mrec = mrec_next;
         cm += 1u;
       } else if (AGENT == COBEL_AGENT_DYNAQ) {
-        plan_dynaq_batch(mdraw, fresh_idx, fresh_r);
+        if (iflags & 2u) plan_dynaq_batch(mdraw, fresh_idx, fresh_r);
         cm += 1u;
       } else {
         // experiences of the next batch are gathered now, behind this batch's updates
@@ -746,7 +771,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       iflags &= ~1u;
       if (episodic && B > 0) {
         refresh_draws(cp >> 2);
-        plan_dynaq_batch(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
+        if (iflags & 2u) plan_dynaq_batch(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
         cm += 1u;
       }
       if (!begin_trial()) break;
@@ -784,7 +809,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
     inst[COBEL_I_CTR_MEMORY] = (int32_t)cm;
     inst[COBEL_I_LOG_LEN] = (int32_t)loglen;
-    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    inst[COBEL_I_FLAGS] = (int32_t)(iflags & ~2u);   // (COBEL_IF_NONZERO lives in the launch only)
     const unsigned long long executed = (unsigned long long)(budget0 - budget);
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
     *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
