@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
   };
 
-  // ---- B sequential TD updates, executed as conflict-free prefixes --------------------------
+  // ---- B sequential TD updates, executed as speculative rounds / conflict-free prefixes ------
   // Lane j < B holds replay j = (idx -> (s, a), r, ns, nt).  The reference applies them in order
   // (agent/dyna_q.py:329-330); j may run once every earlier lane that writes a cell j reads —
   // s_i == ns_j (row of the max) or idx_i == idx_j (the cell itself) — has written.
