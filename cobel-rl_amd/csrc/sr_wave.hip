@@ -76,11 +76,69 @@ struct row_regs {
   float4 c[NV];
 };
 
-template <int NV>
-__device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane) {
+// (quads: float4 groups a row really has — S / 4; NV * 64 for the sizes the layout fills exactly)
+template <int NV, bool ANY_S>
+__device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane,
+                                         int quads) {
   const float4* const p = reinterpret_cast<const float4*>(src) + lane;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) d.c[j] = p[j * 64];
+  for (int j = 0; j < NV; ++j) {
+    if (!ANY_S || j * 64 + lane < quads) d.c[j] = p[j * 64];
+    else d.c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// np.sum(row * R) over n float32 products in NumPy's pairwise order, by ONE lane (the rare dense
+// path of worlds whose size the leaf layout of dense_values does not fit): blocks of at most 128
+// elements are summed with eight accumulators and combined ((0+1)+(2+3))+((4+5)+(6+7)), longer
+// ranges are split at n / 2 rounded down to a multiple of 8 (numpy/core/src/umath/loops_utils.h).
+__device__ __attribute__((noinline)) float pairwise_dot_one_lane(const float* __restrict__ row,
+                                              const float* __restrict__ R, int n) {
+  // the recursion written out: depth-first, left half before right half (depth <= 4 for n <= 1024)
+  struct frame { int lo, len, state; float left; };
+  frame st[8];
+  int top = 0;
+  st[0] = {0, n, 0, 0.0f};
+  float ret = 0.0f;
+  while (top >= 0) {
+    frame& f = st[top];
+    if (f.state == 0) {
+      if (f.len < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < f.len; ++i) res = res + ld_l2(row + f.lo + i) * ld_l2(R + f.lo + i);
+        ret = res;
+        --top;
+      } else if (f.len <= 128) {
+        float r8[8];
+        for (int k = 0; k < 8; ++k) r8[k] = ld_l2(row + f.lo + k) * ld_l2(R + f.lo + k);
+        int i = 8;
+        for (; i < f.len - (f.len % 8); i += 8)
+          for (int k = 0; k < 8; ++k)
+            r8[k] = r8[k] + ld_l2(row + f.lo + i + k) * ld_l2(R + f.lo + i + k);
+        float res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        for (; i < f.len; ++i) res = res + ld_l2(row + f.lo + i) * ld_l2(R + f.lo + i);
+        ret = res;
+        --top;
+      } else {
+        int n2 = f.len / 2;
+        n2 -= n2 % 8;
+        f.state = 1;
+        st[top + 1] = {f.lo, n2, 0, 0.0f};
+        ++top;
+      }
+    } else if (f.state == 1) {
+      int n2 = f.len / 2;
+      n2 -= n2 % 8;
+      f.left = ret;
+      f.state = 2;
+      st[top + 1] = {f.lo + n2, f.len - n2, 0, 0.0f};
+      ++top;
+    } else {
+      ret = f.left + ret;
+      --top;
+    }
+  }
+  return ret;
 }
 
 // Element e of a row held in registers, as a wave-uniform value (e wave-uniform).
@@ -114,13 +172,16 @@ __device__ __forceinline__ const srw_args* rare_args() {
 // NV = S / 256 float4 per lane (S = 256, 512, 1024).  OCC: visit counts in LDS.  PSETS: per-
 // instance hyper-parameters.  Six waves per SIMD (80 registers): 24 rows of 4 KiB in flight per
 // CU, more than the ~64 KB per CU that 8 TB/s at 2 us of latency take.
-template <int NV, bool OCC, bool PSETS>
+// ANY_S: any state count that is a multiple of four up to NV * 256 (rows are float4 streams; the
+// register layout is the same, lanes past the end of a row hold zeros and neither load nor store).
+template <int NV, bool OCC, bool PSETS, bool ANY_S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
-  constexpr int S = NV * 256;
-  constexpr int NL = S / 128;   // leaves of NumPy's pairwise sum, all 128 long
+  const int S = ANY_S ? A.S : NV * 256;
+  const int quads = S >> 2;
+  constexpr int NL = NV * 2;   // !ANY_S: leaves of NumPy's pairwise sum, all 128 long
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x;
   const uint32_t g = A.r.instance_base + (uint32_t)i;
@@ -148,7 +209,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const float4* const R4 = reinterpret_cast<const float4*>(Rg) + lane;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const float4 v = R4[j * 64];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!ANY_S || j * 64 + lane < quads) v = R4[j * 64];
 #pragma unroll
       for (int comp = 0; comp < 4; ++comp) {
         const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
@@ -246,6 +308,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     wait_vm0();
     stored_state = -1;
     float qv[4];
+    if (ANY_S) {   // lane a < 4 sums row T[.][a] alone, in NumPy's order for this length
+      float acc = 0.0f;
+      if (lane < 4) acc = pairwise_dot_one_lane(SRg + (size_t)t_of(tq, lane) * S, Rg, S);
+      rows_read += 4u;
+      q0 = rlf(acc, 0); q1 = rlf(acc, 1); q2 = rlf(acc, 2); q3 = rlf(acc, 3);
+      return;
+    }
     const int l = lane >> 3, k = lane & 7;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -278,7 +347,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     tcur = load_trow(s);
     left_state = -1;
     if (learn) {
-      load_row<NV>(cur, SRg + (size_t)s * S, lane);
+      load_row<NV, ANY_S>(cur, SRg + (size_t)s * S, lane, quads);
       rows_read += 1u;
     }
     if (dense) {
@@ -348,7 +417,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // SR[ns] (sr.py:276-281): loaded, or — after a bump (ns == state) — the row in hand
     row_regs<NV> nxt = cur;
     if (learn && nt != 0u && ns != state) {
-      load_row<NV>(nxt, SRg + (size_t)ns * S, lane);
+      load_row<NV, ANY_S>(nxt, SRg + (size_t)ns * S, lane, quads);
       rows_read += 1u;
     }
     if (t_load) tnxt = ((uint64_t)rfl((uint32_t)(traw >> 32)) << 32) | (uint64_t)rfl((uint32_t)traw);
@@ -412,7 +481,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         o4.y = upd1(e + 1, cs4.y, cn4.y);
         o4.z = upd1(e + 2, cs4.z, cn4.z);
         o4.w = upd1(e + 3, cs4.w, cn4.w);
-        out[j * 64] = o4;
+        if (!ANY_S || j * 64 + lane < quads) out[j * 64] = o4;
         if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
           if (nz > 0 && (e0 >> 8) == j) {
             const int comp = e0 & 3;
@@ -499,31 +568,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   }
 }
 
-template <int NV, bool OCC, bool PSETS>
+template <int NV, bool OCC, bool PSETS, bool ANY_S>
 int launch(const srw_args& A, hipStream_t st) {
-  size_t lds = OCC ? (size_t)NV * 256 * 4 : 0;
+  size_t lds = OCC ? (size_t)A.S * 4 : 0;
   if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) {   // occupancy experiments
     lds += (size_t)atoi(pad);
     if (lds > 64 * 1024)
-      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      COBEL_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
-template <int NV>
+template <int NV, bool ANY_S>
 int launch_nv(const srw_args& A, bool occ, bool psets, hipStream_t st) {
-  if (psets) return occ ? launch<NV, true, true>(A, st) : launch<NV, false, true>(A, st);
-  return occ ? launch<NV, true, false>(A, st) : launch<NV, false, false>(A, st);
+  if (psets)
+    return occ ? launch<NV, true, true, ANY_S>(A, st) : launch<NV, false, true, ANY_S>(A, st);
+  return occ ? launch<NV, true, false, ANY_S>(A, st) : launch<NV, false, false, ANY_S>(A, st);
 }
 
 }  // namespace
 
 bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   const int S = world->n_states;
-  return (S == 256 || S == 512 || S == 1024) && world->max_rewarded_states <= 2 &&
+  // rows are streamed as float4 groups: any multiple of four up to 1 024 states (256 / 512 /
+  // 1 024 fill the register layout exactly and take instantiations without bounds checks)
+  return S >= 4 && S <= 1024 && S % 4 == 0 && world->max_rewarded_states <= 2 &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 
@@ -540,9 +613,11 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   const bool occ = r.occupancy != nullptr, psets = r.param_index != nullptr;
-  switch (world->n_states) {
-    case 256: return launch_nv<1>(A, occ, psets, st);
-    case 512: return launch_nv<2>(A, occ, psets, st);
-    default: return launch_nv<4>(A, occ, psets, st);
-  }
+  const int S = world->n_states;
+  if (S == 256) return launch_nv<1, false>(A, occ, psets, st);
+  if (S == 512) return launch_nv<2, false>(A, occ, psets, st);
+  if (S == 1024) return launch_nv<4, false>(A, occ, psets, st);
+  if (S < 256) return launch_nv<1, true>(A, occ, psets, st);
+  if (S < 512) return launch_nv<2, true>(A, occ, psets, st);
+  return launch_nv<4, true>(A, occ, psets, st);
 }

@@ -231,3 +231,71 @@ def test_wave_kernel_param_sets(torch_cuda):
         sel = torch.as_tensor(np.flatnonzero(which == k), device='cuda')
         assert torch.equal(mixed._sr[sel], uni._sr[sel]), k
         assert torch.equal(mixed._T[sel], uni._T[sel]) and torch.equal(mixed.inst[sel], uni.inst[sel])
+
+
+@pytest.mark.parametrize('h,w', [(2, 2), (4, 5), (10, 10), (12, 13), (20, 20), (24, 24), (30, 30)])
+def test_wave_kernel_any_multiple_of_four_states(torch_cuda, h, w):
+    """State counts that are multiples of four but not 256 / 512 / 1 024 take the bounds-checked
+    instantiations of k_sr_wave: identical tables, counters and monitors to the row-streaming
+    kernel on the same run, and the kernel-counted traffic says which one ran."""
+    torch = torch_cuda
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    S = h * w
+    assert S % 4 == 0
+    world = make_gridworld(h, w, terminals=[S - 1], rewards=np.array([[S - 1, 1.0], [1, -0.5]]),
+                           goals=[S - 1], invalid_transitions=[(0, 1), (1, 0)] if w > 2 else [])
+
+    def run(stream_rows):
+        env = Gridworld(world, n_envs=96, seed=11, instance_base=5)
+        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.2))
+        ag.track_instances = True
+        ag.track_occupancy = True
+        ag.stream_rows = stream_rows
+        ag.train(env, 5, 40)
+        ag.train(env, 2, 40)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (a, ea), (b, eb) = run(False), run(True)
+    assert int(a.traffic[1]) > 0 and int(b.traffic[1]) == 0     # wave kernel / row-streaming kernel
+    assert torch.equal(a._sr, b._sr) and torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
+    assert torch.equal(a.inst, b.inst) and torch.equal(ea.env_ctr, eb.env_ctr)
+    assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
+    assert torch.equal(a.monitors.occupancy, b.monitors.occupancy)
+
+
+def test_wave_kernel_any_size_with_many_reward_estimates(torch_cuda):
+    """More than two non-zero reward estimates (set by the caller; the world itself has two
+    rewarded states) on a size without the 128-element leaf layout: the kernel's one-lane pairwise
+    sums equal the row-streaming kernel's values, step for step."""
+    torch = torch_cuda
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    for h, w in ((10, 10), (18, 22), (3, 4)):
+        S = h * w
+        world = make_gridworld(h, w, terminals=[S - 1], rewards=np.array([[S - 1, 1.0]]), goals=[S - 1])
+
+        def run(stream_rows):
+            env = Gridworld(world, n_envs=40, seed=3)
+            ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+            ag.track_instances = True
+            ag.stream_rows = stream_rows
+            ag.train(env, 1, 3)                       # binds the tables
+            gen = torch.Generator(device='cuda').manual_seed(5)
+            ag._rw.copy_(torch.randn(ag._rw.shape, generator=gen, device='cuda') *
+                         (torch.rand(ag._rw.shape, generator=gen, device='cuda') < 0.3))
+            ag._sr.add_(torch.rand(ag._sr.shape, generator=gen, device='cuda') * 0.01)
+            ag.train(env, 4, 30)
+            torch.cuda.synchronize()
+            return ag
+
+        a, b = run(False), run(True)
+        assert int(a.traffic[3]) > 0                  # the dense path ran in the wave kernel
+        assert torch.equal(a._sr, b._sr) and torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
+        assert torch.equal(a.inst, b.inst)
+        assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
