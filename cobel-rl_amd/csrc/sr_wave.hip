@@ -619,5 +619,6 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   if (S == 1024) return launch_nv<4, false>(A, occ, psets, st);
   if (S < 256) return launch_nv<1, true>(A, occ, psets, st);
   if (S < 512) return launch_nv<2, true>(A, occ, psets, st);
+  if (S <= 768) return launch_nv<3, true>(A, occ, psets, st);
   return launch_nv<4, true>(A, occ, psets, st);
 }
