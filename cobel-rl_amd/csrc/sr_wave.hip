@@ -77,9 +77,21 @@ struct row_regs {
 };
 
 // (quads: float4 groups a row really has — S / 4; NV * 64 for the sizes the layout fills exactly)
+// (odd: the state count is not a multiple of four — rows are then not 16-byte aligned and end
+//  inside a group: its elements are moved one by one; only offered for S < 256, one group per lane)
 template <int NV, bool ANY_S>
 __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane,
-                                         int quads) {
+                                         int quads, int S, bool odd) {
+  if (ANY_S && NV == 1 && odd) {
+    const int e = lane * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e + 0 < S) v.x = src[e + 0];
+    if (e + 1 < S) v.y = src[e + 1];
+    if (e + 2 < S) v.z = src[e + 2];
+    if (e + 3 < S) v.w = src[e + 3];
+    d.c[0] = v;
+    return;
+  }
   const float4* const p = reinterpret_cast<const float4*>(src) + lane;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
+  const bool odd = ANY_S && NV == 1 && (S & 3) != 0;
   constexpr int NL = NV * 2;   // !ANY_S: leaves of NumPy's pairwise sum, all 128 long
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x;
@@ -210,7 +223,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!ANY_S || j * 64 + lane < quads) v = R4[j * 64];
+      if (odd) {
+        const int e = lane * 4;
+        if (e + 0 < S) v.x = Rg[e + 0];
+        if (e + 1 < S) v.y = Rg[e + 1];
+        if (e + 2 < S) v.z = Rg[e + 2];
+        if (e + 3 < S) v.w = Rg[e + 3];
+      } else if (!ANY_S || j * 64 + lane < quads) {
+        v = R4[j * 64];
+      }
 #pragma unroll
       for (int comp = 0; comp < 4; ++comp) {
         const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     tcur = load_trow(s);
     left_state = -1;
     if (learn) {
-      load_row<NV, ANY_S>(cur, SRg + (size_t)s * S, lane, quads);
+      load_row<NV, ANY_S>(cur, SRg + (size_t)s * S, lane, quads, S, odd);
       rows_read += 1u;
     }
     if (dense) {
@@ -417,7 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // SR[ns] (sr.py:276-281): loaded, or — after a bump (ns == state) — the row in hand
     row_regs<NV> nxt = cur;
     if (learn && nt != 0u && ns != state) {
-      load_row<NV, ANY_S>(nxt, SRg + (size_t)ns * S, lane, quads);
+      load_row<NV, ANY_S>(nxt, SRg + (size_t)ns * S, lane, quads, S, odd);
       rows_read += 1u;
     }
     if (t_load) tnxt = ((uint64_t)rfl((uint32_t)(traw >> 32)) << 32) | (uint64_t)rfl((uint32_t)traw);
@@ -481,7 +502,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         o4.y = upd1(e + 1, cs4.y, cn4.y);
         o4.z = upd1(e + 2, cs4.z, cn4.z);
         o4.w = upd1(e + 3, cs4.w, cn4.w);
-        if (!ANY_S || j * 64 + lane < quads) out[j * 64] = o4;
+        if (odd) {
+          float* const o1 = SRg + (size_t)state * S + e;
+          if (e + 0 < S) o1[0] = o4.x;
+          if (e + 1 < S) o1[1] = o4.y;
+          if (e + 2 < S) o1[2] = o4.z;
+          if (e + 3 < S) o1[3] = o4.w;
+        } else if (!ANY_S || j * 64 + lane < quads) {
+          out[j * 64] = o4;
+        }
         if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
           if (nz > 0 && (e0 >> 8) == j) {
             const int comp = e0 & 3;
@@ -596,7 +625,8 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   const int S = world->n_states;
   // rows are streamed as float4 groups: any multiple of four up to 1 024 states (256 / 512 /
   // 1 024 fill the register layout exactly and take instantiations without bounds checks)
-  return S >= 4 && S <= 1024 && S % 4 == 0 && world->max_rewarded_states <= 2 &&
+  // (state counts that are not multiples of four: up to 255, one element at a time)
+  return S >= 2 && S <= 1024 && (S % 4 == 0 || S < 256) && world->max_rewarded_states <= 2 &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 
