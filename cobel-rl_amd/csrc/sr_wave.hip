@@ -78,18 +78,21 @@ struct row_regs {
 
 // (quads: float4 groups a row really has — S / 4; NV * 64 for the sizes the layout fills exactly)
 // (odd: the state count is not a multiple of four — rows are then not 16-byte aligned and end
-//  inside a group: its elements are moved one by one; only offered for S < 256, one group per lane)
+//  inside a group: their elements are moved one by one)
 template <int NV, bool ANY_S>
 __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane,
                                          int quads, int S, bool odd) {
-  if (ANY_S && NV == 1 && odd) {
-    const int e = lane * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e + 0 < S) v.x = src[e + 0];
-    if (e + 1 < S) v.y = src[e + 1];
-    if (e + 2 < S) v.z = src[e + 2];
-    if (e + 3 < S) v.w = src[e + 3];
-    d.c[0] = v;
+  if (ANY_S && odd) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int e = (j * 64 + lane) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e + 0 < S) v.x = src[e + 0];
+      if (e + 1 < S) v.y = src[e + 1];
+      if (e + 2 < S) v.z = src[e + 2];
+      if (e + 3 < S) v.w = src[e + 3];
+      d.c[j] = v;
+    }
     return;
   }
   const float4* const p = reinterpret_cast<const float4*>(src) + lane;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
-  const bool odd = ANY_S && NV == 1 && (S & 3) != 0;
+  const bool odd = ANY_S && (S & 3) != 0;
   constexpr int NL = NV * 2;   // !ANY_S: leaves of NumPy's pairwise sum, all 128 long
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     for (int j = 0; j < NV; ++j) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (odd) {
-        const int e = lane * 4;
+        const int e = (j * 64 + lane) * 4;
         if (e + 0 < S) v.x = Rg[e + 0];
         if (e + 1 < S) v.y = Rg[e + 1];
         if (e + 2 < S) v.z = Rg[e + 2];
@@ -625,8 +628,10 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   const int S = world->n_states;
   // rows are streamed as float4 groups: any multiple of four up to 1 024 states (256 / 512 /
   // 1 024 fill the register layout exactly and take instantiations without bounds checks)
-  // (state counts that are not multiples of four: up to 255, one element at a time)
-  return S >= 2 && S <= 1024 && (S % 4 == 0 || S < 256) && world->max_rewarded_states <= 2 &&
+  // (state counts that are not multiples of four: rows move one element at a time, which beats
+  //  the row-streaming kernel up to ~640 states: 17x17 6.3e8 env-steps/s against 3.0e8, 25x25
+  //  3.3e8 against 2.8e8, 31x31 2.3e8 against 2.5e8 — scripts/exp_sr_sizes.py)
+  return S >= 2 && S <= 1024 && (S % 4 == 0 || S <= 640) && world->max_rewarded_states <= 2 &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 
@@ -647,8 +652,8 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   if (S == 256) return launch_nv<1, false>(A, occ, psets, st);
   if (S == 512) return launch_nv<2, false>(A, occ, psets, st);
   if (S == 1024) return launch_nv<4, false>(A, occ, psets, st);
-  if (S < 256) return launch_nv<1, true>(A, occ, psets, st);
-  if (S < 512) return launch_nv<2, true>(A, occ, psets, st);
+  if (S <= 256) return launch_nv<1, true>(A, occ, psets, st);
+  if (S <= 512) return launch_nv<2, true>(A, occ, psets, st);
   if (S <= 768) return launch_nv<3, true>(A, occ, psets, st);
   return launch_nv<4, true>(A, occ, psets, st);
 }

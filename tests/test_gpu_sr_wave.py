@@ -234,7 +234,7 @@ def test_wave_kernel_param_sets(torch_cuda):
 
 
 @pytest.mark.parametrize('h,w', [(2, 2), (4, 5), (10, 10), (12, 13), (20, 20), (24, 24), (30, 30),
-                                 (1, 3), (5, 5), (7, 9), (15, 17), (3, 7)])
+                                 (1, 3), (5, 5), (7, 9), (15, 17), (3, 7), (17, 17), (23, 25), (25, 25)])
 def test_wave_kernel_any_multiple_of_four_states(torch_cuda, h, w):
     """State counts other than 256 / 512 / 1 024 — multiples of four up to 1 024, anything below
     256 (rows moved element by element) — take the bounds-checked instantiations of k_sr_wave: identical tables, counters and monitors to the row-streaming
@@ -276,7 +276,7 @@ def test_wave_kernel_any_size_with_many_reward_estimates(torch_cuda):
     from cobel_amd.interface import Gridworld
     from cobel_amd.misc.gridworld_tools import make_gridworld
     from cobel_amd.policy import EpsilonGreedy
-    for h, w in ((10, 10), (18, 22), (3, 4), (5, 5), (9, 11)):
+    for h, w in ((10, 10), (18, 22), (3, 4), (5, 5), (9, 11), (21, 27)):
         S = h * w
         world = make_gridworld(h, w, terminals=[S - 1], rewards=np.array([[S - 1, 1.0]]), goals=[S - 1])
 
