@@ -534,6 +534,14 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
     res['roofline'].update(extra)
+    if cfg['agent'] == 'dynaq':
+        res['roofline']['note'] = (
+            'algorithmic bytes = SURVEY 8d per env step (67 + 11 + 31 B per planning update).  On '
+            'young agents the kernel does not evaluate planning batches that cannot change a table: '
+            'instances whose Q and model reward estimates are still all zero (94 % of them after 512 '
+            'steps, 73 % after 2 560, scripts/exp_c3_zero_q.py) skip the batch, results bit-identical '
+            '(DESIGN.md section 4.1).  repeat_windows.value_last is the rate of trained agents, where '
+            'every update of every batch is evaluated')
     # global monitor sums (after the one collective): identical for any split of the instances
     res['monitors'] = {'trials_finished': int(sums.lat_cnt.sum()),
                        'escape_latency_sum': int(sums.lat_sum.sum()),
