@@ -462,7 +462,9 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
             elapsed = float(t.item())
         return elapsed, launch_ms, sums
 
+    batches_before = int(agent.batches_done.item()) if cfg['agent'] == 'dynaq' else 0
     elapsed, launch_ms, sums = window()
+    batches_timed = (int(agent.batches_done.item()) - batches_before) if cfg['agent'] == 'dynaq' else 0
     if sfma:
         replays = int(agent.replays_done.item()) - replays_before
     if cfg['agent'] == 'sr':
@@ -535,13 +537,17 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     }
     res['roofline'].update(extra)
     if cfg['agent'] == 'dynaq':
+        # (this rank's instances; counted by the kernel: cobel_tab_run_t.batches_done)
+        res['roofline']['planning_batches_drawn'] = steps_per_launch * args.steps
+        res['roofline']['planning_batches_evaluated'] = batches_timed
         res['roofline']['note'] = (
             'algorithmic bytes = SURVEY 8d per env step (67 + 11 + 31 B per planning update).  On '
             'young agents the kernel does not evaluate planning batches that cannot change a table: '
             'instances whose Q and model reward estimates are still all zero (94 % of them after 512 '
             'steps, 73 % after 2 560, scripts/exp_c3_zero_q.py) skip the batch, results bit-identical '
-            '(DESIGN.md section 4.1).  repeat_windows.value_last is the rate of trained agents, where '
-            'every update of every batch is evaluated')
+            '(DESIGN.md section 4.1); planning_batches_evaluated / _drawn are counted by the kernel '
+            'over the timed window.  repeat_windows.value_last is the rate of trained agents, where '
+            'nearly every batch is evaluated')
     # global monitor sums (after the one collective): identical for any split of the instances
     res['monitors'] = {'trials_finished': int(sums.lat_cnt.sum()),
                        'escape_latency_sum': int(sums.lat_sum.sum()),

@@ -140,7 +140,7 @@ class TabRun(C.Structure):
         ('alpha', C.c_double), ('gamma', C.c_double), ('epsilon', C.c_double),
         ('model_lr', C.c_double), ('seed', C.c_uint64),
         ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
-        ('mon_stripes', C.c_int32),
+        ('mon_stripes', C.c_int32), ('batches_done', C.c_void_p),
     ]
 
 

@@ -32,6 +32,9 @@ class TabularAgent(FusedAgent):
     def _alloc_tables(self) -> None:
         self._q = torch.zeros((self.n_envs, self.n_states, self.n_actions), dtype=torch.float32,
                               device=self.device)
+        # planning / replay batches the kernels evaluated (cobel_tab_run_t.batches_done): a Dyna-Q
+        # batch is drawn every learning step, but evaluated only if it can change a table
+        self.batches_done = torch.zeros(1, dtype=torch.int64, device=self.device)
         if self._q_host is not None:
             self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
 
@@ -95,6 +98,7 @@ class TabularAgent(FusedAgent):
         run.lat_trace = _lib.ptr(mon.lat_trace)
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done = _lib.ptr(mon.steps_done)
+        run.batches_done = _lib.ptr(self.batches_done)
         run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base = interface.instance_base

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
   uint32_t loglen = (uint32_t)inst[COBEL_I_LOG_LEN];
   uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
   double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO);
-  unsigned long long executed = 0;
+  unsigned long long executed = 0, batches = 0;
 
   const uint32_t flags = G.r.flags;
   const bool learn = flags & COBEL_F_LEARN;
@@ -448,8 +448,10 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     if (replay_each_step) {
       if (AGENT == COBEL_AGENT_DYNAQ) {
         plan_dynaq();
+        batches += 1ull;
       } else {
         if (loglen > 0u) {   // q.py:353-354: idx = rng.choice(len(M), batch_size), one vector draw
+          batches += 1ull;
           for (int j = 0; j < B; ++j) {
             const uint32_t idx =
                 cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, loglen);
@@ -476,7 +478,10 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
       }
       trial += 1;
       iflags &= ~1u;
-      if (episodic) plan_dynaq();   // dyna_q.py:210-211
+      if (episodic) {   // dyna_q.py:210-211
+        plan_dynaq();
+        batches += 1ull;
+      }
     } else {
       step += 1;
     }
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
   *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
   *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
   if (G.r.steps_done && executed) atomicAdd(G.r.steps_done, executed);
+  if (G.r.batches_done && batches) atomicAdd(G.r.batches_done, batches);
 }
 
 }  // namespace

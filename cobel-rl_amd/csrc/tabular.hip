@@ -540,6 +540,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 
   const int budget0 = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
   int budget = budget0;   // steps executed by this call = budget0 - budget
+  uint32_t batches = 0u;  // batches evaluated (a per-lane register on purpose: the loop is short
+  asm volatile("" : "+v"(batches));   // of scalar ones)
 #if defined(COBEL_STAMPS)
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
           idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
           mg_next = (uint32_t)Mg[idx_next];
           if (iflags & 2u) {   // (COBEL_IF_NONZERO: otherwise no update of the batch can move Q)
+            batches += 1u;
             if (__builtin_expect((m & 0x8000u) != 0u, 0))
               r = __builtin_bit_cast(float, model32[2u * idx_cur]);
             if (idx_cur == fresh_idx) r = fresh_r;
@@ -735,7 +738,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         mrec = mrec_next;
         cm += 1u;
       } else if (AGENT == COBEL_AGENT_DYNAQ) {
-        if (iflags & 2u) plan_dynaq_batch(mdraw, fresh_idx, fresh_r);
+        if (iflags & 2u) {
+          plan_dynaq_batch(mdraw, fresh_idx, fresh_r);
+          batches += 1u;
+        }
         cm += 1u;
       } else {
         // experiences of the next batch are gathered now, behind this batch's updates
@@ -747,6 +753,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         if (bound_now > 0u) {
           if (lane < B && cobel_bounded(qx, bound_now) == fresh_idx) qrec = fresh_rec;
           replay_log(qrec);
+          batches += 1u;
         }
         cm += 1u;
         qx = qx_next;
@@ -771,7 +778,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       iflags &= ~1u;
       if (episodic && B > 0) {
         refresh_draws(cp >> 2);
-        if (iflags & 2u) plan_dynaq_batch(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
+        if (iflags & 2u) {
+          plan_dynaq_batch(cobel_word(blk, cm & 3u), fresh_idx, fresh_r);
+          batches += 1u;
+        }
         cm += 1u;
       }
       if (!begin_trial()) break;
@@ -814,6 +824,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
     *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
     if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
+    if (A.r.batches_done && batches) atomicAdd(A.r.batches_done, (unsigned long long)batches);
   }
 }
 

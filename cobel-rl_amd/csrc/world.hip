@@ -23,7 +23,7 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1010; }
+extern "C" int cobel_abi_version(void) { return 1011; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {

@@ -320,6 +320,12 @@ typedef struct {
                             and workgroup b adds into copy b % mon_stripes (spreads the atomics of
                             many instances finishing the same trials over L2 channels); the caller
                             sums the copies.  0 or 1: one copy.                                 */
+  unsigned long long* batches_done; /* [1] or NULL: planning / replay batches EVALUATED by this call
+                            (added).  A Dyna-Q batch is drawn in every learning step but evaluated
+                            only if it can change a table: not while the instance's Q and the
+                            reward estimates of its model are all +0.0f (every update of such a
+                            batch is 0 + alpha (0 + gamma nt 0 - 0) = 0).  steps_done minus this is
+                            the number of batches skipped that way (episodic replay: per trial).  */
 } cobel_tab_run_t;
 
 /* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —

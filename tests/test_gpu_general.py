@@ -267,3 +267,44 @@ def test_dqn_on_hexagonal_topology(torch_cuda):
     assert int(vec.M.actions.max().item()) == 5
     for a, b in zip(vec._online.get_weights(2), one._online.get_weights(0)):
         assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_batches_done_counts_what_planning_evaluates(torch_cuda):
+    """cobel_tab_run_t.batches_done: a Dyna-Q batch is drawn in every learning step but evaluated
+    only once the instance's Q or its model's reward estimates hold something other than +0.0f.
+    In a world without rewards nothing is ever evaluated (and Q stays zero); with a reward, the
+    evaluated batches are the steps from the first rewarded one on; the general kernel and
+    Q-learning's log replay evaluate every batch."""
+    torch = torch_cuda
+    from cobel_amd.agent import DynaQ, QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    bare = make_gridworld(4, 4, terminals=[15], rewards=np.array([[15, 0.0]]), goals=[15])
+    env = Gridworld(bare, n_envs=70, seed=1)
+    ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.3))
+    ag.train(env, 3, 20, 16)
+    steps = int(ag.monitors.steps_done.item())
+    assert steps > 0 and int(ag.batches_done.item()) == 0 and float(ag._q.abs().max()) == 0.0
+    ag.force_general = True                          # the general kernel plans unconditionally
+    ag.train(env, 1, 20, 16)
+    assert int(ag.batches_done.item()) == int(ag.monitors.steps_done.item()) - steps
+    paid = make_gridworld(4, 4, terminals=[15], rewards=np.array([[15, 1.0]]), goals=[15])
+    env = Gridworld(paid, n_envs=70, seed=1)
+    ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.3))
+    ag.track_instances = True
+    ag.train(env, 6, 30, 16)
+    steps, evaluated = int(ag.monitors.steps_done.item()), int(ag.batches_done.item())
+    assert 0 < evaluated < steps
+    # an instance evaluates its batches from the step that first pays on: at least one batch per
+    # instance that has been rewarded, at most its steps after the first trial's first step
+    rewarded = int((ag._q.abs().amax(dim=(1, 2)) > 0).sum())
+    assert rewarded > 0 and evaluated >= rewarded
+    never = ag._q.abs().amax(dim=(1, 2)) == 0
+    if bool(never.any()):     # instances that never reached the goal contributed nothing
+        lat = ag.monitors.lat_trace[:, :6] + 1
+        assert evaluated <= steps - int(lat[never].sum())
+    env = Gridworld(paid, n_envs=3, seed=2)
+    qa = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.3))
+    qa.train(env, 2, 10, 8)
+    assert int(qa.batches_done.item()) == int(qa.monitors.steps_done.item())
