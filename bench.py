@@ -62,7 +62,7 @@ CONFIGS = {
     # (512 steps per launch: loading and storing the 16 KiB Q table of an instance once per launch
     #  is 2 GB of traffic for 65 536 instances; at 256 steps per launch C3 runs 3 % slower)
     'C3': dict(instances=65536, env_steps_per_launch=512, steps_per_trial=200, batch=50,
-               bytes_per_step=1628, agent='dynaq', limiter='issue',
+               bytes_per_step=1628, agent='dynaq', limiter='issue', train_until=0.95,
                desc='65536 instances over 64 32x32 obstacle mazes (p_wall .20, seeds 1234..1297), '
                     'Dyna-Q (alpha .99, gamma .99, eps .1, model lr .9), 50 planning updates/step, '
                     '200 steps/trial'),
@@ -160,51 +160,71 @@ def _mlp(n_in, n_out, dtype_name='f64'):
     return net.double() if dtype_name == 'f64' else net.float()
 
 
-def run_next_rows(device):
-    """SURVEY.md §8f rows beside SFMA (C6), each with its own number: rank 1 Dyna-DQN and Dyna-DSR
-    (demo/gridworld/demo_dyna_dqn.py / demo_dyna_dsr.py: 5x5 open field, one-hot inputs, 64-64
-    float64 networks, gamma .8, batch 32, 50 steps/trial) with one set of networks per instance;
-    rank 4 the grid search with all combinations x runs as instances of one launch."""
-    import tempfile
-    from cobel_amd.agent import DynaDQN, DynaDSR, DynaQ
+def _timed_network_agent(agent, env, n, iters, device, warm=4):
+    agent._run(env, 4096, 50, 32, True, budget=warm)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    agent._run(env, 4096, 50, 32, True, budget=iters)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
+            'dtype': 'f64'}
+
+
+def _hbm_roofline(bytes_per_step, value, kernel, limiter, note=None):
+    gbs = bytes_per_step * value / 1e9
+    r = {'bound': 'hbm', 'limiter': limiter, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'kernel': kernel,
+         'algorithmic_bytes_per_env_step': bytes_per_step}
+    if note:
+        r['note'] = note
+    return r
+
+
+def run_dyna_dqn(device, n=8192, iters=128):
+    """SURVEY.md §8f rank 1 (demo/gridworld/demo_dyna_dqn.py: 5x5 open field, one-hot inputs, a
+    25-64-64-4 float64 network per instance, gamma .8, model-sampled batches of 32)."""
+    from cobel_amd.agent import DynaDQN
     from cobel_amd.interface import Gridworld
     from cobel_amd.misc.gridworld_tools import make_open_field
     from cobel_amd.network import TorchNetwork
-    from cobel_amd.optimizer import GridSearchOptimizer, spread_over_instances
     from cobel_amd.policy import EpsilonGreedy
-    out = {}
     torch.manual_seed(0)
-
-    def timed(agent, env, n, iters, warm=4):
-        agent._run(env, 4096, 50, 32, True, budget=warm)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        agent._run(env, 4096, 50, 32, True, budget=iters)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
-        return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
-                'dtype': 'f64', 'roofline': None}
-
-    n = 8192
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 4)), gamma=0.8)
-    timed(agent, env, n, 128)          # (warm-up of the timed length, as for C5)
-    r = timed(agent, env, n, 128)
+    _timed_network_agent(agent, env, n, iters, device)   # (warm-up of the timed length, as for C5)
+    r = _timed_network_agent(agent, env, n, iters, device)
+    fused = agent.fused_steps > 0
     r['config'] = {'workload': 'Dyna-DQN: %d x 5x5 open field, MLP 25-64-64-4 f64 per instance, '
                                'model-sampled batches of 32, %s' % (
                                    n, 'two launches per lockstep step: cobel_dqn_act (world-model '
-                                   'mode) + cobel_dqn_replay' if agent.fused_steps else
-                                   'PyTorch-ROCm loop'),
-                   'instances_per_gpu': n, 'lockstep_iterations': 128}
-    out['dyna_dqn'] = r
-    del agent, env
+                                   'mode) + cobel_dqn_replay' if fused else 'PyTorch-ROCm loop'),
+                   'instances_per_gpu': n, 'lockstep_iterations': iters}
+    # cobel_dqn_replay: 8 streams over the instance's parameters (online, two Adam moments, target:
+    # read + write) + the batch: 32 sampled model records (8 B) and their one-hot rows are indices
+    n_params = sum(p.numel() for p in agent.model_online.model.parameters())
+    bytes_per_step = 8 * n_params * 8 + 32 * 8 + 78
+    r['roofline'] = _hbm_roofline(bytes_per_step, r['value'], 'k_dqn_replay', 'latency',
+                                  '8 parameter streams of 8 B x %d parameters + 32 model records + '
+                                  'the online step (78 B); one workgroup per CU at 25 inputs (93 KB '
+                                  'of LDS, DESIGN.md section 4.4)' % n_params)
+    return r
 
-    n = 8192
+
+def run_dyna_dsr(device, n=8192, iters=48):
+    """SURVEY.md §8f rank 1 (demo/gridworld/demo_dyna_dsr.py): four online + four target successor
+    networks 25-64-64-25 and one reward network per instance, float64."""
+    from cobel_amd.agent import DynaDSR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    torch.manual_seed(0)
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 25)), TorchNetwork(_mlp(25, 1)), gamma=0.8)
-    r = timed(agent, env, n, 48, warm=8)
+    r = _timed_network_agent(agent, env, n, iters, device, warm=8)
     fused = agent.fused_steps > 0
     r['config'] = {'workload': 'Dyna-DSR: %d x 5x5 open field, four online + four target successor '
                                'networks 25-64-64-25 and one reward network f64 per instance, batches '
@@ -212,29 +232,32 @@ def run_next_rows(device):
                                               'cobel_mlp_forward, 2 x cobel_mlp_fit) + elementwise '
                                               'torch for the targets, 8 steps per HIP graph' if fused
                                               else 'PyTorch-ROCm loop, one step per HIP graph'),
-                   'instances_per_gpu': n, 'lockstep_iterations': 48}
-    if fused:
-        # per instance and step: the four online successor networks move 8 streams over their
-        # parameters (p, m, v, target: read + write), the reward network 6 (no target), and the
-        # forward passes read the four target networks and the reward network once more
-        p_sr = sum(p.numel() for p in agent.models_online[0].model.parameters())
-        p_rw = sum(p.numel() for p in agent.model_reward.model.parameters())
-        bytes_per_step = (4 * 8 * p_sr + 6 * p_rw + 4 * p_sr + p_rw) * 8
-        gbs = bytes_per_step * r['value'] / 1e9
-        r['roofline'] = {'bound': 'hbm', 'limiter': 'latency', 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'k_mlp_fit', 'algorithmic_bytes_per_env_step': bytes_per_step,
-                         'note': 'one workgroup per CU: a 25-64-64-25 float64 network needs 107 KB '
-                                 'of LDS (DESIGN.md section 4.4b)'}
-    out['dyna_dsr'] = r
-    del agent, env
+                   'instances_per_gpu': n, 'lockstep_iterations': iters}
+    # per instance and step: the four online successor networks move 8 streams over their
+    # parameters (p, m, v, target: read + write), the reward network 6 (no target), and the
+    # forward passes read the four target networks and the reward network once more
+    p_sr = sum(p.numel() for p in agent.models_online[0].model.parameters())
+    p_rw = sum(p.numel() for p in agent.model_reward.model.parameters())
+    bytes_per_step = (4 * 8 * p_sr + 6 * p_rw + 4 * p_sr + p_rw) * 8
+    r['roofline'] = _hbm_roofline(bytes_per_step, r['value'], 'k_mlp_fit' if fused else 'torch',
+                                  'latency', 'DESIGN.md section 4.4b')
+    return r
 
-    # grid search: learning_rate x gamma x epsilon, every combination x run one instance
+
+def run_grid_search(device, runs=16):
+    """learning_rate x gamma x epsilon, every combination x run one instance
+    of ONE Dyna-Q launch (optimizer/grid_search.py:173-262 simulates them one at a time)."""
+    import tempfile
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.optimizer import GridSearchOptimizer, spread_over_instances
+    from cobel_amd.policy import EpsilonGreedy
     grid = {'learning_rate': list(np.linspace(0.1, 0.99, 16)), 'gamma': list(np.linspace(0.5, 0.99, 16)),
             'epsilon': [0.05, 0.1, 0.2, 0.3]}
-    runs, trials, steps = 16, 50, 50
+    trials, steps, batch = 50, 50, 32
     world = make_open_field(5, 5, 0, 1)
-    stats = {}
+    stats = {'env_steps': 0, 'batches': 0, 'kernel_ms': 0.0}
 
     def simulation_batch(task, combinations, nb_runs):
         arrays, which = spread_over_instances(combinations, nb_runs)
@@ -242,9 +265,14 @@ def run_next_rows(device):
         ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(arrays['epsilon']),
                    learning_rate=arrays['learning_rate'], gamma=arrays['gamma'])
         ag.track_instances = True
-        ag.train(env, trials, steps, 32)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ag.train(env, trials, steps, batch)
+        e1.record()
         lat = ag.monitors.lat_trace[:, :trials].double().mean(dim=1).cpu().numpy()
-        stats['env_steps'] = stats.get('env_steps', 0) + ag.env_steps()
+        stats['env_steps'] += ag.env_steps()
+        stats['batches'] += int(ag.batches_done.item())
+        stats['kernel_ms'] += e0.elapsed_time(e1)
         return [list(lat[which == c]) for c in range(len(combinations))]
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -256,15 +284,83 @@ def run_next_rows(device):
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
     combos = 16 * 16 * 4
-    out['grid_search'] = {
-        'value': combos * runs / dt, 'unit': 'simulations/s',
-        'env_steps_per_s': stats['env_steps'] / dt, 'seconds': dt,
-        'config': {'workload': 'GridSearchOptimizer.fit_vectorised: %d combinations x %d runs of '
-                               'Dyna-Q (5x5, 32 planning updates, %d trials x <= %d steps) as %d '
-                               'instances of one launch, files written as the reference does'
-                               % (combos, runs, trials, steps, combos * runs)},
-        'roofline': None}
-    return out
+    # SURVEY 8d by work done: 78 B per env step + 31 B per planning update of evaluated batches
+    alg = 78 * stats['env_steps'] + 31 * batch * stats['batches']
+    roof = _hbm_roofline(alg / max(1, stats['env_steps']), stats['env_steps'] / (stats['kernel_ms'] * 1e-3),
+                         'k_tab_wpi<DYNAQ, PSETS>', 'issue',
+                         'over the launch itself (HIP events around DynaQ.train: %.1f ms of the %.2f s '
+                         'the whole fit takes, the rest is the host enumerating combinations and '
+                         'writing the result files as the reference does); 5x5 tables are LDS '
+                         'resident' % (stats['kernel_ms'], dt))
+    return {'value': combos * runs / dt, 'unit': 'simulations/s',
+            'env_steps_per_s': stats['env_steps'] / dt, 'seconds': dt,
+            'env_steps_per_s_kernel': stats['env_steps'] / (stats['kernel_ms'] * 1e-3),
+            'config': {'workload': 'GridSearchOptimizer.fit_vectorised: %d combinations x %d runs of '
+                                   'Dyna-Q (5x5, 32 planning updates, %d trials x <= %d steps) as %d '
+                                   'instances of one launch, files written as the reference does'
+                                   % (combos, runs, trials, steps, combos * runs)},
+            'roofline': roof}
+
+
+def run_general(device, which, n=65536, env_steps=64, launches=4):
+    """What leaving the four-action / <= 62-update wavefront kernels costs:
+    `hex_q` = QAgent with a replay batch of 32 on a six-action hexagonal Topology
+    (misc/topology_tools.py:175-272) — k_tab_general, one lane per instance; `dynaq_b100` = Dyna-Q
+    on C3's mazes with 100 planning updates per step (agent/dyna_q.py:319-330 has no limit) — the
+    generic k_tab_wpi in two passes of <= 62 lanes."""
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ, QAgent
+    from cobel_amd.interface import Gridworld, Topology
+    from cobel_amd.misc.topology_tools import hexagonal
+    from cobel_amd.policy import EpsilonGreedy
+    if which == 'hex_q':
+        nodes, starts = hexagonal(16)
+        env = Topology(nodes, starts, n_envs=n, seed=SEED, device=device)
+        agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        batch, spt, A = 32, 100, int(env.action_space.n)
+        agent._bind(env)
+        agent.reserve_replay(env_steps * (launches + 2))
+        desc = ('QAgent (alpha .9, gamma .8, eps .1, replay batch 32 from the experience log) on a '
+                'hexagonal Topology of %d nodes, %d actions' % (len(nodes), A))
+        # online step: state r/w 8 + Q[s,:] 4A + next 2 + reward 4 + terminal 1 + Q[ns,:] 4A +
+        # Q[s,a] write 4 + counters 16, log append 8; one replayed update: record 8 + Q[ns,:] 4A +
+        # Q[s,a] RMW 8
+        b_step, b_upd = 8 + 4 * A + 2 + 4 + 1 + 4 * A + 4 + 16 + 8, 8 + 4 * A + 8
+    else:
+        env = Gridworld(make_worlds('C3'), n_envs=n, seed=SEED, device=device)
+        agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        batch, spt = 100, 200
+        desc = 'Dyna-Q on the 64 32x32 mazes of C3 with 100 planning updates per step'
+        b_step, b_upd = 78, 31
+    cfg = dict(env_steps_per_launch=env_steps, steps_per_trial=spt, batch=batch)
+    runner = Runner(cfg, env, agent)
+    for _ in range(2):
+        runner.launch()
+    torch.cuda.synchronize(device)
+    b0 = int(agent.batches_done.item())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    ev[0].record()
+    for k in range(launches):
+        runner.launch()
+        ev[k + 1].record()
+    torch.cuda.synchronize(device)
+    ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(launches)]
+    batches = int(agent.batches_done.item()) - b0
+    steps = n * env_steps * launches
+    sec = sum(ms) * 1e-3
+    what = runner.describe()
+    names = {_lib.TAB_KERNEL_GENERAL: 'k_tab_general', _lib.TAB_KERNEL_WPI: 'k_tab_wpi (generic, %d '
+             'passes)' % -(-batch // _lib.MAX_BATCH)}
+    kernel = names.get(what['kernel'], 'kernel %d' % what['kernel'])
+    alg = b_step * steps + b_upd * batch * batches
+    roof = _hbm_roofline(alg / steps, steps / sec, kernel,
+                         'latency' if what['kernel'] == _lib.TAB_KERNEL_GENERAL else 'issue',
+                         '%d B per env step + %d B per replayed / planned update of the batches the '
+                         'kernel evaluated (%d of %d drawn)' % (b_step, b_upd, batches, steps))
+    return {'value': steps / sec, 'unit': 'env-steps/s', 'ms_per_step': float(np.mean(ms)),
+            'td_updates_per_s': (steps + batch * batches) / sec, 'dtype': 'f32',
+            'config': {'workload': desc, 'instances_per_gpu': n, 'env_steps_per_launch': env_steps},
+            'roofline': roof}
 
 
 def make_worlds(cfg_name):
@@ -329,7 +425,7 @@ class Runner:
 
     def describe(self):
         """Kernel variant / LDS footprint of the launches (tabular agents: cobel_tab_describe)."""
-        if not hasattr(self.agent, 'describe_launch'):
+        if getattr(self.agent, 'describe_launch', None) is None:
             return None
         c = self.cfg
         return self.agent.describe_launch(self.env, self.agent.policy, self.flags, 0x7fffffff,
@@ -420,18 +516,52 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     # and 12 ms in the first launch, 4.66e7 and 28.7 ms from the ~30th on
     # (scripts/exp_c6_trend.py).  The timed window starts in that steady state.
     warm = max(args.warmup, cfg.get('min_warmup', 0))
+    dynaq = cfg['agent'] == 'dynaq'
+    per_launch = n * cfg['env_steps_per_launch']          # env steps = planning batches drawn
     first_ms = None
+    warm_ev, warm_batches = [], []      # per warm-up launch: HIP events, evaluated-batch counter
+
+    def warm_launch():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        runner.launch()
+        e1.record()
+        warm_ev.append((e0, e1))
+        if dynaq:
+            warm_batches.append(agent.batches_done.clone())
+
+    def evaluated_fraction(k):
+        """planning batches evaluated / drawn in warm-up launch k (this rank; all ranks' minimum
+        when there are several, so that every rank leaves the warm-up after the same launch)"""
+        prev = int(warm_batches[k - 1].item()) if k else 0
+        f = (int(warm_batches[k].item()) - prev) / max(1, per_launch)
+        if dist is not None:
+            t = torch.tensor([f], dtype=torch.float64,
+                             device='cpu' if dist.get_backend() == 'gloo' else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            f = float(t.item())
+        return f
+
     for k in range(warm):
-        if k == 0:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            runner.launch()
-            e1.record()
-            torch.cuda.synchronize(device)
-            first_ms = e0.elapsed_time(e1)
-        else:
-            runner.launch()
+        warm_launch()
     torch.cuda.synchronize(device)
+    # C3: a Dyna-Q kernel does not evaluate a planning batch that cannot change a table (an
+    # instance whose Q and reward estimates are still all +0.0f, DESIGN.md section 4.1), so young
+    # agents are cheaper per env step than trained ones.  The timed window is the FULL-WORK state:
+    # untimed pre-training until the kernel itself reports that >= train_until of the batches it
+    # draws are evaluated (checked every 8 launches, at most --max-pretrain launches).
+    frac_at_start = None
+    if dynaq and cfg.get('train_until') and not args.no_pretrain:
+        while warm > 0 and len(warm_ev) < args.max_pretrain:
+            frac_at_start = evaluated_fraction(len(warm_ev) - 1)
+            if frac_at_start >= cfg['train_until']:
+                break
+            for _ in range(8):
+                warm_launch()
+            torch.cuda.synchronize(device)
+        warm = len(warm_ev)
+    if warm_ev:
+        first_ms = warm_ev[0][0].elapsed_time(warm_ev[0][1])
     before = agent.monitors.all_reduce().steps_done       # (global; untimed)
     sfma = cfg['agent'] == 'sfma'
     replays_before = int(agent.replays_done.item()) if sfma else 0
@@ -462,9 +592,9 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
             elapsed = float(t.item())
         return elapsed, launch_ms, sums
 
-    batches_before = int(agent.batches_done.item()) if cfg['agent'] == 'dynaq' else 0
+    batches_before = int(agent.batches_done.item()) if dynaq else 0
     elapsed, launch_ms, sums = window()
-    batches_timed = (int(agent.batches_done.item()) - batches_before) if cfg['agent'] == 'dynaq' else 0
+    batches_timed = (int(agent.batches_done.item()) - batches_before) if dynaq else 0
     if sfma:
         replays = int(agent.replays_done.item()) - replays_before
     if cfg['agent'] == 'sr':
@@ -484,6 +614,11 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     steps_per_launch = n * cfg['env_steps_per_launch']           # this rank's launches
     sec8d_bytes_per_launch = cfg['bytes_per_step'] * steps_per_launch
     alg_bytes_per_launch, extra = sec8d_bytes_per_launch, {}
+    if dynaq:
+        # work DONE, not work drawn: SURVEY 8d's b0 + bm = 78 B per env step and br = 31 B per
+        # planning update of the batches the kernel evaluated (counted by the kernel)
+        alg_bytes_per_launch = (78 * steps_per_launch
+                                + 31 * cfg['batch'] * batches_timed // args.steps)
     if sfma:   # reactivations per launch depend on the trial lengths: count them (this rank)
         alg_bytes_per_launch += cfg['bytes_per_reactivation'] * replays // args.steps
     kernel = {'q': 'k_tab_lpi', 'dynaq': 'k_tab_wpi<DYNAQ>', 'sr': 'k_sr', 'sfma': 'k_sfma'}[cfg['agent']]
@@ -536,18 +671,38 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
     res['roofline'].update(extra)
-    if cfg['agent'] == 'dynaq':
+    if dynaq:
         # (this rank's instances; counted by the kernel: cobel_tab_run_t.batches_done)
-        res['roofline']['planning_batches_drawn'] = steps_per_launch * args.steps
+        drawn = steps_per_launch * args.steps
+        res['roofline']['planning_batches_drawn'] = drawn
         res['roofline']['planning_batches_evaluated'] = batches_timed
+        res['roofline']['evaluated_fraction'] = batches_timed / max(1, drawn)
+        res['roofline']['sec8d_bytes_per_env_step'] = cfg['bytes_per_step']
         res['roofline']['note'] = (
-            'algorithmic bytes = SURVEY 8d per env step (67 + 11 + 31 B per planning update).  On '
-            'young agents the kernel does not evaluate planning batches that cannot change a table: '
-            'instances whose Q and model reward estimates are still all zero (94 % of them after 512 '
-            'steps, 73 % after 2 560, scripts/exp_c3_zero_q.py) skip the batch, results bit-identical '
-            '(DESIGN.md section 4.1); planning_batches_evaluated / _drawn are counted by the kernel '
-            'over the timed window.  repeat_windows.value_last is the rate of trained agents, where '
-            'nearly every batch is evaluated')
+            'algorithmic bytes = SURVEY 8d by work done: 78 B per env step (b0 + bm) + 31 B per '
+            'planning update of the batches the kernel EVALUATED (cobel_tab_run_t.batches_done); a '
+            'batch drawn for an instance whose Q and reward estimates are still all +0.0f cannot '
+            'change a table and is skipped, bit-identically (DESIGN.md section 4.1).  The timed '
+            'window starts after untimed pre-training (`pretraining`) so that nearly every batch '
+            'is evaluated: value / ms_per_step / frac are full-work numbers; `young_agents` is the '
+            'rate of the first launches after one warm-up launch')
+        pre = {'launches': warm, 'env_steps_per_instance': warm * cfg['env_steps_per_launch'],
+               'evaluated_fraction_at_start': frac_at_start,
+               'train_until': None if args.no_pretrain else cfg.get('train_until'),
+               'note': 'untimed; the agents learn exactly as in the timed window'}
+        res['pretraining'] = pre
+        k_young = [k for k in range(1, min(5, len(warm_ev)))]
+        if k_young:
+            ms = [warm_ev[k][0].elapsed_time(warm_ev[k][1]) for k in k_young]
+            ev = int(warm_batches[k_young[-1]].item()) - int(warm_batches[0].item())
+            b = 78 * steps_per_launch * len(k_young) + 31 * cfg['batch'] * ev
+            res['young_agents'] = {
+                'launches': '2..%d' % (k_young[-1] + 1), 'launch_ms_mean': float(np.mean(ms)),
+                'value_this_rank': steps_per_launch * len(k_young) / (sum(ms) * 1e-3),
+                'evaluated_fraction': ev / (steps_per_launch * len(k_young)),
+                'frac': b / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'note': 'agents 1..%d x %d steps old: most instances have not met a reward yet and '
+                        'skip their planning batches' % (k_young[-1] + 1, cfg['env_steps_per_launch'])}
     # global monitor sums (after the one collective): identical for any split of the instances
     res['monitors'] = {'trials_finished': int(sums.lat_cnt.sum()),
                        'escape_latency_sum': int(sums.lat_sum.sum()),
@@ -579,6 +734,30 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     return res, cfg
 
 
+def spawn_ranks(argv, n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH processes through
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.
+    Called before anything in this process has touched the GPU; this process never does."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = int(sock.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    return proc.returncode if (proc.returncode or lines) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -595,18 +774,31 @@ def main():
                     help='every rank runs the full instance count (default: the instances of the '
                          'configuration are split over the ranks, BASELINE config 3)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='gloo: rehearse several ranks on one GPU (LOCAL_RANK is ignored)')
+                    help='gloo: rehearse several ranks on one GPU (ranks share the cards round robin)')
     ap.add_argument('--instances', type=int, default=0)
     ap.add_argument('--env-steps', type=int, default=0)
+    ap.add_argument('--scale', type=float, default=1.0,
+                    help='multiply the instance count of EVERY leg (tests: all legs in seconds)')
+    ap.add_argument('--no-pretrain', action='store_true',
+                    help='C3: time the window right after --warmup launches (young agents)')
+    ap.add_argument('--max-pretrain', type=int, default=400,
+                    help='C3: upper bound of the untimed pre-training, in launches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-c5', action='store_true', help='skip the PyTorch DQN leg (profiling runs)')
+    ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(sys.argv[1:], args.gpus))   # (nothing here has touched the GPU yet)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    assert args.gpus == world_size, '--gpus must equal the number of launched ranks'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
-    device = torch.device('cuda', 0 if args.backend == 'gloo' else local_rank)
+    n_dev = torch.cuda.device_count()
+    assert args.backend == 'gloo' or local_rank < n_dev, \
+        'rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank' % (local_rank, n_dev)
+    device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     dist = None
     if world_size > 1:
@@ -616,8 +808,12 @@ def main():
             dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
         else:   # rehearsal of the N > 1 path with several ranks on ONE GPU (tests)
             dist.init_process_group(args.backend)
-    assert args.gpus == world_size, '--gpus must equal the number of launched ranks'
 
+    def scaled(count):
+        return max(64, int(round(count * args.scale))) if args.scale != 1.0 else count
+
+    for c in CONFIGS.values():
+        c['instances'] = scaled(c['instances'])
     res, cfg = run_config(args.config, args, rank, world_size, device, dist, args.min_seconds)
     others = {}
     if world_size == 1 and not args.instances and args.also:
@@ -639,18 +835,24 @@ def main():
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
-        for dt_name in (() if args.no_c5 else ('f64', 'f32')):
+        legs = [] if args.no_c5 else [
+            ('C5_f64', lambda: run_c5(device, 'f64', n=scaled(8192))),
+            ('C5_f32', lambda: run_c5(device, 'f32', n=scaled(8192))),
+            ('dyna_dqn', lambda: run_dyna_dqn(device, scaled(8192))),
+            ('dyna_dsr', lambda: run_dyna_dsr(device, scaled(8192))),
+            ('grid_search', lambda: run_grid_search(device, 16 if args.scale == 1.0 else 4)),
+            ('general_hex_q', lambda: run_general(device, 'hex_q', scaled(65536))),
+            ('general_dynaq_b100', lambda: run_general(device, 'dynaq_b100', scaled(65536))),
+        ]
+        for name, leg in legs:
             try:
-                others['C5_' + dt_name] = run_c5(device, dt_name)
-            except Exception as e:
-                others['C5_' + dt_name] = {'error': '%s: %s' % (type(e).__name__, e)}
-        if not args.no_c5:
-            try:
-                others.update(run_next_rows(device))
+                others[name] = leg()
             except Exception as e:
                 import traceback
                 traceback.print_exc()      # (stderr: the JSON line on stdout stays one line)
-                others['next_rows'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+            gc.collect()
+            torch.cuda.empty_cache()
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.config, cfg)

@@ -34,9 +34,15 @@ class QAgent(TabularAgent):
         self._log = None
         self._log_cap = 0
         # The reference appends every experience to ``M`` whether or not it replays (q.py:213), so
-        # a later session with batch_size > 0 samples from all of them.  False: sessions with
-        # batch_size 0 keep no log (8 B per instance and step saved).
-        self.log_experiences = True
+        # a later session with batch_size > 0 samples from all of them.  On device that is 8 B per
+        # instance and step — of HBM for the log ([N, trials * steps] int64, reserved up front) and
+        # of write traffic in the kernel that otherwise only touches LDS.  None (default): sessions
+        # with batch_size 0 log while the log stays within ``log_budget_bytes`` and otherwise run
+        # without one, with a warning (65 536 instances x 100 trials x 200 steps would reserve
+        # 10 TB); True: always log (the reservation may fail); False: never log at batch_size 0.
+        self.log_experiences = None
+        self.log_budget_bytes = 4 << 30
+        self._log_now = True
 
     def reserve_replay(self, entries: int) -> None:
         """Make room for ``entries`` logged experiences per instance (8 B each)."""
@@ -71,15 +77,26 @@ class QAgent(TabularAgent):
         return {(i,): q[i] for i in range(q.shape[0])}
 
     def _extra(self, run) -> None:
-        keep = run.batch > 0 or self.log_experiences
+        keep = run.batch > 0 or self._log_now
         run.replay_log = _lib.ptr(self._log) if keep else None
         run.log_cap = self._log_cap if keep else 0
 
     def train(self, interface, trials: int, steps: int = 32, batch_size: int = 32) -> None:
         assert batch_size >= 0     # (above _lib.MAX_BATCH: the general kernel, any size)
         self._bind(interface)
-        if batch_size > 0 or self.log_experiences:
-            used = int(self.inst[:, _lib.I_LOG_LEN].max().item())
+        used = int(self.inst[:, _lib.I_LOG_LEN].max().item())
+        need = (used + trials * steps) * 8 * self.n_envs
+        self._log_now = bool(self.log_experiences) or (
+            self.log_experiences is None and (need <= self.log_budget_bytes
+                                              or (used + trials * steps) <= self._log_cap))
+        if batch_size == 0 and self.log_experiences is None and not self._log_now:
+            import warnings
+            warnings.warn('QAgent.train(batch_size=0): logging every experience of this session '
+                          'would reserve %.1f GB (%d instances x %d steps x 8 B, log_budget_bytes = '
+                          '%.1f GB); the session runs without the log.  Set log_experiences = True '
+                          'to force it, False to silence this.'
+                          % (need / 1e9, self.n_envs, trials * steps, self.log_budget_bytes / 1e9))
+        if batch_size > 0 or self._log_now:
             self.reserve_replay(used + trials * steps)
         self._session(interface, trials, steps, batch_size, True)
 

@@ -36,6 +36,7 @@ class CallbacksSFMA(Callbacks):
 
 class SFMA(TabularAgent):
     CallbacksSFMA = CallbacksSFMA
+    describe_launch = None     # (cobel_tab_describe covers cobel_tab_run; SFMA has its own kernel)
 
     def __init__(self, observation_space, action_space, policy, memory, policy_test=None,
                  learning_rate: float = 0.99, gamma: float = 0.99, custom_callbacks=None,

@@ -13,7 +13,8 @@ from conftest import free_port
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--also', '', '--min-seconds', '0']
+COMMON = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--also', '', '--no-pretrain',
+          '--min-seconds', '0']
 
 
 def _line(out: str) -> dict:
@@ -63,3 +64,69 @@ def test_weak_scaling_option_runs_the_full_count_per_rank():
     rep = r['repeat_windows']
     assert rep['count'] >= 1 and rep['seconds'] >= 0.2 and r['steps'] == 2
     assert rep['ms_per_step_min'] <= rep['ms_per_step_median'] <= rep['ms_per_step_max']
+
+
+def test_plain_invocation_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (as a driver may call it): bench.py
+    starts the two ranks itself, as fresh processes, and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    args = ['--config', 'C3', '--instances', '768', '--env-steps', '64'] + COMMON
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend',
+                          'gloo'] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = _line(one.stdout), _line(two.stdout)
+    assert b['n_gpus'] == 2 and b['config']['instances_per_gpu'] == 384
+    assert b['monitors']['collectives_in_timed_region'] == 1
+    for key in ('trials_finished', 'escape_latency_sum', 'trial_reward_sum'):
+        assert a['monitors'][key] == b['monitors'][key], key
+
+
+def test_two_gpus_over_rccl_report_the_same_monitors():
+    """The real collective: one rank per GPU, backend "nccl" (= RCCL).  Needs two cards."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU: RCCL needs one card per rank (the gloo tests rehearse the path)')
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    args = ['--config', 'C3', '--instances', '768', '--env-steps', '64'] + COMMON
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-2000:], two.stderr[-2000:])
+    a, b = _line(one.stdout), _line(two.stdout)
+    assert b['n_gpus'] == 2
+    assert a['monitors'] == dict(b['monitors'], collectives_in_timed_region=0)
+
+
+def test_every_default_leg_runs_and_carries_a_roofline():
+    """The default command at 1/50 of the instance counts: no leg may end in an "error" key (round
+    2's C6 leg did, unnoticed) and every leg states its roofline."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--scale', '0.02',
+                          '--steps', '2', '--warmup', '1', '--min-seconds', '0', '--max-pretrain',
+                          '24'], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out.stdout)
+    assert r['metric'].startswith('gridworld env-steps/sec') and r['n_gpus'] == 1
+    assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['cores'] == 1
+    roof = r['roofline']
+    assert 0 < roof['frac'] <= 1.0 and roof['planning_batches_evaluated'] <= roof['planning_batches_drawn']
+    # the bytes follow the work the kernel counted, not the work drawn
+    per_launch = r['config']['instances_per_gpu'] * r['config']['env_steps_per_launch']
+    want = 78 * per_launch + 31 * 50 * roof['planning_batches_evaluated'] // r['steps']
+    assert roof['algorithmic_bytes_per_launch'] == want
+    assert r['pretraining']['launches'] == r['warmup'] and 'young_agents' in r
+    legs = r['other_configs']
+    assert set(legs) >= {'C2', 'C4', 'C6', 'C5_f64', 'C5_f32', 'dyna_dqn', 'dyna_dsr', 'grid_search',
+                         'general_hex_q', 'general_dynaq_b100'}
+    for name, leg in legs.items():
+        assert 'error' not in leg, (name, leg)
+        assert leg['roofline'] is not None and leg['roofline']['frac'] > 0, name
+        assert leg['value'] > 0, name
