@@ -17,8 +17,10 @@ STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST, STREAM_AGENT = 0, 
 SUB_DOUBLE = 1
 AGENT_Q, AGENT_DYNAQ = 0, 1
 F_LEARN, F_NO_REPLAY, F_EPISODIC, F_MASK_ACTIONS, F_TEST_STREAM, F_FORCE_WAVE = 1, 2, 4, 8, 16, 32
-F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS, F_TAB_GENERAL = 64, 128, 256, 512
+F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS, F_TAB_GENERAL, F_NO_PWG = 64, 128, 256, 512, 1024
+F_PWG_GLOBAL = 2048
 TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX, TAB_KERNEL_GENERAL = range(5)
+TAB_KERNEL_PWG = 5
 MAX_BATCH = 62       # largest batch of the wavefront kernels; larger ones run on the general kernel
 MAX_ACTIONS = 8
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,

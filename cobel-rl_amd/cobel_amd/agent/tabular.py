@@ -17,6 +17,7 @@ class TabularAgent(FusedAgent):
     agent_kind = _lib.AGENT_Q
     general_actions = True     # cobel_tab_run's general kernel takes any action count
     force_general = False      # True: always the general kernel (tests, A/B comparisons)
+    extra_flags = 0            # COBEL_F_* testing switches ORed into every launch (F_NO_PWG, ...)
 
     def __init__(self, observation_space, action_space, policy, policy_test, learning_rate,
                  gamma, custom_callbacks) -> None:
@@ -103,7 +104,7 @@ class TabularAgent(FusedAgent):
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base = interface.instance_base
         run.agent = self.agent_kind
-        run.flags = flags | (_lib.F_TAB_GENERAL if self.force_general else 0)
+        run.flags = flags | self.extra_flags | (_lib.F_TAB_GENERAL if self.force_general else 0)
         run.trials_target, run.steps_per_trial, run.step_budget = trials_target, steps, budget
         run.batch = batch
         run.seed = interface.seed

@@ -24,6 +24,7 @@ struct cobel_world {
   int32_t* start_off;    // [dev] [n_worlds + 1]
   int32_t* h_start_off;  // [host] copy for argument checks
   int32_t max_rewarded_states;  // max over worlds of #{s : reward[s] != 0}
+  uint32_t* queue;       // [dev] one word: instance counter of the persistent-workgroup kernel
   // action counts other than four (cobel_world_create_n): `rec` is NULL and these hold the world
   int32_t n_actions;
   uint16_t* next_n;     // [dev] [n_worlds][S][n_actions]
@@ -54,6 +55,11 @@ int cobel_env_step_general(const cobel_world* world, int32_t* state, const uint8
                            float* reward_out, uint8_t* done_out, uint32_t* env_ctr, uint64_t seed,
                            int32_t n, uint32_t instance_base, hipStream_t st);
 int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
+
+// tabular_pwg.hip: plain Dyna-Q training as one persistent workgroup per CU (Q in LDS + Q in L2)
+bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int* nl, int* ng,
+                        size_t* lds_bytes);
+int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
 
 // sr_wave.hip: the sparse-reward form of the SR agent (one wavefront per instance)
 bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);

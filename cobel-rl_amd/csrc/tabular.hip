@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   uint32_t mb_idx = ~0u, pb_idx = 0x7fffffffu;
   int refresh_in = 0;          // MIDX: steps left before the cached draws must be renewed
   uint2 m4 = {0u, 0u};         // !MIDX: the four 16-bit model entries of the current state
-  uint2 mrec = {0u, 0u};       // MIDX, lane k < 4: model record (state, k), gathered one step ahead
+  uint32_t mrec = 0u;          // MIDX, lane k < 4: reward estimate (bits) of model record (state, k),
+                               //       gathered one step ahead
   uint32_t fix_sa = ~0u;       // MIDX: the pair whose record the previous step rewrote (possibly
   float fix_r = 0.0f;          //       after that gather had been issued), and its new reward
   uint32_t idx_cur = 0;        // MIDX, lane j < B: pair sampled by this step's replay j ...
@@ -315,8 +316,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
     if (!WLDS && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
-    if (MIDX && lane < 4)
-      mrec = *reinterpret_cast<const uint2*>(&model[(uint32_t)s * 4u + (uint32_t)lane]);
+    if (MIDX && lane < 4) mrec = model32[2u * ((uint32_t)s * 4u + (uint32_t)lane)];
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
   };
 
@@ -478,7 +478,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       const uint32_t m = L.M16[idx];
       ns = m & 0x3fffu;
       nt = (m >> 14) & 1u;
-      if (m & 0x8000u) r = __builtin_bit_cast(float, model32[2u * idx]);
+      if (m & 0x8000u) {
+        r = __builtin_bit_cast(float, model32[2u * idx]);
+        asm volatile("" : "+v"(r));   // (consumed inside the branch, see the MIDX path)
+      }
       if (idx == fresh_idx) r = fresh_r;
     }
     run_batch(idx, ns, nt, r);
@@ -625,12 +628,20 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // Successor records for the next step: issued before this step's stores (a wave's memory
     // operations retire in order, so a load issued behind a store would also wait for the
     // store's acknowledgement) and consumed one step later, behind the planning.
-    uint2 mrec_next = {0u, 0u};
+    // (MIDX: the model record gathered for THIS state is consumed before the next requests go out — a
+    //  wait for a register loaded across the loop edge is a wait for every load in flight, and a
+    //  64-bit load whose high half is dead lets the allocator reuse that half at once, which is a
+    //  wait for the load as well)
+    uint32_t mrec_now = 0u;
+    if (MIDX) {
+      mrec_now = rl(mrec, a);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t mrec_next = 0u;
     if (!trial_over) {
       if (lane < 4) {
         if (!WLDS) cand = W4[next_of(nw0, nw1, lane)];
-        if (MIDX)
-          mrec_next = *reinterpret_cast<const uint2*>(&model[(uint32_t)ns * 4u + (uint32_t)lane]);
+        if (MIDX) mrec_next = model32[2u * ((uint32_t)ns * 4u + (uint32_t)lane)];
       }
       mask_cur = amask ? (uint32_t)amask[ns] & 15u : 15u;
     }
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         if (MIDX) {
           // the record of (state, a) came in with the successor records, one step ahead; if the
           // previous step rewrote it after that gather was issued, its value is still at hand
-          R = __builtin_bit_cast(float, rl(mrec.x, a));
+          R = __builtin_bit_cast(float, mrec_now);
           if (sa == fix_sa) R = fix_r;
         } else {
           const uint32_t pair = (a & 2) ? m4.y : m4.x;
@@ -726,8 +737,12 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
           mg_next = (uint32_t)Mg[idx_next];
           if (iflags & 2u) {   // (COBEL_IF_NONZERO: otherwise no update of the batch can move Q)
             batches += 1u;
-            if (__builtin_expect((m & 0x8000u) != 0u, 0))
+            if (__builtin_expect((m & 0x8000u) != 0u, 0)) {
               r = __builtin_bit_cast(float, model32[2u * idx_cur]);
+              // (consumed here: a wait for this rare load after the branches have joined would be
+              //  a wait for every gather this step has just sent out)
+              asm volatile("" : "+v"(r));
+            }
             if (idx_cur == fresh_idx) r = fresh_r;
             run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r, true);
           }
@@ -1310,6 +1325,22 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
 #undef COBEL_LPI
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;
+  }
+  // plain training with the digest in HBM on worlds whose Q table lets LDS hold fewer instances
+  // than the register file: one persistent workgroup per CU, part of its waves with Q in L2
+  if (midx && !occ && !lds_pad && !(r.flags & (COBEL_F_NO_PWG | COBEL_F_FORCE_WAVE))) {
+    int nl = 0, ng = 0;
+    size_t wg_lds = 0;
+    if (cobel_tab_pwg_plan(world, r, &nl, &ng, &wg_lds)) {
+      if (describe) {
+        describe[0] = COBEL_TAB_KERNEL_PWG;
+        describe[1] = (int32_t)wg_lds;
+        describe[2] = 1;
+        describe[3] = nl + ng;
+        return COBEL_OK;
+      }
+      return cobel_tab_pwg_launch(world, r, st);
+    }
   }
   if (describe) {
     describe[0] = midx ? COBEL_TAB_KERNEL_WPI_INDEX

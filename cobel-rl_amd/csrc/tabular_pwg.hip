@@ -1,0 +1,591 @@
+// Dyna-Q planning kernel, persistent-workgroup form (plain training runs on worlds whose Q table
+// limits the LDS-resident kernel of tabular.hip to fewer instances per CU than the register file
+// would hold).
+//
+// k_tab_wpi keeps an instance's Q table (16 B per state) in LDS, so at 32 x 32 states nine
+// instances fit on a CU (17 408 B each).  The step is a chain of dependent work, not a stream:
+// measured on trained agents, the same kernel on 24 x 24 mazes padded to 9 / 10 / 11 / 12 / 14 / 16
+// instances per CU takes 16.75 / 15.45 / 14.37 / 13.43 / 12.05 / 11.03 ms per launch
+// (scripts/exp_occ_trained.py) — every further resident wave is throughput.  LDS is full at nine;
+// registers allow sixteen.  So here ONE workgroup of sixteen wavefronts owns a CU for the whole
+// launch: `nl` of its waves keep their instance's Q table in LDS exactly as k_tab_wpi does, the
+// other `ng` waves work on the caller's Q table where it lies, in global memory (L2 resident while
+// the instance is in flight: 16 KiB).  All waves take instances from one atomic counter until it
+// runs out, so the two kinds may run at different speeds.
+//
+// Q in global memory (QG) without a memory round trip per planning round:
+//   * everything a step reads from Q is requested at the top of the step, after the previous
+//     step's stores have been acknowledged: Q[s], the rows of the four possible successors, and for
+//     the planning lanes the row Q[ns_j] and the cell Q[s_j][a_j] of the pair each will replay
+//     (the pairs are known one step ahead, as in k_tab_wpi);
+//   * the one cell the online TD update writes before planning reads is patched in registers;
+//   * the speculative rounds of k_tab_wpi (agent/dyna_q.py:327-330 applies the B updates one after
+//     another) run on those registers: lanes whose inputs were changed by an earlier lane of the
+//     round take the new values from the writers' registers (ds_bpermute over their exact conflict
+//     set) instead of re-reading the table.  Only changed cells are stored.
+// Same draws, same arithmetic, same order of effects as k_tab_wpi: identical tables, digests,
+// counters and monitors (tests/test_gpu_pwg.py compares the two kernels and the oracle).
+//
+// Reference behaviour restated: agent/dyna_q.py:164-215 (train loop), :290-299 (TD), :327-330
+// (replay); memory/dyna_q.py:92-96 (store), :137-155 (retrieve_batch).
+#include <stdlib.h>
+#include <string.h>
+
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+namespace {
+
+struct pwg_args {
+  const cobel_wrec* rec;
+  const uint16_t* starts;
+  const int32_t* start_off;
+  int32_t S, n_worlds;
+  cobel_tab_run_t r;
+  uint64_t thr[16][3];   // integer CDF thresholds of the epsilon-greedy tie patterns
+  float alpha_f, gamma_f, model_lr_f;
+  uint32_t* queue;       // eight heads, 32 B apart: next instance of each XCD's share (zeroed before the launch)
+  int32_t nl, ng;        // waves per workgroup with Q in LDS / with Q in global memory
+};
+
+constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
+constexpr int kMaxGlobalWaves = 4;
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float max4(const float4 v) {
+  float m;
+  asm("v_max_f32 %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"
+      : "=&v"(m)
+      : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  return m;
+}
+__device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
+  const uint32_t w = (a & 2) ? w1 : w0;
+  return (a & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+// this wave's earlier global stores are complete before anything after this point is issued
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One instance, all the steps of the call.  QG: the Q table stays in global memory.
+template <bool QG>
+__device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
+                                             unsigned char* const lds, const int lane,
+                                             const uint64_t thr_mine, const uint32_t stripe) {
+  const int S = A.S;
+  float4* const Qs = reinterpret_cast<float4*>(lds);
+  float* const Qf = reinterpret_cast<float*>(lds);
+  unsigned long long* const H =
+      reinterpret_cast<unsigned long long*>(lds + (QG ? (size_t)0 : (size_t)S * 16));
+  const uint32_t g = A.r.instance_base + (uint32_t)i;
+  const int world = (int)(g % (uint32_t)A.n_worlds);
+  const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
+  float4* const Qg = reinterpret_cast<float4*>(A.r.q) + (size_t)i * S;
+  float* const Qgf = reinterpret_cast<float*>(Qg);
+  uint64_t* const model = A.r.model + (size_t)i * S * 4;
+  const uint32_t* const model32 = reinterpret_cast<const uint32_t*>(model);
+  const uint32_t SA = (uint32_t)S * 4u;
+  uint16_t* const Mg = A.r.model_index + (size_t)i * SA;
+
+  // ---- stage ---------------------------------------------------------------------------------
+  uint32_t nonzero = 0u;
+  for (int s = lane; s < S; s += 64) {
+    const float4 qv = Qg[s];
+    if (!QG) Qs[s] = qv;
+    nonzero |= fbits(qv.x) | fbits(qv.y) | fbits(qv.z) | fbits(qv.w);
+  }
+  for (int b = lane; b < 128; b += 64) H[b] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+
+  int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
+  int state = inst[COBEL_I_STATE];
+  int step = inst[COBEL_I_STEP];
+  int trial = inst[COBEL_I_TRIAL];
+  uint32_t ce = (uint32_t)inst[COBEL_I_CTR_ENV];
+  uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
+  uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
+  uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  // COBEL_IF_NONZERO (bit 1, launch-local): see k_tab_wpi
+  if (!__ballot(nonzero != 0u))
+    for (uint32_t e = (uint32_t)lane; e < SA; e += 64u) nonzero |= (uint32_t)Mg[e] & 0x8000u;
+  if (__ballot(nonzero != 0u)) iflags |= 2u;
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO + (lane & 0));
+  asm volatile("" : "+v"(trew));
+
+  const int B = A.r.batch;
+  uint64_t seed = A.r.seed;
+  asm volatile("" : "+v"(seed));
+  const int start_lo = A.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
+  double alpha = A.r.alpha, gamma = A.r.gamma;
+  float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
+  asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
+
+  // ---- values carried from one step to the next (as in k_tab_wpi, MIDX) -----------------------
+  uint32_t cw0 = 0, cw1 = 0;
+  uint4 cand = {0, 0, 0, 0};
+  cobel_u4 blk = {0, 0, 0, 0};
+  int refresh_in = 0;
+  uint32_t mrec = 0u;   // lane k < 4: reward estimate (bits) of the model record (state, k)
+  uint32_t fix_sa = ~0u;
+  float fix_r = 0.0f;
+  uint32_t idx_cur = 0, mg_cur = 0;
+
+  auto draw_m = [&](uint32_t counter) -> uint32_t {
+    const cobel_u4 b = cobel_philox(counter >> 2, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed);
+    return cobel_word(b, counter & 3u);
+  };
+  auto refresh_draws = [&](uint32_t pq) {
+    const uint32_t mi = (cm + 1u) >> 2;
+    const bool p0 = lane == 62, p1 = lane == 63;
+    blk = cobel_philox(p1 ? 2u * pq + 1u : (p0 ? 2u * pq : mi), (p0 || p1) ? 0u : (uint32_t)lane,
+                       g, (p0 || p1) ? COBEL_STREAM_POLICY : COBEL_STREAM_MEMORY, seed);
+  };
+  auto enter_state = [&](int s) {
+    const uint4 c = W4[s];
+    cw0 = rfl(c.x);
+    cw1 = rfl(c.y);
+    if (lane < 4) {
+      cand = W4[next_of(cw0, cw1, lane)];
+      mrec = model32[2u * ((uint32_t)s * 4u + (uint32_t)lane)];
+    }
+  };
+  auto begin_trial = [&]() -> bool {
+    if (trial >= A.r.trials_target) return false;
+    state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                             start_cnt)];
+    ce += 1u;
+    step = 0;
+    trew = 0.0;
+    asm volatile("" : "+v"(trew));
+    iflags |= 1u;
+    enter_state(state);
+    return true;
+  };
+  // the float64 planning update (NumPy promotion of dyna_q.py:290-299 with a float32 table)
+  auto plan_td = [&](float q, float m, float r, uint32_t nt) -> float {
+    const double gnt = gamma * (double)nt;
+    double td = (double)r + gnt * (double)m;
+    td = td - (double)q;
+    return (float)((double)q + alpha * td);
+  };
+  // exact conflict sets (see k_tab_wpi): all EARLIER lanes that write a cell this lane reads
+  auto conflict_sets = [&](uint32_t idx, uint32_t ns) -> unsigned long long {
+    unsigned long long* const H1 = H;
+    unsigned long long* const H2 = H + 64;
+    const uint32_t h1 = idx & 63u, h2 = idx >> 6;
+    const unsigned long long bit = 1ull << lane;
+    atomicOr(&H1[h1], bit);
+    atomicOr(&H2[h2], bit);
+    __builtin_amdgcn_wave_barrier();
+    const ulonglong2* const r4 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 15u) * 4u]);
+    const ulonglong2 ra = r4[0], rb = r4[1];
+    const unsigned long long cell = H1[h1] & H2[h2];
+    const unsigned long long row = ((ra.x | ra.y) | (rb.x | rb.y)) & H2[ns >> 4];
+    const unsigned long long cnd = (cell | row) & (bit - 1ull);
+    __builtin_amdgcn_wave_barrier();
+    H1[h1] = 0ull;
+    H2[h2] = 0ull;
+    return cnd;
+  };
+  // ---- one batch, Q in LDS (called under lane < B) -------------------------------------------
+  auto run_batch_lds = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
+    int first = 0;
+    bool have_conf = false;
+    unsigned long long conf = 0ull;
+    do {
+      const bool act = lane >= first;
+      float q = 0.0f, qn = 0.0f;
+      if (act) {
+        const float4 row = Qs[ns];
+        q = Qf[idx];
+        qn = plan_td(q, max4(row), r, nt);
+      }
+      const bool ch = act && fbits(qn) != fbits(q);
+      const unsigned long long changed = __ballot(ch);
+      int stop = B;
+      if (changed) {
+        if (!have_conf) {
+          conf = conflict_sets(idx, ns);
+          have_conf = true;
+        }
+        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
+        if (blocked) stop = __ffsll((long long)blocked) - 1;
+        if (ch && lane < stop) Qf[idx] = qn;
+        __builtin_amdgcn_wave_barrier();
+      }
+      first = stop;
+    } while (first < B);
+  };
+  // ---- one batch, Q in global memory: inputs (row, q) already in registers -------------------
+  auto run_batch_glb = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r, float4 row, float q) {
+    int first = 0;
+    bool have_conf = false;
+    unsigned long long conf = 0ull;
+    do {
+      const bool act = lane >= first;
+      float qn = q;
+      if (act) qn = plan_td(q, max4(row), r, nt);
+      const bool ch = act && fbits(qn) != fbits(q);
+      const unsigned long long changed = __ballot(ch);
+      int stop = B;
+      if (changed) {
+        if (!have_conf) {
+          conf = conflict_sets(idx, ns);
+          have_conf = true;
+        }
+        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
+        if (blocked) stop = __ffsll((long long)blocked) - 1;
+        if (ch && lane < stop) Qgf[idx] = qn;
+        if (stop < B) {
+          // the lanes that go again take what the committed lanes of their conflict sets wrote,
+          // in lane order (a later writer of the same cell wins, as in the table)
+          const unsigned long long committed = changed & ((1ull << stop) - 1ull);
+          unsigned long long pend = lane >= stop ? (conf & committed) : 0ull;
+          while (__ballot(pend != 0ull)) {
+            const int e = pend ? (__ffsll((long long)pend) - 1) : 0;
+            const uint32_t ie = (uint32_t)__shfl((int)idx, e);
+            const float ve = __shfl(qn, e);
+            if (pend) {
+              if (ie == idx) q = ve;
+              if ((ie >> 2) == ns) {
+                const uint32_t c = ie & 3u;
+                row.x = c == 0u ? ve : row.x;
+                row.y = c == 1u ? ve : row.y;
+                row.z = c == 2u ? ve : row.z;
+                row.w = c == 3u ? ve : row.w;
+              }
+              pend &= pend - 1ull;
+            }
+          }
+        }
+      }
+      first = stop;
+    } while (first < B);
+  };
+
+  // ---- prologue -------------------------------------------------------------------------------
+  bool live = true;
+  if (iflags & 1u) enter_state(state);
+  else live = begin_trial();
+  refresh_draws(cp >> 2);
+  {
+    const int jp = 3 - (int)(cp & 3u), jm = 4 - (int)((cm + 1u) & 3u);
+    refresh_in = jp < jm ? jp : jm;
+  }
+  idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
+  mg_cur = lane < B ? (uint32_t)Mg[idx_cur] : 0u;
+
+  const int budget0 = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  int budget = budget0;
+  uint32_t batches = 0u;
+  asm volatile("" : "+v"(batches));
+
+  while (live) {
+    if (budget == 0) break;
+    budget -= 1;
+
+    // ---- draws ----------------------------------------------------------------------------------
+    const int src_lane = 62 + (int)((cp >> 1) & 1u);
+    const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
+    const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
+    if (__builtin_expect(refresh_in == 0, 0)) {
+      refresh_draws((cp + 1u) >> 2);
+      const int jp = 4 - (int)((cp + 1u) & 3u), jm = 4 - (int)((cm + 1u) & 3u);
+      refresh_in = jp < jm ? jp : jm;
+    }
+    refresh_in -= 1;
+    cp += 1u;
+
+    // ---- everything this step reads from Q ----------------------------------------------------------
+    const uint32_t succ = next_of(cw0, cw1, lane & 3);
+    float4 qrow, srow;
+    float4 prow = {0.0f, 0.0f, 0.0f, 0.0f};   // QG, lane j < B: Q[ns_j] ...
+    float pq = 0.0f;                           // ... and Q[s_j][a_j] of the pair it replays
+    if (QG) {
+      stores_done();   // (the previous step's planning stores, by other lanes of this wave)
+      qrow = Qg[state];
+      srow = Qg[succ];
+      if (lane < B && (iflags & 2u)) {
+        prow = Qg[mg_cur & 0x3fffu];
+        pq = Qgf[idx_cur];
+      }
+    } else {
+      qrow = Qs[state];
+      srow = Qs[succ];
+    }
+    const float smax = max4(srow);
+
+    // ---- select (policy/greedy.py:40-88): integer thresholds of the tie pattern's CDF ---------------
+    int a;
+    {
+      const float m = max4(qrow);
+      const int t = (int)(((uint32_t)__ballot(qrow.x == m) & 1u) | ((uint32_t)__ballot(qrow.y == m) & 2u) |
+                          ((uint32_t)__ballot(qrow.z == m) & 4u) | ((uint32_t)__ballot(qrow.w == m) & 8u));
+      const uint64_t K = cobel_u53(w0, w1);
+      const unsigned long long passed = __ballot(thr_mine <= K);
+      a = __popcll((passed >> (t * 3)) & 7ull);
+    }
+    // ---- env.step (interface/gridworld.py:115-126) --------------------------------------------------
+    const int ns = (int)next_of(cw0, cw1, a);
+    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
+    const uint32_t r_bits = rl(cand.z, a);
+    const float r = __builtin_bit_cast(float, r_bits);
+    if (r_bits != 0u) iflags |= 2u;
+    const uint32_t end = rl(cand.w, a);
+    const float ns_max = __builtin_bit_cast(float, rl(fbits(smax), a));
+    const uint32_t nt = 1u - end;
+    const uint32_t sa = (uint32_t)state * 4u + (uint32_t)a;
+    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
+    // (everything the previous step requested is consumed BEFORE this step's requests go out: the
+    //  wait for a register loaded across the loop edge is a wait for every load in flight)
+    float R = __builtin_bit_cast(float, rl(mrec, a));
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t mrec_next = 0u;
+    if (!trial_over && lane < 4) {
+      cand = W4[next_of(nw0, nw1, lane)];
+      mrec_next = model32[2u * ((uint32_t)ns * 4u + (uint32_t)lane)];
+    }
+
+    // ---- model store (memory/dyna_q.py:92-96) and online TD (agent/dyna_q.py:290-299), float32 ------
+    if (sa == fix_sa) R = fix_r;
+    const float d = r - R;
+    const float Rn = R + mlr_f * d;
+    const uint32_t fresh_idx = sa;
+    const float fresh_r = Rn;
+    const uint32_t fresh_m = (uint32_t)ns | (nt << 14) | (fbits(Rn) ? 0x8000u : 0u);
+    fix_sa = sa;
+    fix_r = Rn;
+    const float q_sa = (a & 2) ? ((a & 1) ? qrow.w : qrow.z) : ((a & 1) ? qrow.y : qrow.x);
+    const float gnt = nt ? gamma_f : 0.0f;
+    float td = r + gnt * ns_max;
+    td = td - q_sa;
+    const float qn_online = q_sa + alpha_f * td;
+    if (lane == 0) {
+      if (QG) Qgf[sa] = qn_online;
+      else Qf[sa] = qn_online;
+      model[sa] = cobel_model_pack(fresh_r, (uint32_t)ns, nt);
+      Mg[sa] = (uint16_t)fresh_m;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- bookkeeping ----------------------------------------------------------------------------------
+    trew += (double)r;
+    const int s_prev = state;
+    state = ns;
+    cw0 = nw0;
+    cw1 = nw1;
+
+    // ---- planning: next step's batch is drawn and its digest entries requested, then this batch runs -
+    {
+      uint32_t idx_next = 0u, mg_next = 0u;
+      const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
+      if (lane < B) {
+        float rj = 0.0f;
+        idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
+        mg_next = (uint32_t)Mg[idx_next];
+        if (iflags & 2u) {
+          batches += 1u;
+          if (__builtin_expect((m & 0x8000u) != 0u, 0)) {
+            rj = __builtin_bit_cast(float, model32[2u * idx_cur]);
+            // (consumed here: a wait for this rare load after the branches have joined would be a
+            //  wait for every gather this step has just sent out)
+            asm volatile("" : "+v"(rj));
+          }
+          if (idx_cur == fresh_idx) rj = fresh_r;
+          const uint32_t nsj = m & 0x3fffu;
+          if (QG) {
+            // a pair that replays the entry this very step stored plans towards the state just
+            // entered: its row is the successor row read above
+            if (__ballot(idx_cur == fresh_idx)) {
+              const float4 nrow = {__builtin_bit_cast(float, rl(fbits(srow.x), a)),
+                                   __builtin_bit_cast(float, rl(fbits(srow.y), a)),
+                                   __builtin_bit_cast(float, rl(fbits(srow.z), a)),
+                                   __builtin_bit_cast(float, rl(fbits(srow.w), a))};
+              if (idx_cur == fresh_idx) prow = nrow;
+            }
+            // the online update wrote Q[s][a] after these registers were loaded
+            if (idx_cur == sa) pq = qn_online;
+            if (nsj == (uint32_t)s_prev) {
+              prow.x = a == 0 ? qn_online : prow.x;
+              prow.y = a == 1 ? qn_online : prow.y;
+              prow.z = a == 2 ? qn_online : prow.z;
+              prow.w = a == 3 ? qn_online : prow.w;
+            }
+            run_batch_glb(idx_cur, nsj, (m >> 14) & 1u, rj, prow, pq);
+          } else {
+            run_batch_lds(idx_cur, nsj, (m >> 14) & 1u, rj);
+          }
+        }
+        if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
+      }
+      idx_cur = idx_next;
+      mg_cur = mg_next;
+      mrec = mrec_next;
+      cm += 1u;
+    }
+
+    if (__builtin_expect(trial_over, 0)) {
+      // agent/dyna_q.py:207-212: current_trial += 1; logs['steps'] = step (0-based)
+      if (lane == 0 && trial >= 0 && trial < A.r.trial_cap) {
+        const size_t mo = (size_t)stripe * (size_t)A.r.trial_cap + (size_t)trial;
+        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + mo, (unsigned long long)step);
+        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + mo, 1ull);
+        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + mo, trew);
+        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + mo, 1ull);
+        if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
+      }
+      trial += 1;
+      iflags &= ~1u;
+      if (!begin_trial()) break;
+    } else {
+      step += 1;
+    }
+  }
+
+  // ---- write back -------------------------------------------------------------------------------
+  __builtin_amdgcn_wave_barrier();
+  if (!QG)
+    for (int s = lane; s < S; s += 64) Qg[s] = Qs[s];
+  if (lane == 0) {
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_CTR_MEMORY] = (int32_t)cm;
+    inst[COBEL_I_FLAGS] = (int32_t)(iflags & ~2u);
+    const unsigned long long executed = (unsigned long long)(budget0 - budget);
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
+    if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
+    if (A.r.batches_done && batches) atomicAdd(A.r.batches_done, (unsigned long long)batches);
+  }
+  // (the next instance of this wave reuses the LDS slice: its staging stores follow these loads in
+  //  the wave's own program order)
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = (int)rfl(threadIdx.x >> 6);
+  const int waves = A.nl + A.ng;
+  const size_t slice_l = (size_t)A.S * 16 + kHashBytes;
+  const bool qg = wave >= A.nl;
+  unsigned char* const lds =
+      lds_raw + (qg ? (size_t)A.nl * slice_l + (size_t)(wave - A.nl) * kHashBytes
+                    : (size_t)wave * slice_l);
+  const uint64_t thr_mine = A.thr[(lane % 48) / 3][lane % 3];
+  const uint32_t wave_id = (uint32_t)blockIdx.x * (uint32_t)waves + (uint32_t)wave;
+  const uint32_t stripe = A.r.mon_stripes > 1 ? wave_id % (uint32_t)A.r.mon_stripes : 0u;
+  // Instances are handed out per XCD: instance i belongs to queue i % 8, and a workgroup serves the
+  // queue of the XCD it runs on first (then the others, until all eight are empty).  The world of
+  // an instance is (global id) % n_worlds, so an XCD's L2 sees an eighth of the worlds' records
+  // and the same instances launch after launch — what the round-robin placement of one workgroup
+  // per instance gives k_tab_wpi for free.  Speed only: any wave may run any instance.
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  int k0 = 0;   // queues (xcc + k) % 8, k < k0, are known to be empty
+  for (;;) {
+    int i = -1;
+    while (k0 < 8) {
+      const uint32_t q = (xcc + (uint32_t)k0) & 7u;
+      uint32_t t = 0u;
+      if (lane == 0) t = atomicAdd(A.queue + q * 8u, 1u);
+      const uint32_t c = rfl(t) * 8u + q;
+      if (c < (uint32_t)A.r.n) {
+        i = (int)c;
+        break;
+      }
+      k0 += 1;
+    }
+    if (i < 0) break;
+    if (qg) pwg_instance<true>(A, i, lds, lane, thr_mine, stripe);
+    else pwg_instance<false>(A, i, lds, lane, thr_mine, stripe);
+  }
+}
+
+}  // namespace
+
+// Does this run qualify, and with how many waves of each kind?  (plain Dyna-Q training with the
+// digest in HBM, exact dependency lookup, no visit counters, no parameter sets)
+bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int* nl_out, int* ng_out,
+                        size_t* lds_out) {
+  static const char* const force = getenv("COBEL_DEBUG_PWG");   // "nl,ng" (experiments)
+  const int S = world->n_states;
+  if (r.agent != COBEL_AGENT_DYNAQ || !r.model_index || r.occupancy || r.param_index ||
+      r.last_exp || S * 4 > 4096 || S <= 256 || r.batch < 1 || r.batch > COBEL_MAX_BATCH)
+    return false;
+  if (!world->queue) return false;
+  const size_t slice_l = (size_t)S * 16 + kHashBytes, total = 160 * 1024;
+  int nl = (int)(total / slice_l);
+  if (nl > 16) nl = 16;
+  int ng = (int)((total - (size_t)nl * slice_l) / kHashBytes);
+  if (ng > 16 - nl) ng = 16 - nl;
+  // Measured on C3 (32 x 32, trained agents, scripts/exp_pwg.py): 9 + 0 / 3 / 4 / 5 / 6 / 7 waves take
+  // 14.1 / 12.9 / 12.75 / 12.8 / 14.7 / 17.2 ms per launch — the Q tables of the global-memory waves
+  // compete for the XCD's 4 MiB of L2 with the digests and model records of all of them.
+  if (ng > kMaxGlobalWaves) ng = kMaxGlobalWaves;
+  if (force) {
+    int a = 0, b = 0;
+    if (sscanf(force, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b >= 1 && a + b <= 16 &&
+        (size_t)a * slice_l + (size_t)b * kHashBytes <= total) {
+      nl = a;
+      ng = b;
+    }
+  } else if (r.flags & COBEL_F_PWG_GLOBAL) {
+    nl = 0;
+    ng = 16;
+  } else if (ng == 0) {
+    return false;   // LDS is not what limits the resident instances: k_tab_wpi as it is
+  }
+  *nl_out = nl;
+  *ng_out = ng;
+  *lds_out = (size_t)nl * slice_l + (size_t)ng * kHashBytes;
+  return true;
+}
+
+int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st) {
+  int nl = 0, ng = 0;
+  size_t lds = 0;
+  if (!cobel_tab_pwg_plan(world, r, &nl, &ng, &lds))
+    return cobel_fail(COBEL_E_UNSUPPORTED, "cobel_tab_pwg_launch: run not covered");
+  pwg_args A;
+  A.rec = world->rec;
+  A.starts = world->starts;
+  A.start_off = world->start_off;
+  A.S = world->n_states;
+  A.n_worlds = world->n_worlds;
+  A.r = r;
+  const cobel_eps_consts eps = cobel_make_eps_consts(r.epsilon);
+  memcpy(A.thr, eps.thr, sizeof(A.thr));
+  A.alpha_f = (float)r.alpha;
+  A.gamma_f = (float)r.gamma;
+  A.model_lr_f = (float)r.model_lr;
+  A.queue = world->queue;
+  A.nl = nl;
+  A.ng = ng;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    COBEL_HIP_TRY(hipGetDeviceProperties(&prop, world->device));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int waves = nl + ng;
+  int grid = (r.n + waves - 1) / waves;
+  if (grid > n_cu) grid = n_cu;
+  COBEL_HIP_TRY(hipMemsetAsync(world->queue, 0, 256, st));
+  if (lds > 64 * 1024)
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_pwg),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_tab_pwg, dim3(grid), dim3(64 * waves), lds, st, A);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

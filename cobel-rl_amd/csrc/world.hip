@@ -23,7 +23,7 @@ int cobel_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1011; }
+extern "C" int cobel_abi_version(void) { return 1012; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {
@@ -108,6 +108,7 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   hipError_t e = hipMalloc((void**)&w->rec, total * sizeof(cobel_wrec));
   if (e == hipSuccess) e = hipMalloc((void**)&w->starts, sizeof(uint16_t) * n_starts);
   if (e == hipSuccess) e = hipMalloc((void**)&w->start_off, sizeof(int32_t) * (n_worlds + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->queue, 256);
   if (e == hipSuccess)
     e = hipMemcpy(w->rec, rec.data(), total * sizeof(cobel_wrec), hipMemcpyHostToDevice);
   if (e == hipSuccess)
@@ -128,6 +129,7 @@ extern "C" int cobel_world_destroy(cobel_world_t* w) {
   if (w->rec) (void)hipFree(w->rec);
   if (w->starts) (void)hipFree(w->starts);
   if (w->start_off) (void)hipFree(w->start_off);
+  if (w->queue) (void)hipFree(w->queue);
   if (w->next_n) (void)hipFree(w->next_n);
   if (w->reward_s) (void)hipFree(w->reward_s);
   if (w->terminal_s) (void)hipFree(w->terminal_s);

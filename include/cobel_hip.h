@@ -249,6 +249,9 @@ enum { COBEL_AGENT_Q = 0, COBEL_AGENT_DYNAQ = 1 };
 #define COBEL_F_FORCE_LDS_MODEL 64u /* ignore model_index, keep the model digest in LDS (testing) */
 #define COBEL_F_NO_PREFETCH 128u   /* SR: load value rows at the top of each step (testing)        */
 #define COBEL_F_TAB_GENERAL 512u   /* cobel_tab_run: always take the general kernel (testing)          */
+#define COBEL_F_NO_PWG 1024u       /* Dyna-Q: never take the persistent-workgroup kernel (testing,
+                                      A/B measurements): k_tab_wpi, one workgroup per instance      */
+#define COBEL_F_PWG_GLOBAL 2048u   /* ... its wavefronts ALL work on Q in global memory (testing)          */
 #define COBEL_F_SR_STREAM_ROWS 256u /* SR: always take the row-streaming kernel, also where the
                                       sparse-reward kernel applies (testing, A/B measurements)    */
 
@@ -351,6 +354,9 @@ enum {
   COBEL_TAB_KERNEL_WPI = 1,       /* one wavefront per instance, every run-time switch          */
   COBEL_TAB_KERNEL_WPI_FAST = 2,  /* ... plain Dyna-Q training, model digest in LDS             */
   COBEL_TAB_KERNEL_WPI_INDEX = 3, /* ... plain Dyna-Q training, model digest in HBM (model_index) */
+  COBEL_TAB_KERNEL_PWG = 5,       /* plain Dyna-Q training, one persistent workgroup of 16 wavefronts
+                                     per CU: some keep Q in LDS, the others work on it in L2; out[1]
+                                     = LDS of the workgroup, out[2] = 1, out[3] = its wavefronts    */
   COBEL_TAB_KERNEL_GENERAL = 4    /* one lane per instance, tables in HBM: any action count, batch
                                      size and state count                                        */
 };

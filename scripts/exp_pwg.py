@@ -1,0 +1,30 @@
+"""Scratch (round 3): launch time of the persistent-workgroup Dyna-Q kernel on C3 for one mix of
+LDS / global-memory waves (COBEL_DEBUG_PWG="nl,ng", read once per process) on trained agents.
+`python scripts/exp_pwg.py [pretrain launches] [nopwg]`"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from cobel_amd import _lib  # noqa: E402
+dev = torch.device('cuda', 0)
+pre = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+cfg = dict(bench.CONFIGS['C3'])
+env, agent = bench.build_agent('C3', cfg, cfg['instances'], 0, dev)
+if 'nopwg' in sys.argv:
+    agent.extra_flags = _lib.F_NO_PWG
+r = bench.Runner(cfg, env, agent)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(pre + 5)]
+for k in range(pre + 4):
+    ev[k].record()
+    r.launch()
+ev[pre + 4].record()
+torch.cuda.synchronize()
+ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(pre + 4)]
+what = r.describe()
+print('PWG=%s %s kernel %d: launches 2-5 %s | last 4 %s ms  -> %.3e steps/s' % (
+    os.environ.get('COBEL_DEBUG_PWG', '-'), 'nopwg' if 'nopwg' in sys.argv else '', what['kernel'],
+    ' '.join('%.2f' % m for m in ms[1:5]), ' '.join('%.2f' % m for m in ms[-4:]),
+    cfg['instances'] * cfg['env_steps_per_launch'] / (min(ms[-4:]) * 1e-3)), flush=True)

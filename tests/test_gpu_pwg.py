@@ -1,0 +1,90 @@
+"""The persistent-workgroup Dyna-Q kernel (csrc/tabular_pwg.hip: sixteen wavefronts per CU, part of
+them with Q in LDS, the others working on Q in global memory) against the one-workgroup-per-instance
+kernel it replaces on large worlds, and against the NumPy oracle: same tables, digests, counters,
+monitors — bit for bit, whichever kind of wave an instance happens to get."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra_flags, n, side, seeds, launches, steps, batch=50, spt=60, alpha=0.99, eps=0.1):
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze
+    from cobel_amd.policy import EpsilonGreedy
+    worlds = [make_obstacle_maze(side, side, s) for s in seeds]
+    env = Gridworld(worlds, n_envs=n, seed=SEED, device=torch.device('cuda', 0))
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha)
+    agent.extra_flags = extra_flags
+    agent.track_instances = True
+    agent._bind(env)
+    agent._env_in(env)
+    flags = _lib.F_LEARN | agent._policy_in(agent.policy, env, False)
+    agent.monitors.reserve(2048, n, True)
+    kinds = set()
+    for _ in range(launches):
+        kinds.add(agent.describe_launch(env, agent.policy, flags, 0x7fffffff, spt, steps, batch)['kernel'])
+        agent._launch(env, agent.policy, flags, 0x7fffffff, spt, steps, batch)
+    torch.cuda.synchronize()
+    mon = agent.monitors
+    return {'q': agent._q.cpu().numpy(), 'model': agent.M.table.cpu().numpy(),
+            'index': agent.M.index.cpu().numpy(), 'inst': agent.inst.cpu().numpy(),
+            'lat_sum': mon.lat_sum.cpu().numpy(), 'lat_cnt': mon.lat_cnt.cpu().numpy(),
+            'reward_sum': mon.reward_sum.cpu().numpy(), 'lat_trace': mon.lat_trace.cpu().numpy(),
+            'batches': int(agent.batches_done.item()), 'steps': agent.env_steps(), 'kinds': kinds,
+            'worlds': worlds}
+
+
+def _same(a, b):
+    for key in ('q', 'model', 'index', 'inst', 'lat_sum', 'lat_cnt', 'reward_sum', 'lat_trace'):
+        assert np.array_equal(a[key], b[key]), key
+    assert a['batches'] == b['batches'] and a['steps'] == b['steps']
+
+
+@pytest.mark.parametrize('side,n', [(32, 700), (20, 300), (31, 130)])
+def test_persistent_workgroups_equal_the_wave_per_instance_kernel(side, n):
+    from cobel_amd import _lib
+    seeds = [1234, 1235, 1236]
+    args = dict(n=n, side=side, seeds=seeds, launches=3, steps=700)
+    plain = _run(_lib.F_NO_PWG, **args)
+    mixed = _run(0, **args)
+    glob = _run(_lib.F_PWG_GLOBAL, **args)
+    assert plain['kinds'] == {_lib.TAB_KERNEL_WPI_INDEX}
+    assert glob['kinds'] == {_lib.TAB_KERNEL_PWG}
+    # (20 x 20: sixteen Q tables fit in LDS, the plain kernel stays)
+    assert mixed['kinds'] == ({_lib.TAB_KERNEL_PWG} if side > 24 else {_lib.TAB_KERNEL_WPI_INDEX})
+    assert plain['q'].any() and plain['batches'] > 0 and plain['lat_cnt'].sum() > 0
+    _same(plain, mixed)
+    _same(plain, glob)
+
+
+def test_global_q_waves_against_the_oracle():
+    """Every wave with Q in global memory, young and trained instances, a small learning rate so
+    that most planning updates change their cell (many speculative rounds)."""
+    from cobel_amd import _lib
+    from oracle import philox, ref_loop
+    n, side, spt, steps, batch = 40, 32, 40, 300, 62
+    out = _run(_lib.F_PWG_GLOBAL, n=n, side=side, seeds=[77], launches=2, steps=steps, batch=batch,
+               spt=spt, alpha=0.5, eps=0.3)
+    assert out['kinds'] == {_lib.TAB_KERNEL_PWG}
+    tabs = out['worlds'][0].compact()
+    for i in (0, 7, 39):
+        env = ref_loop.RefGridworld(tabs, philox.TapeRNG(SEED, i, philox.STREAM_ENV))
+        pol = ref_loop.RefEpsilonGreedy(0.3, philox.TapeRNG(SEED, i, philox.STREAM_POLICY))
+        ref = ref_loop.RefDynaQ(side * side, 4, pol, philox.TapeRNG(SEED, i, philox.STREAM_MEMORY),
+                                dtype=np.float32, learning_rate=0.5)
+        trials = int(out['inst'][i, 2])
+        tr = ref_loop.new_trace()
+        ref.train(env, trials, spt, batch, trace=tr)
+        done = sum(s + 1 for s in tr['steps'])
+        # the oracle runs whole trials: continue into the running one for the remaining steps
+        left = 2 * steps - done
+        assert 0 <= left <= spt
+        if left:
+            ref.train(env, 1, left, batch, trace=tr)
+        assert np.array_equal(out['q'][i], ref.Q), i
