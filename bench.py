@@ -622,6 +622,9 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     if sfma:   # reactivations per launch depend on the trial lengths: count them (this rank)
         alg_bytes_per_launch += cfg['bytes_per_reactivation'] * replays // args.steps
     kernel = {'q': 'k_tab_lpi', 'dynaq': 'k_tab_wpi<DYNAQ>', 'sr': 'k_sr', 'sfma': 'k_sfma'}[cfg['agent']]
+    what = runner.describe()
+    if what is not None and what['kernel'] == runner._lib.TAB_KERNEL_PWG:
+        kernel = 'k_tab_pwg'      # one persistent workgroup per CU (csrc/tabular_pwg.hip)
     limiter = cfg['limiter']
     if cfg['agent'] == 'sr':
         moved = sr_moved
@@ -720,10 +723,10 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
                                          'on C3 a launch takes longer once Q has filled and most '
                                          'planning updates move their cell (DESIGN.md section 4.1), '
                                          'so the last window is the rate of well-trained agents'}
-    what = runner.describe()
     if what is not None:
         res['roofline']['lds_bytes_per_workgroup'] = what['lds_bytes']
         res['roofline']['workgroups_per_cu_by_lds'] = what['workgroups_per_cu']
+        res['roofline']['instances_per_workgroup'] = what['instances_per_workgroup']
     if sfma:
         res['reactivations_per_s'] = replays * world_size / elapsed
         res['roofline']['algorithmic_bytes_per_reactivation'] = cfg['bytes_per_reactivation']

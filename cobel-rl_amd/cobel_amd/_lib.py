@@ -242,6 +242,7 @@ _SIGNATURES = {
                                   C.POINTER(C.c_uint8)]),
     'cobel_model_init': (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     'cobel_model_index_build': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    'cobel_pairwise_order': (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(C.c_int32)]),
     'cobel_sr_init': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     'cobel_sr_run': (C.c_int, [_P, C.POINTER(SRRun), _P]),
     'cobel_sr_retrieve_q': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),

@@ -17,6 +17,20 @@ struct __attribute__((aligned(16))) cobel_wrec {
 };
 static_assert(sizeof(cobel_wrec) == 16, "world record must be 16 bytes");
 
+// The rewarded states of one world (reward != 0), at most eight of them, and the order in which
+// NumPy's pairwise summation (numpy/core/src/umath/loops_utils.h) adds the products of a row with a
+// vector that is zero everywhere else: a sum over S elements of which all but k are zero is the sum
+// of those k in the grouping the summation tree gives them (an addition of zero changes nothing),
+// so k - 1 additions in this order return np.sum(row * R) bit for bit (up to the sign of a zero).
+struct cobel_rw_info {
+  uint16_t pos[8];      // ascending states
+  uint8_t k;            // how many (0 .. 8); 255: more than eight
+  uint8_t root;         // slot that holds the sum after the last step
+  uint8_t dst[7], src[7];   // step t: value[dst[t]] += value[src[t]]
+  uint8_t pad_[8];
+};
+static_assert(sizeof(cobel_rw_info) == 40, "cobel_rw_info layout");
+
 struct cobel_world {
   int32_t n_states, n_worlds, device;
   cobel_wrec* rec;       // [dev] [n_worlds][S]
@@ -25,6 +39,7 @@ struct cobel_world {
   int32_t* h_start_off;  // [host] copy for argument checks
   int32_t max_rewarded_states;  // max over worlds of #{s : reward[s] != 0}
   uint32_t* queue;       // [dev] one word: instance counter of the persistent-workgroup kernel
+  cobel_rw_info* rw;     // [dev] [n_worlds] rewarded states + pairwise combine order (four-action worlds)
   // action counts other than four (cobel_world_create_n): `rec` is NULL and these hold the world
   int32_t n_actions;
   uint16_t* next_n;     // [dev] [n_worlds][S][n_actions]
@@ -60,6 +75,10 @@ int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r,
 bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int* nl, int* ng,
                         size_t* lds_bytes);
 int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
+
+// world.hip: the additions NumPy's pairwise sum performs on k non-zero elements at `pos` (ascending)
+// of a vector of n elements; returns the slot holding the result (-1: k == 0)
+int cobel_pairwise_schedule(int n, const int* pos, int k, uint8_t* dst, uint8_t* src);
 
 // sr_wave.hip: the sparse-reward form of the SR agent (one wavefront per instance)
 bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);

@@ -37,6 +37,7 @@ struct srw_args {
   cobel_sr_run_t r;
   cobel_eps_consts eps;
   float alpha_f, gamma_f;
+  const cobel_rw_info* rw;   // [n_worlds] rewarded states + NumPy's combine order (KX kernels)
 };
 
 __device__ __forceinline__ int t_of(uint64_t row, int k) { return (int)((row >> (16 * k)) & 0xffffu); }
@@ -189,10 +190,18 @@ __device__ __forceinline__ const srw_args* rare_args() {
 // CU, more than the ~64 KB per CU that 8 TB/s at 2 us of latency take.
 // ANY_S: any state count that is a multiple of four up to NV * 256 (rows are float4 streams; the
 // register layout is the same, lanes past the end of a row hold zeros and neither load nor store).
-template <int NV, bool OCC, bool PSETS, bool ANY_S>
+// KX: worlds with three to eight rewarded states.  The agent's reward estimate can only be non-zero
+// at those states, so V[j] = sum_k SR[j][k] R[k] is a sum of at most eight products — added in the
+// grouping NumPy's pairwise summation gives exactly these positions (cobel_rw_info, built on the
+// host per world; products whose estimate is still zero are added like the others: x + 0 = x).
+// Lane 8a + n gathers element pos[n] of value row a, holds R[pos[n]] and its product; the k - 1
+// additions run as shuffles inside the groups of eight lanes.  The values of the row a step
+// rewrites are read back from an LDS copy of the new row.
+template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
+  __shared__ __attribute__((aligned(16))) float frow[KX ? NV * 256 : 4];
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
@@ -221,6 +230,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   int nz = 0, e0 = 0, e1 = 0;
   float r0 = 0.0f, r1 = 0.0f;
   bool dense = false;
+  // KX: slot n = lane & 7 of each group of eight lanes
+  int Kw = 0, kroot = 0;
+  uint32_t sched_d = 0u, sched_s = 0u;   // 3 bits per step
+  uint32_t elane = 0u;
+  float rlane = 0.0f;
+  int nzc = 0;
+  if (KX) {
+    const cobel_rw_info* const I = A.rw + world;
+    Kw = (int)I->k;
+    kroot = (int)I->root;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      sched_d |= (uint32_t)I->dst[t] << (3 * t);
+      sched_s |= (uint32_t)I->src[t] << (3 * t);
+    }
+    if ((lane & 7) < Kw) elane = (uint32_t)I->pos[lane & 7];
+  }
   {
     const float4* const R4 = reinterpret_cast<const float4*>(Rg) + lane;
 #pragma unroll
@@ -239,6 +265,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       for (int comp = 0; comp < 4; ++comp) {
         const float x = comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w));
         unsigned long long m = __ballot(x != 0.0f);
+        if (KX) {
+          nzc += __popcll(m);
+          m = 0ull;
+        }
         while (m) {
           const int l = __builtin_ctzll(m);
           m &= m - 1;
@@ -252,6 +282,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       }
     }
     if (dense) nz = 2;
+    if (KX) {
+      // every non-zero estimate must sit at one of the world's rewarded states (only a caller's
+      // edit of `rewards` can break that): otherwise the full sums from memory
+      if ((lane & 7) < Kw) rlane = Rg[elane];
+      const int listed = __popcll(__ballot(lane < 8 && rlane != 0.0f));
+      dense = nzc != listed;
+    }
   }
   __syncthreads();   // (one wave: orders the LDS writes above)
 
@@ -326,6 +363,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     }
     q0 = qv[0]; q1 = qv[1]; q2 = qv[2]; q3 = qv[3];
   };
+  // KX: lane 8a + n reads element pos[n] of row tq[a]
+  auto issue_gathers_x = [&](uint64_t tq, int fresh) -> float {
+    float gv = 0.0f;
+    if (stored_state >= 0 && (t_of(tq, 0) == stored_state || t_of(tq, 1) == stored_state ||
+                              t_of(tq, 2) == stored_state || t_of(tq, 3) == stored_state)) {
+      wait_vm0();
+      stored_state = -1;
+    }
+    const int j = t_of(tq, (lane >> 3) & 3);
+    if (lane < 32 && (lane & 7) < Kw && j != fresh) gv = ld_l2(SRg + (size_t)j * S + elane);
+    gathers += (uint32_t)(4 * Kw);
+    return gv;
+  };
+  auto assemble_x = [&](uint64_t tq, int fresh, float gv) {
+    const bool is_fresh = t_of(tq, (lane >> 3) & 3) == fresh;
+    float fv = 0.0f;
+    if (is_fresh && lane < 32 && (lane & 7) < Kw) fv = frow[elane];
+    float p = (is_fresh ? fv : gv) * rlane;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      if (t < Kw - 1) {
+        const int dst = (int)((sched_d >> (3 * t)) & 7u), src = (int)((sched_s >> (3 * t)) & 7u);
+        const float other = __shfl(p, (lane & ~7) | src);
+        if ((lane & 7) == dst) p = p + other;
+      }
+    }
+    q0 = rlf(p, kroot);
+    q1 = rlf(p, 8 + kroot);
+    q2 = rlf(p, 16 + kroot);
+    q3 = rlf(p, 24 + kroot);
+  };
   // Full pairwise sums from memory (more than two non-zero reward estimates): lane (l, k) runs
   // accumulator k of leaf l, then the butterflies of NumPy's combine order (as k_sr does in LDS).
   auto dense_values = [&](uint64_t tq) {
@@ -376,6 +444,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     }
     if (dense) {
       dense_values(tcur);
+    } else if (KX) {
+      const float gv = issue_gathers_x(tcur, -1);
+      assemble_x(tcur, -1, gv);
     } else {
       const float gv = issue_gathers(tcur, -1);
       assemble(tcur, -1, 0.0f, 0.0f, gv);
@@ -451,7 +522,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     if (learn) {
       // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
       float old;
+      unsigned long long slot_m = 0ull;
       if (dense) old = rflf(ld_l2(Rg + ns));
+      else if (KX) {
+        slot_m = __ballot((lane & 7) < Kw && elane == (uint32_t)ns);
+        old = slot_m ? rlf(rlane, __builtin_ctzll(slot_m)) : 0.0f;
+      }
       else old = (nz > 0 && ns == e0) ? r0 : ((nz > 1 && ns == e1) ? r1 : 0.0f);
       const float d = r - old;
       const float upd = old + d * alpha_f;
@@ -459,7 +535,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         Rg[ns] = upd;
         Tg[state * 4 + a] = (uint16_t)ns;
       }
-      if (!dense) {
+      if (KX) {
+        if (!dense) {
+          if (slot_m) {
+            if ((lane & 7) < Kw && elane == (uint32_t)ns) rlane = upd;
+          } else if (upd != 0.0f) {
+            dense = true;   // (a non-zero estimate outside the world's rewarded states)
+          }
+        }
+      } else if (!dense) {
         if (nz > 0 && ns == e0) r0 = upd;
         else if (nz > 1 && ns == e1) r1 = upd;
         else if (upd != 0.0f) {
@@ -472,7 +556,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       if (ns == state) tq = tcur;
     }
     const int fresh = learn ? state : -1;
-    if (!trial_over && !dense) gv = issue_gathers(tq, fresh);
+    if (!trial_over && !dense) gv = KX ? issue_gathers_x(tq, fresh) : issue_gathers(tq, fresh);
 
     if (learn) {
       // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
@@ -514,7 +598,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         } else if (!ANY_S || j * 64 + lane < quads) {
           out[j * 64] = o4;
         }
-        if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
+        if (KX) {
+          if (want_fresh) reinterpret_cast<float4*>(frow)[j * 64 + lane] = o4;
+        } else if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
           if (nz > 0 && (e0 >> 8) == j) {
             const int comp = e0 & 3;
             f0 = rlf(comp == 0 ? o4.x : (comp == 1 ? o4.y : (comp == 2 ? o4.z : o4.w)),
@@ -557,6 +643,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
       step += 1;
       if (dense) dense_values(tq);
+      else if (KX) assemble_x(tq, fresh, gv);
       else assemble(tq, fresh, f0, f1, gv);
     } else {
       const cobel_sr_run_t& rr = rare_args()->r;
@@ -600,26 +687,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   }
 }
 
-template <int NV, bool OCC, bool PSETS, bool ANY_S>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
   if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) {   // occupancy experiments
     lds += (size_t)atoi(pad);
     if (lds > 64 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S>),
+          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S, KX>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
 template <int NV, bool ANY_S>
-int launch_nv(const srw_args& A, bool occ, bool psets, hipStream_t st) {
+int launch_nv(const srw_args& A, bool occ, bool psets, bool kx, hipStream_t st) {
+  if (kx)   // (three to eight rewarded states; launch-wide hyper-parameters only)
+    return occ ? launch<NV, true, false, ANY_S, true>(A, st)
+               : launch<NV, false, false, ANY_S, true>(A, st);
   if (psets)
-    return occ ? launch<NV, true, true, ANY_S>(A, st) : launch<NV, false, true, ANY_S>(A, st);
-  return occ ? launch<NV, true, false, ANY_S>(A, st) : launch<NV, false, false, ANY_S>(A, st);
+    return occ ? launch<NV, true, true, ANY_S, false>(A, st)
+               : launch<NV, false, true, ANY_S, false>(A, st);
+  return occ ? launch<NV, true, false, ANY_S, false>(A, st)
+             : launch<NV, false, false, ANY_S, false>(A, st);
 }
 
 }  // namespace
@@ -631,7 +723,11 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   // (state counts that are not multiples of four: rows move one element at a time, which beats
   //  the row-streaming kernel up to ~640 states: 17x17 6.3e8 env-steps/s against 3.0e8, 25x25
   //  3.3e8 against 2.8e8, 31x31 2.3e8 against 2.5e8 — scripts/exp_sr_sizes.py)
-  return S >= 2 && S <= 1024 && (S % 4 == 0 || S <= 640) && world->max_rewarded_states <= 2 &&
+  // at most two rewarded states (every maze / open field builder of the reference), or up to eight
+  // with launch-wide hyper-parameters (the KX kernels)
+  const bool rewards_ok = world->max_rewarded_states <= 2 ||
+                          (world->max_rewarded_states <= 8 && world->rw && !r.param_index);
+  return S >= 2 && S <= 1024 && (S % 4 == 0 || S <= 640) && rewards_ok &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 
@@ -647,13 +743,15 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   A.eps = cobel_make_eps_consts(r.epsilon);
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
+  A.rw = world->rw;
   const bool occ = r.occupancy != nullptr, psets = r.param_index != nullptr;
+  const bool kx = world->max_rewarded_states > 2;
   const int S = world->n_states;
-  if (S == 256) return launch_nv<1, false>(A, occ, psets, st);
-  if (S == 512) return launch_nv<2, false>(A, occ, psets, st);
-  if (S == 1024) return launch_nv<4, false>(A, occ, psets, st);
-  if (S <= 256) return launch_nv<1, true>(A, occ, psets, st);
-  if (S <= 512) return launch_nv<2, true>(A, occ, psets, st);
-  if (S <= 768) return launch_nv<3, true>(A, occ, psets, st);
-  return launch_nv<4, true>(A, occ, psets, st);
+  if (S == 256) return launch_nv<1, false>(A, occ, psets, kx, st);
+  if (S == 512) return launch_nv<2, false>(A, occ, psets, kx, st);
+  if (S == 1024) return launch_nv<4, false>(A, occ, psets, kx, st);
+  if (S <= 256) return launch_nv<1, true>(A, occ, psets, kx, st);
+  if (S <= 512) return launch_nv<2, true>(A, occ, psets, kx, st);
+  if (S <= 768) return launch_nv<3, true>(A, occ, psets, kx, st);
+  return launch_nv<4, true>(A, occ, psets, kx, st);
 }

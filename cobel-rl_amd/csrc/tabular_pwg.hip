@@ -46,10 +46,18 @@ struct pwg_args {
   float alpha_f, gamma_f, model_lr_f;
   uint32_t* queue;       // eight heads, 32 B apart: next instance of each XCD's share (zeroed before the launch)
   int32_t nl, ng;        // waves per workgroup with Q in LDS / with Q in global memory
+  uint32_t reserve;      // instances per queue the global-memory waves leave to the others
 };
 
 constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
 constexpr int kMaxGlobalWaves = 4;
+#if defined(COBEL_PWG_NT)
+#define NT_LD(p) __builtin_nontemporal_load(p)
+#define NT_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define NT_LD(p) (*(p))
+#define NT_ST(v, p) (*(p) = (v))
+#endif
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -131,7 +139,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   uint4 cand = {0, 0, 0, 0};
   cobel_u4 blk = {0, 0, 0, 0};
   int refresh_in = 0;
-  uint32_t mrec = 0u;   // lane k < 4: reward estimate (bits) of the model record (state, k)
+  uint2 mdig = {0u, 0u};   // the four digest entries of the current state (requested a step ahead)
   uint32_t fix_sa = ~0u;
   float fix_r = 0.0f;
   uint32_t idx_cur = 0, mg_cur = 0;
@@ -150,10 +158,8 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
     const uint4 c = W4[s];
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
-    if (lane < 4) {
-      cand = W4[next_of(cw0, cw1, lane)];
-      mrec = model32[2u * ((uint32_t)s * 4u + (uint32_t)lane)];
-    }
+    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    mdig = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)s * 4u]);
   };
   auto begin_trial = [&]() -> bool {
     if (trial >= A.r.trials_target) return false;
@@ -344,12 +350,20 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     // (everything the previous step requested is consumed BEFORE this step's requests go out: the
     //  wait for a register loaded across the loop edge is a wait for every load in flight)
-    float R = __builtin_bit_cast(float, rl(mrec, a));
+    // The reward estimate of (state, a): +0.0f unless its digest entry is flagged — then, rarely
+    // (pairs that lead into a rewarded state), it is fetched from the packed record.  The model
+    // records themselves are never read otherwise: their lines stay out of the L2.
+    const uint32_t dpair = rfl((a & 2) ? mdig.y : mdig.x);
+    const uint32_t dold = (a & 1) ? (dpair >> 16) : (dpair & 0xffffu);
+    float R = 0.0f;
+    if (__builtin_expect((dold & 0x8000u) != 0u, 0)) {
+      R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
+    }
     __builtin_amdgcn_sched_barrier(0);
-    uint32_t mrec_next = 0u;
-    if (!trial_over && lane < 4) {
-      cand = W4[next_of(nw0, nw1, lane)];
-      mrec_next = model32[2u * ((uint32_t)ns * 4u + (uint32_t)lane)];
+    uint2 mdig_next = {0u, 0u};
+    if (!trial_over) {
+      if (lane < 4) cand = W4[next_of(nw0, nw1, lane)];
+      mdig_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
     }
 
     // ---- model store (memory/dyna_q.py:92-96) and online TD (agent/dyna_q.py:290-299), float32 ------
@@ -369,7 +383,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
     if (lane == 0) {
       if (QG) Qgf[sa] = qn_online;
       else Qf[sa] = qn_online;
-      model[sa] = cobel_model_pack(fresh_r, (uint32_t)ns, nt);
+      NT_ST(cobel_model_pack(fresh_r, (uint32_t)ns, nt), &model[sa]);
       Mg[sa] = (uint16_t)fresh_m;
     }
     __builtin_amdgcn_wave_barrier();
@@ -426,7 +440,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
       }
       idx_cur = idx_next;
       mg_cur = mg_next;
-      mrec = mrec_next;
+      mdig = mdig_next;
       cm += 1u;
     }
 
@@ -498,7 +512,16 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
     while (k0 < 8) {
       const uint32_t q = (xcc + (uint32_t)k0) & 7u;
       uint32_t t = 0u;
-      if (lane == 0) t = atomicAdd(A.queue + q * 8u, 1u);
+      if (lane == 0) {
+        // a wave with Q in global memory needs about three times as long for an instance: it
+        // leaves the last `reserve` instances of a queue to the LDS waves, which finish them
+        // sooner than it would finish one
+        if (qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                      A.reserve >= ((uint32_t)A.r.n + 7u - q) / 8u)
+          t = 0x10000000u;
+        else
+          t = atomicAdd(A.queue + q * 8u, 1u);
+      }
       const uint32_t c = rfl(t) * 8u + q;
       if (c < (uint32_t)A.r.n) {
         i = (int)c;
@@ -581,6 +604,11 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   const int waves = nl + ng;
   int grid = (r.n + waves - 1) / waves;
   if (grid > n_cu) grid = n_cu;
+  {
+    static const char* const k_env = getenv("COBEL_DEBUG_PWG_RESERVE");   // (experiments)
+    const double k = k_env ? atof(k_env) : 2.5;
+    A.reserve = nl ? (uint32_t)((double)nl * grid * k / 8.0) : 0u;
+  }
   COBEL_HIP_TRY(hipMemsetAsync(world->queue, 0, 256, st));
   if (lds > 64 * 1024)
     COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_pwg),

@@ -60,6 +60,79 @@ extern "C" void cobel_unpack_model(uint64_t rec, float* reward, uint16_t* next_s
   if (nonterminal) *nonterminal = (uint8_t)((hi >> 16) & 1u);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// NumPy's pairwise summation restricted to the elements that are not zero (see cobel_rw_info).
+// Values are slots 0 .. k-1 (element pos[slot]), -1 stands for an exact zero.
+namespace {
+struct pw_builder {
+  const int* pos;
+  int k, steps;
+  uint8_t* dst;
+  uint8_t* src;
+  int add(int x, int y) {
+    if (x < 0) return y;
+    if (y < 0) return x;
+    dst[steps] = (uint8_t)x;
+    src[steps] = (uint8_t)y;
+    steps += 1;
+    return x;
+  }
+  int slot_at(int e) const {
+    for (int s = 0; s < k; ++s)
+      if (pos[s] == e) return s;
+    return -1;
+  }
+  bool any_in(int lo, int len) const {
+    for (int s = 0; s < k; ++s)
+      if (pos[s] >= lo && pos[s] < lo + len) return true;
+    return false;
+  }
+  int sum(int lo, int len) {
+    if (!any_in(lo, len)) return -1;
+    if (len < 8) {
+      int res = -1;
+      for (int i = 0; i < len; ++i) res = add(res, slot_at(lo + i));
+      return res;
+    }
+    if (len <= 128) {
+      int r[8];
+      for (int j = 0; j < 8; ++j) r[j] = slot_at(lo + j);
+      int i = 8;
+      for (; i < len - (len % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] = add(r[j], slot_at(lo + i + j));
+      int res = add(add(add(r[0], r[1]), add(r[2], r[3])), add(add(r[4], r[5]), add(r[6], r[7])));
+      for (; i < len; ++i) res = add(res, slot_at(lo + i));
+      return res;
+    }
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    const int left = sum(lo, n2);
+    const int right = sum(lo + n2, len - n2);
+    return add(left, right);
+  }
+};
+}  // namespace
+
+int cobel_pairwise_schedule(int n, const int* pos, int k, uint8_t* dst, uint8_t* src) {
+  pw_builder b{pos, k, 0, dst, src};
+  return b.sum(0, n);
+}
+
+// exported for tests: evaluates nothing on the device
+extern "C" int cobel_pairwise_order(int32_t n, const int32_t* pos, int32_t k, uint8_t* dst,
+                                    uint8_t* src, int32_t* root) {
+  COBEL_REQUIRE(n > 0 && pos && dst && src && root && k >= 0 && k <= 8, COBEL_E_ARG,
+                "cobel_pairwise_order: bad arguments");
+  for (int j = 0; j < k; ++j)
+    COBEL_REQUIRE(pos[j] >= 0 && pos[j] < n && (j == 0 || pos[j] > pos[j - 1]), COBEL_E_RANGE,
+                  "cobel_pairwise_order: positions must ascend inside [0, n)");
+  int p[8];
+  for (int j = 0; j < k; ++j) p[j] = pos[j];
+  *root = cobel_pairwise_schedule(n, p, k, dst, src);
+  return COBEL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
                                   const uint8_t* terminal, const uint16_t* starts,
@@ -98,10 +171,24 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   w->n_worlds = n_worlds;
   w->device = device;
   w->n_actions = 4;
+  std::vector<cobel_rw_info> rw((size_t)n_worlds);
   for (int k = 0; k < n_worlds; ++k) {
     int32_t rewarded = 0;
-    for (int32_t s = 0; s < n_states; ++s) rewarded += reward[(size_t)k * n_states + s] != 0.0f;
+    int pos[8];
+    for (int32_t s = 0; s < n_states; ++s)
+      if (reward[(size_t)k * n_states + s] != 0.0f) {
+        if (rewarded < 8) pos[rewarded] = s;
+        rewarded += 1;
+      }
     if (rewarded > w->max_rewarded_states) w->max_rewarded_states = rewarded;
+    cobel_rw_info& info = rw[(size_t)k];
+    memset(&info, 0, sizeof(info));
+    info.k = rewarded <= 8 ? (uint8_t)rewarded : (uint8_t)255;
+    if (rewarded <= 8) {
+      for (int j = 0; j < rewarded; ++j) info.pos[j] = (uint16_t)pos[j];
+      const int root = cobel_pairwise_schedule(n_states, pos, rewarded, info.dst, info.src);
+      info.root = (uint8_t)(root < 0 ? 0 : root);
+    }
   }
   w->h_start_off = (int32_t*)malloc(sizeof(int32_t) * (n_worlds + 1));
   memcpy(w->h_start_off, start_offsets, sizeof(int32_t) * (n_worlds + 1));
@@ -109,6 +196,9 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   if (e == hipSuccess) e = hipMalloc((void**)&w->starts, sizeof(uint16_t) * n_starts);
   if (e == hipSuccess) e = hipMalloc((void**)&w->start_off, sizeof(int32_t) * (n_worlds + 1));
   if (e == hipSuccess) e = hipMalloc((void**)&w->queue, 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&w->rw, sizeof(cobel_rw_info) * (size_t)n_worlds);
+  if (e == hipSuccess)
+    e = hipMemcpy(w->rw, rw.data(), sizeof(cobel_rw_info) * (size_t)n_worlds, hipMemcpyHostToDevice);
   if (e == hipSuccess)
     e = hipMemcpy(w->rec, rec.data(), total * sizeof(cobel_wrec), hipMemcpyHostToDevice);
   if (e == hipSuccess)
@@ -130,6 +220,7 @@ extern "C" int cobel_world_destroy(cobel_world_t* w) {
   if (w->starts) (void)hipFree(w->starts);
   if (w->start_off) (void)hipFree(w->start_off);
   if (w->queue) (void)hipFree(w->queue);
+  if (w->rw) (void)hipFree(w->rw);
   if (w->next_n) (void)hipFree(w->next_n);
   if (w->reward_s) (void)hipFree(w->reward_s);
   if (w->terminal_s) (void)hipFree(w->terminal_s);

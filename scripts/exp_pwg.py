@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch  # noqa: E402
 import bench  # noqa: E402
 from cobel_amd import _lib  # noqa: E402
+if os.environ.get('COBEL_LIB'):      # A/B builds of the library
+    _lib.LIB_PATH = os.path.join(ROOT, 'cobel-rl_amd', 'lib', os.environ['COBEL_LIB'])
 dev = torch.device('cuda', 0)
 pre = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cfg = dict(bench.CONFIGS['C3'])
@@ -24,7 +26,7 @@ ev[pre + 4].record()
 torch.cuda.synchronize()
 ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(pre + 4)]
 what = r.describe()
-print('PWG=%s %s kernel %d: launches 2-5 %s | last 4 %s ms  -> %.3e steps/s' % (
-    os.environ.get('COBEL_DEBUG_PWG', '-'), 'nopwg' if 'nopwg' in sys.argv else '', what['kernel'],
+print('lib=%s PWG=%s %s kernel %d: launches 2-5 %s | last 4 %s ms  -> %.3e steps/s' % (
+    os.environ.get('COBEL_LIB', '-'), os.environ.get('COBEL_DEBUG_PWG', '-'), 'nopwg' if 'nopwg' in sys.argv else '', what['kernel'],
     ' '.join('%.2f' % m for m in ms[1:5]), ' '.join('%.2f' % m for m in ms[-4:]),
     cfg['instances'] * cfg['env_steps_per_launch'] / (min(ms[-4:]) * 1e-3)), flush=True)

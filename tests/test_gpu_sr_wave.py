@@ -299,3 +299,76 @@ def test_wave_kernel_any_size_with_many_reward_estimates(torch_cuda):
         assert torch.equal(a._sr, b._sr) and torch.equal(a._T, b._T) and torch.equal(a._rw, b._rw)
         assert torch.equal(a.inst, b.inst)
         assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
+
+
+def _multi_reward_worlds():
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    four = make_gridworld(32, 32, terminals=[0, 1023], goals=[0],
+                          rewards=np.array([[0, 1.0], [1023, 0.5], [517, 0.25], [130, -0.125]]),
+                          starting_states=[33, 500, 700, 990, 520, 131])
+    eight = make_gridworld(32, 32, terminals=[5], goals=[5],
+                           rewards=np.array([[5, 1.0], [6, 0.5], [37, -0.25], [38, 0.125], [100, 2.0],
+                                             [255, 0.75], [256, -1.5], [900, 0.3]]),
+                           starting_states=[4, 7, 36, 39, 69, 101, 257])
+    three_odd = make_gridworld(13, 17, terminals=[0], goals=[0],       # 221 states: rows move by element
+                               rewards=np.array([[0, 1.0], [1, 0.5], [18, 0.25]]),
+                               starting_states=[2, 19, 35, 36])
+    five_any = make_gridworld(20, 24, terminals=[10], goals=[10],      # 480 states: float4 rows, bounds
+                              rewards=np.array([[10, 1.0], [11, 0.5], [34, 0.25], [35, -0.5], [58, 0.1]]),
+                              starting_states=[9, 12, 33, 36, 59, 82])
+    return {'four_32x32': four, 'eight_32x32': eight, 'three_13x17': three_odd,
+            'five_20x24': five_any}
+
+
+@pytest.mark.parametrize('name,n,budgets,spt', [
+    ('four_32x32', 12, (180, 33, 120), 120),
+    ('eight_32x32', 20, (150, 150, 7), 40),
+    ('three_13x17', 16, (90, 111), 30),
+    ('five_20x24', 16, (128, 128), 35),
+])
+def test_three_to_eight_rewarded_states_take_the_wave_kernel(torch_cuda, name, n, budgets, spt):
+    """Worlds with three to eight rewarded states (make_gridworld(rewards=...)): the sparse-reward
+    kernel adds the up-to-eight products of a value row in NumPy's pairwise grouping
+    (cobel_pairwise_order) — SR, transition tables, reward estimates, counters and monitors equal
+    the row-streaming kernel's and the C oracle's full row sums, bit for bit."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    world = _multi_reward_worlds()[name]
+    env, ag = _agent(torch, world, n, 777, base=3, eps=0.25)
+    _launches(torch, env, ag, budgets, spt)
+    env2, ref = _agent(torch, world, n, 777, base=3, eps=0.25, stream_rows=True)
+    _launches(torch, env2, ref, budgets, spt)
+    _same(torch, ag, ref)
+    traffic = ag.traffic.cpu().numpy()
+    assert traffic[1] == n * sum(budgets) and traffic[3] == 0, 'the wave kernel ran, sparse path'
+    assert ref.traffic.sum().item() == 0
+    rw = ag._rw.cpu().numpy()
+    assert int(((rw != 0).sum(axis=1) >= 2).sum()) >= 2, 'several estimates became non-zero'
+    o = c_oracle.SROracle(_oracle_world(world), n, env.seed, True, instance_base=3, epsilon=0.25,
+                          trial_cap=64, occupancy=True)
+    for b in budgets:
+        o.run(0x7fffffff, spt, step_budget=b)
+    assert np.array_equal(ag._T.cpu().numpy().astype(np.int64), o.T)
+    assert np.array_equal(ag._rw.cpu().numpy().astype(np.float64), o.RW)
+    assert np.array_equal(ag._sr.cpu().numpy().astype(np.float64), o.SR)
+    assert np.array_equal(ag.monitors.lat_trace.cpu().numpy(), o.lat_trace)
+
+
+def test_multi_reward_world_with_a_foreign_estimate_falls_back_to_full_sums(torch_cuda):
+    """A non-zero estimate at a state the world does not reward (a caller's edit): full pairwise
+    sums from memory, equal to the row-streaming kernel."""
+    torch = torch_cuda
+    world = _multi_reward_worlds()['four_32x32']
+    n = 6
+    edit = np.zeros((n, 1024), dtype=np.float32)
+    edit[1:, 444] = 0.5
+    edit[:, 517] = 0.25
+    out = []
+    for stream_rows in (False, True):
+        env, ag = _agent(torch, world, n, 11, eps=0.2, stream_rows=stream_rows)
+        ag._bind(env)
+        ag._rw.copy_(torch.as_tensor(edit, device='cuda'))
+        _launches(torch, env, ag, (60, 45), 50)
+        out.append(ag)
+    _same(torch, out[0], out[1])
+    assert out[0].traffic[3].item() == (n - 1) * 2, 'five instances on the dense path, per launch'

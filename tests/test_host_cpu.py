@@ -666,3 +666,32 @@ def test_deterministic_flag_and_stochastic_rows():
         gt.successor_table(np.zeros((2, 4, 2)))   # rows without any successor
     with pytest.raises(ValueError):
         gt.transition_lists(-np.ones((2, 4, 2)))
+
+
+def test_pairwise_order_reproduces_numpy_sums_of_sparse_vectors():
+    """cobel_pairwise_order (host function of the library): adding the k <= 8 non-zero elements of a
+    float32 vector in the order it returns gives np.sum of the whole vector bit for bit — the
+    grouping NumPy's pairwise summation applies to those positions (agent/sr.py:302-306)."""
+    import ctypes as C
+    from cobel_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(12)
+    for trial in range(400):
+        n = int(rng.choice([5, 7, 8, 25, 100, 128, 129, 221, 256, 400, 480, 512, 640, 961, 1024]))
+        k = int(rng.integers(0, min(8, n) + 1))
+        pos = np.sort(rng.choice(n, size=k, replace=False)).astype(np.int32)
+        vals = (rng.standard_normal(k) * 10.0 ** rng.integers(-6, 6, k)).astype(np.float32)
+        vec = np.zeros(n, dtype=np.float32)
+        vec[pos] = vals
+        dst, src = (C.c_uint8 * 7)(), (C.c_uint8 * 7)()
+        root = C.c_int32(-2)
+        rc = lib.cobel_pairwise_order(n, pos.ctypes.data_as(C.c_void_p), k, dst, src, C.byref(root))
+        assert rc == 0
+        slots = [np.float32(v) for v in vals]
+        for t in range(max(0, k - 1)):
+            slots[dst[t]] = np.float32(slots[dst[t]] + slots[src[t]])
+        got = slots[root.value] if k else np.float32(0)
+        assert (root.value >= 0) == (k > 0)
+        want = np.sum(vec)
+        assert got == want and (got != 0 or want == 0), (n, pos, vals, got, want)
+        assert np.float32(got).tobytes() == np.float32(want).tobytes() or got == 0
