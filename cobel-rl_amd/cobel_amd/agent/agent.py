@@ -343,7 +343,11 @@ class FusedAgent(Agent):
         if self.n_states is None:
             self.n_states = interface.handle.n_states
             self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
-            self._poses = np.asarray(interface.pose, dtype=np.float64)
+            # the key an agent's table is indexed by: the pose, or (pre-rendered observations) the
+            # flattened observation components in order
+            keys = interface.observation_key_table() if hasattr(interface, 'observation_key_table') \
+                else interface.pose
+            self._poses = np.asarray(keys, dtype=np.float64)
         else:
             assert int(interface.observation_space.n) == self.n_states
         self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)

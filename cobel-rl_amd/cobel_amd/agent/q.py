@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib
-from ..spaces import Box, Discrete
+from ..spaces import Box, Dict, Discrete
 from .tabular import TabularAgent
 
 
@@ -24,8 +24,10 @@ class QAgent(TabularAgent):
     def __init__(self, observation_space, action_space, policy, policy_test=None,
                  learning_rate: float = 0.9, gamma: float = 0.8, custom_callbacks=None,
                  rng=None) -> None:
-        assert type(observation_space) in (Discrete, Box), \
-            'Discrete observations and Topology poses (Box) are accelerated'
+        # (Dict: the pre-rendered observations of an OfflineSimulator-backed Topology, which the
+        #  reference concatenates in key order, agent/q.py:156-158)
+        assert type(observation_space) in (Discrete, Box, Dict), \
+            'Discrete observations, Topology poses (Box) and dictionary observations are accelerated'
         assert type(action_space) is Discrete, 'Wrong action space!'
         super().__init__(observation_space, action_space, policy, policy_test, learning_rate,
                          gamma, custom_callbacks)

@@ -71,6 +71,9 @@ class TabularAgent(FusedAgent):
     def _node_index(self, batch) -> np.ndarray:
         """Pose observations -> node indices (the reference keys Q by tuple(pose), q.py:154-155;
         an unseen pose is a KeyError there as well)."""
+        if len(batch) and isinstance(batch[0], dict):     # agent/q.py:156-158
+            batch = [np.concatenate([np.asarray(o, dtype=np.float64).flatten()
+                                     for _, o in b.items()]) for b in batch]
         obs = np.asarray(batch, dtype=np.float64).reshape(-1, self._poses.shape[1])
         hit = (obs[:, None, :] == self._poses[None, :, :]).all(axis=2)
         if not hit.any(axis=1).all():

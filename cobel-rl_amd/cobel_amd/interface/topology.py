@@ -9,7 +9,10 @@ API of the reference's ``cobel.interface.Topology`` (interface/topology.py:28-19
 ``cobel_env_reset`` and observations are pose rows gathered on device
 (``cobel_gather_rows``).  Reference quirks kept: the constructor draws one start node
 (topology.py:109); ``step`` returns ``truncated == end_trial`` (topology.py:157).
-Simulators (Godot / Unity / offline observation dictionaries) are out of scope.
+An ``OfflineSimulator`` (interface/simulator/offline.py:51-72: pre-rendered observations per pose,
+plain arrays, lists or dictionaries of arrays — unit_tests/test_topology.py, test_q.py
+"Topology-Dict") becomes one device table per observation component, gathered by node index like
+the poses; the rendering simulators (Godot / Unity) are out of scope.
 """
 from __future__ import annotations
 
@@ -17,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..spaces import Box, Discrete
+from ..spaces import Box, Dict, Discrete, Tuple  # noqa: F401
 from .gridworld import WorldHandle, _as_seed
 from .interface import Interface
 
@@ -27,7 +30,8 @@ class Topology(Interface):
                  n_envs: int = 1, seed: int | None = None, device=None,
                  instance_base: int = 0) -> None:
         super().__init__(widget)
-        assert simulator is None, 'simulator-backed observations are outside the accelerated path'
+        assert simulator is None or hasattr(simulator, 'observations'), \
+            'only pre-rendered observations (OfflineSimulator) are on the accelerated path'
         self.nodes = nodes
         self.ids = list(nodes.keys())
         index = {k: i for i, k in enumerate(self.ids)}
@@ -57,10 +61,13 @@ class Topology(Interface):
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
         self.handle = WorldHandle([world], self.device)
-        self.simulator = None
-        self.observation_space = Box(low=np.array([-np.inf, -np.inf, -np.inf, 0.0, 0.0, 0.0]),
-                                     high=np.array([np.inf, np.inf, np.inf, 360.0, 360.0, 360.0]),
-                                     dtype=np.float64)
+        self.simulator = simulator
+        if simulator is None:
+            self.observation_space = Box(low=np.array([-np.inf, -np.inf, -np.inf, 0.0, 0.0, 0.0]),
+                                         high=np.array([np.inf, np.inf, np.inf, 360.0, 360.0, 360.0]),
+                                         dtype=np.float64)
+        else:
+            self.observation_space = simulator.observation_space
         self.action_space = Discrete(n_act)
         self.state = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
         self.env_ctr = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
@@ -68,8 +75,46 @@ class Topology(Interface):
         self._done = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
         self._pose_dev = torch.as_tensor(self.pose, device=self.device).contiguous()
         self._obs = torch.zeros((self.n_envs, 6), dtype=torch.float64, device=self.device)
+        # pre-rendered observations: per component a table [S, D] (rows = nodes) on the device
+        self._sim_kind, self._sim_keys, self._sim_tabs, self._sim_shapes, self._sim_out = \
+            None, None, None, None, None
+        if simulator is not None:
+            self._compile_observations(simulator.observations)
         self._draw()   # the constructor's start-node draw
         self.observation = None
+
+    def _compile_observations(self, observations: dict) -> None:
+        """interface/simulator/offline.py:51-72 + topology.py:174-193: ``observations[pose]`` is an
+        array, a list / tuple of arrays or a dictionary of arrays; every node's pose must be a key."""
+        first = observations[tuple(self.nodes[self.ids[0]]['pose'])]
+        if isinstance(first, dict):
+            self._sim_kind, self._sim_keys = 'dict', list(first.keys())
+            parts = lambda o: [o[k] for k in self._sim_keys]      # noqa: E731
+        elif isinstance(first, (list, tuple)):
+            self._sim_kind, self._sim_keys = 'list', list(range(len(first)))
+            parts = lambda o: list(o)                              # noqa: E731
+        else:
+            self._sim_kind, self._sim_keys = 'array', [0]
+            parts = lambda o: [o]                                  # noqa: E731
+        rows = [[] for _ in self._sim_keys]
+        for k in self.ids:
+            pose = tuple(self.nodes[k]['pose'])
+            if pose not in observations:
+                raise KeyError(pose)        # what the reference raises at the first visit
+            for c, part in enumerate(parts(observations[pose])):
+                rows[c].append(np.asarray(part, dtype=np.float64))
+        self._sim_shapes = [r[0].shape for r in rows]
+        self._sim_tabs = [torch.as_tensor(np.stack([x.reshape(-1) for x in r]), device=self.device)
+                          .contiguous() for r in rows]
+        self._sim_out = [torch.zeros((self.n_envs, t.shape[1]), dtype=torch.float64,
+                                     device=self.device) for t in self._sim_tabs]
+
+    def observation_key_table(self) -> np.ndarray:
+        """``[S, D]``: per node the tuple an agent keys its table by (agent/q.py:150-158: Box
+        observations flattened, dictionary observations concatenated in key order)."""
+        if self.simulator is None:
+            return self.pose
+        return np.concatenate([t.cpu().numpy() for t in self._sim_tabs], axis=1)
 
     def _stream(self):
         return _lib.current_stream(self.device)
@@ -95,7 +140,29 @@ class Topology(Interface):
             len(self.ids), self._stream()))
         return self._obs
 
+    def _observe_sim(self):
+        """Gathered rows of every observation component, in the container the simulator uses."""
+        for tab, out in zip(self._sim_tabs, self._sim_out):
+            _lib.check(_lib.lib().cobel_gather_rows(
+                _lib.ptr(tab), _lib.ptr(self.state), _lib.ptr(out), self.n_envs, tab.shape[1],
+                len(self.ids), self._stream()))
+        if self.n_envs == 1:
+            parts = [o[0].cpu().numpy().reshape(sh) for o, sh in zip(self._sim_out, self._sim_shapes)]
+        else:
+            parts = [o.reshape((self.n_envs,) + tuple(sh))
+                     for o, sh in zip(self._sim_out, self._sim_shapes)]
+        if self._sim_kind == 'dict':
+            return dict(zip(self._sim_keys, parts))
+        return parts if self._sim_kind == 'list' else parts[0]
+
     def get_observation(self, pose=None):
+        if self.simulator is not None:
+            if pose is not None:     # topology.py:190-191
+                import copy
+                self.observation = self.simulator.get_observation(tuple(pose))
+                return copy.deepcopy(self.observation)
+            self.observation = self._observe_sim()
+            return self.observation
         if pose is not None:
             self.observation = np.array(pose)
             return np.array(pose)

@@ -30,3 +30,27 @@ except Exception:  # gymnasium absent
             self.low, self.high = np.asarray(low), np.asarray(high)
             self.shape = tuple(shape) if shape is not None else self.low.shape
             self.dtype = dtype
+
+
+try:  # pragma: no cover - depends on the environment
+    from gymnasium.spaces import Dict, Tuple  # type: ignore
+except Exception:  # gymnasium absent
+
+    class Dict(dict):  # noqa: D101
+        """``gymnasium.spaces.Dict``: named sub-spaces (``.spaces`` is the mapping itself)."""
+
+        def __init__(self, spaces=None) -> None:
+            dict.__init__(self, spaces or {})
+            self.spaces = self
+
+    class Tuple:  # noqa: D101
+        """``gymnasium.spaces.Tuple``: a sequence of sub-spaces in ``.spaces``."""
+
+        def __init__(self, spaces) -> None:
+            self.spaces = list(spaces)
+
+        def __len__(self) -> int:
+            return len(self.spaces)
+
+        def __getitem__(self, k):
+            return self.spaces[k]

@@ -555,21 +555,39 @@ def gen_qagent_topology():
         'hex5_b0_f32': (('hex', 5, (0.0, 2.0), 3.0, '7'), 4, True, 30, 40, 0),
         'hex5_b8_f32': (('hex', 5, (0.0, 2.0), 3.0, '7'), 5, True, 30, 40, 8),
         'hex4_b70_f32': (('hex', 4, (0.0, 1.0), 1.0, None), 6, True, 12, 30, 70),
+        # pre-rendered dictionary observations (unit_tests/test_q.py:24-41, 57-62 "Topology-Dict"):
+        # OfflineSimulator, Q keyed by the concatenated components (agent/q.py:156-158)
+        'trackdict_b8_f32': ((10, 2, 1., 20., 'right', 'dict'), 7, True, 25, 60, 8),
+        'trackdict_b0_f32': ((10, 2, 1., 20., 'right', 'dict'), 8, True, 20, 80, 0),
     }
     out = {}
     for name, (args, inst, f32, trials, steps, B) in cases.items():
+        dict_obs = len(args) == 6 and args[5] == 'dict'
+        if dict_obs:
+            args = args[:5]
         if args[0] == 'hex':
             nodes, starts = tt.hexagonal(*args[1:])
             args = (float(args[1]), 0.0, 0.0, 0.0, 'hex')
         else:
             nodes, starts = tt.linear_track(*args)
         n_act = len(nodes[starts[0]]['neighbors'])
-        env = Topology(nodes, starts, rng=TapeRNG(SEED, inst, STREAM_ENV))
+        simulator = None
+        if dict_obs:
+            import gymnasium
+            from cobel.interface import OfflineSimulator
+            obs = {node['pose']: {'1': np.array(node['pose']), '2': np.array(node['pose'])}
+                   for node in nodes.values()}
+            space = gymnasium.spaces.Dict({'1': gymnasium.spaces.Box(0., 1., (6,)),
+                                           '2': gymnasium.spaces.Box(0., 1., (6,))})
+            simulator = OfflineSimulator(obs, space)
+        env = Topology(nodes, starts, simulator, rng=TapeRNG(SEED, inst, STREAM_ENV))
         pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
         ag = QAgent(env.observation_space, env.action_space, pol,
                     rng=TapeRNG(SEED, inst, STREAM_MEMORY))
         ids = list(nodes.keys())
-        key = {tuple(np.array(nodes[k]['pose']).flatten()): i for i, k in enumerate(ids)}
+        rep = 2 if dict_obs else 1
+        key = {tuple(np.tile(np.array(nodes[k]['pose']).flatten(), rep)): i
+               for i, k in enumerate(ids)}
         if f32:
             for k in key:
                 ag.Q[k] = np.zeros(n_act, dtype=np.float32)
@@ -592,13 +610,19 @@ def gen_qagent_topology():
         for k, row in ag.Q.items():
             Q[key[k]] = row
         probe = np.array([nodes[k]['pose'] for k in ids[:5]], dtype=np.float64)
+        if dict_obs:
+            # (the reference's predict_on_batch on dictionary observations raises TypeError — it
+            #  looks Q up with an ndarray, agent/q.py:340 — so the rows are read from Q directly)
+            probe_q = np.array([ag.Q[tuple(np.tile(p, 2))] for p in probe], dtype=np.float64)
+        else:
+            probe_q = np.array(ag.predict_on_batch(probe), dtype=np.float64)
         d = dict(state=a[:, 0].astype(np.int16), action=a[:, 1].astype(np.int8), reward=a[:, 2],
                  next_state=a[:, 3].astype(np.int16), nonterminal=a[:, 4].astype(np.int8),
                  td=np.array(tds), steps=np.array(steps_log, dtype=np.int32),
                  trial_reward=np.array(rewards), Q=Q, log_len=np.int64(len(ag.M)),
                  cfg=np.array([inst, f32, trials, steps, B], dtype=np.int64),
                  track=np.array(args[:4], dtype=np.float64), side=np.array(args[4]),
-                 probe=probe, probe_q=np.array(ag.predict_on_batch(probe), dtype=np.float64))
+                 probe=probe, probe_q=probe_q)
         for k, v in d.items():
             out['%s/%s' % (name, k)] = v
     np.savez_compressed(_out('qagent_topology_traces.npz'), **out)

@@ -412,3 +412,120 @@ def test_dqn_single_instance_honours_hooks_and_stop(cobel, golden):
     assert seen == [0, 1] and stopped.current_trial == 2
     stopped2 = run({'on_trial_end': [stop_after_two], 'on_step_end': [lambda l: None]})
     assert stopped2.current_trial == 2
+
+
+def _offline_obs(kind, nodes):
+    """unit_tests/test_topology.py:14-57 / test_q.py:24-41: every pose observed as two copies."""
+    from cobel.spaces import Box, Dict, Tuple
+    if kind == 'List':
+        obs = {node['pose']: [np.array(node['pose']), np.array(node['pose'])] for node in nodes.values()}
+        return obs, Tuple([Box(-np.inf, np.inf, (6,)), Box(-np.inf, np.inf, (6,))])
+    obs = {node['pose']: {'1': np.array(node['pose']), '2': np.array(node['pose'])}
+           for node in nodes.values()}
+    return obs, Dict({'1': Box(-np.inf, np.inf, (6,)), '2': Box(-np.inf, np.inf, (6,))})
+
+
+def test_topology_with_prerendered_observations(cobel):
+    """unit_tests/test_topology.py:60-110 in all three observation modes: pose, list and dictionary
+    observations of an OfflineSimulator (interface/simulator/offline.py:51-72), the same known
+    trajectory in each; vectorised, the gathered components are device tensors."""
+    from cobel.interface import OfflineSimulator, Topology
+    from cobel.misc.topology_tools import t_maze
+    from cobel.spaces import Box, Dict, Discrete, Tuple
+    nodes, nodes_starting = t_maze(4, 3, 1)
+    for kind in (None, 'List', 'Dict'):
+        simulator = None if kind is None else OfflineSimulator(*_offline_obs(kind, nodes))
+        env = Topology(nodes, nodes_starting, simulator)
+        assert isinstance(env.action_space, Discrete) and env.action_space.n == 4
+        if kind is None:
+            assert isinstance(env.observation_space, Box) and env.observation_space.shape == (6,)
+        elif kind == 'List':
+            assert isinstance(env.observation_space, Tuple)
+            assert [s.shape for s in env.observation_space.spaces] == [(6,), (6,)]
+        else:
+            assert isinstance(env.observation_space, Dict)
+            assert env.observation_space.spaces['1'].shape == (6,)
+        obs, _ = env.reset()
+        assert env.current_node == '10'
+        pose = np.array(nodes['10']['pose'])
+        if kind == 'List':
+            assert isinstance(obs, list) and all(np.array_equal(o, pose) for o in obs)
+        elif kind == 'Dict':
+            assert sorted(obs) == ['1', '2'] and all(np.array_equal(o, pose) for o in obs.values())
+        states, rewards, terminals = [], [], []
+        for action in [1, 1, 1, 1, 1, 2, 2, 2]:
+            obs, reward, terminal, _, _ = env.step(action)
+            states.append(env.current_node)
+            rewards.append(reward)
+            terminals.append(terminal)
+            here = np.array(nodes[env.current_node]['pose'])
+            got = obs if kind is None else (obs[0] if kind == 'List' else obs['2'])
+            assert np.array_equal(got, here)
+        assert states == ['9', '8', '7', '3', '3', '4', '5', '6']
+        assert rewards == [0.] * 7 + [1.] and terminals == [False] * 7 + [True]
+    # a pose without an observation is a KeyError (the reference raises it at the first visit)
+    obs, space = _offline_obs('Dict', nodes)
+    del obs[nodes['5']['pose']]
+    with pytest.raises(KeyError):
+        Topology(nodes, nodes_starting, OfflineSimulator(obs, space))
+    # vectorised: rows gathered on the device
+    env = Topology(nodes, nodes_starting, OfflineSimulator(*_offline_obs('Dict', nodes)), n_envs=7, seed=3)
+    obs, _ = env.reset()
+    assert obs['1'].shape == (7, 6) and obs['1'].is_cuda
+    want = np.array([nodes[env.ids[int(s)]]['pose'] for s in env.state.cpu().numpy()])
+    assert np.array_equal(obs['2'].cpu().numpy(), want)
+
+
+def test_q_simulations_on_dictionary_observations(cobel):
+    """unit_tests/test_q.py:46-87, the "Topology-Dict" case with and without a test policy."""
+    from cobel.agent import QAgent
+    from cobel.interface import OfflineSimulator, Topology
+    from cobel.misc.topology_tools import linear_track
+    from cobel.policy import EpsilonGreedy
+    for use_test_policy in (True, False):
+        nodes, starting_nodes = linear_track(10, 2, 1, 20)
+        simulator = OfflineSimulator(*_offline_obs('Dict', nodes))
+        env = Topology(nodes, starting_nodes, simulator)
+        agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(),
+                       EpsilonGreedy(0.) if use_test_policy else None)
+        agent.train(env, 5, 20, 32)
+        agent.test(env, 5, 20)
+        assert agent.current_trial == 10 and np.isfinite(agent.Q).all()
+        assert all(len(k) == 12 for k in agent.Q_dict)
+
+
+@pytest.mark.parametrize('name', ['trackdict_b8_f32', 'trackdict_b0_f32'])
+def test_qagent_on_dictionary_observations_matches_reference(cobel, golden, name):
+    """QAgent on an OfflineSimulator-backed Topology: the reference keys Q by the concatenated
+    observation components (agent/q.py:156-158); trajectory, TD errors and Q rows of its float32
+    run, bit for bit."""
+    from conftest import SEED
+    from cobel.agent import QAgent
+    from cobel.interface import OfflineSimulator, Topology
+    from cobel.misc.topology_tools import linear_track
+    from cobel.policy import EpsilonGreedy
+    Z = golden('qagent_topology_traces')
+    g = lambda k: Z['%s/%s' % (name, k)]      # noqa: E731
+    inst, f32, trials, steps, B = [int(x) for x in g('cfg')]
+    a, b, sp, rw = g('track')
+    nodes, starts = linear_track(int(a), int(b), float(sp), float(rw), str(g('side')))
+    env = Topology(nodes, starts, OfflineSimulator(*_offline_obs('Dict', nodes)), seed=SEED,
+                   instance_base=inst)
+    sarsn, tds, steps_log = [], [], []
+    cbs = {'on_step_end': [lambda l: (sarsn.append((l['state'], l['action'], l['reward'],
+                                                    l['next_state'], l['terminal'])),
+                                      tds.append(l['td']))],
+           'on_trial_end': [lambda l: steps_log.append(l['steps'])]}
+    agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1), custom_callbacks=cbs)
+    agent.train(env, trials, steps, B)
+    arr = np.array(sarsn, dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(arr[:, col], g(key)), key
+    if B == 0:
+        assert np.array_equal(np.array(tds, dtype=np.float64), g('td'))
+    assert np.array_equal(steps_log, g('steps'))
+    assert np.array_equal(np.asarray(agent.Q, dtype=np.float64), g('Q')) and g('Q').max() > 0
+    probe = [{'1': p, '2': p} for p in g('probe')]
+    assert np.array_equal(agent.predict_on_batch(probe).astype(np.float64), g('probe_q'))
+    assert len(agent.M) == int(g('log_len'))
+    assert all(len(k) == 12 for k in agent.Q_dict)
