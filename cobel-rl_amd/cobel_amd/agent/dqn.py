@@ -318,7 +318,12 @@ class DQN(Agent):
         # leaves the loop (one graph launch per 16 steps instead of 32 ctypes calls).
         per_graph = 16
         graph = None
-        if self.fused_graph and self.use_graph is not False and (budget or steps) >= per_graph:
+        # (recording and instantiating a graph costs more than the steps of one trial replayed
+        #  from it: the one-trial runs that trial hooks on a single instance force, _run, launch
+        #  their steps directly)
+        worth = not getattr(self, '_one_trial_runs', False)
+        if self.fused_graph and self.use_graph is not False and worth and \
+                (budget or steps) >= per_graph:
             pair()                                   # (lazy initialisations outside the capture)
             done_first = 1
             torch.cuda.synchronize(dev)
@@ -357,10 +362,14 @@ class DQN(Agent):
         if single and self.callbacks.has('on_step_begin', 'on_step_end'):
             self._run_hooks(interface, trials, steps, batch_size, learn)
         elif single and self.callbacks.has('on_trial_begin', 'on_trial_end'):
-            for t in range(trials):          # one trial per run: same streams, same kernels
-                self._run_core(interface, 1, steps, batch_size, learn, 0, session0=t)
-                if self.stop:
-                    break
+            self._one_trial_runs = True
+            try:
+                for t in range(trials):          # one trial per run: same streams, same kernels
+                    self._run_core(interface, 1, steps, batch_size, learn, 0, session0=t)
+                    if self.stop:
+                        break
+            finally:
+                self._one_trial_runs = False
         else:
             self._run_core(interface, trials, steps, batch_size, learn, budget)
 

@@ -371,7 +371,12 @@ class DynaDSR(DynaDQN):
 
         graph, done = None, 0
         per_graph = 8
-        if self.fused_graph and self.use_graph is not False and (budget or steps) >= per_graph:
+        # (recording and instantiating a graph costs more than the steps of one trial replayed
+        #  from it: the one-trial runs that trial hooks on a single instance force, _run, launch
+        #  their steps directly)
+        worth = not getattr(self, '_one_trial_runs', False)
+        if self.fused_graph and self.use_graph is not False and worth and \
+                (budget or steps) >= per_graph:
             one_step()
             done = 1
             torch.cuda.synchronize(dev)

@@ -17,6 +17,9 @@ from .tabular import TabularAgent
 
 class DynaQ(TabularAgent):
     agent_kind = _lib.AGENT_DYNAQ
+    # the model records and their digest are laid out for four actions (the reference's DynaQ takes
+    # Discrete observations only — gridworlds — so other action counts cannot reach it either)
+    general_actions = False
 
     def __init__(self, observation_space, action_space, policy, policy_test=None,
                  learning_rate: float = 0.99, gamma: float = 0.99, memory=None,

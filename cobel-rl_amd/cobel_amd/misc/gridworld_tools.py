@@ -44,16 +44,23 @@ def transition_lists(sas):
     S, A, _ = sas.shape
     if (sas < 0).any() or not (np.count_nonzero(sas, axis=2) >= 1).all():
         raise ValueError('rows of world["sas"] must be probability vectors')
+    # Generator.choice's own check (numpy/random/_generator.pyx: `abs(kahan_sum(p) - 1.) > atol`
+    # with atol = sqrt(eps) of float64): the reference raises here too, at the first draw
+    if (np.abs(sas.sum(axis=2) - 1.0) > np.sqrt(np.finfo(np.float64).eps)).any():
+        raise ValueError('probabilities do not sum to 1')
     off = np.zeros(S * A + 1, dtype=np.uint32)
     states, cdf = [], []
     for p, row in enumerate(sas.reshape(S * A, S)):
         c = np.cumsum(row)
         c /= c[-1]
-        nz = np.flatnonzero(row)
-        states.append(nz.astype(np.uint16))
-        cdf.append(c[nz])
+        # a successor is kept where the cumulative sum ADVANCES: an entry too small to move the
+        # float64 cumsum can never be returned by searchsorted(side='right') — the same draws
+        # select the same states with or without it — and the list stays strictly increasing
+        keep = np.flatnonzero(np.diff(np.concatenate(([0.0], c))) > 0)
+        states.append(keep.astype(np.uint16))
+        cdf.append(c[keep])
         cdf[-1][-1] = 1.0
-        off[p + 1] = off[p] + len(nz)
+        off[p + 1] = off[p] + len(keep)
     return off, np.concatenate(states), np.concatenate(cdf)
 
 

@@ -85,6 +85,10 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);
 int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipStream_t st);
 
 int cobel_fail(int code, const char* fmt, ...);
+// COBEL_DEBUG_LDS_PAD=<bytes> (occupancy experiments, scripts/exp_occ*.py): extra dynamic LDS per
+// workgroup.  Honoured only if it is a plain number that keeps `base + pad` within `limit`; anything
+// else (a stray or malformed variable) is ignored, so it can change occupancy, never break a launch.
+size_t cobel_debug_lds_pad(size_t base, size_t limit);
 int cobel_world_check(const cobel_world* w, const char* who);   // non-NULL, on the current device
 int cobel_world_check4(const cobel_world* w, const char* who);  // ... and a four-action world
 

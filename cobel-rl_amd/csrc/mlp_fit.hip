@@ -714,7 +714,7 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   fit_args A;
   A.r = r;
   hipStream_t st = (hipStream_t)stream;
-  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
+  lds += cobel_debug_lds_pad(lds, 160 * 1024);   // (occupancy experiments only)
   if (r.is_float64) {
     if (int rc = raise_lds(&k_mlp_fit<double>, lds)) return rc;
     hipLaunchKernelGGL(k_mlp_fit<double>, dim3(r.n), dim3(kFitThreads), lds, st, A);

@@ -659,7 +659,7 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   const bool occ = r.occupancy != nullptr;
   const int leaves = count_leaves(S);
   size_t lds = sr_lds_bytes(S, leaves, occ);
-  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
+  lds += cobel_debug_lds_pad(lds, kLdsLimit);   // (occupancy experiments only)
   COBEL_REQUIRE(S <= 4096 && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
                 "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu)", S, lds,
                 kLdsLimit);

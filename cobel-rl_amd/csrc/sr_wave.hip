@@ -201,7 +201,11 @@ template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
-  __shared__ __attribute__((aligned(16))) float frow[KX ? NV * 256 : 4];
+  // The row written in the previous step, kept on chip (4 KiB at 32 x 32): a step straight back — a
+  // quarter of a random walk's moves — reads SR[ns] from here instead of HBM, single elements of
+  // that row (value gathers) come from here instead of waiting for the store to reach L2, and the
+  // values of the row a step rewrites are read back from it.
+  __shared__ __attribute__((aligned(16))) float frow[NV * 256];
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   uint64_t tcur = 0;     // T[state][0..3], carried from step to step
   uint64_t tleft = 0;    // the row of the state just left, after that step's write
   int left_state = -1;
-  int stored_state = -1; // the row whose store may still be in flight (written in the last step)
+  int lds_row = -1;      // the state whose row, as written in the last step, is in `frow`
   row_regs<NV> cur;      // SR[state] (learning runs)
 #pragma unroll
   for (int j = 0; j < NV; ++j) cur.c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -336,15 +340,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // unless that row is `fresh` (being rewritten in this step: its values come from registers).
   auto issue_gathers = [&](uint64_t tq, int fresh) -> float {
     float gv = 0.0f;
-    if (stored_state >= 0 && (t_of(tq, 0) == stored_state || t_of(tq, 1) == stored_state ||
-                              t_of(tq, 2) == stored_state || t_of(tq, 3) == stored_state)) {
-      wait_vm0();   // last step's row store has to be in L2 before single elements are read back
-      stored_state = -1;
-    }
     if (lane < 8) {
       const int n = lane & 1;
       const int j = t_of(tq, lane >> 1);
-      if (n < nz && j != fresh) gv = ld_l2(SRg + (size_t)j * S + (n ? e1 : e0));
+      // (the one row whose store may still be on its way to L2 is the one in `frow`)
+      if (n < nz && j != fresh) {
+        if (j == lds_row) gv = frow[n ? e1 : e0];
+        else gv = ld_l2(SRg + (size_t)j * S + (n ? e1 : e0));
+      }
     }
     gathers += (uint32_t)(4 * nz);
     return gv;
@@ -366,13 +369,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // KX: lane 8a + n reads element pos[n] of row tq[a]
   auto issue_gathers_x = [&](uint64_t tq, int fresh) -> float {
     float gv = 0.0f;
-    if (stored_state >= 0 && (t_of(tq, 0) == stored_state || t_of(tq, 1) == stored_state ||
-                              t_of(tq, 2) == stored_state || t_of(tq, 3) == stored_state)) {
-      wait_vm0();
-      stored_state = -1;
-    }
     const int j = t_of(tq, (lane >> 3) & 3);
-    if (lane < 32 && (lane & 7) < Kw && j != fresh) gv = ld_l2(SRg + (size_t)j * S + elane);
+    if (lane < 32 && (lane & 7) < Kw && j != fresh) {
+      if (j == lds_row) gv = frow[elane];
+      else gv = ld_l2(SRg + (size_t)j * S + elane);
+    }
     gathers += (uint32_t)(4 * Kw);
     return gv;
   };
@@ -398,7 +399,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // accumulator k of leaf l, then the butterflies of NumPy's combine order (as k_sr does in LDS).
   auto dense_values = [&](uint64_t tq) {
     wait_vm0();
-    stored_state = -1;
     float qv[4];
     if (ANY_S) {   // lane a < 4 sums row T[.][a] alone, in NumPy's order for this length
       float acc = 0.0f;
@@ -439,8 +439,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     tcur = load_trow(s);
     left_state = -1;
     if (learn) {
-      load_row<NV, ANY_S>(cur, SRg + (size_t)s * S, lane, quads, S, odd);
-      rows_read += 1u;
+      if (s == lds_row) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) cur.c[j] = reinterpret_cast<const float4*>(frow)[j * 64 + lane];
+      } else {
+        load_row<NV, ANY_S>(cur, SRg + (size_t)s * S, lane, quads, S, odd);
+        rows_read += 1u;
+      }
     }
     if (dense) {
       dense_values(tcur);
@@ -512,8 +517,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // SR[ns] (sr.py:276-281): loaded, or — after a bump (ns == state) — the row in hand
     row_regs<NV> nxt = cur;
     if (learn && nt != 0u && ns != state) {
-      load_row<NV, ANY_S>(nxt, SRg + (size_t)ns * S, lane, quads, S, odd);
-      rows_read += 1u;
+      if (ns == lds_row) {   // a step straight back: the row written in the last step
+#pragma unroll
+        for (int j = 0; j < NV; ++j) nxt.c[j] = reinterpret_cast<const float4*>(frow)[j * 64 + lane];
+      } else {
+        load_row<NV, ANY_S>(nxt, SRg + (size_t)ns * S, lane, quads, S, odd);
+        rows_read += 1u;
+      }
     }
     if (t_load) tnxt = ((uint64_t)rfl((uint32_t)(traw >> 32)) << 32) | (uint64_t)rfl((uint32_t)traw);
 
@@ -598,24 +608,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         } else if (!ANY_S || j * 64 + lane < quads) {
           out[j * 64] = o4;
         }
-        if (KX) {
-          if (want_fresh) reinterpret_cast<float4*>(frow)[j * 64 + lane] = o4;
-        } else if (want_fresh) {   // the new row's elements e0 / e1, wave-uniform
-          if (nz > 0 && (e0 >> 8) == j) {
-            const int comp = e0 & 3;
-            f0 = rlf(comp == 0 ? o4.x : (comp == 1 ? o4.y : (comp == 2 ? o4.z : o4.w)),
-                     (e0 >> 2) & 63);
-          }
-          if (nz > 1 && (e1 >> 8) == j) {
-            const int comp = e1 & 3;
-            f1 = rlf(comp == 0 ? o4.x : (comp == 1 ? o4.y : (comp == 2 ? o4.z : o4.w)),
-                     (e1 >> 2) & 63);
-          }
-        }
+        reinterpret_cast<float4*>(frow)[j * 64 + lane] = o4;
         // the row the next step starts from: SR[ns], or the row just written after a bump
         cur.c[j] = (ns == state) ? o4 : cn4;
       }
-      stored_state = state;
+      lds_row = state;
+      if (!KX && want_fresh) {   // the new row's elements e0 / e1, wave-uniform
+        if (nz > 0) f0 = rflf(frow[e0]);
+        if (nz > 1) f1 = rflf(frow[e1]);
+      }
     }
 
     if (A.r.step_budget == 1 && rare_args()->r.last_exp && lane == 0) {
@@ -690,9 +691,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
-  if (const char* pad = getenv("COBEL_DEBUG_LDS_PAD")) {   // occupancy experiments
-    lds += (size_t)atoi(pad);
-    if (lds > 64 * 1024)
+  if (const size_t pad = cobel_debug_lds_pad(lds + 8 * 1024, 160 * 1024)) {   // (occupancy experiments)
+    lds += pad;
+    if (lds > 48 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(
           reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

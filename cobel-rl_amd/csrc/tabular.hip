@@ -1202,6 +1202,9 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                 "cobel_tab_run: unknown agent %d", r.agent);
   COBEL_REQUIRE(r.agent != COBEL_AGENT_DYNAQ || r.model, COBEL_E_ARG,
                 "cobel_tab_run: Dyna-Q needs the model table");
+  COBEL_REQUIRE(r.agent != COBEL_AGENT_DYNAQ || world->n_actions == 4, COBEL_E_UNSUPPORTED,
+                "cobel_tab_run: Dyna-Q model records are laid out for four-action worlds (this one "
+                "has %d); Q-learning takes any action count", world->n_actions);
   COBEL_REQUIRE(r.batch >= 0, COBEL_E_RANGE, "cobel_tab_run: batch %d", r.batch);
   COBEL_REQUIRE(r.steps_per_trial > 0, COBEL_E_RANGE, "cobel_tab_run: steps_per_trial = %d",
                 r.steps_per_trial);
@@ -1264,11 +1267,12 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
   // (debug switches are read once per process, not per launch)
   static const bool no_exact_hash = getenv("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
-  const char* const lds_pad = getenv("COBEL_DEBUG_LDS_PAD");   // (per launch: scripts/exp_occupancy.py)
+  // (per launch: scripts/exp_occupancy.py; validated against the limit below)
   static const char* const lpw_env = getenv("COBEL_DEBUG_LPW");
   A.hash_exact = (world->n_states * 4 <= 4096 && !no_exact_hash) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
-  if (lds_pad) lds += (size_t)atoi(lds_pad);  // occupancy experiments
+  const size_t lds_pad = cobel_debug_lds_pad(lds, (size_t)kLdsLimit);   // occupancy experiments
+  lds += lds_pad;
   hipStream_t st = (hipStream_t)stream;
   // No planning in this call and nothing but Q to keep per instance: 64 instances per wave.
   const bool learn = (r.flags & COBEL_F_LEARN) != 0;

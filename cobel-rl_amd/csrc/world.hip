@@ -22,6 +22,15 @@ int cobel_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+size_t cobel_debug_lds_pad(size_t base, size_t limit) {
+  const char* const v = getenv("COBEL_DEBUG_LDS_PAD");
+  if (!v || !*v) return 0;
+  char* end = nullptr;
+  const long pad = strtol(v, &end, 10);
+  if (*end != '\0' || pad <= 0 || base + (size_t)pad > limit) return 0;
+  return (size_t)pad;
+}
+
 extern "C" const char* cobel_last_error(void) { return g_err; }
 extern "C" int cobel_abi_version(void) { return 1012; }
 

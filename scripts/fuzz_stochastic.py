@@ -1,6 +1,7 @@
 """Randomised parity sweep for worlds whose transition rows are distributions (the reference's
 Gridworld.step draws the successor, interface/gridworld.py:119-123): random gridworlds whose dense
-sas is edited at random — 1 to 4 possible successors anywhere in the world, unnormalised weights,
+sas is edited at random — 1 to 4 possible successors anywhere in the world, random weights
+(normalised to 1 within float64 round-off: anything else is a ValueError in Generator.choice and here),
 some rows left one-hot — Dyna-Q and Q-learning through cobel_tab_run's general kernel against the
 NumPy restatement (oracle/ref_loop.py) fed with the build's streams.
 
@@ -67,6 +68,7 @@ def run_case(c: dict):
         sas[s, a] = 0.0
         for t, p in zip(succ, wts):
             sas[s, a, t] += p
+        sas[s, a] /= sas[s, a].sum()
     env = Gridworld(world, n_envs=c['n'], seed=SEED, instance_base=c['base'])
     cls = DynaQ if c['kind'] == 'dynaq' else QAgent
     ag = cls(env.observation_space, env.action_space, EpsilonGreedy(c['eps']),

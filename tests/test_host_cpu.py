@@ -695,3 +695,34 @@ def test_pairwise_order_reproduces_numpy_sums_of_sparse_vectors():
         want = np.sum(vec)
         assert got == want and (got != 0 or want == 0), (n, pos, vals, got, want)
         assert np.float32(got).tobytes() == np.float32(want).tobytes() or got == 0
+
+
+def test_transition_lists_follow_generator_choice():
+    """Rows of a dense sas that are distributions (interface/gridworld.py:119-123 draws from them):
+    an entry too small to move the float64 cumulative sum is left out of the successor list (no
+    draw can select it, and the list stays strictly increasing as cobel_world_set_transitions
+    requires); a row that does not sum to 1 is the ValueError Generator.choice raises."""
+    from cobel_amd.misc.gridworld_tools import transition_lists
+    sas = np.zeros((2, 4, 2))
+    sas[:, :, 0] = 1.0
+    sas[0, 1] = [0.25, 0.75]
+    sas[1, 2] = [1.0, 1e-300]          # valid for numpy: sums to 1 within tolerance
+    off, states, cdf = transition_lists(sas)
+    assert list(off[1:3] - off[0:2]) == [1, 2] and off[-1] == len(states) == len(cdf)
+    lo = off[1 * 4 + 2]
+    assert off[1 * 4 + 3] - lo == 1 and states[lo] == 0 and cdf[lo] == 1.0
+    rng = np.random.default_rng(3)
+    for _ in range(50):                # the same uniforms select the same states either way
+        u = rng.random()
+        c = np.cumsum(sas[1, 2])
+        c /= c[-1]
+        assert np.arange(2)[np.searchsorted(c, u, side='right')] == 0
+    for p in range(8):
+        seg = cdf[off[p]:off[p + 1]]
+        assert (np.diff(seg) > 0).all() and seg[-1] == 1.0
+    bad = sas.copy()
+    bad[0, 0] = [0.5, 0.4]
+    with pytest.raises(ValueError, match='do not sum to 1'):
+        transition_lists(bad)
+    with pytest.raises(ValueError):
+        np.random.default_rng(0).choice(2, p=bad[0, 0])
