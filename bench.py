@@ -334,6 +334,12 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
         b_step, b_upd = 78, 31
     cfg = dict(env_steps_per_launch=env_steps, steps_per_trial=spt, batch=batch)
     runner = Runner(cfg, env, agent)
+    if which == 'dynaq_b100':
+        # trained agents (nearly every planning batch is evaluated), as the headline: untimed
+        # pre-training with the headline's own launches, B = 50
+        pre = Runner(dict(CONFIGS['C3']), env, agent)
+        for _ in range(48):
+            pre.launch()
     for _ in range(2):
         runner.launch()
     torch.cuda.synchronize(device)

@@ -78,20 +78,23 @@ struct row_regs {
 };
 
 // (quads: float4 groups a row really has — S / 4; NV * 64 for the sizes the layout fills exactly)
-// (odd: the state count is not a multiple of four — rows are then not 16-byte aligned and end
-//  inside a group: their elements are moved one by one)
+// (odd: the state count is not a multiple of four — rows are then not 16-byte aligned: they are
+//  moved one element per lane and instruction, 64 consecutive floats at a time, and live in the
+//  registers lane-strided: component c of c[j] = element (4 j + c) * 64 + lane)
 template <int NV, bool ANY_S>
 __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restrict__ src, int lane,
                                          int quads, int S, bool odd) {
   if (ANY_S && odd) {
+    // rows that are not 16-byte aligned: component c of c[j] holds element (4 j + c) * 64 + lane, so
+    // that every load instruction reads 64 consecutive floats (one pass over each cache line)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int e = (j * 64 + lane) * 4;
+      const int e = (4 * j) * 64 + lane;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e + 0 < S) v.x = src[e + 0];
-      if (e + 1 < S) v.y = src[e + 1];
-      if (e + 2 < S) v.z = src[e + 2];
-      if (e + 3 < S) v.w = src[e + 3];
+      if (e < S) v.x = src[e];
+      if (e + 64 < S) v.y = src[e + 64];
+      if (e + 128 < S) v.z = src[e + 128];
+      if (e + 192 < S) v.w = src[e + 192];
       d.c[j] = v;
     }
     return;
@@ -210,6 +213,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
   const bool odd = ANY_S && (S & 3) != 0;
+  // where element e of the row kept in `frow` (an image of the row registers) sits
+  auto fpos = [&](int e) -> int {
+    return odd ? ((((e >> 8) * 64 + (e & 63)) * 4) + ((e >> 6) & 3)) : e;
+  };
   constexpr int NL = NV * 2;   // !ANY_S: leaves of NumPy's pairwise sum, all 128 long
   const int lane = (int)threadIdx.x;
   const int i = (int)blockIdx.x;
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       const int j = t_of(tq, lane >> 1);
       // (the one row whose store may still be on its way to L2 is the one in `frow`)
       if (n < nz && j != fresh) {
-        if (j == lds_row) gv = frow[n ? e1 : e0];
+        if (j == lds_row) gv = frow[fpos(n ? e1 : e0)];
         else gv = ld_l2(SRg + (size_t)j * S + (n ? e1 : e0));
       }
     }
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     float gv = 0.0f;
     const int j = t_of(tq, (lane >> 3) & 3);
     if (lane < 32 && (lane & 7) < Kw && j != fresh) {
-      if (j == lds_row) gv = frow[elane];
+      if (j == lds_row) gv = frow[fpos((int)elane)];
       else gv = ld_l2(SRg + (size_t)j * S + elane);
     }
     gathers += (uint32_t)(4 * Kw);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   auto assemble_x = [&](uint64_t tq, int fresh, float gv) {
     const bool is_fresh = t_of(tq, (lane >> 3) & 3) == fresh;
     float fv = 0.0f;
-    if (is_fresh && lane < 32 && (lane & 7) < Kw) fv = frow[elane];
+    if (is_fresh && lane < 32 && (lane & 7) < Kw) fv = frow[fpos((int)elane)];
     float p = (is_fresh ? fv : gv) * rlane;
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
@@ -593,18 +600,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       for (int j = 0; j < NV; ++j) {
         const float4 cs4 = cur.c[j];
         const float4 cn4 = nxt.c[j];
-        const int e = (j * 64 + lane) * 4;
+        // elements of the four components: consecutive, or (odd sizes) 64 apart
+        const int e = odd ? (4 * j) * 64 + lane : (j * 64 + lane) * 4;
+        const int de = odd ? 64 : 1;
         float4 o4;
-        o4.x = upd1(e + 0, cs4.x, cn4.x);
-        o4.y = upd1(e + 1, cs4.y, cn4.y);
-        o4.z = upd1(e + 2, cs4.z, cn4.z);
-        o4.w = upd1(e + 3, cs4.w, cn4.w);
+        o4.x = upd1(e, cs4.x, cn4.x);
+        o4.y = upd1(e + de, cs4.y, cn4.y);
+        o4.z = upd1(e + 2 * de, cs4.z, cn4.z);
+        o4.w = upd1(e + 3 * de, cs4.w, cn4.w);
         if (odd) {
           float* const o1 = SRg + (size_t)state * S + e;
-          if (e + 0 < S) o1[0] = o4.x;
-          if (e + 1 < S) o1[1] = o4.y;
-          if (e + 2 < S) o1[2] = o4.z;
-          if (e + 3 < S) o1[3] = o4.w;
+          if (e < S) o1[0] = o4.x;
+          if (e + 64 < S) o1[64] = o4.y;
+          if (e + 128 < S) o1[128] = o4.z;
+          if (e + 192 < S) o1[192] = o4.w;
         } else if (!ANY_S || j * 64 + lane < quads) {
           out[j * 64] = o4;
         }
@@ -614,8 +623,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       }
       lds_row = state;
       if (!KX && want_fresh) {   // the new row's elements e0 / e1, wave-uniform
-        if (nz > 0) f0 = rflf(frow[e0]);
-        if (nz > 1) f1 = rflf(frow[e1]);
+        if (nz > 0) f0 = rflf(frow[fpos(e0)]);
+        if (nz > 1) f1 = rflf(frow[fpos(e1)]);
       }
     }
 
@@ -728,7 +737,7 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   // with launch-wide hyper-parameters (the KX kernels)
   const bool rewards_ok = world->max_rewarded_states <= 2 ||
                           (world->max_rewarded_states <= 8 && world->rw && !r.param_index);
-  return S >= 2 && S <= 1024 && (S % 4 == 0 || S <= 640) && rewards_ok &&
+  return S >= 2 && S <= 1024 && rewards_ok &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 

@@ -6,8 +6,8 @@
         -- python3 bench.py --no-cpu-baseline --no-c5
     python scripts/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> NN
 
-Per launch of the dominant kernel of each config (mean over the TIMED launches, i.e. all but the
-warm-up dispatches of that kernel: one, for C6 the 40 that take it to its steady state).  Units and the gfx950 correction
+Per launch of the dominant kernel of each config (mean over the TIMED launches: the last four
+dispatches of that kernel; the ones before are bench.py's untimed warm-up / pre-training).  Units and the gfx950 correction
 follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE
 count KiB; FETCH_SIZE reports half the bytes of wide coalesced reads, so
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -17,10 +17,10 @@ import json
 import os
 import sys
 
-KERNELS = {'C3': 'k_tab_wpi<', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma'}
-# untimed launches of each kernel at the head of a bench.py run (bench.py: warm-up; C6 warms up
-# into its steady state, CONFIGS['C6']['min_warmup'])
-WARMUP = {'C3': 1, 'C2': 1, 'C4': 1, 'C6': 40}
+KERNELS = {'C3': 'k_tab_pwg', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma'}
+# bench.py times the LAST `--steps` (4) launches of each kernel; everything before them is untimed
+# warm-up (C3: the pre-training that takes the agents to the full-work state, C6: 40 launches)
+TIMED = 4
 
 
 def per_kernel(path, counter):
@@ -51,7 +51,7 @@ def main():
     fetch, write = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
     out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 '
                     'bench.py --no-cpu-baseline --no-c5` on MI355X, per launch of the dominant '
-                    'kernel, mean over the timed launches (the warm-up launch is dropped). '
+                    'kernel, mean over the four timed launches (the untimed warm-up / pre-training launches before them are dropped). '
                     'FETCH_SIZE and WRITE_SIZE are in KiB. Per MI355X_MICROARCH.md (HBM section) '
                     'FETCH_SIZE on gfx950 reports exactly half of the bytes of a wide coalesced '
                     'read, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; the table loads '
@@ -60,7 +60,7 @@ def main():
     for cfg, tag in KERNELS.items():
         names = [k for k in fetch if tag in k]
         assert len(names) == 1 and names[0] in write, (cfg, names)
-        f, w = fetch[names[0]][WARMUP[cfg]:], write[names[0]][WARMUP[cfg]:]   # bench.py's warm-up
+        f, w = fetch[names[0]][-TIMED:], write[names[0]][-TIMED:]   # the timed launches
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         start = names[0].index(tag.rstrip('<'))
         short = names[0][start:names[0].index('(', start)]

@@ -13,11 +13,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 python3 bench.py > $O/r${R}_bench.json 2> $O/r${R}_bench.err
 echo "bench done"
-# (--min-seconds 0: the launches of the timed windows only, so that the kernel averages are the
-#  ones bench.py's roofline objects quote; the second pass is the default command, whose repeat
-#  windows run the headline kernel on agents that have learnt for longer)
+# (--min-seconds 0 --no-pretrain-timing is not needed: the C3 kernel's pre-training launches run
+#  the same kernel on younger agents, so the per-kernel average of the trace is LOWER than the timed
+#  launches'; scripts/kernel_stats_timed.py extracts the timed launches from the kernel trace)
 rocprofv3 --kernel-trace --stats -d $O/r${R}_stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --min-seconds 0 > $O/r${R}_stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/r${R}_stats_repeats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 --also "" > $O/r${R}_stats_repeats.log 2>&1
+python3 scripts/kernel_stats_timed.py $O/r${R}_stats/s_kernel_trace.csv $O/r${R}_kernel_stats_timed.csv > /dev/null
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fetch -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-c5 --min-seconds 0 > $O/r${R}_pmc_fetch.log 2>&1
 echo "fetch done"

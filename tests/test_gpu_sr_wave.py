@@ -316,8 +316,14 @@ def _multi_reward_worlds():
     five_any = make_gridworld(20, 24, terminals=[10], goals=[10],      # 480 states: float4 rows, bounds
                               rewards=np.array([[10, 1.0], [11, 0.5], [34, 0.25], [35, -0.5], [58, 0.1]]),
                               starting_states=[9, 12, 33, 36, 59, 82])
+    # 961 and 841 states: rows that are neither 16-byte aligned nor short (lane-strided registers)
+    one_31 = make_gridworld(31, 31, terminals=[0], goals=[0], rewards=np.array([[0, 1.0]]),
+                            starting_states=[1, 31, 32, 63, 500])
+    three_29 = make_gridworld(29, 29, terminals=[5], goals=[5],
+                              rewards=np.array([[5, 1.0], [6, -0.5], [34, 0.25]]),
+                              starting_states=[4, 7, 33, 35, 64])
     return {'four_32x32': four, 'eight_32x32': eight, 'three_13x17': three_odd,
-            'five_20x24': five_any}
+            'five_20x24': five_any, 'one_31x31': one_31, 'three_29x29': three_29}
 
 
 @pytest.mark.parametrize('name,n,budgets,spt', [
@@ -325,6 +331,8 @@ def _multi_reward_worlds():
     ('eight_32x32', 20, (150, 150, 7), 40),
     ('three_13x17', 16, (90, 111), 30),
     ('five_20x24', 16, (128, 128), 35),
+    ('one_31x31', 10, (100, 77), 40),
+    ('three_29x29', 12, (90, 90), 30),
 ])
 def test_three_to_eight_rewarded_states_take_the_wave_kernel(torch_cuda, name, n, budgets, spt):
     """Worlds with three to eight rewarded states (make_gridworld(rewards=...)): the sparse-reward
@@ -343,7 +351,10 @@ def test_three_to_eight_rewarded_states_take_the_wave_kernel(torch_cuda, name, n
     assert traffic[1] == n * sum(budgets) and traffic[3] == 0, 'the wave kernel ran, sparse path'
     assert ref.traffic.sum().item() == 0
     rw = ag._rw.cpu().numpy()
-    assert int(((rw != 0).sum(axis=1) >= 2).sum()) >= 2, 'several estimates became non-zero'
+    if name != 'one_31x31':
+        assert int(((rw != 0).sum(axis=1) >= 2).sum()) >= 2, 'several estimates became non-zero'
+    else:
+        assert (rw != 0).any()
     o = c_oracle.SROracle(_oracle_world(world), n, env.seed, True, instance_base=3, epsilon=0.25,
                           trial_cap=64, occupancy=True)
     for b in budgets:
