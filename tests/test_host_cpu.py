@@ -652,7 +652,10 @@ def test_deterministic_flag_and_stochastic_rows():
     assert c.compact()['next'][0, 2] == 3 and 'transitions' not in c.compact()
     # the same world with the flag off: lists (ascending states, normalised cumulative sums)
     c['deterministic'] = False
-    sas[1, 0] = [2.0, 0.0, 1.0, 1.0]              # unnormalised rows are normalised like choice(p=)
+    sas[1, 0] = [2.0, 0.0, 1.0, 1.0]              # Generator.choice(p=) refuses such a row, so do we
+    with pytest.raises(ValueError, match='do not sum to 1'):
+        c.compact()
+    sas[1, 0] = [0.5, 0.0, 0.25, 0.25]
     t = c.compact()
     off, succ, cdf = t['transitions']
     assert len(off) == 17 and off[-1] == len(succ) == len(cdf) == 16 + 1 + 2
