@@ -41,6 +41,8 @@ constexpr int kA = 4;         // actions
 constexpr int kB = 32;        // replay batch
 constexpr int kRow = 66;      // LDS row stride of activations and of the transposed 64 x 64 matrix
 constexpr int kMaxD = 32;     // input width limit
+constexpr int kW1Iters = kH * kMaxD / 256;   // first-layer elements per thread (256 threads)
+constexpr int kXIters = kB * kMaxD / 256;    // batch-row elements per thread
 
 struct mlp_args {
   cobel_dqn_replay_t r;
@@ -62,11 +64,13 @@ struct mlp_lds {
   T* boot;  // [32]
   int* pick;  // [32] DDQN: argmax_a Q_online(s')
   int* slot;  // [32] row of each sample inside the instance's batch / replay ring
+  int* idx_s; // [32] world-model mode: observation-table rows of the sampled states ...
+  int* idx_n; // [32] ... and of their successors
 };
 
 __host__ __device__ inline size_t mlp_lds_elems(int D) {
   return (size_t)kH * kRow + (size_t)D * kH + kA * kH + kH + kH + 8 + (size_t)kB * D +
-         2 * (size_t)kB * kRow + 2 * kB * kA + kB + 2 * kB /* pick, slot: as T-sized cells */;
+         2 * (size_t)kB * kRow + 2 * kB * kA + kB + 4 * kB /* pick, slot, two index rows: as T-sized cells */;
 }
 
 // Threads of a workgroup talk through LDS only, so its barriers wait for the LDS counter, not for
@@ -184,9 +188,30 @@ __device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_re
     const int e = t + 256 * u;
     L.wt2[(e & 63) * kRow + (e >> 6)] = P.w2[u];
   }
-  for (int e = t; e < kH * D; e += 256) {
-    const int j = e / D, d = e - j * D;
-    L.wt1[d * kH + j] = w1[e];
+  // (float64: all of the thread's loads in flight, then their LDS writes.  Written as one plain
+  //  loop every element waits for its own trip to memory — `s_waitcnt vmcnt(0)` per iteration,
+  //  seven of them at 25 inputs.  The float32 instantiation runs under a 128-register cap with four
+  //  workgroups per CU to cover that latency and keeps the plain loop: the staged form spills.)
+  if (sizeof(T) == 8) {
+    T r1[kW1Iters];
+#pragma unroll
+    for (int u = 0; u < kW1Iters; ++u) {
+      const int e = t + 256 * u;
+      r1[u] = e < kH * D ? w1[e] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kW1Iters; ++u) {
+      const int e = t + 256 * u;
+      if (e < kH * D) {
+        const int j = e / D, d = e - j * D;
+        L.wt1[d * kH + j] = r1[u];
+      }
+    }
+  } else {
+    for (int e = t; e < kH * D; e += 256) {
+      const int j = e / D, d = e - j * D;
+      L.wt1[d * kH + j] = w1[e];
+    }
   }
   L.w3[t] = P.w3;
   if (t < kH) {
@@ -258,17 +283,48 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
 
 template <typename T>
 __device__ void load_rows_table(T* dst, const double* table, const int32_t* index, int D, int t) {
-  for (int e = t; e < kB * D; e += 256) {
-    const int s = e / D, d = e - s * D;
-    dst[e] = (T)table[(size_t)index[s] * D + d];
+  // (`index`: the 32 row numbers, staged in LDS; float64: the thread's loads in flight together)
+  if (sizeof(T) == 8) {
+    double r[kXIters];
+#pragma unroll
+    for (int u = 0; u < kXIters; ++u) {
+      const int e = t + 256 * u;
+      const int s = e < kB * D ? e / D : 0, d = e - s * D;
+      r[u] = e < kB * D ? table[(size_t)index[s] * D + d] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kXIters; ++u) {
+      const int e = t + 256 * u;
+      if (e < kB * D) dst[e] = (T)r[u];
+    }
+  } else {
+    for (int e = t; e < kB * D; e += 256) {
+      const int s = e / D, d = e - s * D;
+      dst[e] = (T)table[(size_t)index[s] * D + d];
+    }
   }
 }
 
 template <typename T>
 __device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
-  for (int e = t; e < kB * D; e += 256) {
-    const int s = e / D, d = e - s * D;
-    dst[e] = src[(size_t)slot[s] * D + d];
+  if (sizeof(T) == 8) {
+    T r[kXIters];
+#pragma unroll
+    for (int u = 0; u < kXIters; ++u) {
+      const int e = t + 256 * u;
+      const int s = e < kB * D ? e / D : 0, d = e - s * D;
+      r[u] = e < kB * D ? src[(size_t)slot[s] * D + d] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kXIters; ++u) {
+      const int e = t + 256 * u;
+      if (e < kB * D) dst[e] = r[u];
+    }
+  } else {
+    for (int e = t; e < kB * D; e += 256) {
+      const int s = e / D, d = e - s * D;
+      dst[e] = src[(size_t)slot[s] * D + d];
+    }
   }
 }
 
@@ -296,7 +352,9 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     L.qt = p;  p += kB * kA;
     L.boot = p; p += kB;
     L.pick = reinterpret_cast<int*>(p); p += kB;
-    L.slot = reinterpret_cast<int*>(p);
+    L.slot = reinterpret_cast<int*>(p); p += kB;
+    L.idx_s = reinterpret_cast<int*>(p); p += kB;
+    L.idx_n = reinterpret_cast<int*>(p);
   }
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)kA * kH;
   T* const w1 = (T*)R.w[0] + (size_t)i * n1;
@@ -315,7 +373,13 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   const size_t rows = R.batch_slots ? (size_t)R.ring_slots : (size_t)kB;
   const T* const xs = (const T*)R.states + (size_t)i * rows * D;
   const T* const xn = (const T*)R.next_states + (size_t)i * rows * D;
-  if (t < kB) L.slot[t] = R.batch_slots ? R.batch_slots[(size_t)i * kB + t] : t;
+  if (t < kB) {
+    L.slot[t] = R.batch_slots ? R.batch_slots[(size_t)i * kB + t] : t;
+    if (R.state_index) {   // world-model mode: the batch's observations are rows of a table
+      L.idx_s[t] = R.state_index[(size_t)i * kB + t];
+      L.idx_n[t] = R.next_index[(size_t)i * kB + t];
+    }
+  }
   lds_barrier();
 
   T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
@@ -342,7 +406,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   params_load<T>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
   params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);
   params_store<T>(L, PT, tw1, D, t);
-  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, R.next_index + (size_t)i * kB, D, t);
+  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, L.idx_n, D, t);
   else load_rows<T>(L.x, xn, L.slot, D, t);
   lds_barrier();
   // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
@@ -371,7 +435,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
     lds_barrier();
   }
-  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, R.state_index + (size_t)i * kB, D, t);
+  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, L.idx_s, D, t);
   else load_rows<T>(L.x, xs, L.slot, D, t);
   lds_barrier();
   forward<T>(L, L.q, D, t);
@@ -541,17 +605,45 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       L.wt2[(16 * kt + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
-  for (int e = t; e < kH * D; e += 256) {   // (a small tensor: its state is loaded here)
-    adam_slot<T> s1;
-    s1.m = m_w1[e];
-    s1.v = v_w1[e];
-    s1.target = tw1[e];
-    const int j = e / D, d = e - j * D;
-    T g = (T)0;
+  // (a small tensor: its optimizer state is loaded here — in float64 for all of the thread's
+  //  elements at once: the registers of the second layer's tile are free by now, and one element
+  //  per trip to memory, as the plain loop of the float32 instantiation does it, was seven exposed
+  //  trips at 25 inputs)
+  if (sizeof(T) == 8) {
+    adam_slot<T> s1[kW1Iters];
+#pragma unroll
+    for (int u = 0; u < kW1Iters; ++u) {
+      const int e = t + 256 * u;
+      const bool in = e < kH * D;
+      s1[u].m = in ? m_w1[e] : (T)0;
+      s1[u].v = in ? v_w1[e] : (T)0;
+      s1[u].target = in ? tw1[e] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kW1Iters; ++u) {
+      const int e = t + 256 * u;
+      if (e < kH * D) {
+        const int j = e / D, d = e - j * D;
+        T g = (T)0;
 #pragma unroll 8
-    for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
-    L.wt1[d * kH + j] =
-        adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1, c);
+        for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
+        L.wt1[d * kH + j] =
+            adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
+      }
+    }
+  } else {
+    for (int e = t; e < kH * D; e += 256) {
+      adam_slot<T> s1;
+      s1.m = m_w1[e];
+      s1.v = v_w1[e];
+      s1.target = tw1[e];
+      const int j = e / D, d = e - j * D;
+      T g = (T)0;
+#pragma unroll 8
+      for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
+      L.wt1[d * kH + j] =
+          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1, c);
+    }
   }
   if (t < kH) {
     T gb = (T)0;

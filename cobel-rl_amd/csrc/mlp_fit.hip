@@ -77,6 +77,25 @@ __device__ __forceinline__ float fma_t<float>(float a, float b, float c) {
   return __builtin_fmaf(a, b, c);
 }
 
+
+// dst(e, value) for the elements e = t, t + NT, ... < n of src: ALL of the thread's loads first, then
+// the writes.  Written as one plain loop each element waits for its own trip to memory
+// (`s_waitcnt vmcnt(0)` per iteration) — with one workgroup per CU nothing else covers it.
+template <int MAXI, int NT, typename T, typename Put>
+__device__ __forceinline__ void staged_copy(const T* __restrict__ src, int n, int t, Put put) {
+  T r[MAXI];
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    const int e = t + NT * u;
+    r[u] = e < n ? src[e] : (T)0;
+  }
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    const int e = t + NT * u;
+    if (e < n) put(e, r[u]);
+  }
+}
+
 template <typename T>
 struct adam_consts {
   T bc2_sqrt, step_size, one_m_b1, b2, one_m_b2, eps, wd, tau;
@@ -171,11 +190,11 @@ __device__ void stage_params(const net_lds<T>& L, const T* __restrict__ w1,
     const int e = t + NT * u;
     L.wt2[(e & 63) * kRow + (e >> 6)] = w2r[u];
   }
-  for (int e = t; e < kH * D; e += NT) {
+  staged_copy<(kH * kMaxD + NT - 1) / NT, NT, T>(w1, kH * D, t, [&](int e, T v) {
     const int j = e / D, d = e - j * D;
-    L.wt1[d * kH + j] = w1[e];
-  }
-  for (int e = t; e < O * kH; e += NT) L.w3[e] = w3[e];
+    L.wt1[d * kH + j] = v;
+  });
+  staged_copy<(kMaxO * kH + NT - 1) / NT, NT, T>(w3, O * kH, t, [&](int e, T v) { L.w3[e] = v; });
   if (t < kH) {
     L.b1[t] = b1[t];
     L.b2[t] = b2[t];
@@ -234,9 +253,28 @@ __device__ void forward32(const net_lds<T>& L, T* out, int D, int O, int t) {
 template <typename T, int NT>
 __device__ void load_inputs(T* dst, const double* table, const int32_t* index, const T* dense,
                             int D, int t) {
-  for (int e = t; e < kB * D; e += NT) {
-    const int s = e / D, d = e - s * D;
-    dst[e] = table ? (T)table[(size_t)index[s] * D + d] : dense[e];
+  constexpr int U = (kB * kMaxD + NT - 1) / NT;
+  if (table) {   // the row numbers first (all at once), then the rows (all at once)
+    int row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = t + NT * u;
+      row[u] = e < kB * D ? index[e / D] : 0;
+    }
+    double r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = t + NT * u;
+      const int d = e - (e / D) * D;
+      r[u] = e < kB * D ? table[(size_t)row[u] * D + d] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = t + NT * u;
+      if (e < kB * D) dst[e] = (T)r[u];
+    }
+  } else {
+    staged_copy<U, NT, T>(dense, kB * D, t, [&](int e, T v) { dst[e] = v; });
   }
 }
 
@@ -278,10 +316,10 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
       const int e = t + 256 * u;
       wt2[(e & 63) * kRow + (e >> 6)] = w2r[u];
     }
-    for (int e = t; e < kH * D; e += 256) {
+    staged_copy<kH * kMaxD / 256, 256, T>(w1, kH * D, t, [&](int e, T v) {
       const int jj = e / D, d = e - jj * D;
-      wt1[d * kH + jj] = w1[e];
-    }
+      wt1[d * kH + jj] = v;
+    });
     if (t < kH) {
       bias1[t] = ((const T*)R.b[0] + net * kH)[t];
       bias2[t] = ((const T*)R.b[1] + net * kH)[t];
@@ -328,7 +366,7 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
       acc1 = mfma(h1[(16 + li) * kRow + k0 + lq], b, acc1);
     }
     lds_barrier();   // (every read of h1 is done: the output layer's weights take its place)
-    for (int e = t; e < O * kH; e += 256) w3l[e] = w3[e];
+    staged_copy<kMaxO * kH / 256, 256, T>(w3, O * kH, t, [&](int e, T v) { w3l[e] = v; });
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int r = mfma_acc<T>::row(lane, v);
@@ -456,11 +494,11 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     }
     const T scale = (T)1 / (T)(count * O);
     const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
-    for (int e = t; e < kB * O; e += NT) {
+    staged_copy<(kB * kMaxO + NT - 1) / NT, NT, T>(y, kB * O, t, [&](int e, T yv) {
       const int s = e / O;
-      const T d = L.q[e] - y[e];
+      const T d = L.q[e] - yv;
       L.q[e] = (!mask || mask[s]) ? ((T)2 * d) * scale : (T)0;   // delta3
-    }
+    });
     lds_barrier();
 
     // ---- Adam constants of this network (its own step count) ------------------------------------
