@@ -792,6 +792,10 @@ def main():
                     help='C3: time the window right after --warmup launches (young agents)')
     ap.add_argument('--max-pretrain', type=int, default=400,
                     help='C3: upper bound of the untimed pre-training, in launches')
+    ap.add_argument('--dist-single', action='store_true',
+                    help='with one rank: initialise the process group all the same, so that the '
+                         'barriers, the MIN all-reduce of the pre-training and the monitor all-gather '
+                         'go through the backend (RCCL on a one-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
     args = ap.parse_args()
@@ -810,9 +814,13 @@ def main():
     device = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(device)
     dist = None
-    if world_size > 1:
+    if world_size > 1 or args.dist_single:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world_size == 1:      # --dist-single without a launcher: a group of one
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
         else:   # rehearsal of the N > 1 path with several ranks on ONE GPU (tests)

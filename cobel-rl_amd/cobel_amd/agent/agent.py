@@ -185,7 +185,9 @@ class DeviceMonitors:
         this again — a second monitor, a second reporting interval — counts nothing twice."""
         import torch.distributed as dist
         flat = self._pack()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        # (a process group of ONE rank still takes the collective: the same RCCL call, tensor types
+        #  and unpacking as with eight — what a one-GPU box can rehearse of the multi-GPU path)
+        if not (dist.is_available() and dist.is_initialized()):
             return MonitorSums.unpack(flat.cpu().numpy()[None, :], self._layout())
         world = dist.get_world_size()
         if dist.get_backend() == 'gloo':      # CPU rehearsals of the multi-GPU path

@@ -130,3 +130,26 @@ def test_every_default_leg_runs_and_carries_a_roofline():
         assert 'error' not in leg, (name, leg)
         assert leg['roofline'] is not None and leg['roofline']['frac'] > 0, name
         assert leg['value'] > 0, name
+
+
+def test_one_rank_process_group_over_rccl():
+    """What a one-GPU box can execute of the multi-GPU path: a process group of ONE rank on the
+    "nccl" backend (= RCCL) — barriers, the MIN all-reduce that ends the pre-training and the monitor
+    all-gather are the same calls, tensor types and unpacking as with eight ranks."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    args = ['--config', 'C3', '--instances', '1024', '--env-steps', '64', '--steps', '2', '--warmup', '1',
+            '--no-cpu-baseline', '--also', '', '--min-seconds', '0', '--max-pretrain', '17']
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args,
+                           capture_output=True, text=True, timeout=900, env=env)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    rccl = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dist-single', '--backend',
+                           'nccl'] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert rccl.returncode == 0, rccl.stderr[-3000:]
+    a, b = _line(plain.stdout), _line(rccl.stdout)
+    assert a['monitors']['collectives_in_timed_region'] == 0
+    assert b['monitors']['collectives_in_timed_region'] == 1 and b['n_gpus'] == 1
+    assert a['warmup'] == b['warmup'] == 17
+    for key in ('trials_finished', 'escape_latency_sum', 'trial_reward_sum'):
+        assert a['monitors'][key] == b['monitors'][key], key
