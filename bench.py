@@ -7,9 +7,12 @@
 
 One bench "step" = ONE launch of the fused agent kernel that advances every instance on the GPU
 by `env_steps_per_launch` env steps (select -> env.step -> learn -> B planning updates, with
-per-instance auto-reset).  W untimed warm-up launches, then exactly K launches timed between
-barrier + torch.cuda.synchronize() pairs; the max over ranks is used and rank 0 prints one JSON
-line.  Instances are independent: with --gpus N the configuration's instances are SPLIT evenly over
+per-instance auto-reset).  W untimed warm-up launches — on C3 followed by untimed pre-training until
+the kernel reports that >= 95 % of the planning batches it draws are evaluated, so that the timed
+window is the full-work state of trained agents (`pretraining`; the rate of the first launches is
+kept as `young_agents`) —, then exactly K launches timed between barrier + torch.cuda.synchronize()
+pairs; the max over ranks is used and rank 0 prints one JSON line.  `python bench.py --gpus N` with
+no launcher around it starts its N ranks itself (torch.distributed.run) and relays that line.  Instances are independent: with --gpus N the configuration's instances are SPLIT evenly over
 the ranks (BASELINE config 3: "batch split 1 -> 8 MI355X"; contiguous ranges of global instance
 ids, cobel_amd.misc.sharding) — strong scaling — or, with --weak, every rank runs the full
 instance count.  Global instance ids key the random streams and the world of an instance, so the
@@ -25,7 +28,8 @@ Workloads, all synthetic, tables zero-initialised as the refere
   C6: 65 536 x the 5x5 walled world of demo/gridworld/demo_sfma.py, SFMA with the DR metric in
       reverse mode, 32 reactivations per trial (reported beside the headline).
 
-`roofline.achieved` = algorithmic bytes per env step (C2 67 B, C3 1 628 B; C4: the
+`roofline.achieved` = algorithmic bytes per env step (C2 67 B; C3 by the work done:
+78 B per env step + 31 B per planning update of the batches the kernel evaluated; C4: the
 SR rows and value elements the sparse-reward kernel actually asks for, counted by the kernel —
 DESIGN.md §4.2; §8d's eight-row figure of 32 817 B is reported beside it as `sec8d_*`) x env steps
 per launch / mean launch duration, the latter measured with HIP events on the launch stream.
@@ -651,7 +655,7 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
         else:
             limiter = 'latency'
     achieved = alg_bytes_per_launch / mean_launch_s / 1e9
-    traffic = pmc_traffic(cfg_name, cfg, kernel) if (n == cfg['instances']) else None
+    traffic = pmc_traffic(cfg_name, cfg, kernel) if (n == cfg['instances'] and args.scale == 1.0) else None
     res = {
         'metric': 'gridworld env-steps/sec (whole job)',
         'value': total_steps / elapsed,
