@@ -807,6 +807,13 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(sys.argv[1:], args.gpus))   # (nothing here has touched the GPU yet)
 
+    # stdout carries exactly ONE line, rank 0's JSON: everything else that lands on file descriptor
+    # 1 — RCCL prints a five-line version banner there when its first communicator is created — goes
+    # to stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
@@ -879,7 +886,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline(args.config, cfg)
         if others:
             res['other_configs'] = others
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 

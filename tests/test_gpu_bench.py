@@ -148,6 +148,9 @@ def test_one_rank_process_group_over_rccl():
                            'nccl'] + args, capture_output=True, text=True, timeout=900, env=env)
     assert rccl.returncode == 0, rccl.stderr[-3000:]
     a, b = _line(plain.stdout), _line(rccl.stdout)
+    # (RCCL prints a version banner on file descriptor 1 at communicator creation: bench.py keeps
+    #  its stdout to the one JSON line all the same)
+    assert rccl.stdout.strip().count('\n') == 0 and plain.stdout.strip().count('\n') == 0
     assert a['monitors']['collectives_in_timed_region'] == 0
     assert b['monitors']['collectives_in_timed_region'] == 1 and b['n_gpus'] == 1
     assert a['warmup'] == b['warmup'] == 17
