@@ -165,6 +165,11 @@ def _mlp(n_in, n_out, dtype_name='f64'):
 
 
 def _timed_network_agent(agent, env, n, iters, device, warm=4):
+    # `iters` = 1 + a whole number of graph chunks (16 steps for the DQN loop, 8 for Dyna-DSR): the
+    # first step of a run is launched directly, the chunks are replayed from ONE graph recorded at
+    # the start of the run (inside the timed region: a one-off of some tens of milliseconds that a
+    # training run of thousands of steps does not notice; steps that do not fill a chunk would be
+    # launched one by one from the host, ~10 ms each for Dyna-DSR's 29 kernels)
     agent._run(env, 4096, 50, 32, True, budget=warm)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -185,7 +190,7 @@ def _hbm_roofline(bytes_per_step, value, kernel, limiter, note=None):
     return r
 
 
-def run_dyna_dqn(device, n=8192, iters=128):
+def run_dyna_dqn(device, n=8192, iters=129):
     """SURVEY.md §8f rank 1 (demo/gridworld/demo_dyna_dqn.py: 5x5 open field, one-hot inputs, a
     25-64-64-4 float64 network per instance, gamma .8, model-sampled batches of 32)."""
     from cobel_amd.agent import DynaDQN
@@ -216,7 +221,7 @@ def run_dyna_dqn(device, n=8192, iters=128):
     return r
 
 
-def run_dyna_dsr(device, n=8192, iters=48):
+def run_dyna_dsr(device, n=8192, iters=201):
     """SURVEY.md §8f rank 1 (demo/gridworld/demo_dyna_dsr.py): four online + four target successor
     networks 25-64-64-25 and one reward network per instance, float64."""
     from cobel_amd.agent import DynaDSR

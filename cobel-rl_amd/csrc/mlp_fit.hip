@@ -14,11 +14,10 @@
 //                      four actions).
 // Together they carry DynaDSR.replay (agent/dyna_q.py:1042-1150): nine networks per agent.
 //
-// Same structure as k_dqn_replay (mlp.hip), which stays the specialised kernel of the DQN step: a
-// workgroup of 256 threads per network, parameters staged in LDS (the 64 x 64 matrix transposed),
-// activations in LDS and overwritten by the deltas, the three 64 x 64 products as 16 x 16 x 4
-// MFMAs in the network's dtype, gradients only ever in registers, Adam applied by the thread that
-// accumulated the element.  The output layer is O wide here, so its loops run over O x 64 elements.
+// Unlike k_dqn_replay (mlp.hip, parameters staged in LDS) these kernels take the weight operand of
+// every product straight from memory in the MFMA's operand layout and keep only the activations in
+// LDS (see "Layout" below): all products are 16 x 16 x 4 MFMAs in the network's dtype, gradients
+// only ever live in accumulator registers, Adam is applied by the lane that holds the element.
 #include <stdlib.h>
 
 #include <cstdlib>
@@ -67,226 +66,216 @@ __device__ __forceinline__ v4f mfma(float a, float b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 template <typename T>
-__device__ __forceinline__ T fma_t(T a, T b, T c);
-template <>
-__device__ __forceinline__ double fma_t<double>(double a, double b, double c) {
-  return __builtin_fma(a, b, c);
-}
-template <>
-__device__ __forceinline__ float fma_t<float>(float a, float b, float c) {
-  return __builtin_fmaf(a, b, c);
-}
-
-
-// dst(e, value) for the elements e = t, t + NT, ... < n of src: ALL of the thread's loads first, then
-// the writes.  Written as one plain loop each element waits for its own trip to memory
-// (`s_waitcnt vmcnt(0)` per iteration) — with one workgroup per CU nothing else covers it.
-template <int MAXI, int NT, typename T, typename Put>
-__device__ __forceinline__ void staged_copy(const T* __restrict__ src, int n, int t, Put put) {
-  T r[MAXI];
-#pragma unroll
-  for (int u = 0; u < MAXI; ++u) {
-    const int e = t + NT * u;
-    r[u] = e < n ? src[e] : (T)0;
-  }
-#pragma unroll
-  for (int u = 0; u < MAXI; ++u) {
-    const int e = t + NT * u;
-    if (e < n) put(e, r[u]);
-  }
-}
-
-template <typename T>
 struct adam_consts {
   T bc2_sqrt, step_size, one_m_b1, b2, one_m_b2, eps, wd, tau;
   bool has_wd, blend;
 };
 
-// torch.optim.Adam, one element (the operation order of k_adam in adam.hip); returns the new
-// parameter and writes parameter, moments and — when blending — the target network's copy.
-// The optimizer state of an element (and the target network's copy of the parameter), requested at
-// the START of the kernel — the workgroup owns a whole CU's register file (one wave per SIMD), so
-// every element a thread will update fits — and consumed in the backward pass, by which time the
-// loads have long returned.  Loaded where used, each update waited for HBM on its own.
+// torch.optim.Adam, one element (the operation order of k_adam in adam.hip).  The element's
+// parameter, moments and — when blending — the target network's copy are requested together
+// (slot_load), a matrix product later the update is applied and written back (adam_apply).
 template <typename T>
 struct adam_slot {
-  T m, v, target;
+  T p, m, v, target;
 };
 template <typename T>
-__device__ __forceinline__ adam_slot<T> slot_load(const T* __restrict__ m, const T* __restrict__ v,
-                                                  const T* __restrict__ tgt, size_t e, bool blend) {
+__device__ __forceinline__ adam_slot<T> slot_load(const T* __restrict__ p, const T* __restrict__ m,
+                                                  const T* __restrict__ v,
+                                                  const T* __restrict__ tgt, uint32_t e, bool blend,
+                                                  bool valid, bool with_target = true) {
   adam_slot<T> s;
-  s.m = __builtin_nontemporal_load(m + e);
-  s.v = __builtin_nontemporal_load(v + e);
-  s.target = blend ? __builtin_nontemporal_load(tgt + e) : (T)0;
+  s.p = s.m = s.v = s.target = (T)0;
+  if (valid) {
+    s.p = p[e];
+    s.m = __builtin_nontemporal_load(m + e);
+    s.v = __builtin_nontemporal_load(v + e);
+    // (without a blend: tgt == p, unused)
+    if (with_target) s.target = __builtin_nontemporal_load(tgt + e);
+  }
   return s;
 }
 
 template <typename T>
 __device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m, T* __restrict__ v,
-                                        T* __restrict__ tgt, size_t e, T p_old, T g,
-                                        const adam_slot<T>& s, const adam_consts<T>& c) {
-  if (c.has_wd) g = g + c.wd * p_old;
+                                        T* __restrict__ tgt, uint32_t e, T g, const adam_slot<T>& s,
+                                        const adam_consts<T>& c) {
+  if (c.has_wd) g = g + c.wd * s.p;
   const T m0 = s.m, v0 = s.v;
   const T mn = m0 + c.one_m_b1 * (g - m0);
   const T vn = v0 * c.b2 + (c.one_m_b2 * g) * g;
   const T denom = sqrt(vn) / c.bc2_sqrt + c.eps;
-  const T pn = p_old - c.step_size * (mn / denom);
-  m[e] = mn;
-  v[e] = vn;
+  const T pn = s.p - c.step_size * (mn / denom);
+  __builtin_nontemporal_store(mn, m + e);
+  __builtin_nontemporal_store(vn, v + e);
   p[e] = pn;
-  if (c.blend) tgt[e] = s.target + c.tau * (pn - s.target);
+  if (c.blend) __builtin_nontemporal_store(s.target + c.tau * (pn - s.target), tgt + e);
   return pn;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layout.  A network's parameters are used by exactly 32 rows, i.e. by two 16-row MFMA tiles:
+// nothing is gained by parking them in LDS first.  Every product takes its weight operand straight
+// from memory in the MFMA's B layout (lane (li, lq) supplies B[k][n0 + li] for ITS quarter of the
+// summation index, k = lq * KS + step — a product may sum in any order, so each lane reads KS
+// consecutive elements of one row: whole cache lines for the 64-wide layers), and LDS holds only
+// the activations: x [32][33], h1 / h2 [32][66], q [32][33] and the three bias vectors — 52 KB in
+// float64, three training workgroups per CU where the parameter-staging layout (107 KB) had one.
+//   forward   h1 = relu(x W1' + b1)     M = rows, N = 64,  K = D   B from W1 (memory)
+//             h2 = relu(h1 W2' + b2)                        K = 64  B from W2
+//             q  = h2 W3' + b3          N = O               K = 64  B from W3
+//   backward  delta2 = (delta3 W3) . (h2 > 0)   K = O   B from W3 (the weights the step started from)
+//             dW3 = delta3' h2                  K = 32  both operands from LDS
+//             delta1 = (delta2 W2) . (h1 > 0)   K = 64  B from W2
+//             dW2 = delta2' h1,  dW1 = delta1' x
+// A gradient tile stays in the accumulator registers of the wave that summed it; that wave applies
+// Adam to its 4 elements per lane and tile (consecutive lanes = consecutive addresses).
+constexpr int kXRow = 33;
+
 template <typename T>
-struct net_lds {
-  T* wt2;   // [64][66]  wt2[k * 66 + j] = W2[j][k]
-  T* wt1;   // [D][64]   wt1[d * 64 + j] = W1[j][d]
-  T* w3;    // [O][64]
-  T* b1;    // [64]
-  T* b2;    // [64]
-  T* b3;    // [32]
-  T* x;     // [32][D]
-  T* h1;    // [32][66]
-  T* h2;    // [32][66]
-  T* q;     // [32][O]  outputs -> delta3
+struct act_lds {
+  T* x;    // [32][33]  inputs, columns >= D zero
+  T* h1;   // [32][66]  -> delta1
+  T* h2;   // [32][66]  -> delta2
+  T* q;    // [32][33]  outputs -> delta3, columns >= O zero
+  T* b1;   // [64]
+  T* b2;   // [64]
+  T* b3;   // [32]
 };
 
-__host__ __device__ inline size_t net_lds_elems(int D, int O) {
-  return (size_t)kH * kRow + (size_t)D * kH + (size_t)O * kH + kH + kH + kMaxO + (size_t)kB * D +
-         2 * (size_t)kB * kRow + (size_t)kB * O;
+__host__ __device__ inline size_t fit_lds_elems() {
+  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + 2 * kH + kMaxO;
+}
+// forward only: the inputs sit where h2 will be written (read for the last time before that)
+__host__ __device__ inline size_t fwd_lds_elems() {
+  return 2 * (size_t)kB * kRow + 2 * kH + kMaxO;
 }
 
 template <typename T>
-__device__ __forceinline__ net_lds<T> carve(unsigned char* raw, int D, int O) {
-  net_lds<T> L;
+__device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
+  act_lds<T> L;
   T* p = reinterpret_cast<T*>(raw);
-  L.wt2 = p; p += kH * kRow;
-  L.wt1 = p; p += D * kH;
-  L.w3 = p;  p += O * kH;
-  L.b1 = p;  p += kH;
-  L.b2 = p;  p += kH;
-  L.b3 = p;  p += kMaxO;
-  L.x = p;   p += kB * D;
-  L.h1 = p;  p += kB * kRow;
-  L.h2 = p;  p += kB * kRow;
-  L.q = p;
+  L.h1 = p; p += kB * kRow;
+  L.h2 = p; p += kB * kRow;
+  L.x = p;  p += kB * kXRow;
+  L.q = p;  p += kB * kXRow;
+  L.b1 = p; p += kH;
+  L.b2 = p; p += kH;
+  L.b3 = p;
+  return L;
+}
+template <typename T>
+__device__ __forceinline__ act_lds<T> carve_fwd(unsigned char* raw) {
+  act_lds<T> L;
+  T* p = reinterpret_cast<T*>(raw);
+  L.h1 = p; p += kB * kRow;
+  L.h2 = p; L.x = p; p += kB * kRow;
+  L.q = nullptr;
+  L.b1 = p; p += kH;
+  L.b2 = p; p += kH;
+  L.b3 = p;
   return L;
 }
 
-// One network's parameters (torch.nn.Linear layout [out][in]) into LDS.
+// the 32 input rows of an instance — rows of a float64 table by index, or a dense [32][D] block —
+// into x [32][33], columns D .. 31 zero: every load of a thread before its first LDS write
 template <typename T, int NT>
-__device__ void stage_params(const net_lds<T>& L, const T* __restrict__ w1,
-                             const T* __restrict__ b1, const T* __restrict__ w2,
-                             const T* __restrict__ b2, const T* __restrict__ w3,
-                             const T* __restrict__ b3, int D, int O, int t) {
-  constexpr int U = kH * kH / NT;
-  T w2r[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) w2r[u] = __builtin_nontemporal_load(w2 + t + NT * u);
-#pragma unroll
-  for (int u = 0; u < U; ++u) {   // transposed write
-    const int e = t + NT * u;
-    L.wt2[(e & 63) * kRow + (e >> 6)] = w2r[u];
-  }
-  staged_copy<(kH * kMaxD + NT - 1) / NT, NT, T>(w1, kH * D, t, [&](int e, T v) {
-    const int j = e / D, d = e - j * D;
-    L.wt1[d * kH + j] = v;
-  });
-  staged_copy<(kMaxO * kH + NT - 1) / NT, NT, T>(w3, O * kH, t, [&](int e, T v) { L.w3[e] = v; });
-  if (t < kH) {
-    L.b1[t] = b1[t];
-    L.b2[t] = b2[t];
-  }
-  if (t < O) L.b3[t] = b3[t];
-}
-
-// h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2), out[s][a] = W3 h2 + b3 for the 32 rows of L.x, by a
-// workgroup of NT = 512 threads: first layer one sample x four neurons per thread, second layer one
-// 16 x 16 MFMA tile per wave (2 sample tiles x 4 neuron tiles = 8 waves).
-template <typename T, int NT>
-__device__ void forward32(const net_lds<T>& L, T* out, int D, int O, int t) {
-  static_assert(NT == 512, "eight waves per workgroup");
-  {
-    const int j0 = (t & 15) * 4, s0 = t >> 4;
-    T acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = L.b1[j0 + c];
-    for (int d = 0; d < D; ++d) {
-      const T x0 = L.x[s0 * D + d];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = fma_t<T>(L.wt1[d * kH + j0 + c], x0, acc[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L.h1[s0 * kRow + j0 + c] = acc[c] > (T)0 ? acc[c] : (T)0;
-  }
-  lds_barrier();
-  {
-    typedef typename mfma_acc<T>::type acc_t;
-    const int lane = t & 63, wave = t >> 6;
-    const int jt = (wave & 3) * 16, st = (wave >> 2) * 16;
-    const int li = lane & 15, lq = lane >> 4;
-    const T bias = L.b2[jt + li];
-    acc_t acc0 = {bias, bias, bias, bias};
-#pragma unroll 4
-    for (int k0 = 0; k0 < kH; k0 += 4)
-      acc0 = mfma(L.h1[(st + li) * kRow + k0 + lq], L.wt2[(k0 + lq) * kRow + jt + li], acc0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = mfma_acc<T>::row(lane, v);
-      L.h2[(st + r) * kRow + jt + li] = acc0[v] > (T)0 ? acc0[v] : (T)0;
-    }
-  }
-  lds_barrier();
-  for (int e = t; e < kB * O; e += NT) {
-    const int s = e / O, a = e - s * O;
-    T acc = L.b3[a];
-#pragma unroll 8
-    for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[a * kH + k], L.h2[s * kRow + k], acc);
-    out[e] = acc;
-  }
-  lds_barrier();
-}
-
-// the 32 input rows of an instance: rows of a float64 table by index, or a dense [32][D] block
-template <typename T, int NT>
-__device__ void load_inputs(T* dst, const double* table, const int32_t* index, const T* dense,
-                            int D, int t) {
-  constexpr int U = (kB * kMaxD + NT - 1) / NT;
-  if (table) {   // the row numbers first (all at once), then the rows (all at once)
+__device__ __forceinline__ void load_inputs(T* x, const double* table, const int32_t* index,
+                                            const T* dense, int D, int t) {
+  constexpr int U = kB * 32 / NT;
+  T r[U];
+  if (table) {
     int row[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = t + NT * u;
-      row[u] = e < kB * D ? index[e / D] : 0;
-    }
-    double r[U];
+    for (int u = 0; u < U; ++u) row[u] = index[(t + NT * u) >> 5];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = t + NT * u;
-      const int d = e - (e / D) * D;
-      r[u] = e < kB * D ? table[(size_t)row[u] * D + d] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = t + NT * u;
-      if (e < kB * D) dst[e] = (T)r[u];
+      const int d = (t + NT * u) & 31;
+      r[u] = d < D ? (T)table[(size_t)row[u] * D + d] : (T)0;
     }
   } else {
-    staged_copy<U, NT, T>(dense, kB * D, t, [&](int e, T v) { dst[e] = v; });
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = t + NT * u, d = e & 31;
+      r[u] = d < D ? dense[(e >> 5) * D + d] : (T)0;
+    }
   }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = t + NT * u;
+    x[(e >> 5) * kXRow + (e & 31)] = r[u];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ typename mfma_acc<T>::type splat(T v) {
+  typename mfma_acc<T>::type a = {v, v, v, v};
+  return a;
+}
+
+// KS consecutive elements of a row of a 64-wide matrix (16-byte aligned: whole vector loads)
+template <typename T, int KS>
+__device__ __forceinline__ void load_run(T (&b)[KS], const T* p, bool valid) {
+  const T* const q = reinterpret_cast<const T*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+  for (int s = 0; s < KS; ++s) b[s] = valid ? q[s] : (T)0;
+}
+
+// The weight operand of a forward product for the 16 outputs n0 .. of a layer, requested from memory:
+// lane (li, lq) takes W[n0 + li][lq KS .. lq KS + KS) (k >= kmax, n >= nmax: zero).  Requested at
+// the START of a pass for all three layers — a layer's operand is then in registers when the layer
+// before it has finished, instead of one more trip to memory per layer.
+template <typename T, int KS, bool ALIGNED>
+__device__ __forceinline__ void weight_rows(T (&b)[KS], const T* __restrict__ W, int ld, int kmax,
+                                            int nmax, int n0, int lane) {
+  const int li = lane & 15, lq = lane >> 4;
+  const bool valid = n0 + li < nmax;
+  const T* const wr = W + (uint32_t)((valid ? n0 + li : 0) * ld + lq * KS);
+  if (ALIGNED) {
+    load_run<T, KS>(b, wr, valid);
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[s] = valid && lq * KS + s < kmax ? wr[s] : (T)0;
+  }
+}
+
+// One hidden layer for MT row tiles: out[m][n0 + li] = relu(bias + sum_k in[m][k] W[n0 + li][k]),
+// K = 4 KS, `in` with row stride IS, the weight operand b as above.
+template <typename T, int KS, int MT>
+__device__ __forceinline__ void dense_relu(const T (&b)[KS], const T* in, int IS, const T* bias,
+                                           T* out, int m0, int n0, int lane) {
+  typedef typename mfma_acc<T>::type acc_t;
+  const int li = lane & 15, lq = lane >> 4;
+  const T bv = bias[n0 + li];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    acc_t acc = splat<T>(bv);
+    const T* const ar = in + (m0 + 16 * i + li) * IS + lq * KS;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = mfma(ar[s], b[s], acc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      out[(m0 + 16 * i + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] =
+          acc[v] > (T)0 ? acc[v] : (T)0;
+  }
+}
+
+// The output layer's tile (rows m0 .., outputs n0 ..): q[m][n0 + li] = b3 + sum_k h2[m][k] W3[n][k]
+template <typename T>
+__device__ __forceinline__ typename mfma_acc<T>::type output_tile(const T (&b)[16], int O,
+                                                                  const T* h2, const T* b3, int m0,
+                                                                  int n0, int lane) {
+  typedef typename mfma_acc<T>::type acc_t;
+  const int li = lane & 15, lq = lane >> 4;
+  acc_t acc = splat<T>(n0 + li < O ? b3[n0 + li] : (T)0);
+  const T* const ar = h2 + (m0 + li) * kRow + lq * 16;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = mfma(ar[s], b[s], acc);
+  return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward only.  No backward pass means no buffer has to outlive the layer that reads it: the first
-// layer's weights sit where h2 will be written, the output layer's where h1 was, the inputs are
-// read straight from memory and the outputs written straight to it — 69 KB in float64 instead of
-// the 94 KB of the training layout: two workgroups per CU.
-__host__ __device__ inline size_t fwd_lds_elems() {
-  return (size_t)kH * kRow + 2 * (size_t)kB * kRow + 2 * kH + kMaxO;
-}
-
+// Forward only: four waves per instance; wave w owns the 16 neurons n0 = 16 w of a hidden layer
+// for both row tiles (its weights are loaded once), and one of the (up to) four output tiles.
 template <typename T>
 __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -294,94 +283,38 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
   const int D = R.n_inputs, O = R.n_outputs;
   if (R.active && !R.active[j / R.act_div]) return;
-  T* const wt2 = reinterpret_cast<T*>(lds_raw);          // [64][66]
-  T* const h1 = wt2 + kH * kRow;                         // [32][66]; later w3 [O][64]
-  T* const h2 = h1 + kB * kRow;                          // [32][66]; before that wt1 [D][64]
-  T* const bias1 = h2 + kB * kRow;
-  T* const bias2 = bias1 + kH;
-  T* const bias3 = bias2 + kH;
-  T* const wt1 = h2;
-  T* const w3l = h1;
+  const act_lds<T> L = carve_fwd<T>(lds_raw);
+  const int lane = t & 63, wave = t >> 6;
   const size_t net = (size_t)(j / R.net_div);
-  const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)O * kH;
-  const T* const w1 = (const T*)R.w[0] + net * n1;
-  const T* const w2 = (const T*)R.w[1] + net * n2;
-  const T* const w3 = (const T*)R.w[2] + net * n3;
-  {
-    T w2r[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) w2r[u] = w2[t + 256 * u];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = t + 256 * u;
-      wt2[(e & 63) * kRow + (e >> 6)] = w2r[u];
-    }
-    staged_copy<kH * kMaxD / 256, 256, T>(w1, kH * D, t, [&](int e, T v) {
-      const int jj = e / D, d = e - jj * D;
-      wt1[d * kH + jj] = v;
-    });
-    if (t < kH) {
-      bias1[t] = ((const T*)R.b[0] + net * kH)[t];
-      bias2[t] = ((const T*)R.b[1] + net * kH)[t];
-    }
-    if (t < O) bias3[t] = ((const T*)R.b[2] + net * O)[t];
+  const T* const w1 = (const T*)R.w[0] + net * (size_t)kH * D;
+  const T* const w2 = (const T*)R.w[1] + net * (size_t)kH * kH;
+  const T* const w3 = (const T*)R.w[2] + net * (size_t)O * kH;
+  const int m3 = 16 * (wave >> 1), n3 = 16 * (wave & 1);
+  T bw1[8], bw2[16], bw3[16];
+  weight_rows<T, 8, false>(bw1, w1, D, D, kH, 16 * wave, lane);
+  weight_rows<T, 16, true>(bw2, w2, kH, kH, kH, 16 * wave, lane);
+  weight_rows<T, 16, true>(bw3, w3, kH, kH, O, n3, lane);
+  load_inputs<T, 256>(L.x, R.in_table,
+                      R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
+                      R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
+  if (t < kH) {
+    L.b1[t] = ((const T*)R.b[0] + net * kH)[t];
+    L.b2[t] = ((const T*)R.b[1] + net * kH)[t];
   }
+  if (t < kMaxO) L.b3[t] = t < O ? ((const T*)R.b[2] + net * O)[t] : (T)0;
   lds_barrier();
-  // layer 1: thread tile 2 samples x 4 neurons, inputs from memory (16 threads share a sample)
-  {
-    const int j0 = (t & 15) * 4, s0 = (t >> 4) * 2;
-    const int32_t* const idx = R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr;
-    const double* const r0 = R.in_table ? R.in_table + (size_t)idx[s0] * D : nullptr;
-    const double* const r1 = R.in_table ? R.in_table + (size_t)idx[s0 + 1] * D : nullptr;
-    const T* const dn = R.in_table ? nullptr : (const T*)R.in_dense + ((size_t)j * kB + s0) * D;
-    T acc[2][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[0][c] = acc[1][c] = bias1[j0 + c];
-    for (int d = 0; d < D; ++d) {
-      const T x0 = R.in_table ? (T)r0[d] : dn[d], x1 = R.in_table ? (T)r1[d] : dn[D + d];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const T w = wt1[d * kH + j0 + c];
-        acc[0][c] = fma_t<T>(w, x0, acc[0][c]);
-        acc[1][c] = fma_t<T>(w, x1, acc[1][c]);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      h1[s0 * kRow + j0 + c] = acc[0][c] > (T)0 ? acc[0][c] : (T)0;
-      h1[(s0 + 1) * kRow + j0 + c] = acc[1][c] > (T)0 ? acc[1][c] : (T)0;
-    }
-  }
-  lds_barrier();   // (every read of wt1 is done: h2 may be written)
-  {
-    typedef typename mfma_acc<T>::type acc_t;
-    const int lane = t & 63, jt = (t >> 6) * 16;
-    const int li = lane & 15, lq = lane >> 4;
-    const T bias = bias2[jt + li];
-    acc_t acc0 = {bias, bias, bias, bias}, acc1 = acc0;
-#pragma unroll 4
-    for (int k0 = 0; k0 < kH; k0 += 4) {
-      const T b = wt2[(k0 + lq) * kRow + jt + li];
-      acc0 = mfma(h1[li * kRow + k0 + lq], b, acc0);
-      acc1 = mfma(h1[(16 + li) * kRow + k0 + lq], b, acc1);
-    }
-    lds_barrier();   // (every read of h1 is done: the output layer's weights take its place)
-    staged_copy<kMaxO * kH / 256, 256, T>(w3, O * kH, t, [&](int e, T v) { w3l[e] = v; });
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = mfma_acc<T>::row(lane, v);
-      h2[r * kRow + jt + li] = acc0[v] > (T)0 ? acc0[v] : (T)0;
-      h2[(16 + r) * kRow + jt + li] = acc1[v] > (T)0 ? acc1[v] : (T)0;
-    }
-  }
+  dense_relu<T, 8, 2>(bw1, L.x, kXRow, L.b1, L.h1, 0, 16 * wave, lane);
+  lds_barrier();   // (every read of x is done: h2 takes its place)
+  dense_relu<T, 16, 2>(bw2, L.h1, kRow, L.b2, L.h2, 0, 16 * wave, lane);
   lds_barrier();
-  T* const out = (T*)R.out + (size_t)j * kB * O;
-  for (int e = t; e < kB * O; e += 256) {
-    const int s = e / O, a = e - s * O;
-    T acc = bias3[a];
-#pragma unroll 8
-    for (int k = 0; k < kH; ++k) acc = fma_t<T>(w3l[a * kH + k], h2[s * kRow + k], acc);
-    out[e] = acc;
+  if (n3 < O) {
+    const typename mfma_acc<T>::type acc = output_tile<T>(bw3, O, L.h2, L.b3, m3, n3, lane);
+    T* const out = (T*)R.out + (size_t)j * kB * O;
+    const int a = n3 + (lane & 15);
+    if (a < O) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) out[(m3 + mfma_acc<T>::row(lane, v)) * O + a] = acc[v];
+    }
   }
 }
 
@@ -391,16 +324,20 @@ __global__ __launch_bounds__(256) void k_mlp_forward(const fwd_args A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One optimisation step: eight waves per network.  Wave w owns the tile (rows 16 (w / 4) ..,
+// columns 16 (w % 4) ..) of every rows x 64 product and one or two tiles of every gradient.
 template <typename T>
 __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
-  constexpr int NT = kFitThreads;   // eight waves: the workgroup is alone on its CU (LDS), so the
-                                    // parallelism inside it is all there is to hide latency
+  constexpr int NT = kFitThreads;
+  typedef typename mfma_acc<T>::type acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_mlp_fit_t& R = A.r;
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
   if (R.active && !R.active[j / R.act_div]) return;
   const int D = R.n_inputs, O = R.n_outputs;
-  const net_lds<T> L = carve<T>(lds_raw, D, O);
+  const act_lds<T> L = carve_fit<T>(lds_raw);
+  const int lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
+  const int m0 = 16 * (wave >> 2), n0 = 16 * (wave & 3);
   const bool train = !R.train || R.train[j];
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)O * kH;
   T* const w1 = (T*)R.w[0] + (size_t)j * n1;
@@ -410,14 +347,19 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   T* const w3 = (T*)R.w[2] + (size_t)j * n3;
   T* const b3 = (T*)R.b[2] + (size_t)j * O;
   const bool blend = R.tau != 0.0 && R.w_target[0] != nullptr;
-  T* const tw1 = blend ? (T*)R.w_target[0] + (size_t)j * n1 : nullptr;
-  T* const tb1 = blend ? (T*)R.b_target[0] + (size_t)j * kH : nullptr;
-  T* const tw2 = blend ? (T*)R.w_target[1] + (size_t)j * n2 : nullptr;
-  T* const tb2 = blend ? (T*)R.b_target[1] + (size_t)j * kH : nullptr;
-  T* const tw3 = blend ? (T*)R.w_target[2] + (size_t)j * n3 : nullptr;
-  T* const tb3 = blend ? (T*)R.b_target[2] + (size_t)j * O : nullptr;
+  // (without a blend the target pointers alias the parameters: loads stay unconditional)
+  T* const tw1 = blend ? (T*)R.w_target[0] + (size_t)j * n1 : w1;
+  T* const tb1 = blend ? (T*)R.b_target[0] + (size_t)j * kH : b1;
+  T* const tw2 = blend ? (T*)R.w_target[1] + (size_t)j * n2 : w2;
+  T* const tb2 = blend ? (T*)R.b_target[1] + (size_t)j * kH : b2;
+  T* const tw3 = blend ? (T*)R.w_target[2] + (size_t)j * n3 : w3;
+  T* const tb3 = blend ? (T*)R.b_target[2] + (size_t)j * O : b3;
 
-  stage_params<T, NT>(L, w1, b1, w2, b2, w3, b3, D, O, t);
+  if (t < kH) {
+    L.b1[t] = b1[t];
+    L.b2[t] = b2[t];
+  }
+  if (t < kMaxO) L.b3[t] = t < O ? b3[t] : (T)0;
 
   if (!train) {
     // No samples for this network in this step: parameters and optimizer state stay as they are;
@@ -441,65 +383,76 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     T* const m_b1 = (T*)R.m_b[0] + (size_t)j * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)j * kH;
     T* const m_b2 = (T*)R.m_b[1] + (size_t)j * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)j * kH;
     T* const m_b3 = (T*)R.m_b[2] + (size_t)j * O;  T* const v_b3 = (T*)R.v_b[2] + (size_t)j * O;
-    // (the inputs are requested BEFORE the optimizer state: loads return in order, and the forward
-    //  pass must not queue behind 3 x 59 KB it does not need)
+    // waves 0 .. 3 also own an output tile: rows r3 .., outputs a3 ..
+    const int r3 = 16 * ((wave >> 1) & 1), a3 = 16 * (wave & 1);
+    const bool has_out = wave < 4 && a3 < O;
+    T fw1[8], fw2[16], fw3[16];
+    weight_rows<T, 8, false>(fw1, w1, D, D, kH, n0, lane);
+    weight_rows<T, 16, true>(fw2, w2, kH, kH, kH, n0, lane);
+    weight_rows<T, 16, true>(fw3, w3, kH, kH, has_out ? O : 0, a3, lane);
     load_inputs<T, NT>(L.x, R.in_table,
-                   R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
-                   R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
-    // second layer: wave w owns the gradient tiles (rows j = 16 (w % 4) .., columns k = 16 kt ..
-    // for kt = 2 (w / 4), 2 (w / 4) + 1) and the delta tile (samples 16 (w / 4) .., columns k =
-    // 16 (w % 4) ..)
-    const int lane2 = t & 63, wave2 = t >> 6, jt2 = (wave2 & 3) * 16, li2 = lane2 & 15;
-    const int kt0 = (wave2 >> 2) * 2, st2 = (wave2 >> 2) * 16;
-    constexpr int kU3 = (kMaxO * kH + NT - 1) / NT, kU1 = (kMaxD * kH + NT - 1) / NT;
-    adam_slot<T> s2[2][4], s3[kU3], s1[kU1], sb1, sb2, sb3;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        s2[kt][v] = slot_load<T>(m_w2, v_w2, tw2,
-                                 (size_t)(jt2 + mfma_acc<T>::row(lane2, v)) * kH + 16 * (kt0 + kt) + li2,
-                                 blend);
-#pragma unroll
-    for (int u = 0; u < kU3; ++u) {
-      const int e = t + NT * u;
-      s3[u].m = s3[u].v = s3[u].target = (T)0;
-      if (e < O * kH) s3[u] = slot_load<T>(m_w3, v_w3, tw3, (size_t)e, blend);
-    }
-#pragma unroll
-    for (int u = 0; u < kU1; ++u) {
-      const int e = t + NT * u;
-      s1[u].m = s1[u].v = s1[u].target = (T)0;
-      if (e < kH * D) s1[u] = slot_load<T>(m_w1, v_w1, tw1, (size_t)e, blend);
-    }
-    sb1.m = sb1.v = sb1.target = sb2.m = sb2.v = sb2.target = sb3.m = sb3.v = sb3.target = (T)0;
-    if (t < kH) {
-      sb1 = slot_load<T>(m_b1, v_b1, tb1, (size_t)t, blend);
-      sb2 = slot_load<T>(m_b2, v_b2, tb2, (size_t)t, blend);
-    }
-    if (t < O) sb3 = slot_load<T>(m_b3, v_b3, tb3, (size_t)t, blend);
-
+                       R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
+                       R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
+    for (int e = t; e < kB * kXRow; e += NT) L.q[e] = (T)0;
     lds_barrier();
-    forward32<T, NT>(L, L.q, D, O, t);
-    if (R.debug_stage == 1) return;
 
-    // ---- loss gradient at the output ----------------------------------------------------------
-    // mean over the marked samples and the O outputs of (out - target)^2: 2 (out - y) / (count O)
+    // ---- forward --------------------------------------------------------------------------------
+    dense_relu<T, 8, 1>(fw1, L.x, kXRow, L.b1, L.h1, m0, n0, lane);
+    lds_barrier();
+    dense_relu<T, 16, 1>(fw2, L.h1, kRow, L.b2, L.h2, m0, n0, lane);
+    // Requested here, a barrier and a product ahead of their use: the targets and the mask of the
+    // output tile, the weights behind delta2 (the column block W3[.][n0 ..], lane (li, lq) takes the
+    // outputs a = 8 lq ..) and the optimizer state of this wave's output-layer gradient tile dW3[a][k]
+    // (outputs g0 = 16 (w / 4) .., neurons n0 ..).
+    __builtin_amdgcn_sched_barrier(0);
     const uint8_t* const mask = R.sample_mask ? R.sample_mask + (size_t)j * kB : nullptr;
+    T yv[4];
+    bool on[4];
     int count = kB;
-    if (mask) {
-      count = 0;
-      for (int s = 0; s < kB; ++s) count += mask[s] ? 1 : 0;
-      count = count > 0 ? count : 1;
+    if (has_out) {
+      const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int s = r3 + mfma_acc<T>::row(lane, v);
+        yv[v] = a3 + li < O ? y[s * O + a3 + li] : (T)0;
+        on[v] = !mask || mask[s];
+      }
+      if (mask) {
+        const bool mine = mask[lane & 31] != 0;
+        count = __popcll(__ballot(mine && lane < kB));
+        count = count > 0 ? count : 1;
+      }
     }
-    const T scale = (T)1 / (T)(count * O);
-    const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
-    staged_copy<(kB * kMaxO + NT - 1) / NT, NT, T>(y, kB * O, t, [&](int e, T yv) {
-      const int s = e / O;
-      const T d = L.q[e] - yv;
-      L.q[e] = (!mask || mask[s]) ? ((T)2 * d) * scale : (T)0;   // delta3
-    });
+    const int g0 = 16 * (wave >> 2);
+    const bool has_g = g0 < O;
+    T cw3[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int a = lq * 8 + s;
+      cw3[s] = a < O ? w3[(uint32_t)(a * kH + n0 + li)] : (T)0;
+    }
+    adam_slot<T> s3[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = g0 + mfma_acc<T>::row(lane, v);
+      s3[v] = slot_load<T>(w3, m_w3, v_w3, tw3, (uint32_t)(a * kH + n0 + li), blend, a < O);
+    }
     lds_barrier();
+    // output tiles and the loss gradient: mean over the marked samples and the O outputs of
+    // (out - target)^2: 2 (out - y) / (count O)
+    if (has_out) {
+      const T scale = (T)1 / (T)(count * O);
+      const acc_t acc = output_tile<T>(fw3, O, L.h2, L.b3, r3, a3, lane);
+      if (a3 + li < O) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int s = r3 + mfma_acc<T>::row(lane, v);
+          const T d = acc[v] - yv[v];
+          L.q[s * kXRow + a3 + li] = on[v] ? ((T)2 * d) * scale : (T)0;   // delta3
+        }
+      }
+    }
+    if (R.debug_stage == 1) return;
 
     // ---- Adam constants of this network (its own step count) ------------------------------------
     adam_consts<T> c;
@@ -517,160 +470,198 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       c.tau = (T)R.tau;
       c.blend = blend;
     }
-
-    // ---- output layer: dW3[a][k] = sum_s delta3[s][a] h2[s][k], db3[a] = sum_s delta3[s][a] ----
-    // (the new weights go to memory now and into LDS once delta2 has used the old ones)
-    T new_w3[kU3];
-#pragma unroll
-    for (int u = 0; u < kU3; ++u) {
-      const int e = t + NT * u;
-      new_w3[u] = (T)0;
-      if (e < O * kH) {
-        const int a = e >> 6, k = e & 63;
-        T g = (T)0;
-#pragma unroll 8
-        for (int s = 0; s < kB; ++s) g = fma_t<T>(L.q[s * O + a], L.h2[s * kRow + k], g);
-        new_w3[u] = adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)e, L.w3[e], g, s3[u], c);
-      }
-    }
-    T new_b3 = (T)0;
-    if (t < O) {
-      T gb = (T)0;
-      for (int s = 0; s < kB; ++s) gb = gb + L.q[s * O + t];
-      new_b3 = adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, sb3, c);
-    }
     lds_barrier();
-    // delta2[s][k] = (sum_a W3[a][k] delta3[s][a]) * (h2[s][k] > 0), in place over h2
-    for (int e = t; e < kB * kH; e += NT) {
-      const int s = e >> 6, k = e & 63;
-      T d = (T)0;
-      for (int a = 0; a < O; ++a) d = fma_t<T>(L.w3[a * kH + k], L.q[s * O + a], d);
-      const T h = L.h2[s * kRow + k];
-      L.h2[s * kRow + k] = h > (T)0 ? d : (T)0;
-    }
-    lds_barrier();
-#pragma unroll
-    for (int u = 0; u < kU3; ++u) {
-      const int e = t + NT * u;
-      if (e < O * kH) L.w3[e] = new_w3[u];
-    }
-    if (t < O) L.b3[t] = new_b3;
-    if (R.debug_stage == 2) return;
 
-    // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k] (MFMA) ---------------------------
-    T new_w2[2][4];
+    // ---- output layer ---------------------------------------------------------------------------
+    // delta2 tile (rows m0 .., neurons n0 ..) from the weights the step started from, and the
+    // gradient tile; the new weights are written once every wave has taken its share of the old
+    // ones (barrier).  cw2: the weights behind delta1 (column block W2[.][n0 ..]), for the next phase.
+    T cw2[16];
     {
-      typedef typename mfma_acc<T>::type acc_t;
-      const int lq = lane2 >> 4;
-      acc_t g2[2];
+      acc_t d2 = splat<T>((T)0);
+      {
+        const T* const ar = L.q + (m0 + li) * kXRow + lq * 8;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) g2[a] = acc_t{(T)0, (T)0, (T)0, (T)0};
-#pragma unroll 2
-      for (int s0 = 0; s0 < kB; s0 += 4) {
-        const T a = L.h2[(s0 + lq) * kRow + jt2 + li2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          g2[kt] = mfma(a, L.h1[(s0 + lq) * kRow + 16 * (kt0 + kt) + li2], g2[kt]);
+        for (int s = 0; s < 8; ++s) d2 = mfma(ar[s], cw3[s], d2);
       }
+      T hv[4];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int v = 0; v < 4; ++v) hv[v] = L.h2[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li];
+      acc_t g3 = splat<T>((T)0);
+      if (has_g) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int jj = jt2 + mfma_acc<T>::row(lane2, v), k = 16 * (kt0 + kt) + li2;
-          new_w2[kt][v] = adam_apply<T>(w2, m_w2, v_w2, tw2, (size_t)jj * kH + k,
-                                        L.wt2[k * kRow + jj], g2[kt][v], s2[kt][v], c);
+        for (int s = 0; s < 8; ++s) {
+          const int r = lq * 8 + s;
+          g3 = mfma(L.q[r * kXRow + g0 + li], L.h2[r * kRow + n0 + li], g3);
         }
-      if (t < kH) {
-        T gb = (T)0;
-        for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
-        L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
       }
-    }
-    if (R.debug_stage == 3) return;
-    lds_barrier();
-    // delta1[s][k] = (sum_j delta2[s][j] W2[j][k]) * (h1[s][k] > 0), in place over h1, from the
-    // weights this step started from (LDS still holds them)
-    {
-      typedef typename mfma_acc<T>::type acc_t;
-      const int lq = lane2 >> 4;
-      acc_t d0 = {(T)0, (T)0, (T)0, (T)0};
-#pragma unroll 4
-      for (int j0 = 0; j0 < kH; j0 += 4)
-        d0 = mfma(L.h2[(st2 + li2) * kRow + j0 + lq], L.wt2[(jt2 + li2) * kRow + j0 + lq], d0);
+      T gb = (T)0;
+      if (t < O)
+        for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kXRow + t];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = st2 + mfma_acc<T>::row(lane2, v), k = jt2 + li2;
-        const T h0 = L.h1[r * kRow + k];
-        L.h1[r * kRow + k] = h0 > (T)0 ? d0[v] : (T)0;
-      }
-    }
-    lds_barrier();
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int s = 0; s < 16; ++s) cw2[s] = w2[(uint32_t)((lq * 16 + s) * kH + n0 + li)];
+      lds_barrier();
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        L.wt2[(16 * (kt0 + kt) + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
-
-    if (R.debug_stage == 4) return;
-    // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] ------------------------------------
+        L.h2[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] = hv[v] > (T)0 ? d2[v] : (T)0;
+      if (has_g) {
 #pragma unroll
-    for (int u = 0; u < kU1; ++u) {
-      const int e = t + NT * u;
-      if (e < kH * D) {
-        const int jj = e / D, d = e - jj * D;
-        T g = (T)0;
-#pragma unroll 8
-        for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + jj], L.x[s * D + d], g);
-        L.wt1[d * kH + jj] =
-            adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + jj], g, s1[u], c);
+        for (int v = 0; v < 4; ++v) {
+          const int a = g0 + mfma_acc<T>::row(lane, v);
+          if (a < O)
+            adam_apply<T>(w3, m_w3, v_w3, tw3, (uint32_t)(a * kH + n0 + li), g3[v], s3[v], c);
+        }
+      }
+      if (t < O) {
+        const adam_slot<T> sb = slot_load<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, blend, true);
+        L.b3[t] = adam_apply<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, gb, sb, c);
       }
     }
-    if (t < kH) {
+    if (R.debug_stage == 2) return;
+
+    // ---- second layer: delta1 tile and two gradient tiles dW2[j][k] (rows n0 .., columns
+    //      k0 = 32 (w / 4) .., + 16).  Optimizer state: the first tile's is requested once delta1's
+    //      weight operand is used up, the second tile's once the first has been applied (128
+    //      registers = two workgroups per CU). ----------------------------------------------------
+    {
+      const int k0 = 32 * (wave >> 2);
+      adam_slot<T> s2a[4], s2b[4], s1[4];
+      lds_barrier();
+      acc_t d1 = splat<T>((T)0);
+      {
+        const T* const ar = L.h2 + (m0 + li) * kRow + lq * 16;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) d1 = mfma(ar[s], cw2[s], d1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)   // (the registers of cw2 are free now)
+        s2a[v] = slot_load<T>(w2, m_w2, v_w2, tw2,
+                              (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + li), blend, true);
+      T hv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) hv[v] = L.h1[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li];
+      acc_t g2[2] = {splat<T>((T)0), splat<T>((T)0)};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int r = lq * 8 + s;
+        const T a = L.h2[r * kRow + n0 + li];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) g2[kt] = mfma(a, L.h1[r * kRow + k0 + 16 * kt + li], g2[kt]);
+      }
       T gb = (T)0;
-      for (int s = 0; s < kB; ++s) gb = gb + L.h1[s * kRow + t];
-      L.b1[t] = adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, sb1, c);
+      if (t < kH)
+        for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
+      lds_barrier();
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        L.h1[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] = hv[v] > (T)0 ? d1[v] : (T)0;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        s2b[v] = slot_load<T>(w2, m_w2, v_w2, tw2,
+                              (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + 16 + li), blend,
+                              true, false);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        adam_apply<T>(w2, m_w2, v_w2, tw2,
+                      (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + li), g2[0][v], s2a[v], c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)   // (the blend is the last thing the update needs)
+        s2b[v].target = __builtin_nontemporal_load(
+            tw2 + (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + 16 + li));
+      // first layer's gradient tile dW1[j][d] (rows n0 .., inputs d0 = 16 (w / 4) ..): its state
+      const int d0 = 16 * (wave >> 2), d = d0 + li;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        s1[v] = slot_load<T>(w1, m_w1, v_w1, tw1,
+                             (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * D + d), blend,
+                             d0 < D && d < D);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        adam_apply<T>(w2, m_w2, v_w2, tw2,
+                      (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + 16 + li), g2[1][v],
+                      s2b[v], c);
+      if (t < kH) {
+        const adam_slot<T> sb = slot_load<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, blend, true);
+        L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, gb, sb, c);
+      }
+      if (R.debug_stage == 3 || R.debug_stage == 4) return;
+      lds_barrier();
+
+      // ---- first layer ------------------------------------------------------------------------
+      if (d0 < D) {
+        acc_t g1 = splat<T>((T)0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int r = lq * 8 + s;
+          g1 = mfma(L.h1[r * kRow + n0 + li], L.x[r * kXRow + d], g1);
+        }
+        if (d < D) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            adam_apply<T>(w1, m_w1, v_w1, tw1, (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * D + d),
+                          g1[v], s1[v], c);
+        }
+      }
+      if (t < kH) {
+        T gb1 = (T)0;
+        for (int s = 0; s < kB; ++s) gb1 = gb1 + L.h1[s * kRow + t];
+        const adam_slot<T> sb = slot_load<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, blend, true);
+        L.b1[t] = adam_apply<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, gb1, sb, c);
+      }
     }
     if (t == 0) R.steps[j] = R.steps[j] + 1.0;
   }
 
   // ---- outputs of the (updated) network for the extra rows -------------------------------------
   if (R.ep_out && R.ep_rows > 0) {
-    lds_barrier();   // LDS holds the current parameters; x / h1 / h2 are free
+    __syncthreads();   // the new parameters are in memory; x / h1 / h2 are free
     const int E = R.ep_rows;
-    for (int e = t; e < E * D; e += NT) {
-      const int r = e / D, d = e - r * D;
-      L.x[e] = R.ep_table ? (T)R.ep_table[(size_t)R.ep_index[j / R.ep_div] * D + d]
-                          : ((const T*)R.ep_dense)[((size_t)j * E + r) * D + d];
+    if (t < kMaxEp * 32) {
+      const int r = t >> 5, d = t & 31;
+      T v = (T)0;
+      if (r < E && d < D)
+        v = R.ep_table ? (T)R.ep_table[(size_t)R.ep_index[j / R.ep_div] * D + d]
+                       : ((const T*)R.ep_dense)[((size_t)j * E + r) * D + d];
+      L.x[r * kXRow + d] = v;
     }
-    lds_barrier();
-    {
-      const int r = t >> 6, k = t & 63;   // rows x 64 neurons (waves beyond the rows idle)
-      if (r < E) {
-        T acc = L.b1[k];
-        for (int d = 0; d < D; ++d) acc = fma_t<T>(L.wt1[d * kH + k], L.x[r * D + d], acc);
-        L.h1[r * kRow + k] = acc > (T)0 ? acc : (T)0;
-      }
+    // one row tile (rows >= E of it are not looked at): waves 0 .. 3, all operands requested at once
+    if (wave < 4) {
+      T fw1[8], fw2[16], fw3[16];
+      weight_rows<T, 8, false>(fw1, w1, D, D, kH, n0, lane);
+      weight_rows<T, 16, true>(fw2, w2, kH, kH, kH, n0, lane);
+      weight_rows<T, 16, true>(fw3, w3, kH, kH, wave < 2 ? O : 0, 16 * wave, lane);
       lds_barrier();
-      if (r < E) {
-        T acc = L.b2[k];
-#pragma unroll 8
-        for (int kk = 0; kk < kH; ++kk) acc = fma_t<T>(L.wt2[kk * kRow + k], L.h1[r * kRow + kk], acc);
-        L.h2[r * kRow + k] = acc > (T)0 ? acc : (T)0;
-      }
+      dense_relu<T, 8, 1>(fw1, L.x, kXRow, L.b1, L.h1, 0, n0, lane);
       lds_barrier();
-      for (int e = t; e < E * O; e += NT) {
-        const int rr = e / O, a = e - rr * O;
-        T acc = L.b3[a];
-#pragma unroll 8
-        for (int kk = 0; kk < kH; ++kk) acc = fma_t<T>(L.w3[a * kH + kk], L.h2[rr * kRow + kk], acc);
-        ((T*)R.ep_out)[((size_t)j * E + rr) * O + a] = acc;
+      dense_relu<T, 16, 1>(fw2, L.h1, kRow, L.b2, L.h2, 0, n0, lane);
+      lds_barrier();
+      if (wave < 2 && 16 * wave < O) {
+        const acc_t acc = output_tile<T>(fw3, O, L.h2, L.b3, 0, 16 * wave, lane);
+        const int a = 16 * wave + li;
+        if (a < O) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int r = mfma_acc<T>::row(lane, v);
+            if (r < E) ((T*)R.ep_out)[((size_t)j * E + r) * O + a] = acc[v];
+          }
+        }
       }
+    } else {   // (the barriers count every wave of the workgroup)
+      lds_barrier();
+      lds_barrier();
+      lds_barrier();
     }
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(kFitThreads) void k_mlp_fit(const fit_args A) {
+__global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mlp_fit(const fit_args A) {
   mlp_fit_body<T>(A);
 }
 
@@ -699,7 +690,7 @@ extern "C" int cobel_mlp_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hi
                 "batch %d)", n_hidden1, n_hidden2, batch);
   if (int rc = shape_ok(n_inputs, n_outputs, "cobel_mlp")) return rc;
   if (lds_bytes)
-    *lds_bytes = (int32_t)(net_lds_elems(n_inputs, n_outputs) * (is_float64 ? 8 : 4));
+    *lds_bytes = (int32_t)(fit_lds_elems() * (is_float64 ? 8 : 4));
   return COBEL_OK;
 }
 
@@ -715,6 +706,8 @@ extern "C" int cobel_mlp_forward(const cobel_mlp_forward_t* run, void* stream) {
                 "cobel_mlp_forward: out and inputs (in_table + in_index, or in_dense) are required");
   COBEL_REQUIRE(r.n >= 0 && r.net_div >= 1 && r.in_div >= 1 && r.act_div >= 1, COBEL_E_RANGE,
                 "cobel_mlp_forward: bad sizes");
+  COBEL_REQUIRE(((uintptr_t)r.w[1] & 15u) == 0 && ((uintptr_t)r.w[2] & 15u) == 0, COBEL_E_ARG,
+                "cobel_mlp_forward: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
   fwd_args A;
   A.r = r;
@@ -748,6 +741,8 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   COBEL_REQUIRE(!r.ep_out || r.ep_rows == 0 ||
                     (r.ep_table ? (r.ep_index != nullptr && r.ep_rows == 1) : r.ep_dense != nullptr),
                 COBEL_E_ARG, "cobel_mlp_fit: extra rows need ep_table + ep_index (one row) or ep_dense");
+  COBEL_REQUIRE(((uintptr_t)r.w[1] & 15u) == 0 && ((uintptr_t)r.w[2] & 15u) == 0, COBEL_E_ARG,
+                "cobel_mlp_fit: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
   fit_args A;
   A.r = r;
