@@ -14,11 +14,18 @@
 //                      four actions).
 // Together they carry DynaDSR.replay (agent/dyna_q.py:1042-1150): nine networks per agent.
 //
-// Unlike k_dqn_replay (mlp.hip, parameters staged in LDS) these kernels take the weight operand of
-// every product straight from memory in the MFMA's operand layout and keep only the activations in
-// LDS (see "Layout" below): all products are 16 x 16 x 4 MFMAs in the network's dtype, gradients
-// only ever live in accumulator registers, Adam is applied by the lane that holds the element.
+//   cobel_dqn_replay   the DQN replay step (agent/dqn.py:346-371) = the same optimisation step with
+//                      the Q-learning targets r + gamma nt max_a' Q_target(s') [DDQN: the online
+//                      network picks a'] at the action taken, i.e. two (three) more forward passes
+//                      in front of it.
+//
+// The kernels take the weight operand of every product straight from memory in the MFMA's operand
+// layout and keep only the activations in LDS (see "Layout" below): all products are 16 x 16 x 4
+// MFMAs in the network's dtype, gradients only ever live in accumulator registers, Adam is applied
+// by the lane that holds the element — not torch's GEMM order, so results agree with the PyTorch
+// path to rounding (1e-10 relative in float64 after ten steps; tests bound it), not bit for bit.
 #include <stdlib.h>
+#include <string.h>
 
 #include <cstdlib>
 
@@ -32,19 +39,38 @@ constexpr int kRow = 66;
 constexpr int kMaxD = 32;
 constexpr int kMaxO = 32;
 constexpr int kMaxEp = 4;
+constexpr int kA = 4;              // actions of the DQN step
 constexpr int kFitThreads = 512;   // threads of a training workgroup
 
 struct fit_args {
   cobel_mlp_fit_t r;
+  // cobel_dqn_replay: the regression targets are the Q-learning targets
+  int32_t dqn, ddqn;
+  int32_t rows;                    // rows per instance of the dense inputs (32, or the ring's slots)
+  int32_t steps_given;             // the step counts already include this step (and stay as they are)
+  const void* next_dense;          // [n][rows][D] next states ...
+  const int32_t* next_index;       // ... or [n][32] rows of in_table
+  const int32_t* slots;            // [n][32] row of each sample, or NULL (sample s = row s)
+  const int64_t* actions;          // [n][rows]
+  const void* rewards;             // [n][rows]
+  const void* nonterminal;         // [n][rows]
+  double gamma;
+  unsigned long long* trace;       // experiments: [n][16] wall-clock stamps of thread 0 (or NULL)
 };
 struct fwd_args {
   cobel_mlp_forward_t r;
 };
 
+// Threads of a workgroup talk through LDS only, so its barriers wait for the LDS counter, not for
+// memory (__syncthreads() also drains vmcnt: the operand and optimizer-state loads issued ahead of
+// their use, and the parameter stores of the previous phase, are meant to stay in flight).
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Operand layout of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (probed on gfx950): lane l
+// supplies A[l % 16][l / 16] and B[l / 16][l % 16]; of the 16 x 16 result it holds column l % 16
+// and, in accumulator element v, row 4 v + l / 16 (float64) or 4 (l / 16) + v (float32).
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <typename T>
@@ -118,8 +144,8 @@ __device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m, T*
 // from memory in the MFMA's B layout (lane (li, lq) supplies B[k][n0 + li] for ITS quarter of the
 // summation index, k = lq * KS + step — a product may sum in any order, so each lane reads KS
 // consecutive elements of one row: whole cache lines for the 64-wide layers), and LDS holds only
-// the activations: x [32][33], h1 / h2 [32][66], q [32][33] and the three bias vectors — 52 KB in
-// float64, three training workgroups per CU where the parameter-staging layout (107 KB) had one.
+// the activations: x [32][33], h1 / h2 [32][66], q [32][33] — 52 KB in float64, two training
+// workgroups per CU (128 registers) where the parameter-staging layout (107 KB) had one.
 //   forward   h1 = relu(x W1' + b1)     M = rows, N = 64,  K = D   B from W1 (memory)
 //             h2 = relu(h1 W2' + b2)                        K = 64  B from W2
 //             q  = h2 W3' + b3          N = O               K = 64  B from W3
@@ -128,27 +154,25 @@ __device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m, T*
 //             delta1 = (delta2 W2) . (h1 > 0)   K = 64  B from W2
 //             dW2 = delta2' h1,  dW1 = delta1' x
 // A gradient tile stays in the accumulator registers of the wave that summed it; that wave applies
-// Adam to its 4 elements per lane and tile (consecutive lanes = consecutive addresses).
+// Adam to its 4 elements per lane and tile (consecutive lanes = consecutive addresses).  Operands and
+// optimizer state are requested a phase ahead of their use (registers permitting).
 constexpr int kXRow = 33;
 
 template <typename T>
 struct act_lds {
-  T* x;    // [32][33]  inputs, columns >= D zero
-  T* h1;   // [32][66]  -> delta1
-  T* h2;   // [32][66]  -> delta2
-  T* q;    // [32][33]  outputs -> delta3, columns >= O zero
-  T* b1;   // [64]
-  T* b2;   // [64]
-  T* b3;   // [32]
+  T* x;     // [32][33]  inputs, columns >= D zero
+  T* h1;    // [32][66]  -> delta1
+  T* h2;    // [32][66]  -> delta2
+  T* q;     // [32][33]  outputs -> delta3, columns >= O zero
+  T* qt;    // [32][4]   DQN: Q_target(s')
+  int* aux; // [64]      DQN: row of each sample; DDQN: argmax_a Q_online(s')
 };
 
 __host__ __device__ inline size_t fit_lds_elems() {
-  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + 2 * kH + kMaxO;
+  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kA + 64;
 }
 // forward only: the inputs sit where h2 will be written (read for the last time before that)
-__host__ __device__ inline size_t fwd_lds_elems() {
-  return 2 * (size_t)kB * kRow + 2 * kH + kMaxO;
-}
+__host__ __device__ inline size_t fwd_lds_elems() { return 2 * (size_t)kB * kRow; }
 
 template <typename T>
 __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
@@ -158,52 +182,52 @@ __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
   L.h2 = p; p += kB * kRow;
   L.x = p;  p += kB * kXRow;
   L.q = p;  p += kB * kXRow;
-  L.b1 = p; p += kH;
-  L.b2 = p; p += kH;
-  L.b3 = p;
-  return L;
-}
-template <typename T>
-__device__ __forceinline__ act_lds<T> carve_fwd(unsigned char* raw) {
-  act_lds<T> L;
-  T* p = reinterpret_cast<T*>(raw);
-  L.h1 = p; p += kB * kRow;
-  L.h2 = p; L.x = p; p += kB * kRow;
-  L.q = nullptr;
-  L.b1 = p; p += kH;
-  L.b2 = p; p += kH;
-  L.b3 = p;
+  L.qt = p; p += kB * kA;
+  L.aux = reinterpret_cast<int*>(p);
   return L;
 }
 
-// the 32 input rows of an instance — rows of a float64 table by index, or a dense [32][D] block —
-// into x [32][33], columns D .. 31 zero: every load of a thread before its first LDS write
+// the 32 input rows of an instance — rows of a float64 table by index, or rows slot[s] (NULL: s) of
+// a dense block — on their way into x [32][33], columns D .. 31 zero: `request` asks for all of a
+// thread's elements, `store` writes them to LDS (as late as the caller likes)
+template <typename T, int NT>
+struct input_rows {
+  static constexpr int U = kB * 32 / NT;
+  T r[U];
+  __device__ __forceinline__ void request(const double* table, const int32_t* index, const T* dense,
+                                          const int* slot, int D, int t) {
+    if (table) {
+      int row[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) row[u] = index[(t + NT * u) >> 5];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int d = (t + NT * u) & 31;
+        r[u] = d < D ? (T)table[(size_t)row[u] * D + d] : (T)0;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = t + NT * u, d = e & 31;
+        const int s = slot ? slot[e >> 5] : e >> 5;
+        r[u] = d < D ? dense[(size_t)s * D + d] : (T)0;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(T* x, int t) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = t + NT * u;
+      x[(e >> 5) * kXRow + (e & 31)] = r[u];
+    }
+  }
+};
 template <typename T, int NT>
 __device__ __forceinline__ void load_inputs(T* x, const double* table, const int32_t* index,
-                                            const T* dense, int D, int t) {
-  constexpr int U = kB * 32 / NT;
-  T r[U];
-  if (table) {
-    int row[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) row[u] = index[(t + NT * u) >> 5];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int d = (t + NT * u) & 31;
-      r[u] = d < D ? (T)table[(size_t)row[u] * D + d] : (T)0;
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = t + NT * u, d = e & 31;
-      r[u] = d < D ? dense[(e >> 5) * D + d] : (T)0;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int e = t + NT * u;
-    x[(e >> 5) * kXRow + (e & 31)] = r[u];
-  }
+                                            const T* dense, const int* slot, int D, int t) {
+  input_rows<T, NT> in;
+  in.request(table, index, dense, slot, D, t);
+  in.store(x, t);
 }
 
 template <typename T>
@@ -212,46 +236,44 @@ __device__ __forceinline__ typename mfma_acc<T>::type splat(T v) {
   return a;
 }
 
-// KS consecutive elements of a row of a 64-wide matrix (16-byte aligned: whole vector loads)
+// The weight operand of a forward product for the 16 outputs n0 .. of a layer, requested from
+// memory: lane (li, lq) takes W[n0 + li][lq KS .. lq KS + KS) (k >= kmax, n >= nmax: zero), and
+// the output's bias.  Requested at the START of a pass for all three layers — a layer's operand is
+// then in registers when the layer before it has finished, instead of one more trip to memory per
+// layer.  ALIGNED: rows of 64 elements, 16-byte aligned (whole vector loads).
 template <typename T, int KS>
-__device__ __forceinline__ void load_run(T (&b)[KS], const T* p, bool valid) {
-  const T* const q = reinterpret_cast<const T*>(__builtin_assume_aligned(p, 16));
-#pragma unroll
-  for (int s = 0; s < KS; ++s) b[s] = valid ? q[s] : (T)0;
-}
-
-// The weight operand of a forward product for the 16 outputs n0 .. of a layer, requested from memory:
-// lane (li, lq) takes W[n0 + li][lq KS .. lq KS + KS) (k >= kmax, n >= nmax: zero).  Requested at
-// the START of a pass for all three layers — a layer's operand is then in registers when the layer
-// before it has finished, instead of one more trip to memory per layer.
+struct weight_op {
+  T b[KS];
+  T bias;
+};
 template <typename T, int KS, bool ALIGNED>
-__device__ __forceinline__ void weight_rows(T (&b)[KS], const T* __restrict__ W, int ld, int kmax,
-                                            int nmax, int n0, int lane) {
+__device__ __forceinline__ weight_op<T, KS> weight_rows(const T* __restrict__ W,
+                                                        const T* __restrict__ bias, int ld, int kmax,
+                                                        int nmax, int n0, int lane) {
+  weight_op<T, KS> w;
   const int li = lane & 15, lq = lane >> 4;
   const bool valid = n0 + li < nmax;
-  const T* const wr = W + (uint32_t)((valid ? n0 + li : 0) * ld + lq * KS);
-  if (ALIGNED) {
-    load_run<T, KS>(b, wr, valid);
-  } else {
+  const T* wr = W + (uint32_t)((valid ? n0 + li : 0) * ld + lq * KS);
+  if (ALIGNED) wr = reinterpret_cast<const T*>(__builtin_assume_aligned(wr, 16));
 #pragma unroll
-    for (int s = 0; s < KS; ++s) b[s] = valid && lq * KS + s < kmax ? wr[s] : (T)0;
-  }
+  for (int s = 0; s < KS; ++s) w.b[s] = valid && (ALIGNED || lq * KS + s < kmax) ? wr[s] : (T)0;
+  w.bias = valid ? bias[n0 + li] : (T)0;
+  return w;
 }
 
 // One hidden layer for MT row tiles: out[m][n0 + li] = relu(bias + sum_k in[m][k] W[n0 + li][k]),
-// K = 4 KS, `in` with row stride IS, the weight operand b as above.
+// K = 4 KS, `in` with row stride IS.
 template <typename T, int KS, int MT>
-__device__ __forceinline__ void dense_relu(const T (&b)[KS], const T* in, int IS, const T* bias,
-                                           T* out, int m0, int n0, int lane) {
+__device__ __forceinline__ void dense_relu(const weight_op<T, KS>& w, const T* in, int IS, T* out,
+                                           int m0, int n0, int lane) {
   typedef typename mfma_acc<T>::type acc_t;
   const int li = lane & 15, lq = lane >> 4;
-  const T bv = bias[n0 + li];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    acc_t acc = splat<T>(bv);
+    acc_t acc = splat<T>(w.bias);
     const T* const ar = in + (m0 + 16 * i + li) * IS + lq * KS;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) acc = mfma(ar[s], b[s], acc);
+    for (int s = 0; s < KS; ++s) acc = mfma(ar[s], w.b[s], acc);
 #pragma unroll
     for (int v = 0; v < 4; ++v)
       out[(m0 + 16 * i + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] =
@@ -261,15 +283,14 @@ __device__ __forceinline__ void dense_relu(const T (&b)[KS], const T* in, int IS
 
 // The output layer's tile (rows m0 .., outputs n0 ..): q[m][n0 + li] = b3 + sum_k h2[m][k] W3[n][k]
 template <typename T>
-__device__ __forceinline__ typename mfma_acc<T>::type output_tile(const T (&b)[16], int O,
-                                                                  const T* h2, const T* b3, int m0,
-                                                                  int n0, int lane) {
+__device__ __forceinline__ typename mfma_acc<T>::type output_tile(const weight_op<T, 16>& w,
+                                                                  const T* h2, int m0, int lane) {
   typedef typename mfma_acc<T>::type acc_t;
   const int li = lane & 15, lq = lane >> 4;
-  acc_t acc = splat<T>(n0 + li < O ? b3[n0 + li] : (T)0);
+  acc_t acc = splat<T>(w.bias);
   const T* const ar = h2 + (m0 + li) * kRow + lq * 16;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) acc = mfma(ar[s], b[s], acc);
+  for (int s = 0; s < 16; ++s) acc = mfma(ar[s], w.b[s], acc);
   return acc;
 }
 
@@ -283,32 +304,34 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
   const int D = R.n_inputs, O = R.n_outputs;
   if (R.active && !R.active[j / R.act_div]) return;
-  const act_lds<T> L = carve_fwd<T>(lds_raw);
+  T* const h1 = reinterpret_cast<T*>(lds_raw);   // [32][66]
+  T* const h2 = h1 + kB * kRow;                  // [32][66]; before that the inputs x [32][33]
+  T* const x = h2;
   const int lane = t & 63, wave = t >> 6;
   const size_t net = (size_t)(j / R.net_div);
   const T* const w1 = (const T*)R.w[0] + net * (size_t)kH * D;
   const T* const w2 = (const T*)R.w[1] + net * (size_t)kH * kH;
   const T* const w3 = (const T*)R.w[2] + net * (size_t)O * kH;
   const int m3 = 16 * (wave >> 1), n3 = 16 * (wave & 1);
-  T bw1[8], bw2[16], bw3[16];
-  weight_rows<T, 8, false>(bw1, w1, D, D, kH, 16 * wave, lane);
-  weight_rows<T, 16, true>(bw2, w2, kH, kH, kH, 16 * wave, lane);
-  weight_rows<T, 16, true>(bw3, w3, kH, kH, O, n3, lane);
-  load_inputs<T, 256>(L.x, R.in_table,
+  const weight_op<T, 8> o1 =
+      weight_rows<T, 8, false>(w1, (const T*)R.b[0] + net * kH, D, D, kH, 16 * wave, lane);
+  const weight_op<T, 16> o2 =
+      weight_rows<T, 16, true>(w2, (const T*)R.b[1] + net * kH, kH, kH, kH, 16 * wave, lane);
+  load_inputs<T, 256>(x, R.in_table,
                       R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
-                      R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
-  if (t < kH) {
-    L.b1[t] = ((const T*)R.b[0] + net * kH)[t];
-    L.b2[t] = ((const T*)R.b[1] + net * kH)[t];
-  }
-  if (t < kMaxO) L.b3[t] = t < O ? ((const T*)R.b[2] + net * O)[t] : (T)0;
+                      R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, nullptr, D,
+                      t);
   lds_barrier();
-  dense_relu<T, 8, 2>(bw1, L.x, kXRow, L.b1, L.h1, 0, 16 * wave, lane);
+  dense_relu<T, 8, 2>(o1, x, kXRow, h1, 0, 16 * wave, lane);
+  // (the output layer's operand once the first layer's registers are free: four workgroups per CU)
+  __builtin_amdgcn_sched_barrier(0);
+  const weight_op<T, 16> o3 =
+      weight_rows<T, 16, true>(w3, (const T*)R.b[2] + net * O, kH, kH, O, n3, lane);
   lds_barrier();   // (every read of x is done: h2 takes its place)
-  dense_relu<T, 16, 2>(bw2, L.h1, kRow, L.b2, L.h2, 0, 16 * wave, lane);
+  dense_relu<T, 16, 2>(o2, h1, kRow, h2, 0, 16 * wave, lane);
   lds_barrier();
   if (n3 < O) {
-    const typename mfma_acc<T>::type acc = output_tile<T>(bw3, O, L.h2, L.b3, m3, n3, lane);
+    const typename mfma_acc<T>::type acc = output_tile<T>(o3, h2, m3, lane);
     T* const out = (T*)R.out + (size_t)j * kB * O;
     const int a = n3 + (lane & 15);
     if (a < O) {
@@ -324,9 +347,46 @@ __global__ __launch_bounds__(256) void k_mlp_forward(const fwd_args A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A forward pass of the eight-wave workgroup over the rows in L.x (all 32, or — ONE_TILE — the
+// first 16 by waves 0 .. 3), in two parts: `request` asks memory for the weight operands (ahead of
+// whatever fills L.x), `run` returns the output tile of the waves that own one (waves 0 .. 3: rows
+// 16 (w / 2) .., outputs 16 (w % 2) ..) and starts with a barrier (the rows are in LDS).
+template <typename T, bool ONE_TILE>
+struct forward_pass {
+  weight_op<T, 8> o1;
+  weight_op<T, 16> o2, o3;
+  bool hidden, has_out;
+  int m0, n0, r3;
+  __device__ __forceinline__ void request(const T* w1, const T* b1, const T* w2, const T* b2,
+                                          const T* w3, const T* b3, int D, int O, int wave,
+                                          int lane) {
+    m0 = 16 * (wave >> 2);
+    n0 = 16 * (wave & 3);
+    r3 = 16 * ((wave >> 1) & 1);
+    const int a3 = 16 * (wave & 1);
+    hidden = !ONE_TILE || wave < 4;
+    has_out = wave < 4 && a3 < O && (!ONE_TILE || r3 == 0);
+    if (hidden) {
+      o1 = weight_rows<T, 8, false>(w1, b1, D, D, kH, n0, lane);
+      o2 = weight_rows<T, 16, true>(w2, b2, kH, kH, kH, n0, lane);
+    }
+    o3 = weight_rows<T, 16, true>(w3, b3, kH, kH, has_out ? O : 0, a3, lane);
+  }
+  __device__ __forceinline__ typename mfma_acc<T>::type run(const act_lds<T>& L, int lane) {
+    lds_barrier();
+    if (hidden) dense_relu<T, 8, 1>(o1, L.x, kXRow, L.h1, m0, n0, lane);
+    lds_barrier();
+    if (hidden) dense_relu<T, 16, 1>(o2, L.h1, kRow, L.h2, m0, n0, lane);
+    lds_barrier();
+    typename mfma_acc<T>::type acc = splat<T>((T)0);
+    if (has_out) acc = output_tile<T>(o3, L.h2, r3, lane);
+    return acc;
+  }
+};
+
 // One optimisation step: eight waves per network.  Wave w owns the tile (rows 16 (w / 4) ..,
 // columns 16 (w % 4) ..) of every rows x 64 product and one or two tiles of every gradient.
-template <typename T>
+template <typename T, bool DQN>
 __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   constexpr int NT = kFitThreads;
   typedef typename mfma_acc<T>::type acc_t;
@@ -334,11 +394,15 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   const cobel_mlp_fit_t& R = A.r;
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
   if (R.active && !R.active[j / R.act_div]) return;
-  const int D = R.n_inputs, O = R.n_outputs;
+  const int D = R.n_inputs, O = DQN ? kA : R.n_outputs;
   const act_lds<T> L = carve_fit<T>(lds_raw);
   const int lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
   const int m0 = 16 * (wave >> 2), n0 = 16 * (wave & 3);
-  const bool train = !R.train || R.train[j];
+  auto stamp = [&](int k) {
+    if (A.trace && t == 0) A.trace[(size_t)j * 16 + k] = wall_clock64();
+  };
+  stamp(0);
+  const bool train = DQN || !R.train || R.train[j];
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)O * kH;
   T* const w1 = (T*)R.w[0] + (size_t)j * n1;
   T* const b1 = (T*)R.b[0] + (size_t)j * kH;
@@ -346,20 +410,18 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   T* const b2 = (T*)R.b[1] + (size_t)j * kH;
   T* const w3 = (T*)R.w[2] + (size_t)j * n3;
   T* const b3 = (T*)R.b[2] + (size_t)j * O;
-  const bool blend = R.tau != 0.0 && R.w_target[0] != nullptr;
-  // (without a blend the target pointers alias the parameters: loads stay unconditional)
-  T* const tw1 = blend ? (T*)R.w_target[0] + (size_t)j * n1 : w1;
-  T* const tb1 = blend ? (T*)R.b_target[0] + (size_t)j * kH : b1;
-  T* const tw2 = blend ? (T*)R.w_target[1] + (size_t)j * n2 : w2;
-  T* const tb2 = blend ? (T*)R.b_target[1] + (size_t)j * kH : b2;
-  T* const tw3 = blend ? (T*)R.w_target[2] + (size_t)j * n3 : w3;
-  T* const tb3 = blend ? (T*)R.b_target[2] + (size_t)j * O : b3;
+  const bool has_target = R.w_target[0] != nullptr;
+  const bool blend = R.tau != 0.0 && has_target;
+  // (without a target network the pointers alias the parameters: loads stay unconditional)
+  T* const tw1 = has_target ? (T*)R.w_target[0] + (size_t)j * n1 : w1;
+  T* const tb1 = has_target ? (T*)R.b_target[0] + (size_t)j * kH : b1;
+  T* const tw2 = has_target ? (T*)R.w_target[1] + (size_t)j * n2 : w2;
+  T* const tb2 = has_target ? (T*)R.b_target[1] + (size_t)j * kH : b2;
+  T* const tw3 = has_target ? (T*)R.w_target[2] + (size_t)j * n3 : w3;
+  T* const tb3 = has_target ? (T*)R.b_target[2] + (size_t)j * O : b3;
 
-  if (t < kH) {
-    L.b1[t] = b1[t];
-    L.b2[t] = b2[t];
-  }
-  if (t < kMaxO) L.b3[t] = t < O ? b3[t] : (T)0;
+  // (the extra row's number: a scalar, fetched long before the row is)
+  const int ep_row = R.ep_out && R.ep_rows > 0 && R.ep_table ? R.ep_index[j / R.ep_div] : 0;
 
   if (!train) {
     // No samples for this network in this step: parameters and optimizer state stay as they are;
@@ -386,41 +448,102 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     // waves 0 .. 3 also own an output tile: rows r3 .., outputs a3 ..
     const int r3 = 16 * ((wave >> 1) & 1), a3 = 16 * (wave & 1);
     const bool has_out = wave < 4 && a3 < O;
-    T fw1[8], fw2[16], fw3[16];
-    weight_rows<T, 8, false>(fw1, w1, D, D, kH, n0, lane);
-    weight_rows<T, 16, true>(fw2, w2, kH, kH, kH, n0, lane);
-    weight_rows<T, 16, true>(fw3, w3, kH, kH, has_out ? O : 0, a3, lane);
-    load_inputs<T, NT>(L.x, R.in_table,
-                       R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
-                       R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, D, t);
+    const int rows = DQN ? A.rows : kB;
+    const int* const slot = DQN ? L.aux : nullptr;
+    const int32_t* const in_index =
+        R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr;
+    const T* const in_dense =
+        R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * rows * D;
     for (int e = t; e < kB * kXRow; e += NT) L.q[e] = (T)0;
+    input_rows<T, NT> xin;
+
+    if (DQN) {
+      // ---- Q_target(s') [and the online network's choice among the next actions] ---------------
+      forward_pass<T, false> tp;
+      tp.request(tw1, tb1, tw2, tb2, tw3, tb3, D, O, wave, lane);
+      if (t < kB) L.aux[t] = A.slots ? A.slots[(size_t)j * kB + t] : t;
+      lds_barrier();
+      load_inputs<T, NT>(L.x, R.in_table, R.in_table ? A.next_index + (size_t)j * kB : nullptr,
+                         R.in_table ? nullptr : (const T*)A.next_dense + (size_t)j * rows * D, slot,
+                         D, t);
+      xin.request(R.in_table, in_index, in_dense, slot, D, t);   // (for the pass after this one)
+      {
+        const acc_t acc = tp.run(L, lane);
+        if (has_out && li < kA) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) L.qt[(r3 + mfma_acc<T>::row(lane, v)) * kA + li] = acc[v];
+        }
+      }
+      stamp(1);
+      if (R.debug_stage == 5) return;
+      if (A.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
+        forward_pass<T, false> op;
+        op.request(w1, b1, w2, b2, w3, b3, D, O, wave, lane);
+        const acc_t acc = op.run(L, lane);
+        if (has_out && li < kA) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) L.q[(r3 + mfma_acc<T>::row(lane, v)) * kXRow + li] = acc[v];
+        }
+        lds_barrier();
+        if (t < kB) {
+          int best = 0;
+          T bv = L.q[t * kXRow];
+#pragma unroll
+          for (int a = 1; a < kA; ++a)
+            if (L.q[t * kXRow + a] > bv) {   // first maximum, as torch.argmax
+              bv = L.q[t * kXRow + a];
+              best = a;
+            }
+          L.aux[kB + t] = best;
+        }
+      }
+    }
+
+    weight_op<T, 8> o1 = weight_rows<T, 8, false>(w1, b1, D, D, kH, n0, lane);
+    weight_op<T, 16> o2 = weight_rows<T, 16, true>(w2, b2, kH, kH, kH, n0, lane);
+    weight_op<T, 16> o3 = weight_rows<T, 16, true>(w3, b3, kH, kH, has_out ? O : 0, a3, lane);
+    if (!DQN) xin.request(R.in_table, in_index, in_dense, slot, D, t);
+    xin.store(L.x, t);
     lds_barrier();
+    stamp(2);
 
     // ---- forward --------------------------------------------------------------------------------
-    dense_relu<T, 8, 1>(fw1, L.x, kXRow, L.b1, L.h1, m0, n0, lane);
+    dense_relu<T, 8, 1>(o1, L.x, kXRow, L.h1, m0, n0, lane);
     lds_barrier();
-    dense_relu<T, 16, 1>(fw2, L.h1, kRow, L.b2, L.h2, m0, n0, lane);
-    // Requested here, a barrier and a product ahead of their use: the targets and the mask of the
-    // output tile, the weights behind delta2 (the column block W3[.][n0 ..], lane (li, lq) takes the
-    // outputs a = 8 lq ..) and the optimizer state of this wave's output-layer gradient tile dW3[a][k]
+    dense_relu<T, 16, 1>(o2, L.h1, kRow, L.h2, m0, n0, lane);
+    // Requested here, a barrier and a product ahead of their use: the targets of the output tile
+    // (the mask and the targets, or the action, reward and terminal flag of the sample), the
+    // weights behind delta2 (the column block W3[.][n0 ..], lane (li, lq) takes the outputs
+    // a = 8 lq ..) and the optimizer state of this wave's output-layer gradient tile dW3[a][k]
     // (outputs g0 = 16 (w / 4) .., neurons n0 ..).
     __builtin_amdgcn_sched_barrier(0);
-    const uint8_t* const mask = R.sample_mask ? R.sample_mask + (size_t)j * kB : nullptr;
-    T yv[4];
+    T yv[4], ntv[4];
     bool on[4];
+    int actv[4];
     int count = kB;
     if (has_out) {
-      const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
+      if (DQN) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int s = r3 + mfma_acc<T>::row(lane, v);
-        yv[v] = a3 + li < O ? y[s * O + a3 + li] : (T)0;
-        on[v] = !mask || mask[s];
-      }
-      if (mask) {
-        const bool mine = mask[lane & 31] != 0;
-        count = __popcll(__ballot(mine && lane < kB));
-        count = count > 0 ? count : 1;
+        for (int v = 0; v < 4; ++v) {
+          const size_t row = (size_t)j * rows + L.aux[r3 + mfma_acc<T>::row(lane, v)];
+          actv[v] = (int)A.actions[row];
+          yv[v] = ((const T*)A.rewards)[row];
+          ntv[v] = ((const T*)A.nonterminal)[row];
+        }
+      } else {
+        const uint8_t* const mask = R.sample_mask ? R.sample_mask + (size_t)j * kB : nullptr;
+        const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int s = r3 + mfma_acc<T>::row(lane, v);
+          yv[v] = a3 + li < O ? y[s * O + a3 + li] : (T)0;
+          on[v] = !mask || mask[s];
+        }
+        if (mask) {
+          const bool mine = mask[lane & 31] != 0;
+          count = __popcll(__ballot(mine && lane < kB));
+          count = count > 0 ? count : 1;
+        }
       }
     }
     const int g0 = 16 * (wave >> 2);
@@ -438,26 +561,49 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       s3[v] = slot_load<T>(w3, m_w3, v_w3, tw3, (uint32_t)(a * kH + n0 + li), blend, a < O);
     }
     lds_barrier();
-    // output tiles and the loss gradient: mean over the marked samples and the O outputs of
-    // (out - target)^2: 2 (out - y) / (count O)
+    // output tiles and the loss gradient delta3
     if (has_out) {
-      const T scale = (T)1 / (T)(count * O);
-      const acc_t acc = output_tile<T>(fw3, O, L.h2, L.b3, r3, a3, lane);
+      const acc_t acc = output_tile<T>(o3, L.h2, r3, lane);
       if (a3 + li < O) {
+        if (DQN) {
+          // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the
+          // 32 x 4 outputs of (Q - targets)^2 with targets == Q except at the action taken, so the
+          // gradient is 2 (Q[s][a] - new[s]) / 128 there and zero elsewhere
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int s = r3 + mfma_acc<T>::row(lane, v);
-          const T d = acc[v] - yv[v];
-          L.q[s * kXRow + a3 + li] = on[v] ? ((T)2 * d) * scale : (T)0;   // delta3
+          for (int v = 0; v < 4; ++v) {
+            const int s = r3 + mfma_acc<T>::row(lane, v);
+            T boot;
+            if (A.ddqn) {
+              boot = L.qt[s * kA + L.aux[kB + s]];
+            } else {
+              boot = L.qt[s * kA];
+#pragma unroll
+              for (int a = 1; a < kA; ++a) boot = L.qt[s * kA + a] > boot ? L.qt[s * kA + a] : boot;
+            }
+            const T target = yv[v] + (boot * ntv[v]) * (T)A.gamma;
+            const T d = acc[v] - target;
+            const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
+            L.q[s * kXRow + li] = li == actv[v] ? g : (T)0;
+          }
+        } else {
+          // mean over the marked samples and the O outputs of (out - target)^2
+          const T scale = (T)1 / (T)(count * O);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int s = r3 + mfma_acc<T>::row(lane, v);
+            const T d = acc[v] - yv[v];
+            L.q[s * kXRow + a3 + li] = on[v] ? ((T)2 * d) * scale : (T)0;
+          }
         }
       }
     }
+    stamp(3);
     if (R.debug_stage == 1) return;
 
     // ---- Adam constants of this network (its own step count) ------------------------------------
     adam_consts<T> c;
     {
-      const double st = R.steps[j] + 1.0;
+      const double st = A.steps_given ? R.steps[j] : R.steps[j] + 1.0;
       const T bc1 = (T)(1.0 - pow(R.beta1, st));
       c.bc2_sqrt = (T)sqrt(1.0 - pow(R.beta2, st));
       c.step_size = (T)R.lr / bc1;
@@ -515,9 +661,10 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       }
       if (t < O) {
         const adam_slot<T> sb = slot_load<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, blend, true);
-        L.b3[t] = adam_apply<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, gb, sb, c);
+        adam_apply<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, gb, sb, c);
       }
     }
+    stamp(4);
     if (R.debug_stage == 2) return;
 
     // ---- second layer: delta1 tile and two gradient tiles dW2[j][k] (rows n0 .., columns
@@ -579,17 +726,25 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       for (int v = 0; v < 4; ++v)
         s1[v] = slot_load<T>(w1, m_w1, v_w1, tw1,
                              (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * D + d), blend,
-                             d0 < D && d < D);
+                             d0 < D && d < D, false);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         adam_apply<T>(w2, m_w2, v_w2, tw2,
                       (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + 16 + li), g2[1][v],
                       s2b[v], c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (d0 < D && d < D) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          s1[v].target = __builtin_nontemporal_load(
+              tw1 + (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * D + d));
+      }
       if (t < kH) {
         const adam_slot<T> sb = slot_load<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, blend, true);
-        L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, gb, sb, c);
+        adam_apply<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, gb, sb, c);
       }
+      stamp(5);
       if (R.debug_stage == 3 || R.debug_stage == 4) return;
       lds_barrier();
 
@@ -612,57 +767,55 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         T gb1 = (T)0;
         for (int s = 0; s < kB; ++s) gb1 = gb1 + L.h1[s * kRow + t];
         const adam_slot<T> sb = slot_load<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, blend, true);
-        L.b1[t] = adam_apply<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, gb1, sb, c);
+        adam_apply<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, gb1, sb, c);
       }
     }
-    if (t == 0) R.steps[j] = R.steps[j] + 1.0;
+    if (t == 0 && !A.steps_given) R.steps[j] = R.steps[j] + 1.0;
   }
+  stamp(6);
 
   // ---- outputs of the (updated) network for the extra rows -------------------------------------
+  // (cobel_dqn_replay: the Q-values of the next observation, what the next action selection needs:
+  //  agent/dqn.py:174 -> retrieve_q)
   if (R.ep_out && R.ep_rows > 0) {
     __syncthreads();   // the new parameters are in memory; x / h1 / h2 are free
+    forward_pass<T, true> ep;
+    ep.request(w1, b1, w2, b2, w3, b3, D, O, wave, lane);
     const int E = R.ep_rows;
     if (t < kMaxEp * 32) {
       const int r = t >> 5, d = t & 31;
       T v = (T)0;
       if (r < E && d < D)
-        v = R.ep_table ? (T)R.ep_table[(size_t)R.ep_index[j / R.ep_div] * D + d]
+        v = R.ep_table ? (T)R.ep_table[(size_t)ep_row * D + d]
                        : ((const T*)R.ep_dense)[((size_t)j * E + r) * D + d];
       L.x[r * kXRow + d] = v;
     }
-    // one row tile (rows >= E of it are not looked at): waves 0 .. 3, all operands requested at once
-    if (wave < 4) {
-      T fw1[8], fw2[16], fw3[16];
-      weight_rows<T, 8, false>(fw1, w1, D, D, kH, n0, lane);
-      weight_rows<T, 16, true>(fw2, w2, kH, kH, kH, n0, lane);
-      weight_rows<T, 16, true>(fw3, w3, kH, kH, wave < 2 ? O : 0, 16 * wave, lane);
-      lds_barrier();
-      dense_relu<T, 8, 1>(fw1, L.x, kXRow, L.b1, L.h1, 0, n0, lane);
-      lds_barrier();
-      dense_relu<T, 16, 1>(fw2, L.h1, kRow, L.b2, L.h2, 0, n0, lane);
-      lds_barrier();
-      if (wave < 2 && 16 * wave < O) {
-        const acc_t acc = output_tile<T>(fw3, O, L.h2, L.b3, 0, 16 * wave, lane);
-        const int a = 16 * wave + li;
-        if (a < O) {
+    // one row tile (rows >= E of it are not looked at)
+    stamp(7);
+    const acc_t acc = ep.run(L, lane);
+    stamp(8);
+    if (wave < 2 && 16 * wave < O) {
+      const int a = 16 * wave + li;
+      if (a < O) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int r = mfma_acc<T>::row(lane, v);
-            if (r < E) ((T*)R.ep_out)[((size_t)j * E + r) * O + a] = acc[v];
-          }
+        for (int v = 0; v < 4; ++v) {
+          const int r = mfma_acc<T>::row(lane, v);
+          if (r < E) ((T*)R.ep_out)[((size_t)j * E + r) * O + a] = acc[v];
         }
       }
-    } else {   // (the barriers count every wave of the workgroup)
-      lds_barrier();
-      lds_barrier();
-      lds_barrier();
     }
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mlp_fit(const fit_args A) {
-  mlp_fit_body<T>(A);
+__global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_mlp_fit(const fit_args A) {
+  mlp_fit_body<T, false>(A);
+}
+template <typename T>
+__global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_dqn_replay(const fit_args A) {
+  mlp_fit_body<T, true>(A);
 }
 
 int shape_ok(int32_t D, int32_t O, const char* who) {
@@ -745,7 +898,11 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
                 "cobel_mlp_fit: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
   fit_args A;
+  memset(&A, 0, sizeof A);
   A.r = r;
+  A.rows = kB;
+  if (const char* v = getenv("COBEL_DEBUG_MLP_TRACE"))
+    A.trace = reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0));
   hipStream_t st = (hipStream_t)stream;
   lds += cobel_debug_lds_pad(lds, 160 * 1024);   // (occupancy experiments only)
   if (r.is_float64) {
@@ -754,6 +911,111 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   } else {
     hipLaunchKernelGGL(k_mlp_fit<float>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   }
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
+extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
+                                      int32_t n_actions, int32_t batch, int32_t is_float64,
+                                      int32_t* lds_bytes) {
+  COBEL_REQUIRE(n_inputs >= 1 && n_inputs <= kMaxD && n_hidden1 == kH && n_hidden2 == kH &&
+                    n_actions == kA && batch == kB,
+                COBEL_E_UNSUPPORTED,
+                "cobel_dqn_replay: the fused step covers Linear(D <= %d, 64)-ReLU-Linear(64, 64)-"
+                "ReLU-Linear(64, 4) on batches of 32 (got D %d, %d-%d, %d actions, batch %d)",
+                kMaxD, n_inputs, n_hidden1, n_hidden2, n_actions, batch);
+  if (lds_bytes) *lds_bytes = (int32_t)(fit_lds_elems() * (is_float64 ? 8 : 4));
+  return COBEL_OK;
+}
+
+extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
+  COBEL_REQUIRE(run, COBEL_E_ARG, "cobel_dqn_replay: NULL run");
+  const cobel_dqn_replay_t& r = *run;
+  int32_t lds = 0;
+  if (int rc = cobel_dqn_replay_query(r.n_inputs, r.n_hidden1, r.n_hidden2, r.n_actions, r.batch,
+                                      r.is_float64, &lds))
+    return rc;
+  for (int l = 0; l < 3; ++l)
+    COBEL_REQUIRE(r.w[l] && r.b[l] && r.w_target[l] && r.b_target[l] && r.m_w[l] && r.m_b[l] &&
+                      r.v_w[l] && r.v_b[l],
+                  COBEL_E_ARG, "cobel_dqn_replay: NULL parameter / moment tensor (layer %d)", l);
+  COBEL_REQUIRE(r.actions && r.rewards && r.nonterminal && r.steps, COBEL_E_ARG,
+                "cobel_dqn_replay: NULL batch tensor or step counts");
+  COBEL_REQUIRE(r.state_index ? (r.next_index && r.obs_table && !r.batch_slots)
+                              : (r.states && r.next_states),
+                COBEL_E_ARG, "cobel_dqn_replay: the batch's observations are missing (states + "
+                "next_states, or state_index + next_index + obs_table without batch_slots)");
+  COBEL_REQUIRE(r.n >= 0, COBEL_E_RANGE, "cobel_dqn_replay: n = %d", r.n);
+  COBEL_REQUIRE(!r.batch_slots || r.ring_slots > 0, COBEL_E_RANGE,
+                "cobel_dqn_replay: batch_slots given with ring_slots = %d", r.ring_slots);
+  COBEL_REQUIRE(!r.q_out || (r.obs_index && r.obs_table), COBEL_E_ARG,
+                "cobel_dqn_replay: q_out needs obs_index and obs_table");
+  COBEL_REQUIRE((((uintptr_t)r.w[1] | (uintptr_t)r.w[2] | (uintptr_t)r.w_target[1] |
+                  (uintptr_t)r.w_target[2]) & 15u) == 0,
+                COBEL_E_ARG, "cobel_dqn_replay: the 64-wide weight matrices must be 16-byte aligned");
+  if (r.n == 0) return COBEL_OK;
+  // the optimisation step of cobel_mlp_fit towards the Q-learning targets
+  fit_args A;
+  memset(&A, 0, sizeof A);
+  cobel_mlp_fit_t& f = A.r;
+  for (int l = 0; l < 3; ++l) {
+    f.w[l] = r.w[l];
+    f.b[l] = r.b[l];
+    f.w_target[l] = r.w_target[l];
+    f.b_target[l] = r.b_target[l];
+    f.m_w[l] = r.m_w[l];
+    f.m_b[l] = r.m_b[l];
+    f.v_w[l] = r.v_w[l];
+    f.v_b[l] = r.v_b[l];
+  }
+  f.steps = const_cast<double*>(r.steps);
+  f.active = r.active;
+  if (r.state_index) {
+    f.in_table = r.obs_table;
+    f.in_index = r.state_index;
+    A.next_index = r.next_index;
+  } else {
+    f.in_dense = r.states;
+    A.next_dense = r.next_states;
+  }
+  if (r.q_out) {
+    f.ep_table = r.obs_table;
+    f.ep_index = r.obs_index;
+    f.ep_rows = 1;
+    f.ep_out = r.q_out;
+  }
+  f.n = r.n;
+  f.n_inputs = r.n_inputs;
+  f.n_outputs = kA;
+  f.is_float64 = r.is_float64;
+  f.in_div = f.tgt_div = f.act_div = f.ep_div = 1;
+  f.lr = r.lr;
+  f.beta1 = r.beta1;
+  f.beta2 = r.beta2;
+  f.eps = r.eps;
+  f.weight_decay = r.weight_decay;
+  f.tau = r.tau;
+  A.dqn = 1;
+  A.ddqn = r.ddqn;
+  A.rows = r.batch_slots ? r.ring_slots : kB;
+  A.steps_given = 1;
+  A.slots = r.batch_slots;
+  A.actions = r.actions;
+  A.rewards = r.rewards;
+  A.nonterminal = r.nonterminal;
+  A.gamma = r.gamma;
+  hipStream_t st = (hipStream_t)stream;
+  if (const char* v = getenv("COBEL_DEBUG_MLP_STAGE")) f.debug_stage = atoi(v);   // (phase timings)
+  if (const char* v = getenv("COBEL_DEBUG_MLP_TRACE"))
+    A.trace = reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0));
+  lds += cobel_debug_lds_pad(lds, 160 * 1024);                                    // (occupancy)
+  if (lds > 64 * 1024) {
+    if (int rc = raise_lds(r.is_float64 ? reinterpret_cast<const void*>(&k_dqn_replay<double>)
+                                        : reinterpret_cast<const void*>(&k_dqn_replay<float>), lds))
+      return rc;
+  }
+  if (r.is_float64) hipLaunchKernelGGL(k_dqn_replay<double>, dim3(r.n), dim3(kFitThreads), lds, st, A);
+  else hipLaunchKernelGGL(k_dqn_replay<float>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
