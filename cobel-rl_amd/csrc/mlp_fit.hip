@@ -915,6 +915,18 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   return COBEL_OK;
 }
 
+// Two forms of the DQN step.  The parameter-staging kernel (mlp.hip: four waves, parameters in LDS)
+// has the shorter dependent chain per instance when several of its workgroups share a CU — at
+// least two fit: always in float32, up to 7 inputs in float64 — and is used there (C5: 6 inputs);
+// beyond that it is alone on its CU and the streaming form (k_dqn_replay here: 52 KB whatever the
+// inputs, two workgroups of eight waves per CU) wins: Dyna-DQN's 25 one-hot inputs in float64,
+// 1.34 -> 1.0 ms per step of 8 192 instances.  COBEL_DEBUG_DQN_KERNEL = lds | stream pins one
+// (experiments, tests).
+static bool dqn_staged(int32_t n_inputs, int32_t is_float64) {
+  if (const char* v = getenv("COBEL_DEBUG_DQN_KERNEL")) return v[0] == 'l';
+  return 2 * cobel_dqn_replay_lds_bytes(n_inputs, is_float64) <= 160 * 1024;
+}
+
 extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
                                       int32_t n_actions, int32_t batch, int32_t is_float64,
                                       int32_t* lds_bytes) {
@@ -924,7 +936,10 @@ extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32
                 "cobel_dqn_replay: the fused step covers Linear(D <= %d, 64)-ReLU-Linear(64, 64)-"
                 "ReLU-Linear(64, 4) on batches of 32 (got D %d, %d-%d, %d actions, batch %d)",
                 kMaxD, n_inputs, n_hidden1, n_hidden2, n_actions, batch);
-  if (lds_bytes) *lds_bytes = (int32_t)(fit_lds_elems() * (is_float64 ? 8 : 4));
+  if (lds_bytes)
+    *lds_bytes = dqn_staged(n_inputs, is_float64)
+                     ? (int32_t)cobel_dqn_replay_lds_bytes(n_inputs, is_float64)
+                     : (int32_t)(fit_lds_elems() * (is_float64 ? 8 : 4));
   return COBEL_OK;
 }
 
@@ -954,6 +969,8 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
                   (uintptr_t)r.w_target[2]) & 15u) == 0,
                 COBEL_E_ARG, "cobel_dqn_replay: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dqn_staged(r.n_inputs, r.is_float64)) return cobel_dqn_replay_lds_launch(r, st);
   // the optimisation step of cobel_mlp_fit towards the Q-learning targets
   fit_args A;
   memset(&A, 0, sizeof A);
@@ -1004,7 +1021,6 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   A.rewards = r.rewards;
   A.nonterminal = r.nonterminal;
   A.gamma = r.gamma;
-  hipStream_t st = (hipStream_t)stream;
   if (const char* v = getenv("COBEL_DEBUG_MLP_STAGE")) f.debug_stage = atoi(v);   // (phase timings)
   if (const char* v = getenv("COBEL_DEBUG_MLP_TRACE"))
     A.trace = reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0));

@@ -26,12 +26,13 @@ def main() -> int:
     for n_in in range(1, 33):
         for dtype_name in ('f64', 'f32'):
             ddqn = bool((n_in + (dtype_name == 'f32')) % 2)
-            try:
-                test_gpu_parity.test_fused_dqn_replay_equals_torch_path(torch, dtype_name, n_in, ddqn,
-                                                                        f32_atol=1e-4)
-            except AssertionError as e:
-                failed.append(('dqn_replay', n_in, dtype_name, ddqn, str(e)[:200]))
-                print('MISMATCH', failed[-1], flush=True)
+            for kernel in ('lds', 'stream'):   # both forms of the step, whichever the library picks
+                try:
+                    test_gpu_parity.test_fused_dqn_replay_equals_torch_path(
+                        torch, dtype_name, n_in, ddqn, kernel, f32_atol=1e-4)
+                except AssertionError as e:
+                    failed.append(('dqn_replay', kernel, n_in, dtype_name, ddqn, str(e)[:200]))
+                    print('MISMATCH', failed[-1], flush=True)
     print('dqn_replay sweep done, failing %d' % len(failed), flush=True)
     r = np.random.default_rng(5)
     shapes = {(1, 1), (32, 32), (1, 32), (32, 1)}

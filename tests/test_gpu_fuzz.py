@@ -93,8 +93,9 @@ def test_network_kernels_over_input_and_output_widths():
     import test_gpu_parity
     for n_in, dtype_name, ddqn in ((2, 'f64', True), (13, 'f64', False), (17, 'f32', True),
                                    (31, 'f64', True), (32, 'f64', False), (12, 'f32', True)):
-        test_gpu_parity.test_fused_dqn_replay_equals_torch_path(torch, dtype_name, n_in, ddqn,
-                                                                f32_atol=1e-4)
+        for kernel in (None, 'stream'):
+            test_gpu_parity.test_fused_dqn_replay_equals_torch_path(torch, dtype_name, n_in, ddqn,
+                                                                    kernel, f32_atol=1e-4)
     for D, O, dtype_name in ((1, 1, 'f64'), (1, 32, 'f64'), (32, 1, 'f64'), (7, 29, 'f64'),
                              (31, 18, 'f32'), (19, 5, 'f64'), (30, 31, 'f64')):
         test_gpu_mlp.test_mlp_forward_and_fit_match_pytorch(torch, D, O, dtype_name, f32_atol=1e-4)

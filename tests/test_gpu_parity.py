@@ -5,6 +5,7 @@ Bar: bit-exact for states / actions / rewards / terminals / step counts and for 
 against the reference run with float32 tables; <= 1e-6 against the float64 reference for as long
 as the two trajectories coincide (an exact-equality tie in float32 that is not a tie in float64
 legitimately forks them — SURVEY.md §8c)."""
+import os
 import numpy as np
 import pytest
 
@@ -1600,13 +1601,25 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
 
 # ---------------------------------------------------------------------------------------------
 # Fused DQN replay step (cobel_dqn_replay) against the PyTorch path it replaces
-@pytest.mark.parametrize('dtype_name,n_in,ddqn', [('f64', 6, False), ('f64', 25, True),
-                                                  ('f32', 6, False), ('f64', 1, False)])
-def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, f32_atol=1e-6):
+@pytest.mark.parametrize('dtype_name,n_in,ddqn,kernel', [
+    ('f64', 6, False, None), ('f64', 25, True, None), ('f32', 6, False, None), ('f64', 1, False, None),
+    ('f64', 6, True, 'stream'), ('f32', 25, False, 'stream'), ('f64', 25, True, 'lds'),
+    ('f64', 32, False, 'stream')])
+def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, kernel,
+                                            f32_atol=1e-6):
     """targets -> MSE backward -> Adam -> target blend in one kernel == the same step through
     vmap'ed forward passes, autograd and the optimizer kernel: online and target parameters and
     both Adam moments after every one of 10 steps fed with the same batches (duplicated samples,
-    terminal transitions, an activity mask that changes from step to step, weight decay)."""
+    terminal transitions, an activity mask that changes from step to step, weight decay).
+    kernel: the form of the step cobel_dqn_replay picks by itself (None), or one of the two pinned
+    (COBEL_DEBUG_DQN_KERNEL: parameters staged in LDS / weight operands streamed from memory)."""
+    if kernel:
+        os.environ['COBEL_DEBUG_DQN_KERNEL'] = kernel
+        try:
+            return test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, None,
+                                                           f32_atol)
+        finally:
+            del os.environ['COBEL_DEBUG_DQN_KERNEL']
     torch = torch_cuda
     import bench
     from cobel_amd.network import TorchNetwork

@@ -142,7 +142,9 @@ def test_argument_errors_map_to_reference_exceptions():
         _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 16, 0, None))
     lds = C.c_int32()
     _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 32, 1, C.byref(lds)))
-    assert 50000 < lds.value <= 53 * 1024          # activations only: up to three workgroups per CU
+    assert 70000 < lds.value <= 80 * 1024          # parameter-staging kernel: two workgroups per CU
+    _lib.check(lib.cobel_dqn_replay_query(25, 64, 64, 4, 32, 1, C.byref(lds)))
+    assert 50000 < lds.value <= 53 * 1024          # streaming kernel (activations only) beyond 7 inputs
     _lib.check(lib.cobel_dqn_replay_query(6, 64, 64, 4, 32, 0, C.byref(lds)))
     assert lds.value <= 40 * 1024                  # four in float32
     run = _lib.DQNReplay()
