@@ -166,10 +166,11 @@ struct act_lds {
   T* q;     // [32][33]  outputs -> delta3, columns >= O zero
   T* qt;    // [32][4]   DQN: Q_target(s')
   int* aux; // [64]      DQN: row of each sample; DDQN: argmax_a Q_online(s')
+  T* cst;   // [2]       Adam's bias corrections of this step (computed by one wave)
 };
 
 __host__ __device__ inline size_t fit_lds_elems() {
-  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kA + 64;
+  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kA + 64 + 2;
 }
 // forward only: the inputs sit where h2 will be written (read for the last time before that)
 __host__ __device__ inline size_t fwd_lds_elems() { return 2 * (size_t)kB * kRow; }
@@ -184,6 +185,7 @@ __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
   L.q = p;  p += kB * kXRow;
   L.qt = p; p += kB * kA;
   L.aux = reinterpret_cast<int*>(p);
+  L.cst = p + 64;
   return L;
 }
 
@@ -601,11 +603,20 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     if (R.debug_stage == 1) return;
 
     // ---- Adam constants of this network (its own step count) ------------------------------------
+    // (the two powers are ~500 instructions of float64 arithmetic: one wave without an output tile
+    //  works them out while the output tiles are being summed, the barrier below publishes them)
+    if (wave == 7) {
+      const double st = A.steps_given ? R.steps[j] : R.steps[j] + 1.0;
+      if (lane == 0) {
+        L.cst[0] = (T)(1.0 - pow(R.beta1, st));
+        L.cst[1] = (T)sqrt(1.0 - pow(R.beta2, st));
+      }
+    }
+    lds_barrier();
     adam_consts<T> c;
     {
-      const double st = A.steps_given ? R.steps[j] : R.steps[j] + 1.0;
-      const T bc1 = (T)(1.0 - pow(R.beta1, st));
-      c.bc2_sqrt = (T)sqrt(1.0 - pow(R.beta2, st));
+      const T bc1 = L.cst[0];
+      c.bc2_sqrt = L.cst[1];
       c.step_size = (T)R.lr / bc1;
       c.one_m_b1 = (T)(1.0 - R.beta1);
       c.b2 = (T)R.beta2;
@@ -616,7 +627,6 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       c.tau = (T)R.tau;
       c.blend = blend;
     }
-    lds_barrier();
 
     // ---- output layer ---------------------------------------------------------------------------
     // delta2 tile (rows m0 .., neurons n0 ..) from the weights the step started from, and the
