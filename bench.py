@@ -165,19 +165,31 @@ def _mlp(n_in, n_out, dtype_name='f64'):
 
 
 def _timed_network_agent(agent, env, n, iters, device, warm=4):
-    # `iters` = 1 + a whole number of graph chunks (16 steps for the DQN loop, 8 for Dyna-DSR): the
-    # first step of a run is launched directly, the chunks are replayed from ONE graph recorded at
-    # the start of the run (inside the timed region: a one-off of some tens of milliseconds that a
-    # training run of thousands of steps does not notice; steps that do not fill a chunk would be
-    # launched one by one from the host, ~10 ms each for Dyna-DSR's 29 kernels)
+    """Steady-state rate of a network agent's lockstep loop.  A run launches its first step directly,
+    records ONE HIP graph of a chunk of steps (16 for the DQN loop, 8 for Dyna-DSR's 29 kernels per
+    step) and replays it; `iters` = 1 + a whole number of chunks.  Recording the graph is a one-off
+    of the run (~0.1 s for Dyna-DSR, with the GPU idle) that a training run of thousands of steps
+    does not notice but a benchmark of 200 does: two runs, of `iters` and 2 * iters - 1 steps, are
+    timed and the rate is taken from their DIFFERENCE (the marginal cost of a step); the whole-run
+    figure of the longer one and the one-off are reported next to it."""
+    def run(k):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        agent._run(env, 4096, 50, 32, True, budget=k)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
     agent._run(env, 4096, 50, 32, True, budget=warm)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    agent._run(env, 4096, 50, 32, True, budget=iters)
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    return {'value': n * iters / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / iters * 1e3,
-            'dtype': 'f64'}
+    run(iters)                       # (untimed: working clocks, rings at their final size)
+    long_iters = 2 * iters - 1
+    t_short, t_long = run(iters), run(long_iters)
+    per_step = (t_long - t_short) / (long_iters - iters)
+    return {'value': n / per_step, 'unit': 'env-steps/s', 'ms_per_step': per_step * 1e3,
+            'dtype': 'f64', 'timing': {
+                'method': 'marginal step: (t[%d steps] - t[%d steps]) / %d'
+                          % (long_iters, iters, long_iters - iters),
+                'whole_run_ms_per_step': t_long / long_iters * 1e3,
+                'one_off_ms_per_run': max(0.0, (t_short - per_step * iters) * 1e3)}}
 
 
 def _hbm_roofline(bytes_per_step, value, kernel, limiter, note=None):
@@ -202,26 +214,26 @@ def run_dyna_dqn(device, n=8192, iters=129):
     env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=n, seed=SEED, device=device)
     agent = DynaDQN(env.observation_space, env.action_space, EpsilonGreedy(0.1),
                     TorchNetwork(_mlp(25, 4)), gamma=0.8)
-    _timed_network_agent(agent, env, n, iters, device)   # (warm-up of the timed length, as for C5)
     r = _timed_network_agent(agent, env, n, iters, device)
     fused = agent.fused_steps > 0
     r['config'] = {'workload': 'Dyna-DQN: %d x 5x5 open field, MLP 25-64-64-4 f64 per instance, '
                                'model-sampled batches of 32, %s' % (
                                    n, 'two launches per lockstep step: cobel_dqn_act (world-model '
                                    'mode) + cobel_dqn_replay' if fused else 'PyTorch-ROCm loop'),
-                   'instances_per_gpu': n, 'lockstep_iterations': iters}
+                   'instances_per_gpu': n, 'lockstep_iterations': [iters, 2 * iters - 1]}
     # cobel_dqn_replay: 8 streams over the instance's parameters (online, two Adam moments, target:
     # read + write) + the batch: 32 sampled model records (8 B) and their one-hot rows are indices
     n_params = sum(p.numel() for p in agent.model_online.model.parameters())
     bytes_per_step = 8 * n_params * 8 + 32 * 8 + 78
     r['roofline'] = _hbm_roofline(bytes_per_step, r['value'], 'k_dqn_replay', 'latency',
                                   '8 parameter streams of 8 B x %d parameters + 32 model records + '
-                                  'the online step (78 B); one workgroup per CU at 25 inputs (93 KB '
-                                  'of LDS, DESIGN.md section 4.4)' % n_params)
+                                  'the online step (78 B); the streaming form of the step (weight '
+                                  'operands from memory, 52 KB of LDS: two eight-wave workgroups per '
+                                  'CU, DESIGN.md section 4.4)' % n_params)
     return r
 
 
-def run_dyna_dsr(device, n=8192, iters=201):
+def run_dyna_dsr(device, n=8192, iters=97):
     """SURVEY.md §8f rank 1 (demo/gridworld/demo_dyna_dsr.py): four online + four target successor
     networks 25-64-64-25 and one reward network per instance, float64."""
     from cobel_amd.agent import DynaDSR
@@ -241,7 +253,7 @@ def run_dyna_dsr(device, n=8192, iters=201):
                                               'cobel_mlp_forward, 2 x cobel_mlp_fit) + elementwise '
                                               'torch for the targets, 8 steps per HIP graph' if fused
                                               else 'PyTorch-ROCm loop, one step per HIP graph'),
-                   'instances_per_gpu': n, 'lockstep_iterations': iters}
+                   'instances_per_gpu': n, 'lockstep_iterations': [iters, 2 * iters - 1]}
     # per instance and step: the four online successor networks move 8 streams over their
     # parameters (p, m, v, target: read + write), the reward network 6 (no target), and the
     # forward passes read the four target networks and the reward network once more

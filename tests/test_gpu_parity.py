@@ -1697,13 +1697,18 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, 
                                       tau, None)
 
 
-@pytest.mark.parametrize('dtype_name', ['f64', 'f32'])
-def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, dtype_name):
+@pytest.mark.parametrize('dtype_name,kernel', [('f64', None), ('f32', None), ('f64', 'stream'),
+                                               ('f32', 'stream')])
+def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, monkeypatch, dtype_name, kernel):
     """DQN.train through cobel_dqn_act + cobel_dqn_replay (two launches per lockstep step) against
     the PyTorch loop it replaces: identical transitions in the replay rings, stream counters,
     trial counts and monitors (instances finish at different times; a small ring wraps around;
-    a second train() call continues); weights to round-off in float64."""
+    a second train() call continues); weights to round-off in float64.  kernel: the form of the
+    replay step the library picks for six inputs (parameters staged in LDS) or the streaming form
+    pinned — the batch is read through the ring slots in both."""
     torch = torch_cuda
+    if kernel:
+        monkeypatch.setenv('COBEL_DEBUG_DQN_KERNEL', kernel)
     from cobel_amd.agent import DQN
     from cobel_amd.interface import Topology
     from cobel_amd.memory import DQNMemory
@@ -1807,11 +1812,15 @@ def test_full_size_c5_sample_and_conservation(torch_cuda, golden):
             assert np.allclose(x, y, rtol=1e-9, atol=1e-12), g
 
 
-def test_dyna_dqn_two_kernel_loop_equals_torch_loop(torch_cuda):
+@pytest.mark.parametrize('kernel', [None, 'lds'])
+def test_dyna_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, monkeypatch, kernel):
     """DynaDQN.train through cobel_dqn_act in world-model mode + cobel_dqn_replay reading the
     batch as rows of the observation table, against the PyTorch loop: identical model tables,
-    stream counters, trial counts and monitors; weights to float64 round-off."""
+    stream counters, trial counts and monitors; weights to float64 round-off.  kernel: the form the
+    library picks for 20 one-hot inputs in float64 (streaming) or the parameter-staging one pinned."""
     torch = torch_cuda
+    if kernel:
+        monkeypatch.setenv('COBEL_DEBUG_DQN_KERNEL', kernel)
     import bench
     from cobel_amd.agent import DynaDQN
     from cobel_amd.interface import Gridworld
