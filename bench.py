@@ -136,14 +136,14 @@ def run_c5(device, dtype_name, n=8192, iters=256, warm=8, graph=None):
             'roofline': {'bound': 'hbm', 'achieved': bytes_per_step * n * iters / dt / 1e9,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': bytes_per_step * n * iters / dt / 1e9 / HBM_PEAK_GBS,
-                         'traffic': _c5_traffic(dtype_name, n), 'kernel': 'k_dqn_replay',
+                         'traffic': _c5_traffic(dtype_name, n), 'kernel': 'k_dqn_replay_lds',
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/)',
                          'algorithmic_bytes_per_launch': bytes_per_step * n,
                          'algorithmic_bytes_per_env_step': bytes_per_step}}
 
 
 def _c5_traffic(dtype_name, n):
-    """HBM bytes per launch of k_dqn_replay from the committed PMC passes (scripts/pmc_c5.py),
+    """HBM bytes per launch of k_dqn_replay_lds from the committed PMC passes (scripts/pmc_c5.py),
     for the instance count they were collected with."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
@@ -262,6 +262,12 @@ def run_dyna_dsr(device, n=8192, iters=97):
     bytes_per_step = (4 * 8 * p_sr + 6 * p_rw + 4 * p_sr + p_rw) * 8
     r['roofline'] = _hbm_roofline(bytes_per_step, r['value'], 'k_mlp_fit' if fused else 'torch',
                                   'latency', 'DESIGN.md section 4.4b')
+    if fused and n == 8192:   # the successor-network fit launch alone (scripts/pmc_fit.py, profiles/)
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+        if files:
+            with open(files[-1]) as fh:
+                r['roofline']['fit_launch_pmc'] = json.load(fh).get('dyna_dsr_fit')
     return r
 
 
