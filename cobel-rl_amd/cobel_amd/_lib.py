@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcobel_hip.so')
+# (COBEL_LIB: another build of the library — kernel experiments compare variants side by side)
+LIB_PATH = os.environ.get('COBEL_LIB') or os.path.join(os.path.dirname(_HERE), 'lib',
+                                                     'libcobel_hip.so')
 
 OK, E_ARG, E_RANGE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
 STREAM_ENV, STREAM_POLICY, STREAM_MEMORY, STREAM_POLICY_TEST, STREAM_AGENT = 0, 1, 2, 3, 4

@@ -47,10 +47,12 @@ struct sfma_lds {
   uint16_t* NS;  // [4S] model successor of experience j | nonterminal flag << 15
   double* red;   // [4][8] scratch of the cross-wave reductions (several waves per instance)
   uint64_t* thr; // [48] epsilon-greedy thresholds, entry t * 3 + k
+  double* epsc;  // [16] masked selection: base[1..4], bonus[1..4] (cobel_policy.h); then blend,
+                 //      interp_fwd, interp_rev, decay_inhibition, i_step, alpha, gamma, beta
 };
 
 __host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
-  return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256 + 384;
+  return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256 + 384 + 128;
 }
 
 __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
@@ -75,6 +77,8 @@ __device__ __forceinline__ sfma_lds carve(unsigned char* base, int S) {
   L.red = reinterpret_cast<double*>(base + off);
   off += 256;
   L.thr = reinterpret_cast<uint64_t*>(base + off);
+  off += 384;
+  L.epsc = reinterpret_cast<double*>(base + off);
   return L;
 }
 
@@ -282,6 +286,17 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     L.I[e] = 0.0;
   }
   if (t < 48) L.thr[t] = A.eps_thr[t / 3][t % 3];
+  if (t < 8) L.epsc[t] = t < 4 ? A.eps.base[t + 1] : A.eps.bonus[t - 3];
+  if (t == 8) {
+    L.epsc[8] = A.r.blend;
+    L.epsc[9] = A.r.interp_fwd;
+    L.epsc[10] = A.r.interp_rev;
+    L.epsc[11] = A.r.decay_inhibition;
+    L.epsc[12] = A.r.i_step;
+    L.epsc[13] = A.r.alpha;
+    L.epsc[14] = A.r.gamma;
+    L.epsc[15] = A.r.beta;
+  }
   for (int e = t; e < n4; e += NT) {
     L.C[e] = Cg[e];
     const uint64_t rec = Mg[e];
@@ -321,17 +336,13 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
   // Everything in this kernel is wave-uniform, so the compiler wants it all in scalar registers
   // and then spills (1 300 of 3 000 vector instructions were v_readlane / v_writelane).  Constants
   // that only feed vector arithmetic are pinned to vector registers instead.
-  double alpha = A.r.alpha, gamma = A.r.gamma, beta = A.r.beta, r_thr = A.r.r_threshold;
-  double dec_inh = A.r.decay_inhibition, i_step = A.r.i_step, blend = A.r.blend;
-  double ip_fwd = A.r.interp_fwd, ip_rev = A.r.interp_rev;
+  double r_thr = A.r.r_threshold;
   float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
-  asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(beta), "+v"(r_thr), "+v"(dec_inh), "+v"(i_step),
-               "+v"(blend), "+v"(ip_fwd), "+v"(ip_rev), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
-  // (named scalars, not the struct members: pinning a member sends the whole struct to scratch)
-  double eb1 = A.eps.base[1], eb2 = A.eps.base[2], eb3 = A.eps.base[3], eb4 = A.eps.base[4];
-  double en1 = A.eps.bonus[1], en2 = A.eps.bonus[2], en3 = A.eps.bonus[3], en4 = A.eps.bonus[4];
-  asm volatile("" : "+v"(eb1), "+v"(eb2), "+v"(eb3), "+v"(eb4), "+v"(en1), "+v"(en2), "+v"(en3),
-               "+v"(en4));
+  asm volatile("" : "+v"(r_thr), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
+  // (the constants used once per reactivation or only by some replay modes are read from LDS where
+  //  they are used: blend, interp_fwd / _rev, decay_inhibition, i_step, alpha, gamma, beta — L.epsc[8 ..])
+  // (the eight constants of the masked action selection sit in LDS: 16 vector registers that decide
+  //  between five and six waves per SIMD for the two-experiences-per-lane kernels)
   // cobel_eps_greedy_select_wave (cobel_policy.h) on those scalars: lanes 0..2 take one float64
   // division each, a ballot counts the thresholds of the normalised CDF that u has passed
   auto select_action = [&](const float4 v, uint32_t mask, double u) -> int {
@@ -345,11 +356,8 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     const bool t0 = a0 && v.x == m, t1 = a1 && v.y == m, t2 = a2 && v.z == m, t3 = a3 && v.w == m;
     const int n = __popc(mask & 15u);
     const int nt = (int)t0 + (int)t1 + (int)t2 + (int)t3;
-    // one-hot sums, not select chains (which the optimizer turns into a table in scratch memory)
-    const double base = (((n <= 1 ? eb1 : 0.0) + (n == 2 ? eb2 : 0.0)) + (n == 3 ? eb3 : 0.0)) +
-                        (n >= 4 ? eb4 : 0.0);
-    const double bonus = (((nt <= 1 ? en1 : 0.0) + (nt == 2 ? en2 : 0.0)) + (nt == 3 ? en3 : 0.0)) +
-                         (nt >= 4 ? en4 : 0.0);
+    const double base = L.epsc[(n <= 1 ? 1 : n) - 1];
+    const double bonus = L.epsc[4 + (nt <= 1 ? 1 : nt) - 1];
     const double p0 = a0 ? base + (t0 ? bonus : 0.0) : 0.0;
     const double p1 = a1 ? base + (t1 ? bonus : 0.0) : 0.0;
     const double p2 = a2 ? base + (t2 ? bonus : 0.0) : 0.0;
@@ -392,11 +400,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     const float4 nrow = L.Q[ns];
     const float m = max4_masked(nrow, amask ? (uint32_t)amask[ns] & 15u : 15u);
     const float q = reinterpret_cast<const float*>(L.Q)[s * 4 + a];
-    const double gnt = gamma * (double)nt;
+    const double gnt = L.epsc[14] * (double)nt;
     double td = (double)R + gnt * (double)m;
     td = td - (double)q;
     bsync();
-    if (t == 0) reinterpret_cast<float*>(L.Q)[s * 4 + a] = (float)((double)q + alpha * td);
+    if (t == 0) reinterpret_cast<float*>(L.Q)[s * 4 + a] = (float)((double)q + L.epsc[13] * td);
     bsync();
     td_acc = ((sflags & 1u) ? (double)(float)td_acc : td_acc) + fabs(td);
     sflags &= ~1u;
@@ -490,16 +498,16 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
             break;
           case COBEL_SFMA_BLEND_FORWARD:
 #pragma unroll
-            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + blend * L.Dn[sid[k]];
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + L.epsc[8] * L.Dn[sid[k]];
             break;
           case COBEL_SFMA_BLEND_REVERSE:
 #pragma unroll
-            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + blend * L.Dc[nsv[k]];
+            for (int k = 0; k < CHN; ++k) d[k] = L.Dc[sid[k]] + L.epsc[8] * L.Dc[nsv[k]];
             break;
           case COBEL_SFMA_INTERPOLATE:
 #pragma unroll
             for (int k = 0; k < CHN; ++k)
-              d[k] = ip_fwd * L.Dn[sid[k]] + ip_rev * L.Dc[nsv[k]];
+              d[k] = L.epsc[9] * L.Dn[sid[k]] + L.epsc[10] * L.Dc[nsv[k]];
             break;
           default:
 #pragma unroll
@@ -523,7 +531,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
         bool some = false;
 #pragma unroll
         for (int k = 0; k < CHN; ++k) {
-          const double w = exp((p[k] / rmax) * beta) + -1.0;
+          const double w = exp((p[k] / rmax) * L.epsc[15]) + -1.0;
           p[k] = inb[k] ? w : 0.0;
           some = some || p[k] > 0.0;
         }
@@ -578,10 +586,10 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
             if (mode == COBEL_SFMA_DEFAULT) d = L.Dc[s];
             else if (mode == COBEL_SFMA_FORWARD) d = L.Dn[s];
             else if (mode == COBEL_SFMA_REVERSE) d = L.Dc[L.NS[j] & 0x7fffu];
-            else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + blend * L.Dn[s];
-            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + blend * L.Dc[L.NS[j] & 0x7fffu];
+            else if (mode == COBEL_SFMA_BLEND_FORWARD) d = L.Dc[s] + L.epsc[8] * L.Dn[s];
+            else if (mode == COBEL_SFMA_BLEND_REVERSE) d = L.Dc[s] + L.epsc[8] * L.Dc[L.NS[j] & 0x7fffu];
             else if (mode == COBEL_SFMA_INTERPOLATE)
-              d = ip_fwd * L.Dn[s] + ip_rev * L.Dc[L.NS[j] & 0x7fffu];
+              d = L.epsc[9] * L.Dn[s] + L.epsc[10] * L.Dc[L.NS[j] & 0x7fffu];
             else d = L.Dn[L.NS[j] & 0x7fffu];
             double R = c * d;
             R = R * (1.0 - L.I[s]);
@@ -615,7 +623,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           if (j0 + k < n4) {
             double R = L.P[j0 + k];
             if (sf & COBEL_SF_R_NORMALIZE) R = R / rmax;
-            const double w = exp(R * beta) + -1.0;
+            const double w = exp(R * L.epsc[15]) + -1.0;
             L.P[j0 + k] = w;
             wmax = fmax(wmax, w);
           }
@@ -638,9 +646,12 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       const uint32_t nt = nrec >> 15;
       bsync();
       // inhibition (:336-337)
-      for (int e = t; e < S; e += NT) L.I[e] = L.I[e] * dec_inh;
+      {
+        const double dec_inh = L.epsc[11];
+        for (int e = t; e < S; e += NT) L.I[e] = L.I[e] * dec_inh;
+      }
       bsync();
-      if (t == 0) L.I[cur] = fmin(L.I[cur] + i_step, 1.0);
+      if (t == 0) L.I[cur] = fmin(L.I[cur] + L.epsc[12], 1.0);
       // the reactivated experience
       double td = __builtin_nan("");
       if (update) td = replay_td(cur, action, nxt, R, nt);
@@ -867,13 +878,16 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
   sfma_body<CH, 1>(A);
 }
 // Two experiences per lane (worlds up to 32 states, the reference's demos): five waves per SIMD
-// instead of the four the register allocation settles on by itself — +12 % on C6.  The same hint
+// instead of the four the register allocation settles on by itself — +12 % on C6 —, six for the
+// plain-training instantiation since the constants of the masked action selection and the ones a
+// reactivation uses once (L.epsc) are read from LDS instead of being pinned to vector registers
+// (80 registers, no scratch: +5 %; seven waves measure the same, eight 5 % less).  The same hint
 // costs the wider variants 20-25 % (spills into scratch), so they keep the default.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2(
     const sfma_args A) {
   sfma_body<2, 1>(A);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2_fast(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sfma_2_fast(
     const sfma_args A) {
   sfma_body<2, 1, true>(A);
 }
