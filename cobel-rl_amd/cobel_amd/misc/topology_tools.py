@@ -6,11 +6,14 @@ with ``nodes[id] = {'id', 'pose', 'terminal', 'reward', 'neighbors'}``; ids are 
 construction order, neighbours are ordered [left, up, right, down] and point back at the node
 itself where the graph ends (topology_tools.py:61,70-81).  ``hexagonal`` builds the six-neighbour
 graph as the reference does: a ``Topology`` over it has six actions and runs through the general
-entry points (``cobel_world_create_n``, ``cobel_eps_greedy_n``, the general tabular kernel); the
-shapely-based obstacle pruning is outside the accelerated path.
+entry points (``cobel_world_create_n``, ``cobel_eps_greedy_n``, the general tabular kernel).
+``remove_obstructed_neighbors`` (topology_tools.py:472-505) prunes the edges that cross obstacle
+polygons — host geometry in NumPy here (the reference calls shapely, which this package does not
+require); the pruned graph is an ordinary neighbour table for the env kernels.
 """
 from __future__ import annotations
 
+import copy
 from itertools import product
 from typing import Literal
 
@@ -171,3 +174,89 @@ def hexagonal(nb_nodes: int, limits=(0.0, 1.0), reward: float = 1.0, location=No
     nodes[location].update({'terminal': True, 'reward': reward})
     starting_nodes = [k for k in nodes if k != location]
     return nodes, starting_nodes
+
+
+# ---------------------------------------------------------------------------------------------
+def _rings(polygon) -> list:
+    """Exterior ring first, then the holes, each an (n, 2) array of vertices (closing vertex
+    dropped).  Accepts a sequence of (x, y[, z]) vertices or an object with shapely's
+    ``exterior.coords`` / ``interiors``."""
+    if hasattr(polygon, 'exterior'):
+        rings = [polygon.exterior.coords] + [r.coords for r in getattr(polygon, 'interiors', [])]
+    else:
+        rings = [polygon]
+    out = []
+    for ring in rings:
+        v = np.asarray(list(ring), dtype=np.float64)[:, :2]
+        if len(v) > 1 and np.array_equal(v[0], v[-1]):
+            v = v[:-1]
+        assert len(v) >= 3, 'a polygon needs at least three vertices'
+        out.append(v)
+    return out
+
+
+def _inside(p: np.ndarray, ring: np.ndarray) -> bool:
+    """Even-odd rule (points on the boundary are settled by the distance test, not here)."""
+    x, y = ring[:, 0], ring[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cross = (y > p[1]) != (yn > p[1])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        xi = x + (p[1] - y) * (xn - x) / (yn - y)
+    return bool(np.count_nonzero(cross & (p[0] < xi)) % 2)
+
+
+def _segment_distance(a: np.ndarray, b: np.ndarray, c: np.ndarray, d: np.ndarray) -> float:
+    """Distance between the segments ab and cd (0 when they cross or touch)."""
+    def orient(p, q, r):
+        return (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+
+    def point_segment(p, q, r):
+        qr = r - q
+        den = float(qr @ qr)
+        t = 0.0 if den == 0.0 else min(1.0, max(0.0, float((p - q) @ qr) / den))
+        return float(np.hypot(*(p - (q + t * qr))))
+
+    o1, o2, o3, o4 = orient(a, b, c), orient(a, b, d), orient(c, d, a), orient(c, d, b)
+    if o1 * o2 < 0 and o3 * o4 < 0:   # a proper crossing (touching ends come out of the minima as 0)
+        return 0.0
+    return min(point_segment(a, c, d), point_segment(b, c, d), point_segment(c, a, b),
+               point_segment(d, a, b))
+
+
+def _edge_obstructed(p1: np.ndarray, p2: np.ndarray, polygons: list, buffer_distance: float) -> bool:
+    """Does the segment p1-p2 meet a polygon (boundary included) grown by buffer_distance?"""
+    for rings in polygons:
+        dist = np.inf
+        for ring in rings:
+            nxt = np.roll(ring, -1, axis=0)
+            for c, d in zip(ring, nxt):
+                dist = min(dist, _segment_distance(p1, p2, c, d))
+        if dist <= buffer_distance:
+            return True
+        # no boundary within reach: the segment lies wholly inside or wholly outside the area
+        if _inside(p1, rings[0]) and not any(_inside(p1, hole) for hole in rings[1:]):
+            return True
+    return False
+
+
+def remove_obstructed_neighbors(nodes: dict, obstacles: list, buffer_distance: float = 0.0) -> dict:
+    """Replace every edge of a topology graph that is obstructed by one of the obstacle polygons with
+    a self-loop (the reference's ``remove_obstructed_neighbors``, topology_tools.py:472-505: a deep
+    copy of ``nodes`` in which ``neighbors[i] = own id`` wherever the straight line between the two
+    nodes' (x, y) positions intersects the obstacles grown by ``buffer_distance``; z is ignored).
+
+    ``obstacles``: polygons as sequences of (x, y) vertices, or shapely polygons (exterior +
+    holes are read from them; shapely itself is not needed).  The obstacles are grown by the exact
+    Euclidean distance; shapely's ``buffer`` rounds corners with eight chords per quarter circle,
+    which is smaller by at most 0.5 % of the distance — edges that pass a CORNER within that margin
+    are the only ones on which the two can differ."""
+    assert buffer_distance >= 0, 'The buffer distance has to be non-negative!'
+    nodes_updated = copy.deepcopy(nodes)
+    polygons = [_rings(p) for p in obstacles]
+    for n, node in nodes_updated.items():
+        pos_1 = np.asarray(node['pose'], dtype=np.float64)[:2]
+        for i, neighbor in enumerate(node['neighbors']):
+            pos_2 = np.asarray(nodes_updated[neighbor]['pose'], dtype=np.float64)[:2]
+            if _edge_obstructed(pos_1, pos_2, polygons, float(buffer_distance)):
+                node['neighbors'][i] = n
+    return nodes_updated

@@ -731,3 +731,44 @@ def test_transition_lists_follow_generator_choice():
         transition_lists(bad)
     with pytest.raises(ValueError):
         np.random.default_rng(0).choice(2, p=bad[0, 0])
+
+
+def test_remove_obstructed_neighbors_prunes_edges_like_the_reference():
+    """misc/topology_tools.py:472-505 without shapely: an edge whose straight line meets an obstacle
+    polygon (grown by the buffer distance, boundary included) becomes a self-loop; the input graph is
+    left untouched; z is ignored; polygons come as vertex lists or shapely-like objects."""
+    from cobel_amd.misc import topology_tools as tt
+    nodes, _ = tt.grid(4, (0.0, 3.0))                     # node n at (n % 4, 3 - n // 4)
+    wall = [(1.4, 1.5), (1.6, 1.5), (1.6, 3.5), (1.4, 3.5)]   # between columns 1 and 2, two upper rows
+    out = tt.remove_obstructed_neighbors(nodes, [wall])
+    assert out['1']['neighbors'] == ['0', '1', '1', '5'] and out['2']['neighbors'] == ['2', '2', '3', '6']
+    assert out['5']['neighbors'] == ['4', '1', '5', '9'] and out['6']['neighbors'] == ['6', '2', '7', '10']
+    assert out['9']['neighbors'] == nodes['9']['neighbors']            # below the wall: untouched
+    assert nodes['1']['neighbors'] == ['0', '1', '2', '5']             # deep copy
+    changed = sum(a['neighbors'] != b['neighbors'] for a, b in zip(nodes.values(), out.values()))
+    assert changed == 4
+    # the buffer distance: a square 0.2 above the edge 9 - 10 obstructs it from exactly 0.2 on
+    square = [(1.4, 1.2), (1.6, 1.2), (1.6, 1.4), (1.4, 1.4)]
+    for buf, cut in ((0.0, False), (0.19, False), (0.2, True), (0.5, True)):
+        o = tt.remove_obstructed_neighbors(nodes, [square], buf)
+        assert (o['9']['neighbors'][2] == '9') == cut and (o['10']['neighbors'][0] == '10') == cut, buf
+    # a node inside an obstacle loses every edge, and its neighbours their edges to it
+    o = tt.remove_obstructed_neighbors(nodes, [[(-0.5, 2.5), (0.5, 2.5), (0.5, 3.5), (-0.5, 3.5)]])
+    assert o['0']['neighbors'] == ['0'] * 4 and o['1']['neighbors'][0] == '1' and o['4']['neighbors'][1] == '4'
+    # a hole: the edge inside the hole of a ring-shaped obstacle is free, the ones through the ring are not
+
+    class Ring:      # what the function reads off a shapely polygon
+        class _R:
+            def __init__(self, c):
+                self.coords = c
+        exterior = _R([(0.5, 0.5), (2.5, 0.5), (2.5, 2.5), (0.5, 2.5), (0.5, 0.5)])
+        interiors = [_R([(0.8, 0.8), (2.2, 0.8), (2.2, 2.2), (0.8, 2.2), (0.8, 0.8)])]
+
+    o = tt.remove_obstructed_neighbors(nodes, [Ring])
+    assert o['5']['neighbors'] == ['5', '5', '6', '9']     # 5 = (1, 2) inside the hole: 4 and 1 are outside
+    assert o['6']['neighbors'][0] == '5' and o['9']['neighbors'][2] == '10'
+    with pytest.raises(AssertionError):
+        tt.remove_obstructed_neighbors(nodes, [wall], -1.0)
+    # the pruned graph is an ordinary topology for the environment
+    env_nodes = tt.remove_obstructed_neighbors(nodes, [wall])
+    assert all(len(v['neighbors']) == 4 for v in env_nodes.values())
