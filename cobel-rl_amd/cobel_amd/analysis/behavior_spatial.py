@@ -1,5 +1,6 @@
 """Spatial occupancy maps — ``cobel.analysis.behavior_spatial.get_occupancy_map``
-(analysis/behavior_spatial.py:9-73).
+(analysis/behavior_spatial.py:9-73) — and ``match`` (:76-107: how many states of a template
+sequence line up with a state sequence at every offset).
 
 Two entry points:
   * ``get_occupancy_map(trajectories, width, height, bin_size, margins)`` keeps the reference's
@@ -72,3 +73,27 @@ def occupancy_from_counts(counts, coordinates, width: float, height: float, bin_
     occ = np.zeros(tuple(bins))
     _accumulate(occ, coordinates[:, 0], coordinates[:, 1], counts, bins, bin_size, margins)
     return occ
+
+
+def match(sequence: np.ndarray, template: np.ndarray) -> np.ndarray:
+    """Number of matching states between a sequence of state indices and a template laid over it
+    at every offset: ``out[t] = #{j < len(template) : t + j < len(sequence) and template[j] ==
+    sequence[t + j]}`` for t = 0 .. len(sequence) - 1 — the reference's ``match``
+    (analysis/behavior_spatial.py:76-107), which builds an (n + 2m) x (n + 2m) band matrix padded
+    with -1 and compares it with the padded sequence.  Here: one comparison of the (n, m) matrix of
+    sliding windows, O(n m) instead of O((n + 2m)^2) memory.  (Faithful to the padding too: a -1
+    IN the sequence matches the band matrix's -1 wherever the template does not cover it.)"""
+    sequence, template = np.asarray(sequence), np.asarray(template)
+    assert sequence.ndim == 1 and template.ndim == 1 and template.shape[0] >= 1
+    n, m = sequence.shape[0], template.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    tail = np.concatenate((sequence.astype(np.float64), np.full(m - 1, np.nan)))   # NaN: past the end
+    windows = np.lib.stride_tricks.sliding_window_view(tail, m)                    # [t, j] = sequence[t + j]
+    out = (windows == template.astype(np.float64)[None, :]).sum(axis=1).astype(np.int64)
+    minus = sequence == -1
+    if minus.any():
+        csum = np.concatenate(([0], np.cumsum(minus)))
+        covered = csum[np.minimum(np.arange(n) + m, n)] - csum[np.arange(n)]
+        out += int(minus.sum()) - covered
+    return out

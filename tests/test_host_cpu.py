@@ -772,3 +772,31 @@ def test_remove_obstructed_neighbors_prunes_edges_like_the_reference():
     # the pruned graph is an ordinary topology for the environment
     env_nodes = tt.remove_obstructed_neighbors(nodes, [wall])
     assert all(len(v['neighbors']) == 4 for v in env_nodes.values())
+
+
+def test_analysis_match_and_state_coordinates():
+    """cobel.analysis.behavior_spatial.match (:76-107) and cobel.analysis.utils (:8-53): the number
+    of template states that line up with the sequence at every offset (counted by plain loops here,
+    including the reference's padding rule: a -1 in the sequence matches wherever the template does
+    not cover it), and state index -> (row, column)."""
+    from cobel_amd.analysis import match, state_to_coordinates, states_to_coordinates
+    r = np.random.default_rng(3)
+    for k in range(200):
+        n, m = int(r.integers(1, 40)), int(r.integers(1, 15))
+        lo = -1 if k % 4 == 0 else 0
+        seq, tem = r.integers(lo, 5, n), r.integers(lo, 5, m)
+        want = np.zeros(n, dtype=np.int64)
+        for t in range(n):
+            for c in range(n):
+                j = c - t
+                covered = 0 <= j < m
+                want[t] += int(tem[j] == seq[c]) if covered else int(seq[c] == -1)
+        got = match(seq, tem)
+        assert got.dtype == np.int64 and np.array_equal(got, want), (seq, tem)
+    assert np.array_equal(match(np.array([1, 2, 3, 1, 2]), np.array([1, 2])), [2, 0, 0, 2, 0])
+    assert match(np.zeros(0, dtype=int), np.array([1])).shape == (0,)
+    assert state_to_coordinates(7, 5).tolist() == [1, 2] and state_to_coordinates(7, 5, False).tolist() == [2, 1]
+    assert states_to_coordinates(np.array([0, 7, 24]), 5).tolist() == [[0, 0], [1, 2], [4, 4]]
+    assert states_to_coordinates(np.array([7]), 5, y_first=False).tolist() == [[2, 1]]
+    with pytest.raises(AssertionError):
+        state_to_coordinates(-1, 5)
