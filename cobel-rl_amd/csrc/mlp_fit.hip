@@ -835,6 +835,34 @@ int shape_ok(int32_t D, int32_t O, const char* who) {
   return COBEL_OK;
 }
 
+// Experiments only (scripts/exp_mlp_trace.py): COBEL_DEBUG_MLP_TRACE = address of a device buffer of
+// n x 16 uint64 for the per-phase stamps.  Taken only if it parses completely and names DEVICE memory
+// of the current device; anything else is ignored, so a stray variable cannot send stores anywhere.
+unsigned long long* debug_trace_buffer() {
+  const char* const v = getenv("COBEL_DEBUG_MLP_TRACE");
+  if (!v || !*v) return nullptr;
+  char* end = nullptr;
+  const unsigned long long addr = strtoull(v, &end, 0);
+  if (*end != '\0' || addr == 0 || (addr & 7u)) return nullptr;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, reinterpret_cast<const void*>(addr)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != dev)
+    return nullptr;
+  return reinterpret_cast<unsigned long long*>(addr);
+}
+// COBEL_DEBUG_MLP_STAGE = 1 .. 5: leave the step after that phase (phase timings; any other value: 0)
+int debug_stage_env() {
+  const char* const v = getenv("COBEL_DEBUG_MLP_STAGE");
+  if (!v || !*v) return 0;
+  char* end = nullptr;
+  const long k = strtol(v, &end, 10);
+  return (*end == '\0' && k >= 1 && k <= 5) ? (int)k : 0;
+}
+
 template <typename K>
 int raise_lds(K kernel, int32_t lds) {
   if (lds > 64 * 1024)
@@ -911,8 +939,7 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
   memset(&A, 0, sizeof A);
   A.r = r;
   A.rows = kB;
-  if (const char* v = getenv("COBEL_DEBUG_MLP_TRACE"))
-    A.trace = reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0));
+  A.trace = debug_trace_buffer();
   hipStream_t st = (hipStream_t)stream;
   lds += cobel_debug_lds_pad(lds, 160 * 1024);   // (occupancy experiments only)
   if (r.is_float64) {
@@ -933,7 +960,10 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
 // 1.34 -> 1.0 ms per step of 8 192 instances.  COBEL_DEBUG_DQN_KERNEL = lds | stream pins one
 // (experiments, tests).
 static bool dqn_staged(int32_t n_inputs, int32_t is_float64) {
-  if (const char* v = getenv("COBEL_DEBUG_DQN_KERNEL")) return v[0] == 'l';
+  if (const char* v = getenv("COBEL_DEBUG_DQN_KERNEL")) {   // exactly "lds" or "stream", else ignored
+    if (!strcmp(v, "lds")) return true;
+    if (!strcmp(v, "stream")) return false;
+  }
   return 2 * cobel_dqn_replay_lds_bytes(n_inputs, is_float64) <= 160 * 1024;
 }
 
@@ -1031,9 +1061,8 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   A.rewards = r.rewards;
   A.nonterminal = r.nonterminal;
   A.gamma = r.gamma;
-  if (const char* v = getenv("COBEL_DEBUG_MLP_STAGE")) f.debug_stage = atoi(v);   // (phase timings)
-  if (const char* v = getenv("COBEL_DEBUG_MLP_TRACE"))
-    A.trace = reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0));
+  f.debug_stage = debug_stage_env();
+  A.trace = debug_trace_buffer();
   lds += cobel_debug_lds_pad(lds, 160 * 1024);                                    // (occupancy)
   if (lds > 64 * 1024) {
     if (int rc = raise_lds(r.is_float64 ? reinterpret_cast<const void*>(&k_dqn_replay<double>)

@@ -17,6 +17,7 @@ n = 8192
 rows = n * 4 if what == 'dsr' else n
 trace = torch.zeros((rows, 16), dtype=torch.int64, device='cuda')
 os.environ['COBEL_DEBUG_MLP_TRACE'] = hex(trace.data_ptr())
+os.environ.setdefault('COBEL_DEBUG_DQN_KERNEL', 'stream')   # (the form of the DQN step that carries the stamps)
 if what == 'c5':
     bench.run_c5(torch.device('cuda', 0), dt, n=n, iters=33, warm=17)
 else:
