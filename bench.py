@@ -578,6 +578,13 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     for k in range(warm):
         warm_launch()
     torch.cuda.synchronize(device)
+    # First use of the monitor reduction and of the barrier (buffers, communicator set-up: 10+ ms on
+    # the host) belongs to the warm-up, not in front of the timed window: a GPU that has been idle
+    # for a few milliseconds runs its next launch ~10 % slower (clocks), measured on C3 — 13.8 ms
+    # against 12.5 for the launches that follow.
+    agent.monitors.all_reduce()
+    if dist is not None:
+        dist.barrier()
     # C3: a Dyna-Q kernel does not evaluate a planning batch that cannot change a table (an
     # instance whose Q and reward estimates are still all +0.0f), so young
     # agents are cheaper per env step than trained ones.  The timed window is the FULL-WORK state:
