@@ -338,34 +338,110 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
   }
   const uint32_t SA = (uint32_t)(S * A);
 
-  // one planned / replayed update, in the arithmetic of the reference run with float32 tables:
+  // A planned / replayed update is in the arithmetic of the reference run with float32 tables:
   // Dyna-Q planning in float64 rounded once on store (the sampled `terminal` is np.int64), QAgent
-  // replay in float32 (agent/dyna_q.py:290-299, agent/q.py:305-313)
-  auto td_update = [&](int s, int a, float r, int ns, uint32_t nt, bool f64) {
-    const float m = row_max(ns);
-    const float q = Q[(size_t)s * A + a];
-    float qn;
-    if (f64) {
-      const double gnt = gamma * (double)nt;
-      double td = (double)r + gnt * (double)m;
-      td = td - (double)q;
-      qn = (float)((double)q + alpha * td);
-    } else {
-      const float gnt = nt ? gamma_f : 0.0f;
-      float td = r + gnt * m;
-      td = td - q;
-      qn = q + alpha_f * td;
+  // replay in float32 (agent/dyna_q.py:290-299, agent/q.py:305-313).
+  // One batch of B sequential updates (j = 0 .. B - 1), software-pipelined: this lane is
+  // the only wave of its SIMD (65 536 instances are one wave per SIMD), so nothing else covers the
+  // two dependent trips to memory of an update — record, then Q cells.  The records do not depend
+  // on Q: record j + 2 and the Q cells of update j + 1 (the row of its successor, its own cell) are
+  // requested before update j is finished; what those loads cannot have seen — the cell update j
+  // writes (and, for good measure, update j - 1's) — is patched into the prefetched values.  Same
+  // values, same order of effects as the plain loop: identical tables (tests, fuzz).
+  struct upd_t {
+    int s, a, ns;
+    float r;
+    uint32_t nt;
+  };
+  struct rec_t {       // a drawn index and the 64-bit record found there
+    uint32_t idx;
+    uint64_t bits;
+  };
+  // (slot k of a prefetched row holds action k; beyond A the last action — or, when rows are loaded
+  //  two values at a time, the last PAIR — once more)
+  auto slot_action = [&](int k) -> int {
+    if (A & 1) return k < A ? k : A - 1;
+    return k < A ? k : A - 2 + (k & 1);
+  };
+  auto fetch_cells = [&](const upd_t& u, float (&row)[8], float& q) {
+    // (eight unconditional loads — the last valid action again beyond A — so that the count of
+    //  loads in flight is a constant: with a load under a condition the compiler waits for ALL
+    //  outstanding loads, the prefetch just issued included, before it uses the previous one)
+    if (A & 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) row[k] = Q[(size_t)u.ns * A + (k < A ? k : A - 1)];
+    } else {   // an even action count: rows are 8-byte aligned, four two-value loads (the lanes of a
+               // wave are different instances: every load instruction is 64 separate lines)
+      const float2* const r2 = reinterpret_cast<const float2*>(Q + (size_t)u.ns * A);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 v = r2[2 * k < A ? k : A / 2 - 1];
+        row[2 * k] = v.x;
+        row[2 * k + 1] = v.y;
+      }
     }
-    Q[(size_t)s * A + a] = qn;
+    q = Q[(size_t)u.s * A + u.a];
+  };
+  auto patch_cells = [&](const upd_t& u, float (&row)[8], float& q, int ws, int wa, float wv) {
+    if (ws == u.ns) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) row[k] = slot_action(k) == wa ? wv : row[k];
+    }
+    if (ws == u.s && wa == u.a) q = wv;
+  };
+  auto run_batch = [&](auto load_rec, auto decode, bool f64) {
+    if (B <= 0) return;
+    upd_t cur = decode(load_rec(0));
+    float row[8], q;
+    fetch_cells(cur, row, q);
+    rec_t rec_next = load_rec(B > 1 ? 1 : 0);
+    int w1s = -1, w1a = 0, w2s = -1, w2a = 0;   // the cells of the last two updates and their values
+    float w1v = 0.0f, w2v = 0.0f;
+    for (int j = 0; j < B; ++j) {
+      // (unconditional: the last iterations request the last update's record and cells once more)
+      const upd_t nxt = decode(rec_next);
+      float nrow[8], nq;
+      fetch_cells(nxt, nrow, nq);
+      rec_next = load_rec(j + 2 < B ? j + 2 : B - 1);
+      patch_cells(cur, row, q, w2s, w2a, w2v);
+      patch_cells(cur, row, q, w1s, w1a, w1v);
+      float m = row[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) m = fmaxf(m, row[k]);   // (entries beyond A repeat the last action)
+      float qn;
+      if (f64) {
+        const double gnt = gamma * (double)cur.nt;
+        double td = (double)cur.r + gnt * (double)m;
+        td = td - (double)q;
+        qn = (float)((double)q + alpha * td);
+      } else {
+        const float gnt = cur.nt ? gamma_f : 0.0f;
+        float td = cur.r + gnt * m;
+        td = td - q;
+        qn = q + alpha_f * td;
+      }
+      Q[(size_t)cur.s * A + cur.a] = qn;
+      w2s = w1s; w2a = w1a; w2v = w1v;
+      w1s = cur.s; w1a = cur.a; w1v = qn;
+      cur = nxt;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) row[k] = nrow[k];
+      q = nq;
+    }
   };
   auto plan_dynaq = [&]() {   // memory/dyna_q.py:137-155 + dyna_q.py:329-330
-    for (int j = 0; j < B; ++j) {
-      const uint32_t idx = cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, SA);
-      const uint64_t rec = model[idx];
-      const uint32_t hi = (uint32_t)(rec >> 32);
-      td_update((int)(idx / (uint32_t)A), (int)(idx % (uint32_t)A),
-                __builtin_bit_cast(float, (uint32_t)rec), (int)(hi & 0xffffu), (hi >> 16) & 1u, true);
-    }
+    run_batch(
+        [&](int j) -> rec_t {
+          const uint32_t idx =
+              cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, SA);
+          return rec_t{idx, model[idx]};
+        },
+        [&](const rec_t& rc) -> upd_t {
+          const uint32_t hi = (uint32_t)(rc.bits >> 32);
+          return upd_t{(int)(rc.idx / (uint32_t)A), (int)(rc.idx % (uint32_t)A), (int)(hi & 0xffffu),
+                       __builtin_bit_cast(float, (uint32_t)rc.bits), (hi >> 16) & 1u};
+        },
+        true);
     cm += 1u;
   };
 
@@ -452,16 +528,20 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
       } else {
         if (loglen > 0u) {   // q.py:353-354: idx = rng.choice(len(M), batch_size), one vector draw
           batches += 1ull;
-          for (int j = 0; j < B; ++j) {
-            const uint32_t idx =
-                cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, loglen);
-            const uint64_t rec = rlog[idx];
-            const uint32_t hi = (uint32_t)(rec >> 32);
-            const uint32_t ra = A <= 4 ? (hi >> 28) & 3u : (hi >> 28) & 7u;
-            const uint32_t rnt = A <= 4 ? (hi >> 30) & 1u : (hi >> 31) & 1u;
-            td_update((int)(hi & 0x3fffu), (int)ra, __builtin_bit_cast(float, (uint32_t)rec),
-                      (int)((hi >> 14) & 0x3fffu), rnt, false);
-          }
+          run_batch(
+              [&](int j) -> rec_t {
+                const uint32_t idx =
+                    cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, loglen);
+                return rec_t{idx, rlog[idx]};
+              },
+              [&](const rec_t& rc) -> upd_t {
+                const uint32_t hi = (uint32_t)(rc.bits >> 32);
+                const uint32_t ra = A <= 4 ? (hi >> 28) & 3u : (hi >> 28) & 7u;
+                const uint32_t rnt = A <= 4 ? (hi >> 30) & 1u : (hi >> 31) & 1u;
+                return upd_t{(int)(hi & 0x3fffu), (int)ra, (int)((hi >> 14) & 0x3fffu),
+                             __builtin_bit_cast(float, (uint32_t)rc.bits), rnt};
+              },
+              false);
         }
         cm += 1u;
       }
