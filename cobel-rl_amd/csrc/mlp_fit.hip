@@ -192,12 +192,39 @@ __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
 // the 32 input rows of an instance — rows of a float64 table by index, or rows slot[s] (NULL: s) of
 // a dense block — on their way into x [32][33], columns D .. 31 zero: `request` asks for all of a
 // thread's elements, `store` writes them to LDS (as late as the caller likes)
-template <typename T, int NT>
+// BATCH: every load unconditional — column D - 1 again beyond D, zeroed afterwards.  A load under a
+// condition is a branch, and the compiler then sends a thread's loads out one at a time, each behind
+// a wait for the one before (four dependent trips for the four rows of a forward thread).  The
+// forward kernel has the registers for it; the training kernels, at their 128-register cap, spill
+// prefetched values when everything is in flight at once (measured slower) and keep the plain form.
+template <typename T, int NT, bool BATCH = false>
 struct input_rows {
   static constexpr int U = kB * 32 / NT;
   T r[U];
   __device__ __forceinline__ void request(const double* table, const int32_t* index, const T* dense,
                                           const int* slot, int D, int t) {
+    if (BATCH) {
+      if (table) {
+        int row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) row[u] = index[(t + NT * u) >> 5];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int d = (t + NT * u) & 31;
+          r[u] = (T)table[(size_t)row[u] * D + (d < D ? d : D - 1)];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = t + NT * u, d = e & 31;
+          const int s = slot ? slot[e >> 5] : e >> 5;
+          r[u] = dense[(size_t)s * D + (d < D ? d : D - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = ((t + NT * u) & 31) < D ? r[u] : (T)0;
+      return;
+    }
     if (table) {
       int row[U];
 #pragma unroll
@@ -224,10 +251,10 @@ struct input_rows {
     }
   }
 };
-template <typename T, int NT>
+template <typename T, int NT, bool BATCH = false>
 __device__ __forceinline__ void load_inputs(T* x, const double* table, const int32_t* index,
                                             const T* dense, const int* slot, int D, int t) {
-  input_rows<T, NT> in;
+  input_rows<T, NT, BATCH> in;
   in.request(table, index, dense, slot, D, t);
   in.store(x, t);
 }
@@ -248,13 +275,34 @@ struct weight_op {
   T b[KS];
   T bias;
 };
-template <typename T, int KS, bool ALIGNED>
+template <typename T, int KS, bool ALIGNED, bool BATCH = false>
 __device__ __forceinline__ weight_op<T, KS> weight_rows(const T* __restrict__ W,
                                                         const T* __restrict__ bias, int ld, int kmax,
                                                         int nmax, int n0, int lane) {
   weight_op<T, KS> w;
   const int li = lane & 15, lq = lane >> 4;
   const bool valid = n0 + li < nmax;
+  if (BATCH) {   // unconditional loads of clamped addresses, zeroed afterwards (see input_rows)
+    const int row = valid ? n0 + li : 0;
+    if (ALIGNED) {
+      const T* const wr = reinterpret_cast<const T*>(
+          __builtin_assume_aligned(W + (uint32_t)(row * ld + lq * KS), 16));
+#pragma unroll
+      for (int s = 0; s < KS; ++s) w.b[s] = wr[s];
+    } else {
+      const T* const wr = W + (uint32_t)(row * ld);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = lq * KS + s;
+        w.b[s] = wr[k < kmax ? k : kmax - 1];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) w.b[s] = valid && (ALIGNED || lq * KS + s < kmax) ? w.b[s] : (T)0;
+    w.bias = bias[row];
+    w.bias = valid ? w.bias : (T)0;
+    return w;
+  }
   const T* wr = W + (uint32_t)((valid ? n0 + li : 0) * ld + lq * KS);
   if (ALIGNED) wr = reinterpret_cast<const T*>(__builtin_assume_aligned(wr, 16));
 #pragma unroll
@@ -316,10 +364,10 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   const T* const w3 = (const T*)R.w[2] + net * (size_t)O * kH;
   const int m3 = 16 * (wave >> 1), n3 = 16 * (wave & 1);
   const weight_op<T, 8> o1 =
-      weight_rows<T, 8, false>(w1, (const T*)R.b[0] + net * kH, D, D, kH, 16 * wave, lane);
+      weight_rows<T, 8, false, true>(w1, (const T*)R.b[0] + net * kH, D, D, kH, 16 * wave, lane);
   const weight_op<T, 16> o2 =
-      weight_rows<T, 16, true>(w2, (const T*)R.b[1] + net * kH, kH, kH, kH, 16 * wave, lane);
-  load_inputs<T, 256>(x, R.in_table,
+      weight_rows<T, 16, true, true>(w2, (const T*)R.b[1] + net * kH, kH, kH, kH, 16 * wave, lane);
+  load_inputs<T, 256, true>(x, R.in_table,
                       R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
                       R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, nullptr, D,
                       t);
@@ -328,7 +376,7 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   // (the output layer's operand once the first layer's registers are free: four workgroups per CU)
   __builtin_amdgcn_sched_barrier(0);
   const weight_op<T, 16> o3 =
-      weight_rows<T, 16, true>(w3, (const T*)R.b[2] + net * O, kH, kH, O, n3, lane);
+      weight_rows<T, 16, true, true>(w3, (const T*)R.b[2] + net * O, kH, kH, O, n3, lane);
   lds_barrier();   // (every read of x is done: h2 takes its place)
   dense_relu<T, 16, 2>(o2, h1, kRow, h2, 0, 16 * wave, lane);
   lds_barrier();
