@@ -45,8 +45,11 @@ constexpr int kA = 4;         // actions
 constexpr int kB = 32;        // replay batch
 constexpr int kRow = 66;      // LDS row stride of activations and of the transposed 64 x 64 matrix
 constexpr int kMaxD = 32;     // input width limit
-constexpr int kW1Iters = kH * kMaxD / 256;   // first-layer elements per thread (256 threads)
-constexpr int kXIters = kB * kMaxD / 256;    // batch-row elements per thread
+// First-layer elements (64 D) and batch-row elements (32 D) per thread of the 256: the kernels are
+// instantiated for DI = 2, 4, 8 first-layer elements per thread (inputs up to 8, 16, 32) — every
+// one of them is an unconditional load in flight at once, so the count follows the input width.
+constexpr int kMaxW1Iters = kH * kMaxD / 256;
+static_assert(kMaxW1Iters == 8, "three instantiations: 2, 4, 8");
 
 struct mlp_args {
   cobel_dqn_replay_t r;
@@ -184,7 +187,7 @@ __device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restric
   P.b3 = t < kA ? b3[t] : (T)0;
 }
 
-template <typename T>
+template <typename T, int DI>
 __device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T>& P,
                                              const T* __restrict__ w1, int D, int t) {
 #pragma unroll
@@ -197,14 +200,15 @@ __device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_re
   //  seven of them at 25 inputs.  The float32 instantiation runs under a 128-register cap with four
   //  workgroups per CU to cover that latency and keeps the plain loop: the staged form spills.)
   if (sizeof(T) == 8) {
-    T r1[kW1Iters];
+    T r1[DI];
 #pragma unroll
-    for (int u = 0; u < kW1Iters; ++u) {
+    for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
-      r1[u] = e < kH * D ? w1[e] : (T)0;
+      r1[u] = w1[e < kH * D ? e : kH * D - 1];   // (unconditional: a load under a condition is a
+                                                 //  branch and a wait for every load before it)
     }
 #pragma unroll
-    for (int u = 0; u < kW1Iters; ++u) {
+    for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
       if (e < kH * D) {
         const int j = e / D, d = e - j * D;
@@ -285,19 +289,20 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
   lds_barrier();
 }
 
-template <typename T>
+template <typename T, int DI>
 __device__ void load_rows_table(T* dst, const double* table, const int32_t* index, int D, int t) {
   // (`index`: the 32 row numbers, staged in LDS; float64: the thread's loads in flight together)
   if (sizeof(T) == 8) {
-    double r[kXIters];
+    double r[(DI / 2)];
 #pragma unroll
-    for (int u = 0; u < kXIters; ++u) {
+    for (int u = 0; u < (DI / 2); ++u) {
       const int e = t + 256 * u;
-      const int s = e < kB * D ? e / D : 0, d = e - s * D;
-      r[u] = e < kB * D ? table[(size_t)index[s] * D + d] : 0.0;
+      const int ec = e < kB * D ? e : kB * D - 1;   // (unconditional loads, see params_store)
+      const int s = ec / D, d = ec - s * D;
+      r[u] = table[(size_t)index[s] * D + d];
     }
 #pragma unroll
-    for (int u = 0; u < kXIters; ++u) {
+    for (int u = 0; u < (DI / 2); ++u) {
       const int e = t + 256 * u;
       if (e < kB * D) dst[e] = (T)r[u];
     }
@@ -309,18 +314,19 @@ __device__ void load_rows_table(T* dst, const double* table, const int32_t* inde
   }
 }
 
-template <typename T>
+template <typename T, int DI>
 __device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
   if (sizeof(T) == 8) {
-    T r[kXIters];
+    T r[(DI / 2)];
 #pragma unroll
-    for (int u = 0; u < kXIters; ++u) {
+    for (int u = 0; u < (DI / 2); ++u) {
       const int e = t + 256 * u;
-      const int s = e < kB * D ? e / D : 0, d = e - s * D;
-      r[u] = e < kB * D ? src[(size_t)slot[s] * D + d] : (T)0;
+      const int ec = e < kB * D ? e : kB * D - 1;
+      const int s = ec / D, d = ec - s * D;
+      r[u] = src[(size_t)slot[s] * D + d];
     }
 #pragma unroll
-    for (int u = 0; u < kXIters; ++u) {
+    for (int u = 0; u < (DI / 2); ++u) {
       const int e = t + 256 * u;
       if (e < kB * D) dst[e] = r[u];
     }
@@ -332,7 +338,7 @@ __device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
   }
 }
 
-template <typename T>
+template <typename T, int DI>
 __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_dqn_replay_t& R = A.r;
@@ -409,9 +415,9 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   param_regs<T> P, PT;
   params_load<T>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
   params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);
-  params_store<T>(L, PT, tw1, D, t);
-  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, L.idx_n, D, t);
-  else load_rows<T>(L.x, xn, L.slot, D, t);
+  params_store<T, DI>(L, PT, tw1, D, t);
+  if (R.state_index) load_rows_table<T, DI>(L.x, R.obs_table, L.idx_n, D, t);
+  else load_rows<T, DI>(L.x, xn, L.slot, D, t);
   lds_barrier();
   // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
   // end (the other, small tensors are read again with their moments in the backward pass)
@@ -422,7 +428,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       s2[a][b].target = L.wt2[(16 * a + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, b)];
   forward<T>(L, L.qt, D, t);
   // ---- online network -------------------------------------------------------------------------
-  params_store<T>(L, P, w1, D, t);
+  params_store<T, DI>(L, P, w1, D, t);
   lds_barrier();
   if (R.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
     forward<T>(L, L.q, D, t);
@@ -439,8 +445,8 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
     lds_barrier();
   }
-  if (R.state_index) load_rows_table<T>(L.x, R.obs_table, L.idx_s, D, t);
-  else load_rows<T>(L.x, xs, L.slot, D, t);
+  if (R.state_index) load_rows_table<T, DI>(L.x, R.obs_table, L.idx_s, D, t);
+  else load_rows<T, DI>(L.x, xs, L.slot, D, t);
   lds_barrier();
   forward<T>(L, L.q, D, t);
 
@@ -614,17 +620,17 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   //  per trip to memory, as the plain loop of the float32 instantiation does it, was seven exposed
   //  trips at 25 inputs)
   if (sizeof(T) == 8) {
-    adam_slot<T> s1[kW1Iters];
+    adam_slot<T> s1[DI];
 #pragma unroll
-    for (int u = 0; u < kW1Iters; ++u) {
+    for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
-      const bool in = e < kH * D;
-      s1[u].m = in ? m_w1[e] : (T)0;
-      s1[u].v = in ? v_w1[e] : (T)0;
-      s1[u].target = in ? tw1[e] : (T)0;
+      const int ec = e < kH * D ? e : kH * D - 1;   // (unconditional loads, see params_store)
+      s1[u].m = m_w1[ec];
+      s1[u].v = v_w1[ec];
+      s1[u].target = tw1[ec];
     }
 #pragma unroll
-    for (int u = 0; u < kW1Iters; ++u) {
+    for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
       if (e < kH * D) {
         const int j = e / D, d = e - j * D;
@@ -690,17 +696,37 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
 #ifndef COBEL_MLP_WAVES_F32
 #define COBEL_MLP_WAVES_F32 4
 #endif
-template <typename T>
-__global__ __launch_bounds__(256) void k_dqn_replay_lds(const mlp_args A);
-template <>
-__global__ __launch_bounds__(256) void k_dqn_replay_lds<double>(const mlp_args A) {
-  dqn_replay_body<double>(A);
+template <int DI>
+__global__ __launch_bounds__(256) void k_dqn_replay_lds_f64(const mlp_args A) {
+  dqn_replay_body<double, DI>(A);
 }
-template <>
+template <int DI>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(COBEL_MLP_WAVES_F32, COBEL_MLP_WAVES_F32)))
-void k_dqn_replay_lds<float>(const mlp_args A) {
-  dqn_replay_body<float>(A);
+void k_dqn_replay_lds_f32(const mlp_args A) {
+  dqn_replay_body<float, DI>(A);
+}
+
+template <int DI>
+int launch_lds(const mlp_args& A, int32_t lds, hipStream_t st) {
+  const cobel_dqn_replay_t& r = A.r;
+  if (r.is_float64) {
+    // (raised once per device and instantiation: the call is not free and this entry point runs
+    //  every step; a race between two host threads at worst raises the limit twice)
+    static int raised_to[64] = {0};
+    int dev = 0;
+    COBEL_HIP_TRY(hipGetDevice(&dev));
+    if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || raised_to[dev] < lds)) {
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dqn_replay_lds_f64<DI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      if (dev >= 0 && dev < 64) raised_to[dev] = lds;
+    }
+    hipLaunchKernelGGL(k_dqn_replay_lds_f64<DI>, dim3(r.n), dim3(256), lds, st, A);
+  } else {
+    hipLaunchKernelGGL(k_dqn_replay_lds_f32<DI>, dim3(r.n), dim3(256), lds, st, A);
+  }
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
 }
 
 }  // namespace
@@ -716,21 +742,7 @@ int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st) {
   const int32_t lds = (int32_t)cobel_dqn_replay_lds_bytes(r.n_inputs, r.is_float64);
   mlp_args A;
   A.r = r;
-  if (r.is_float64) {
-    // (raised once per device: the call is not free and this entry point runs every step; a race
-    //  between two host threads at worst raises the limit twice)
-    static int raised_to[64] = {0};
-    int dev = 0;
-    COBEL_HIP_TRY(hipGetDevice(&dev));
-    if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || raised_to[dev] < lds)) {
-      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dqn_replay_lds<double>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      if (dev >= 0 && dev < 64) raised_to[dev] = lds;
-    }
-    hipLaunchKernelGGL(k_dqn_replay_lds<double>, dim3(r.n), dim3(256), lds, st, A);
-  } else {
-    hipLaunchKernelGGL(k_dqn_replay_lds<float>, dim3(r.n), dim3(256), lds, st, A);
-  }
-  COBEL_HIP_TRY(hipGetLastError());
-  return COBEL_OK;
+  if (r.n_inputs <= 8) return launch_lds<2>(A, lds, st);
+  if (r.n_inputs <= 16) return launch_lds<4>(A, lds, st);
+  return launch_lds<8>(A, lds, st);
 }
