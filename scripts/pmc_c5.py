@@ -22,7 +22,7 @@ def main():
                         'r%02d_pmc_traffic.json' % rnd)
     out = json.load(open(path))
     fetch, write = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
-    tag = 'k_dqn_replay_lds<%s>' % ('double' if dt == 'f64' else 'float')
+    tag = 'k_dqn_replay_lds_%s<' % dt
     name = [k for k in fetch if tag in k]
     assert len(name) == 1 and name[0] in write, name
     f, w = fetch[name[0]][8:], write[name[0]][8:]
