@@ -249,9 +249,9 @@ def run_dyna_dsr(device, n=8192, iters=97):
     fused = agent.fused_steps > 0
     r['config'] = {'workload': 'Dyna-DSR: %d x 5x5 open field, four online + four target successor '
                                'networks 25-64-64-25 and one reward network f64 per instance, batches '
-                               'of 32, %s' % (n, 'five launches per lockstep step (cobel_dqn_act, 2 x '
-                                              'cobel_mlp_forward, 2 x cobel_mlp_fit) + elementwise '
-                                              'torch for the targets, 8 steps per HIP graph' if fused
+                               'of 32, %s' % (n, 'six launches per lockstep step (cobel_dqn_act, 2 x '
+                                              'cobel_mlp_forward, cobel_dsr_targets, 2 x '
+                                              'cobel_mlp_fit), 8 steps per HIP graph' if fused
                                               else 'PyTorch-ROCm loop, one step per HIP graph'),
                    'instances_per_gpu': n, 'lockstep_iterations': [iters, 2 * iters - 1]}
     # per instance and step: the four online successor networks move 8 streams over their

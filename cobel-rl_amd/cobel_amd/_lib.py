@@ -127,6 +127,21 @@ class MLPFit(C.Structure):
     ]
 
 
+class DSRTargets(C.Structure):
+    """``cobel_dsr_targets_t``."""
+    _fields_ = [
+        ('successor', C.c_void_p), ('value', C.c_void_p), ('table', C.c_void_p),
+        ('state_index', C.c_void_p), ('next_index', C.c_void_p), ('actions', C.c_void_p),
+        ('nonterminal', C.c_void_p), ('targets', C.c_void_p), ('took', C.c_void_p),
+        ('train', C.c_void_p),
+        ('n', C.c_int32), ('n_actions', C.c_int32), ('n_outputs', C.c_int32),
+        ('is_float64', C.c_int32),
+        ('use_dr', C.c_int32), ('follow_up', C.c_int32), ('ignore_terminality', C.c_int32),
+        ('reserved_', C.c_int32),
+        ('gamma', C.c_double),
+    ]
+
+
 class TabRun(C.Structure):
     """``cobel_tab_run_t``."""
     _fields_ = [
@@ -260,6 +275,7 @@ _SIGNATURES['cobel_dqn_act'] = (C.c_int, [_P, C.POINTER(DQNAct), _P])
 _SIGNATURES['cobel_mlp_query'] = (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)])
 _SIGNATURES['cobel_mlp_forward'] = (C.c_int, [C.POINTER(MLPForward), _P])
 _SIGNATURES['cobel_mlp_fit'] = (C.c_int, [C.POINTER(MLPFit), _P])
+_SIGNATURES['cobel_dsr_targets'] = (C.c_int, [C.POINTER(DSRTargets), _P])
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

@@ -53,6 +53,9 @@ class DynaDSR(DynaDQN):
         self.use_DR = False
         self.use_follow_up_state = False
         self.ignore_terminality = True
+        # the fused loop forms its regression targets in one launch (cobel_dsr_targets); False: the
+        # same expressions as elementwise torch kernels (what the kernel is tested against)
+        self.fused_targets = True
         self._reward_net = None
 
     # -- binding --------------------------------------------------------------------------------
@@ -347,11 +350,29 @@ class DynaDSR(DynaDQN):
         tab = table.to(dt)
         lib, world = _lib.lib(), env.handle.ptr
 
+        # the targets between the forward passes and the fits: one launch (cobel_dsr_targets), or —
+        # fused_targets = False, the form the kernel is tested against — the same expressions as
+        # a dozen elementwise torch kernels
+        tgt = _lib.DSRTargets()
+        tgt.successor, tgt.value, tgt.table = _lib.ptr(fsr), _lib.ptr(val), _lib.ptr(table)
+        tgt.state_index, tgt.next_index = _lib.ptr(si), _lib.ptr(ni)
+        tgt.actions, tgt.nonterminal = _lib.ptr(ba), _lib.ptr(bt)
+        tgt.targets, tgt.took, tgt.train = _lib.ptr(y), _lib.ptr(took), _lib.ptr(train)
+        tgt.n, tgt.n_actions, tgt.n_outputs, tgt.is_float64 = n, A, O, f64
+        tgt.use_dr, tgt.follow_up = int(bool(self.use_DR)), int(bool(self.use_follow_up_state))
+        tgt.ignore_terminality, tgt.gamma = int(bool(self.ignore_terminality)), float(self.gamma)
+        fused_targets = bool(self.fused_targets)
+
         def one_step() -> None:
             st = _lib.current_stream(dev)
             _lib.check(lib.cobel_dqn_act(world, C.byref(act), st))
             _lib.check(lib.cobel_mlp_forward(C.byref(fwd_t), st))
             _lib.check(lib.cobel_mlp_forward(C.byref(fwd_r), st))
+            if fused_targets:
+                _lib.check(lib.cobel_dsr_targets(C.byref(tgt), st))
+                _lib.check(lib.cobel_mlp_fit(C.byref(fit_sr), st))
+                _lib.check(lib.cobel_mlp_fit(C.byref(fit_r), st))
+                return
             # agent/dyna_q.py:1079-1118, for all instances at once (as in ``replay``)
             future = fsr.view(n, A, 32, O)
             if self.use_DR:

@@ -682,6 +682,34 @@ COBEL_API int cobel_mlp_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hid
 COBEL_API int cobel_mlp_forward(const cobel_mlp_forward_t* run, void* stream);
 COBEL_API int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream);
 
+/* The regression targets of DynaDSR.replay (agent/dyna_q.py:1079-1131) for all samples of all
+ * agents in ONE launch — what sits between the two forward passes and the two fits of a step:
+ *   best[s]   = argmax_a value[a][s]   (first maximum)      | use_dr: the mean over the actions
+ *   boot_sr   = successor[best[s]][s][:]                     |         of successor[a][s][:]
+ *   nt        = nonterminal[s] != 0
+ *   boot      = next_obs * ((1 - follow_up)(1 - ignore)) * (1 - nt) + boot_sr * min(nt + ignore, 1)
+ *   targets[s][:] = (follow_up ? next_obs : obs) + gamma * boot
+ *   took[a][s] = actions[s] == a;  train[a] = any_s took[a][s]
+ * with obs / next_obs = rows state_index[s] / next_index[s] of the float64 observation table
+ * converted to the network dtype.  Operation order as in the reference's expressions (and in the
+ * PyTorch path of cobel_amd.agent.DynaDSR), element for element. */
+typedef struct {
+  const void* successor;      /* [n][A][32][O] network dtype: target networks on the next states  */
+  const void* value;          /* [n][A][32]    network dtype: reward network on those             */
+  const double* table;        /* [rows][O] float64 observation table                              */
+  const int32_t* state_index; /* [n][32]                                                          */
+  const int32_t* next_index;  /* [n][32]                                                          */
+  const int64_t* actions;     /* [n][32]                                                          */
+  const void* nonterminal;    /* [n][32] network dtype                                            */
+  void* targets;              /* out [n][32][O] network dtype                                     */
+  uint8_t* took;              /* out [n * A][32]                                                  */
+  uint8_t* train;             /* out [n * A]                                                      */
+  int32_t n, n_actions, n_outputs, is_float64;
+  int32_t use_dr, follow_up, ignore_terminality, reserved_;
+  double gamma;
+} cobel_dsr_targets_t;
+COBEL_API int cobel_dsr_targets(const cobel_dsr_targets_t* run, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Everything of one lockstep DQN training step that is not the network: per instance
  *   epsilon-greedy on the given Q-values (policy/greedy.py:40-88) -> env.step

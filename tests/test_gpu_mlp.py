@@ -182,3 +182,51 @@ def test_dyna_dsr_fused_step_equals_torch_loop(torch_cuda):
         # the user-facing single networks hold instance 0's trained weights afterwards
         for x, y in zip(a.models_online[2].get_weights(), a.get_weights(2, False, 0)):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize('dtype_name,switches', [('f64', False), ('f64', True), ('f32', False)])
+def test_dsr_targets_kernel_equals_torch_expressions(torch_cuda, dtype_name, switches):
+    """cobel_dsr_targets (the regression targets of DynaDSR.replay, agent/dyna_q.py:1079-1131, in
+    one launch) against the elementwise torch kernels it replaces inside the fused loop: the same
+    run with ``fused_targets`` on and off ends in the same networks BIT FOR BIT in float64 (same
+    expressions, same operation order; float32: round-off), with default switches and with
+    use_DR / follow-up state / terminality respected."""
+    torch = torch_cuda
+    import bench
+    from cobel_amd.agent import DynaDSR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_gridworld
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    world = make_gridworld(4, 5, terminals=[3], rewards=np.array([[3, 1.0]]), goals=[3],
+                           invalid_transitions=[(6, 7), (7, 6)])
+
+    def run(fused_targets):
+        torch.manual_seed(11)
+        env = Gridworld(world, n_envs=20, seed=5, instance_base=1)
+        ag = DynaDSR(env.observation_space, env.action_space, EpsilonGreedy(0.3),
+                     TorchNetwork(bench._mlp(20, 20, dtype_name)),
+                     TorchNetwork(bench._mlp(20, 1, dtype_name)), gamma=0.9)
+        if switches:
+            ag.use_DR, ag.use_follow_up_state, ag.ignore_terminality = True, True, False
+        ag.fused_targets = fused_targets
+        ag.use_graph = False                     # (eager steps: both forms launch kernel by kernel)
+        ag.train(env, 3, 10, 32)
+        torch.cuda.synchronize()
+        assert ag.fused_steps > 0
+        return ag
+
+    a, b = run(True), run(False)
+    assert torch.equal(a.trial, b.trial) and torch.equal(a.M.counter, b.M.counter)
+    for i in (0, 7, 19):
+        for act in range(4):
+            for tgt in (False, True):
+                for x, y in zip(a.get_weights(act, tgt, i), b.get_weights(act, tgt, i)):
+                    if dtype_name == 'f64' and not switches:
+                        assert np.array_equal(x, y), (i, act, tgt)
+                    else:      # (use_DR: torch's mean may add the four actions in another order)
+                        assert np.allclose(x, y, rtol=1e-9 if dtype_name == 'f64' else 2e-4,
+                                           atol=1e-12 if dtype_name == 'f64' else 1e-5), (i, act, tgt)
+        for x, y in zip(a.get_reward_weights(i), b.get_reward_weights(i)):
+            assert np.allclose(x, y, rtol=1e-9 if dtype_name == 'f64' else 2e-4,
+                               atol=1e-12 if dtype_name == 'f64' else 1e-5)
