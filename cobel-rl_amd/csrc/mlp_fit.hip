@@ -505,7 +505,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     const T* const in_dense =
         R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * rows * D;
     for (int e = t; e < kB * kXRow; e += NT) L.q[e] = (T)0;
-    input_rows<T, NT> xin;
+    input_rows<T, NT, DQN> xin;   // (DQN: batched requests — its prologue has four row sets to fetch)
 
     if (DQN) {
       // ---- Q_target(s') [and the online network's choice among the next actions] ---------------
@@ -513,7 +513,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       tp.request(tw1, tb1, tw2, tb2, tw3, tb3, D, O, wave, lane);
       if (t < kB) L.aux[t] = A.slots ? A.slots[(size_t)j * kB + t] : t;
       lds_barrier();
-      load_inputs<T, NT>(L.x, R.in_table, R.in_table ? A.next_index + (size_t)j * kB : nullptr,
+      load_inputs<T, NT, true>(L.x, R.in_table, R.in_table ? A.next_index + (size_t)j * kB : nullptr,
                          R.in_table ? nullptr : (const T*)A.next_dense + (size_t)j * rows * D, slot,
                          D, t);
       xin.request(R.in_table, in_index, in_dense, slot, D, t);   // (for the pass after this one)
