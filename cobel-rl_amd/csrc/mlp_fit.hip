@@ -59,6 +59,7 @@ struct fit_args {
 };
 struct fwd_args {
   cobel_mlp_forward_t r;
+  int32_t group;   // consecutive instances per workgroup (they share a network)
 };
 
 // Threads of a workgroup talk through LDS only, so its barriers wait for the LDS counter, not for
@@ -347,18 +348,24 @@ __device__ __forceinline__ typename mfma_acc<T>::type output_tile(const weight_o
 // ---------------------------------------------------------------------------------------------
 // Forward only: four waves per instance; wave w owns the 16 neurons n0 = 16 w of a hidden layer
 // for both row tiles (its weights are loaded once), and one of the (up to) four output tiles.
-template <typename T>
+template <typename T, bool GROUPED>
 __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_mlp_forward_t& R = A.r;
-  const int j = (int)blockIdx.x, t = (int)threadIdx.x;
+  const int t = (int)threadIdx.x;
   const int D = R.n_inputs, O = R.n_outputs;
-  if (R.active && !R.active[j / R.act_div]) return;
+  // A workgroup serves `group` consecutive instances that share ONE network (group divides net_div:
+  // the reward network of Dyna-DSR rates the successor features of an agent's four actions): the
+  // weight operands are requested once and stay in registers for all of them.
+  // (GROUPED is a separate instantiation: holding all three operands across the loop costs the
+  //  one-instance form its fourth workgroup per CU)
+  const int G = GROUPED ? A.group : 1;
+  const int j0 = (int)blockIdx.x * G;
   T* const h1 = reinterpret_cast<T*>(lds_raw);   // [32][66]
   T* const h2 = h1 + kB * kRow;                  // [32][66]; before that the inputs x [32][33]
   T* const x = h2;
   const int lane = t & 63, wave = t >> 6;
-  const size_t net = (size_t)(j / R.net_div);
+  const size_t net = (size_t)(j0 / R.net_div);
   const T* const w1 = (const T*)R.w[0] + net * (size_t)kH * D;
   const T* const w2 = (const T*)R.w[1] + net * (size_t)kH * kH;
   const T* const w3 = (const T*)R.w[2] + net * (size_t)O * kH;
@@ -367,33 +374,49 @@ __device__ __forceinline__ void mlp_forward_body(const fwd_args& A) {
       weight_rows<T, 8, false, true>(w1, (const T*)R.b[0] + net * kH, D, D, kH, 16 * wave, lane);
   const weight_op<T, 16> o2 =
       weight_rows<T, 16, true, true>(w2, (const T*)R.b[1] + net * kH, kH, kH, kH, 16 * wave, lane);
-  load_inputs<T, 256, true>(x, R.in_table,
-                      R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
-                      R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, nullptr, D,
-                      t);
-  lds_barrier();
-  dense_relu<T, 8, 2>(o1, x, kXRow, h1, 0, 16 * wave, lane);
-  // (the output layer's operand once the first layer's registers are free: four workgroups per CU)
-  __builtin_amdgcn_sched_barrier(0);
-  const weight_op<T, 16> o3 =
-      weight_rows<T, 16, true, true>(w3, (const T*)R.b[2] + net * O, kH, kH, O, n3, lane);
-  lds_barrier();   // (every read of x is done: h2 takes its place)
-  dense_relu<T, 16, 2>(o2, h1, kRow, h2, 0, 16 * wave, lane);
-  lds_barrier();
-  if (n3 < O) {
-    const typename mfma_acc<T>::type acc = output_tile<T>(o3, h2, m3, lane);
-    T* const out = (T*)R.out + (size_t)j * kB * O;
-    const int a = n3 + (lane & 15);
-    if (a < O) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) out[(m3 + mfma_acc<T>::row(lane, v)) * O + a] = acc[v];
+  weight_op<T, 16> o3;
+  bool have_o3 = false;
+  input_rows<T, 256, true> xin;
+  auto request_inputs = [&](int j) {
+    xin.request(R.in_table, R.in_table ? R.in_index + (size_t)(j / R.in_div) * kB : nullptr,
+                R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * kB * D, nullptr, D, t);
+  };
+  request_inputs(j0);
+  for (int g = 0; g < G; ++g) {
+    const int j = j0 + g;
+    // (uniform: the whole workgroup skips an instance that sits the step out; its inputs were
+    //  requested all the same — addresses of rows that exist)
+    const bool skip = R.active && !R.active[j / R.act_div];
+    if (!skip) xin.store(x, t);
+    if (g + 1 < G) request_inputs(j + 1);   // (the next instance's rows, behind this one's layers)
+    if (skip) continue;
+    lds_barrier();
+    dense_relu<T, 8, 2>(o1, x, kXRow, h1, 0, 16 * wave, lane);
+    // (the output layer's operand once the first layer has been through: registers)
+    if (!have_o3) {
+      __builtin_amdgcn_sched_barrier(0);
+      o3 = weight_rows<T, 16, true, true>(w3, (const T*)R.b[2] + net * O, kH, kH, O, n3, lane);
+      have_o3 = true;
     }
+    lds_barrier();   // (every read of x is done: h2 takes its place)
+    dense_relu<T, 16, 2>(o2, h1, kRow, h2, 0, 16 * wave, lane);
+    lds_barrier();
+    if (n3 < O) {
+      const typename mfma_acc<T>::type acc = output_tile<T>(o3, h2, m3, lane);
+      T* const out = (T*)R.out + (size_t)j * kB * O;
+      const int a = n3 + (lane & 15);
+      if (a < O) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[(m3 + mfma_acc<T>::row(lane, v)) * O + a] = acc[v];
+      }
+    }
+    if (g + 1 < G) lds_barrier();   // (the next instance's inputs go where h2 is being read)
   }
 }
 
-template <typename T>
+template <typename T, bool GROUPED>
 __global__ __launch_bounds__(256) void k_mlp_forward(const fwd_args A) {
-  mlp_forward_body<T>(A);
+  mlp_forward_body<T, GROUPED>(A);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -950,12 +973,21 @@ extern "C" int cobel_mlp_forward(const cobel_mlp_forward_t* run, void* stream) {
   if (r.n == 0) return COBEL_OK;
   fwd_args A;
   A.r = r;
+  // instances that share a network go to one workgroup, four at most (its weights are fetched once)
+  A.group = 1;
+  for (int g = 4; g > 1; --g)
+    if (r.net_div % g == 0 && r.n % g == 0) {
+      A.group = g;
+      break;
+    }
+  const int grid = r.n / A.group;
   hipStream_t st = (hipStream_t)stream;
-  if (r.is_float64) {
-    if (int rc = raise_lds(&k_mlp_forward<double>, lds)) return rc;
-    hipLaunchKernelGGL(k_mlp_forward<double>, dim3(r.n), dim3(256), lds, st, A);
+  if (A.group > 1) {
+    if (r.is_float64) hipLaunchKernelGGL((k_mlp_forward<double, true>), dim3(grid), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_mlp_forward<float, true>), dim3(grid), dim3(256), lds, st, A);
   } else {
-    hipLaunchKernelGGL(k_mlp_forward<float>, dim3(r.n), dim3(256), lds, st, A);
+    if (r.is_float64) hipLaunchKernelGGL((k_mlp_forward<double, false>), dim3(grid), dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_mlp_forward<float, false>), dim3(grid), dim3(256), lds, st, A);
   }
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
