@@ -1,4 +1,5 @@
-// Everything of one lockstep DQN training step that is not the network, one lane per instance:
+// Everything of one lockstep DQN training step that is not the network, one lane per instance
+// (and one lane per sample for the batch draw at the end):
 // epsilon-greedy on the Q-values the replay kernel left behind -> env.step -> append to the replay
 // ring -> trial bookkeeping, monitors, auto-reset -> draw the replay batch.  With cobel_dqn_replay
 // (mlp.hip) a training step is two launches; through PyTorch the same bookkeeping is ~90 small
@@ -131,28 +132,39 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   // ---- replay batch (memory/dqn.py:137): `batch` indices below the number of stored entries --------
   R.stepped[i] = 1;
   if (R.adam_steps) R.adam_steps[i] += 1.0;
+  // (the batch itself is drawn by k_dqn_batch, one lane per SAMPLE: 32 Philox blocks and dependent
+  //  gathers in a row per lane were two thirds of this kernel's time)
+  if (DYNA || R.batch_slots) R.memory_ctr[i] += 1u;
+}
+
+// The replay batch of every instance that took part in this step, one lane per (instance, sample):
+// sub-stream j of ONE counter of the memory stream (the value k_dqn_act has just counted past).
+//   DYNA: memory/dyna_q.py:137-155 — `batch` pairs drawn uniformly from all n_states x 4 pairs, the
+//         model's entries for them gathered;  ring: memory/dqn.py:137 — indices below the number of
+//         stored entries, as ring slots.
+template <typename T, bool DYNA>
+__global__ __launch_bounds__(256) void k_dqn_batch(const act_args A) {
+  const cobel_dqn_act_t& R = A.r;
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(tid / R.batch), j = (int)(tid - (long long)i * R.batch);
+  if (i >= R.n || !R.stepped[i]) return;
+  const uint32_t g = R.instance_base + (uint32_t)i;
+  const uint32_t mc = R.memory_ctr[i] - 1u;
   if (DYNA) {
-    // memory/dyna_q.py:137-155: `batch` pairs drawn uniformly from all n_states x 4 pairs
-    const uint32_t mc = R.memory_ctr[i];
     const uint32_t pairs = (uint32_t)R.n_states * 4u;
-    const size_t base = (size_t)i * pairs, out = (size_t)i * R.batch;
-    for (int j = 0; j < R.batch; ++j) {
-      const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed, pairs);
-      R.batch_state_index[out + j] = (int32_t)(idx >> 2);
-      R.batch_next_index[out + j] = (int32_t)R.model_states[base + idx];
-      R.batch_actions[out + j] = (int64_t)(idx & 3u);
-      ((T*)R.batch_rewards)[out + j] = (T)R.model_rewards[base + idx];
-      ((T*)R.batch_nonterminal)[out + j] = (T)R.model_nonterminal[base + idx];
-    }
-    R.memory_ctr[i] = mc + 1u;
-  } else if (R.batch_slots) {
-    const uint32_t mc = R.memory_ctr[i];
-    for (int j = 0; j < R.batch; ++j) {
-      const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed,
-                                              (uint32_t)size);
-      R.batch_slots[(size_t)i * R.batch + j] = (int32_t)((head + (long long)idx) % slots);
-    }
-    R.memory_ctr[i] = mc + 1u;
+    const size_t base = (size_t)i * pairs, out = (size_t)i * R.batch + j;
+    const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed, pairs);
+    R.batch_state_index[out] = (int32_t)(idx >> 2);
+    R.batch_next_index[out] = (int32_t)R.model_states[base + idx];
+    R.batch_actions[out] = (int64_t)(idx & 3u);
+    ((T*)R.batch_rewards)[out] = (T)R.model_rewards[base + idx];
+    ((T*)R.batch_nonterminal)[out] = (T)R.model_nonterminal[base + idx];
+  } else {
+    const int size = R.ring_size[i], slots = R.slots;
+    const long long head = R.ring_head[i];
+    const uint32_t idx = cobel_draw_bounded(mc, (uint32_t)j, g, COBEL_STREAM_MEMORY, R.seed,
+                                            (uint32_t)size);
+    R.batch_slots[(size_t)i * R.batch + j] = (int32_t)((head + (long long)idx) % slots);
   }
 }
 
@@ -200,5 +212,12 @@ extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* 
   else if (dyna) hipLaunchKernelGGL((k_dqn_act<float, true>), grid, dim3(64), 0, st, A);
   else hipLaunchKernelGGL((k_dqn_act<float, false>), grid, dim3(64), 0, st, A);
   COBEL_HIP_TRY(hipGetLastError());
+  if (r.batch > 0 && (dyna || r.batch_slots)) {
+    const dim3 bgrid((unsigned)(((long long)r.n * r.batch + 255) / 256));
+    if (r.is_float64 && dyna) hipLaunchKernelGGL((k_dqn_batch<double, true>), bgrid, dim3(256), 0, st, A);
+    else if (dyna) hipLaunchKernelGGL((k_dqn_batch<float, true>), bgrid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_dqn_batch<float, false>), bgrid, dim3(256), 0, st, A);   // (slots: no dtype)
+    COBEL_HIP_TRY(hipGetLastError());
+  }
   return COBEL_OK;
 }
