@@ -38,6 +38,11 @@ struct srw_args {
   cobel_eps_consts eps;
   float alpha_f, gamma_f;
   const cobel_rw_info* rw;   // [n_worlds] rewarded states + NumPy's combine order (KX kernels)
+  // NumPy's pairwise sum over S elements (sizes without the 128-element leaf layout; the rare
+  // path with more than two non-zero reward estimates): its leaves and the order they combine in
+  uint32_t leaf[16];         // lo | len << 16
+  uint8_t comb_dst[16], comb_src[16];
+  int32_t n_leaves;
 };
 
 __device__ __forceinline__ int t_of(uint64_t row, int k) { return (int)((row >> (16 * k)) & 0xffffu); }
@@ -107,58 +112,30 @@ __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restric
   }
 }
 
-// np.sum(row * R) over n float32 products in NumPy's pairwise order, by ONE lane (the rare dense
-// path of worlds whose size the leaf layout of dense_values does not fit): blocks of at most 128
-// elements are summed with eight accumulators and combined ((0+1)+(2+3))+((4+5)+(6+7)), longer
-// ranges are split at n / 2 rounded down to a multiple of 8 (numpy/core/src/umath/loops_utils.h).
-__device__ __attribute__((noinline)) float pairwise_dot_one_lane(const float* __restrict__ row,
-                                              const float* __restrict__ R, int n) {
-  // the recursion written out: depth-first, left half before right half (depth <= 4 for n <= 1024)
-  struct frame { int lo, len, state; float left; };
-  frame st[8];
-  int top = 0;
-  st[0] = {0, n, 0, 0.0f};
-  float ret = 0.0f;
-  while (top >= 0) {
-    frame& f = st[top];
-    if (f.state == 0) {
-      if (f.len < 8) {
-        float res = 0.0f;
-        for (int i = 0; i < f.len; ++i) res = res + ld_l2(row + f.lo + i) * ld_l2(R + f.lo + i);
-        ret = res;
-        --top;
-      } else if (f.len <= 128) {
-        float r8[8];
-        for (int k = 0; k < 8; ++k) r8[k] = ld_l2(row + f.lo + k) * ld_l2(R + f.lo + k);
-        int i = 8;
-        for (; i < f.len - (f.len % 8); i += 8)
-          for (int k = 0; k < 8; ++k)
-            r8[k] = r8[k] + ld_l2(row + f.lo + i + k) * ld_l2(R + f.lo + i + k);
-        float res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-        for (; i < f.len; ++i) res = res + ld_l2(row + f.lo + i) * ld_l2(R + f.lo + i);
-        ret = res;
-        --top;
-      } else {
-        int n2 = f.len / 2;
-        n2 -= n2 % 8;
-        f.state = 1;
-        st[top + 1] = {f.lo, n2, 0, 0.0f};
-        ++top;
-      }
-    } else if (f.state == 1) {
-      int n2 = f.len / 2;
-      n2 -= n2 % 8;
-      f.left = ret;
-      f.state = 2;
-      st[top + 1] = {f.lo + n2, f.len - n2, 0, 0.0f};
-      ++top;
-    } else {
-      ret = f.left + ret;
-      --top;
+// The leaves of np.sum over n float32 values and the order their sums combine in (numpy/core/src/
+// umath/loops_utils.h: ranges of more than 128 elements are split at n / 2 rounded down to a
+// multiple of 8; a leaf runs eight accumulators over its multiple-of-eight part, combines them
+// ((0+1)+(2+3))+((4+5)+(6+7)) and adds the remaining elements one by one).  Leaves of a split range
+// are at least 64 long: at most 16 of them up to 1 024 elements.
+struct leaf_plan {
+  srw_args* A;
+  int build(int lo, int len) {
+    if (len <= 128) {
+      const int l = A->n_leaves++;
+      A->leaf[l & 15] = (uint32_t)lo | ((uint32_t)len << 16);
+      return l;
     }
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    const int left = build(lo, n2);
+    const int right = build(lo + n2, len - n2);
+    const int t = n_comb++;
+    A->comb_dst[t & 15] = (uint8_t)left;
+    A->comb_src[t & 15] = (uint8_t)right;
+    return left;
   }
-  return ret;
-}
+  int n_comb = 0;
+};
 
 // Element e of a row held in registers, as a wave-uniform value (e wave-uniform).
 template <int NV>
@@ -191,8 +168,9 @@ __device__ __forceinline__ const srw_args* rare_args() {
 // NV = S / 256 float4 per lane (S = 256, 512, 1024).  OCC: visit counts in LDS.  PSETS: per-
 // instance hyper-parameters.  Six waves per SIMD (80 registers): 24 rows of 4 KiB in flight per
 // CU, more than the ~64 KB per CU that 8 TB/s at 2 us of latency take.
-// ANY_S: any state count that is a multiple of four up to NV * 256 (rows are float4 streams; the
-// register layout is the same, lanes past the end of a row hold zeros and neither load nor store).
+// ANY_S: any state count up to NV * 256: a multiple of four (rows are float4 streams; the register
+// layout is the same, lanes past the end of a row hold zeros and neither load nor store) or, ODD,
+// any other (rows move by element, see load_row).
 // KX: worlds with three to eight rewarded states.  The agent's reward estimate can only be non-zero
 // at those states, so V[j] = sum_k SR[j][k] R[k] is a sum of at most eight products — added in the
 // grouping NumPy's pairwise summation gives exactly these positions (cobel_rw_info, built on the
@@ -200,7 +178,7 @@ __device__ __forceinline__ const srw_args* rare_args() {
 // Lane 8a + n gathers element pos[n] of value row a, holds R[pos[n]] and its product; the k - 1
 // additions run as shuffles inside the groups of eight lanes.  The values of the row a step
 // rewrites are read back from an LDS copy of the new row.
-template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX, bool ODD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
@@ -212,7 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
-  const bool odd = ANY_S && (S & 3) != 0;
+  constexpr bool odd = ANY_S && ODD;   // (a state count that is not a multiple of four)
   // where element e of the row kept in `frow` (an image of the row registers) sits
   auto fpos = [&](int e) -> int {
     return odd ? ((((e >> 8) * 64 + (e & 63)) * 4) + ((e >> 6) & 3)) : e;
@@ -406,14 +384,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // accumulator k of leaf l, then the butterflies of NumPy's combine order (as k_sr does in LDS).
   auto dense_values = [&](uint64_t tq) {
     wait_vm0();
-    float qv[4];
-    if (ANY_S) {   // lane a < 4 sums row T[.][a] alone, in NumPy's order for this length
-      float acc = 0.0f;
-      if (lane < 4) acc = pairwise_dot_one_lane(SRg + (size_t)t_of(tq, lane) * S, Rg, S);
+    if constexpr (ANY_S) {
+      // Leaf L (of at most 16) belongs to the eight lanes 8 (L & 7) .. + 7 in pass L >> 3, one
+      // accumulator each; its sum is then kept by lane 8 (L & 7) + (L >> 3), and the sums combine
+      // in the order of the plan (the result ends up with leaf 0 = lane 0).
+      const srw_args* const R = rare_args();
+      const int nl = R->n_leaves;
+      const int k = lane & 7;
+      for (int a = 0; a < 4; ++a) {
+        const float* const row = SRg + (size_t)t_of(tq, a) * S;
+        float p = 0.0f;
+        for (int half = 0; half < 2; ++half) {
+          const int L = half * 8 + (lane >> 3);
+          int lo = 0, len = 0;
+          if (L < nl) {
+            const uint32_t w = R->leaf[L];
+            lo = (int)(w & 0xffffu);
+            len = (int)(w >> 16);
+          }
+          const int len8 = len & ~7;
+          float acc = 0.0f;
+          if (len8) {
+            acc = ld_l2(row + lo + k) * ld_l2(Rg + lo + k);
+            for (int e = 8 + k; e < len8; e += 8) {
+              const float prod = ld_l2(row + lo + e) * ld_l2(Rg + lo + e);
+              acc = acc + prod;
+            }
+          }
+          acc = acc + __shfl_xor(acc, 1);
+          acc = acc + __shfl_xor(acc, 2);
+          acc = acc + __shfl_xor(acc, 4);
+          float res = len8 ? acc : 0.0f;
+          for (int e = len8; e < len; ++e) {
+            const float prod = ld_l2(row + lo + e) * ld_l2(Rg + lo + e);
+            res = res + prod;
+          }
+          if (k == half) p = res;
+        }
+        for (int t = 0; t + 1 < nl; ++t) {
+          const int d = (int)R->comb_dst[t], sidx = (int)R->comb_src[t];
+          const float other = __shfl(p, 8 * (sidx & 7) + (sidx >> 3));
+          if (lane == 8 * (d & 7) + (d >> 3)) p = p + other;
+        }
+        const float v = rlf(p, 0);
+        q0 = a == 0 ? v : q0;
+        q1 = a == 1 ? v : q1;
+        q2 = a == 2 ? v : q2;
+        q3 = a == 3 ? v : q3;
+      }
       rows_read += 4u;
-      q0 = rlf(acc, 0); q1 = rlf(acc, 1); q2 = rlf(acc, 2); q3 = rlf(acc, 3);
       return;
     }
+    float qv[4];
     const int l = lane >> 3, k = lane & 7;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -619,7 +641,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         reinterpret_cast<float4*>(frow)[j * 64 + lane] = o4;
         // the row the next step starts from: SR[ns], or the row just written after a bump
-        cur.c[j] = (ns == state) ? o4 : cn4;
+        // (component by component: a choice between two float4 objects is compiled into a choice
+        //  between two addresses in scratch memory)
+        const bool bump = ns == state;
+        cur.c[j] = make_float4(bump ? o4.x : cn4.x, bump ? o4.y : cn4.y, bump ? o4.z : cn4.z,
+                               bump ? o4.w : cn4.w);
       }
       lds_row = state;
       if (!KX && want_fresh) {   // the new row's elements e0 / e1, wave-uniform
@@ -697,31 +723,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   }
 }
 
-template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX, bool ODD>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
   if (const size_t pad = cobel_debug_lds_pad(lds + 8 * 1024, 160 * 1024)) {   // (occupancy experiments)
     lds += pad;
     if (lds > 48 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX>),
+          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S, KX>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
-template <int NV, bool ANY_S>
+template <int NV, bool ANY_S, bool ODD = false>
 int launch_nv(const srw_args& A, bool occ, bool psets, bool kx, hipStream_t st) {
   if (kx)   // (three to eight rewarded states; launch-wide hyper-parameters only)
-    return occ ? launch<NV, true, false, ANY_S, true>(A, st)
-               : launch<NV, false, false, ANY_S, true>(A, st);
+    return occ ? launch<NV, true, false, ANY_S, true, ODD>(A, st)
+               : launch<NV, false, false, ANY_S, true, ODD>(A, st);
   if (psets)
-    return occ ? launch<NV, true, true, ANY_S, false>(A, st)
-               : launch<NV, false, true, ANY_S, false>(A, st);
-  return occ ? launch<NV, true, false, ANY_S, false>(A, st)
-             : launch<NV, false, false, ANY_S, false>(A, st);
+    return occ ? launch<NV, true, true, ANY_S, false, ODD>(A, st)
+               : launch<NV, false, true, ANY_S, false, ODD>(A, st);
+  return occ ? launch<NV, true, false, ANY_S, false, ODD>(A, st)
+             : launch<NV, false, false, ANY_S, false, ODD>(A, st);
 }
 
 }  // namespace
@@ -730,9 +756,9 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   const int S = world->n_states;
   // rows are streamed as float4 groups: any multiple of four up to 1 024 states (256 / 512 /
   // 1 024 fill the register layout exactly and take instantiations without bounds checks)
-  // (state counts that are not multiples of four: rows move one element at a time, which beats
-  //  the row-streaming kernel up to ~640 states: 17x17 6.3e8 env-steps/s against 3.0e8, 25x25
-  //  3.3e8 against 2.8e8, 31x31 2.3e8 against 2.5e8 — scripts/exp_sr_sizes.py)
+  // (state counts that are not multiples of four: rows move one element per lane and instruction,
+  //  the ODD instantiations: 17x17 1.26e9 env-steps/s, 25x25 8.7e8, 31x31 7.2e8 against 3.0 / 2.8 /
+  //  2.5e8 of the row-streaming kernel — scripts/exp_sr_sizes.py)
   // at most two rewarded states (every maze / open field builder of the reference), or up to eight
   // with launch-wide hyper-parameters (the KX kernels)
   const bool rewards_ok = world->max_rewarded_states <= 2 ||
@@ -754,12 +780,24 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.rw = world->rw;
+  A.n_leaves = 0;
+  for (int t = 0; t < 16; ++t) A.leaf[t] = 0u, A.comb_dst[t] = A.comb_src[t] = 0;
+  leaf_plan plan{&A};
+  plan.build(0, world->n_states);
+  COBEL_REQUIRE(A.n_leaves <= 16 && plan.n_comb == A.n_leaves - 1, COBEL_E_ARG,
+                "cobel_sr_run: pairwise plan out of range");
   const bool occ = r.occupancy != nullptr, psets = r.param_index != nullptr;
   const bool kx = world->max_rewarded_states > 2;
   const int S = world->n_states;
   if (S == 256) return launch_nv<1, false>(A, occ, psets, kx, st);
   if (S == 512) return launch_nv<2, false>(A, occ, psets, kx, st);
   if (S == 1024) return launch_nv<4, false>(A, occ, psets, kx, st);
+  if (S & 3) {   // rows that are not float4 streams: instantiations of their own
+    if (S <= 256) return launch_nv<1, true, true>(A, occ, psets, kx, st);
+    if (S <= 512) return launch_nv<2, true, true>(A, occ, psets, kx, st);
+    if (S <= 768) return launch_nv<3, true, true>(A, occ, psets, kx, st);
+    return launch_nv<4, true, true>(A, occ, psets, kx, st);
+  }
   if (S <= 256) return launch_nv<1, true>(A, occ, psets, kx, st);
   if (S <= 512) return launch_nv<2, true>(A, occ, psets, kx, st);
   if (S <= 768) return launch_nv<3, true>(A, occ, psets, kx, st);

@@ -269,14 +269,15 @@ def test_wave_kernel_any_multiple_of_four_states(torch_cuda, h, w):
 
 def test_wave_kernel_any_size_with_many_reward_estimates(torch_cuda):
     """More than two non-zero reward estimates (set by the caller; the world itself has two
-    rewarded states) on a size without the 128-element leaf layout: the kernel's one-lane pairwise
-    sums equal the row-streaming kernel's values, step for step."""
+    rewarded states) on sizes without the 128-element leaf layout: the kernel's pairwise sums (the
+    leaves of NumPy's recursion spread over groups of eight lanes; 1 015 and 1 023 states have nine
+    leaves and take the second pass) equal the row-streaming kernel's values, step for step."""
     torch = torch_cuda
     from cobel_amd.agent import SR
     from cobel_amd.interface import Gridworld
     from cobel_amd.misc.gridworld_tools import make_gridworld
     from cobel_amd.policy import EpsilonGreedy
-    for h, w in ((10, 10), (18, 22), (3, 4), (5, 5), (9, 11), (21, 27)):
+    for h, w in ((10, 10), (18, 22), (3, 4), (5, 5), (9, 11), (21, 27), (29, 35), (31, 33), (12, 43)):
         S = h * w
         world = make_gridworld(h, w, terminals=[S - 1], rewards=np.array([[S - 1, 1.0]]), goals=[S - 1])
 
