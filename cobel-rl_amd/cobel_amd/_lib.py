@@ -264,6 +264,7 @@ _SIGNATURES = {
     'cobel_sr_run': (C.c_int, [_P, C.POINTER(SRRun), _P]),
     'cobel_sr_retrieve_q': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'cobel_sfma_query': (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
+    'cobel_sfma_exp_check': (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]),
     'cobel_sfma_run': (C.c_int, [_P, C.POINTER(SFMARun), _P]),
     'cobel_adam_step': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P,

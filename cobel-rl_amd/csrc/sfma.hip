@@ -126,6 +126,30 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   v = fmax(v, dpp_f64<0x143, 0xc>(v, v));   // row_bcast:31 into rows 2, 3
   return readlane_f64(v, 63);
 }
+// max over the wave of doubles that are >= +0 and not NaN: their order is the order of their bit
+// patterns, so the maximum is the largest high word and, among its holders, the largest low word —
+// twelve 32-bit DPP maxima instead of six float64 maxima with two DPP moves each.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  // (the compiler keeps DPP move and maximum apart — three instructions per stage; the fused form
+  //  needs two wait states after the write of its DPP operand, which inline assembly must supply)
+  asm volatile(
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double wave_max_nonneg_f64(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t hi = (uint32_t)(b >> 32), lo = (uint32_t)b;
+  const uint32_t mh = wave_max_u32(hi);
+  const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+  return __builtin_bit_cast(double, ((uint64_t)mh << 32) | (uint64_t)ml);
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
@@ -174,6 +198,37 @@ __device__ __forceinline__ int wave_first_equal(const double* P, int n4, int chu
 // random / dynamic replays, no strength modulation or decay, no per-step host log, occupancy,
 // replay trace or per-instance latency trace — with those run-time switches fixed at compile time,
 // so that the flags and pointers behind them do not have to stay live across the step loop.
+// a / b for many a and one b, given y = 1 / b correctly rounded (one division per reactivation
+// instead of one per experience): q0 = RN(a y), r = a - b q0 (exact in an fma), RN(q0 + r y) is the
+// correctly rounded quotient (Markstein 1990) — the bits of a / b unless b's significand is all
+// ones or the residual leaves the normal range, which the priorities never do.
+__device__ __forceinline__ double quotient_by(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-q0, b, a);
+  return __builtin_fma(r, y, q0);
+}
+
+// exp(x) for 0 <= x <= 700 as the device library evaluates it (argument reduction by ln 2 in two
+// parts, its degree-11 polynomial, ldexp) without the overflow / underflow selections: the same
+// bits for these arguments, six vector instructions fewer per experience.
+__device__ __forceinline__ double exp_in_range(double x) {
+  const double t = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(t, -0x1.62e42fefa39efp-1, x);
+  r = __builtin_fma(t, -0x1.abc9e3b39803fp-56, r);
+  double p = __builtin_fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = __builtin_fma(r, p, 0x1.71dee623fde64p-19);
+  p = __builtin_fma(r, p, 0x1.a01997c89e6b0p-16);
+  p = __builtin_fma(r, p, 0x1.a01a014761f6ep-13);
+  p = __builtin_fma(r, p, 0x1.6c16c1852b7b0p-10);
+  p = __builtin_fma(r, p, 0x1.1111111122322p-7);
+  p = __builtin_fma(r, p, 0x1.55555555502a1p-5);
+  p = __builtin_fma(r, p, 0x1.5555555555511p-3);
+  p = __builtin_fma(r, p, 0x1.000000000000bp-1);
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  return __builtin_ldexp(p, (int)t);
+}
+
 template <int CH, int NW, bool FAST = false>
 __device__ __forceinline__ void sfma_body(const sfma_args A) {
   static_assert(CH == 0 || NW == 1, "the register path is one wave per instance");
@@ -525,13 +580,18 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           p[k] = inb[k] ? R : 0.0;
           rmax = fmax(rmax, p[k]);
         }
-        rmax = block_max(rmax);
+        // (FAST: r_threshold >= 0 and strengths, similarities and 1 - I are >= 0 — checked on the
+        //  host, resp. true of what the fast launch admits — so the ratings are >= +0)
+        rmax = FAST ? wave_max_nonneg_f64(rmax) : block_max(rmax);
         if (!(rmax > 0.0)) break;
         // softmax weights exp(beta R / max R) - 1 (:319-327, :349-372)
         bool some = false;
+        const double inv_rmax = 1.0 / rmax;
 #pragma unroll
         for (int k = 0; k < CHN; ++k) {
-          const double w = exp((p[k] / rmax) * L.epsc[15]) + -1.0;
+          // (FAST: 0 <= R / max R * beta <= 700 is checked on the host)
+          const double x = quotient_by(p[k], rmax, inv_rmax) * L.epsc[15];
+          const double w = (FAST ? exp_in_range(x) : exp(x)) + -1.0;
           p[k] = inb[k] ? w : 0.0;
           some = some || p[k] > 0.0;
         }
@@ -619,10 +679,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
       } else {
         // softmax(R, offset -1, beta) = exp(beta R) - 1 (:349-372), then the draw
         double wmax = 0.0;
+        const double inv_rmax = 1.0 / rmax;
         for (int k = 0; k < chunk; ++k)
           if (j0 + k < n4) {
             double R = L.P[j0 + k];
-            if (sf & COBEL_SF_R_NORMALIZE) R = R / rmax;
+            if (sf & COBEL_SF_R_NORMALIZE) R = quotient_by(R, rmax, inv_rmax);
             const double w = exp(R * L.epsc[15]) + -1.0;
             L.P[j0 + k] = w;
             wmax = fmax(wmax, w);
@@ -930,6 +991,34 @@ extern "C" int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes) {
   return COBEL_OK;
 }
 
+namespace {
+__global__ void k_exp_check(const double* x, double* a, double* b, const double* d, double* qa,
+                            double* qb, int n) {
+  const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e < n) {
+    a[e] = exp_in_range(x[e]);
+    b[e] = exp(x[e]);
+    if (d) {
+      qa[e] = quotient_by(x[e], d[e], 1.0 / d[e]);
+      qb[e] = x[e] / d[e];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int cobel_sfma_exp_check(const double* x, double* in_range, double* library,
+                                    const double* divisor, double* quotient_by_reciprocal,
+                                    double* quotient, int32_t n, void* stream) {
+  COBEL_REQUIRE(x && in_range && library && n >= 0 &&
+                    (!divisor || (quotient_by_reciprocal && quotient)),
+                COBEL_E_ARG, "cobel_sfma_exp_check: bad arguments");
+  if (n == 0) return COBEL_OK;
+  hipLaunchKernelGGL(k_exp_check, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
+                     in_range, library, divisor, quotient_by_reciprocal, quotient, n);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}
+
 extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run,
                               void* stream) {
   if (int rc = cobel_world_check4(world, "cobel_sfma_run")) return rc;
@@ -991,6 +1080,7 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
     const bool fast = (r.flags & COBEL_F_LEARN) &&
                       !(r.flags & (COBEL_F_NO_REPLAY | COBEL_F_TEST_STREAM)) &&
                       !(r.sfma_flags & slow_sf) && r.nb_replays == 1 && r.decay_strength == 1.0 &&
+                      r.beta >= 0.0 && r.beta <= 700.0 && r.r_threshold >= 0.0 &&
                       !r.last_exp && !r.occupancy && !r.replay_trace && !r.lat_trace;
     if (fast) {
       hipLaunchKernelGGL(k_sfma_2_fast, dim3(A.r.n), dim3(64), (size_t)lds, st, A);

@@ -32,7 +32,7 @@ size_t cobel_debug_lds_pad(size_t base, size_t limit) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1013; }
+extern "C" int cobel_abi_version(void) { return 1014; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {

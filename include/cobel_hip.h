@@ -537,6 +537,14 @@ typedef struct {
 /* 0 = supported; fills *lds_bytes with the LDS one instance needs. */
 COBEL_API int cobel_sfma_query(int32_t n_states, int32_t* lds_bytes);
 COBEL_API int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run, void* stream);
+/* For tests: exp(x[i]) by the routine the plain-training SFMA kernel uses for its softmax weights
+ * (arguments in [0, 700], memory/sfma.py:349-372) and by the device library's exp, which every
+ * other instantiation calls; the two must agree bit for bit on that range.  With `divisor`: x[i] /
+ * divisor[i] through the reciprocal the kernels share over a reactivation's experiences, and by
+ * the division it replaces (the normalisation R / max R, memory/sfma.py:319-321).  Device pointers. */
+COBEL_API int cobel_sfma_exp_check(const double* x, double* in_range, double* library,
+                                   const double* divisor, double* quotient_by_reciprocal,
+                                   double* quotient, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused Adam step for network parameters stacked over instances (the DQN path keeps one network

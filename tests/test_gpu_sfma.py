@@ -490,3 +490,40 @@ def test_sfma_abi_argument_checks_and_zero_work(Z):
     assert lib.cobel_sfma_query(25, C.byref(lds)) == 0 and lds.value > 25 * 128
     with pytest.raises(NotImplementedError):                                   # table larger than LDS
         _lib.check(lib.cobel_sfma_query(40 * 40, C.byref(lds)))
+
+
+def test_in_range_exp_and_shared_reciprocal_equal_the_library_bit_for_bit():
+    """The plain-training kernel evaluates its softmax weights exp(beta R / max R) - 1
+    (memory/sfma.py:349-372) with the device library's exp stripped of the overflow / underflow
+    selections (arguments in [0, 700], checked on the host): same bits on that range — two million
+    arguments: a uniform sweep, values next to multiples of ln 2 / 2 and tiny ones."""
+    import torch
+    from cobel_amd import _lib
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    parts = [torch.rand(1_000_000, generator=gen, device='cuda', dtype=torch.float64) * 700.0,
+             torch.rand(400_000, generator=gen, device='cuda', dtype=torch.float64) * 12.0,
+             torch.rand(200_000, generator=gen, device='cuda', dtype=torch.float64) * 1e-6,
+             torch.tensor([0.0, 700.0, 1.0, 9.0, 5e-324, 1e-300], device='cuda', dtype=torch.float64)]
+    k = torch.arange(0, 2020, device='cuda', dtype=torch.float64) * (0.6931471805599453 / 2)
+    for d in (-2e-13, -1e-16, 0.0, 1e-16, 2e-13):
+        parts.append((k * (1.0 + d)).clamp_(0.0, 700.0))
+    x = torch.cat(parts).contiguous()
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    # priorities R <= max R: the quotient through the shared reciprocal against the division
+    d = torch.rand(x.numel(), generator=gen, device='cuda', dtype=torch.float64) * 3.0 + 1e-9
+    d[::7] = torch.exp((torch.rand(d[::7].numel(), generator=gen, device='cuda', dtype=torch.float64)
+                        - 0.5) * 80.0)
+    num = d * torch.rand(x.numel(), generator=gen, device='cuda', dtype=torch.float64)
+    num[::11] = d[::11]
+    qa, qb = torch.empty_like(x), torch.empty_like(x)
+    lib = _lib.lib()
+    _lib.check(lib.cobel_sfma_exp_check(x.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, None,
+                                        x.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert torch.allclose(a, torch.exp(x), rtol=4e-16, atol=0.0)
+    _lib.check(lib.cobel_sfma_exp_check(num.data_ptr(), a.data_ptr(), b.data_ptr(), d.data_ptr(),
+                                        qa.data_ptr(), qb.data_ptr(), x.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(qa.view(torch.int64), qb.view(torch.int64))
+    assert torch.equal(qb, num / d)
