@@ -100,14 +100,16 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
 // reactivation is a chain of five dependent wave-wide reductions / scans, so their latency is the
 // critical path.  Controls: quad_perm 0x00-0xff, row_shr:n 0x110+n, wave_shr:1 0x138, row_mirror
 // 0x140, row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.
-template <int CTRL, int ROW_MASK = 0xf>
+// (ZERO_FILL: lanes whose source lane does not exist read 0 — bound_ctrl — instead of keeping
+//  `old`: with every row enabled the destination needs no initialisation, two moves less per use)
+template <int CTRL, int ROW_MASK = 0xf, bool ZERO_FILL = false>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
   const uint64_t b = __builtin_bit_cast(uint64_t, v), o = __builtin_bit_cast(uint64_t, old);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)b,
-                                                            CTRL, ROW_MASK, 0xf, false);
+                                                            CTRL, ROW_MASK, 0xf, ZERO_FILL);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32),
                                                             (int)(uint32_t)(b >> 32), CTRL,
-                                                            ROW_MASK, 0xf, false);
+                                                            ROW_MASK, 0xf, ZERO_FILL);
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -157,10 +159,10 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 // inclusive prefix sum over the lanes
 __device__ __forceinline__ double wave_scan_f64(double v) {
-  v = v + dpp_f64<0x111>(0.0, v);           // row_shr:1
-  v = v + dpp_f64<0x112>(0.0, v);           // row_shr:2
-  v = v + dpp_f64<0x114>(0.0, v);           // row_shr:4
-  v = v + dpp_f64<0x118>(0.0, v);           // row_shr:8: prefix within each row of 16
+  v = v + dpp_f64<0x111, 0xf, true>(0.0, v);   // row_shr:1
+  v = v + dpp_f64<0x112, 0xf, true>(0.0, v);   // row_shr:2
+  v = v + dpp_f64<0x114, 0xf, true>(0.0, v);   // row_shr:4
+  v = v + dpp_f64<0x118, 0xf, true>(0.0, v);   // row_shr:8: prefix within each row of 16
   v = v + dpp_f64<0x142, 0xa>(0.0, v);      // rows 1, 3 += last lane of the row before
   v = v + dpp_f64<0x143, 0xc>(0.0, v);      // rows 2, 3 += lane 31
   return v;
@@ -293,7 +295,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     for (int k = 0; k < chunk; ++k)
       if (j0 + k < n4) loc = loc + L.P[j0 + k];
     const double incl = wave_scan_f64(loc);
-    double excl = dpp_f64<0x138>(0.0, incl);   // wave_shr:1, lane 0 keeps 0
+    double excl = dpp_f64<0x138, 0xf, true>(0.0, incl);   // wave_shr:1, lane 0 reads 0
     if (NW > 1) {   // add the totals of the waves before this one
       double* const r = L.red + (slot++ & 3) * 8;
       if (lane == 63) r[wave] = incl;
@@ -479,6 +481,9 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
   };
 
   // SFMAMemory.replay (memory/sfma.py:238-347) [+ the TD updates of SFMA.replay when `update`]
+  // (the kernels with experiences in registers are launched without the normalisation switches)
+  const bool c_norm = CH == 0 && (sf & COBEL_SF_C_NORMALIZE);
+  const bool d_norm = CH == 0 && (sf & COBEL_SF_D_NORMALIZE);
   auto sfma_replay = [&](int start_state, bool update, int kind, int tr) {
     int action = (int)cobel_draw_bounded(cm, 0u, g, COBEL_STREAM_MEMORY, seed, 4u);
     cm += 1u;
@@ -505,7 +510,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     int nxt = (int)(L.NS[action * S + cur] & 0x7fffu);
     for (int e = t; e < S; e += NT) L.I[e] = 0.0;
     double cmax = 1.0;
-    if (sf & COBEL_SF_C_NORMALIZE) {
+    if (c_norm) {
       double m = -__builtin_huge_val();
       for (int e = t; e < n4; e += NT) m = fmax(m, L.C[e]);
       cmax = block_max(m);
@@ -519,14 +524,14 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
         const double* const rc = Dm + (size_t)cur * S;
         const double* const rn = Dm + (size_t)nxt * S;
         double dmax = 1.0;
-        if (sf & COBEL_SF_D_NORMALIZE) {
+        if (d_norm) {
           double m = -__builtin_huge_val();
           for (int e = t; e < S; e += NT) m = fmax(m, rc[e]);
           dmax = block_max(m);
         }
         for (int e = t; e < S; e += NT) {
           const double d = rc[e];
-          L.Dc[e] = (sf & COBEL_SF_D_NORMALIZE) ? d / dmax : d;
+          L.Dc[e] = d_norm ? d / dmax : d;
           if (need_next) L.Dn[e] = rn[e];
         }
       }
@@ -605,7 +610,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
 #pragma unroll
         for (int k = 1; k < CHN; ++k) loc = loc + p[k];
         const double incl = wave_scan_f64(loc);
-        const double excl = dpp_f64<0x138>(0.0, incl);
+        const double excl = dpp_f64<0x138, 0xf, true>(0.0, incl);
         const double total = readlane_f64(excl + loc, (n4 - 1) / CHN);
         const double thr = u * total;
         int idx = 0;
@@ -641,7 +646,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
           const int j = j0 + k;
           if (j < n4) {
             double c = L.C[j];
-            if (sf & COBEL_SF_C_NORMALIZE) c = c / cmax;
+            if (c_norm) c = c / cmax;
             double d;
             if (mode == COBEL_SFMA_DEFAULT) d = L.Dc[s];
             else if (mode == COBEL_SFMA_FORWARD) d = L.Dn[s];
