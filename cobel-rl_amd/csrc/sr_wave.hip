@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       // (the one row whose store may still be on its way to L2 is the one in `frow`)
       if (n < nz && j != fresh) {
         if (j == lds_row) gv = frow[fpos(n ? e1 : e0)];
-        else gv = ld_l2(SRg + (size_t)j * S + (n ? e1 : e0));
+        else gv = ld_l2(SRg + ((uint32_t)j * (uint32_t)S + (uint32_t)(n ? e1 : e0)));
       }
     }
     gathers += (uint32_t)(4 * nz);
@@ -357,7 +357,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int j = t_of(tq, (lane >> 3) & 3);
     if (lane < 32 && (lane & 7) < Kw && j != fresh) {
       if (j == lds_row) gv = frow[fpos((int)elane)];
-      else gv = ld_l2(SRg + (size_t)j * S + elane);
+      // (a 32-bit element offset from the wave-uniform table address: a 64-bit per-lane address
+      //  SRg + elane is loop-invariant, was hoisted, spilled at the 80-register cap and reloaded
+      //  here behind s_waitcnt vmcnt(0) — which made every gather wait for the row load before it)
+      else gv = ld_l2(SRg + ((uint32_t)j * (uint32_t)S + elane));
     }
     gathers += (uint32_t)(4 * Kw);
     return gv;
