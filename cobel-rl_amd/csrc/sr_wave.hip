@@ -94,12 +94,14 @@ __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restric
     // that every load instruction reads 64 consecutive floats (one pass over each cache line)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int e = (4 * j) * 64 + lane;
+      // (unsigned 32-bit element offsets from the wave-uniform row address: nothing 64-bit and
+      //  per-lane for the compiler to hoist out of the step loop and spill)
+      const uint32_t e = (uint32_t)((4 * j) * 64 + lane), n = (uint32_t)S;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < S) v.x = src[e];
-      if (e + 64 < S) v.y = src[e + 64];
-      if (e + 128 < S) v.z = src[e + 128];
-      if (e + 192 < S) v.w = src[e + 192];
+      if (e < n) v.x = src[e];
+      if (e + 64u < n) v.y = src[e + 64u];
+      if (e + 128u < n) v.z = src[e + 128u];
+      if (e + 192u < n) v.w = src[e + 192u];
       d.c[j] = v;
     }
     return;
@@ -634,11 +636,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         o4.z = upd1(e + 2 * de, cs4.z, cn4.z);
         o4.w = upd1(e + 3 * de, cs4.w, cn4.w);
         if (odd) {
-          float* const o1 = SRg + (size_t)state * S + e;
-          if (e < S) o1[0] = o4.x;
-          if (e + 64 < S) o1[64] = o4.y;
-          if (e + 128 < S) o1[128] = o4.z;
-          if (e + 192 < S) o1[192] = o4.w;
+          float* const o1 = SRg + (size_t)state * S;   // (wave-uniform; 32-bit offsets, as load_row)
+          const uint32_t ue = (uint32_t)e, n = (uint32_t)S;
+          if (ue < n) o1[ue] = o4.x;
+          if (ue + 64u < n) o1[ue + 64u] = o4.y;
+          if (ue + 128u < n) o1[ue + 128u] = o4.z;
+          if (ue + 192u < n) o1[ue + 192u] = o4.w;
         } else if (!ANY_S || j * 64 + lane < quads) {
           out[j * 64] = o4;
         }
