@@ -51,6 +51,8 @@ struct sfma_lds {
                  //      interp_fwd, interp_rev, decay_inhibition, i_step, alpha, gamma, beta
 };
 
+constexpr int kFastStates = 32;   // 4 S <= 128 experiences, two per lane
+
 __host__ __device__ __forceinline__ size_t sfma_lds_bytes(int S) {
   return (((size_t)S * (16 + 32 + 32 + 8 + 8 + 8 + 16 + 8) + 15) & ~(size_t)15) + 256 + 384 + 128;
 }
@@ -237,7 +239,9 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int NT = 64 * NW;
   const int S = A.S, n4 = 4 * A.S, chunk = A.chunk;
-  const sfma_lds L = carve(lds_raw, S);
+  // (FAST: two experiences per lane means at most kFastStates states — the layout of that many, so
+  //  that every LDS address is a compile-time offset instead of ten scalar registers)
+  const sfma_lds L = FAST ? carve(lds_raw, kFastStates) : carve(lds_raw, S);
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
   int slot = 0;   // rotating scratch slot: one barrier per cross-wave reduction
@@ -1088,7 +1092,7 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
                       r.beta >= 0.0 && r.beta <= 700.0 && r.r_threshold >= 0.0 &&
                       !r.last_exp && !r.occupancy && !r.replay_trace && !r.lat_trace;
     if (fast) {
-      hipLaunchKernelGGL(k_sfma_2_fast, dim3(A.r.n), dim3(64), (size_t)lds, st, A);
+      hipLaunchKernelGGL(k_sfma_2_fast, dim3(A.r.n), dim3(64), sfma_lds_bytes(kFastStates), st, A);
       COBEL_HIP_TRY(hipGetLastError());
       return COBEL_OK;
     }
