@@ -951,7 +951,8 @@ __global__ __launch_bounds__(64) void k_sfma(const sfma_args A) {
 // instead of the four the register allocation settles on by itself — +12 % on C6 —, six for the
 // plain-training instantiation since the constants of the masked action selection and the ones a
 // reactivation uses once (L.epsc) are read from LDS instead of being pinned to vector registers
-// (80 registers, no scratch: +5 %; seven waves measure the same, eight 5 % less).  The same hint
+// (80 registers, no scratch: +5 %; seven waves measure the same, eight 5 % less; 69 registers —
+// seven waves resident — since the LDS layout is fixed at compile time).  The same hint
 // costs the wider variants 20-25 % (spills into scratch), so they keep the default.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sfma_2(
     const sfma_args A) {
