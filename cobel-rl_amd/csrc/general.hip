@@ -272,7 +272,7 @@ namespace {
 // One lane per instance; nothing is shared between lanes, so lanes return as they finish.
 template <int AGENT>
 __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
-  const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (blocks of 8 .. 64 lanes, see the launch)
   if (i >= G.r.n) return;
   const int S = G.S, A = G.A;
   const uint32_t g = G.r.instance_base + (uint32_t)i;
@@ -602,11 +602,18 @@ int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r,
   G.alpha_f = (float)r.alpha;
   G.gamma_f = (float)r.gamma;
   G.model_lr_f = (float)r.model_lr;
-  const dim3 grid((unsigned)((r.n + 63) / 64));
+  // Lanes per workgroup.  The lanes share nothing, and a lane spends its time waiting for its own
+  // dependent table reads: 65 536 instances as 1 024 full waves are ONE wave per SIMD, with nobody to
+  // run while it waits.  Narrower workgroups (a wave each, partly filled) put up to eight waves on
+  // a SIMD: six-action hexagonal QAgent, 65 536 instances: 3.73 (64 lanes) / 4.08 (32) / 4.11 (16) /
+  // 4.23e8 env-steps/s (8).  Full waves again once there are enough instances to fill the chip.
+  int lpb = 64;
+  while (lpb > 8 && (long long)r.n < 8192ll * lpb) lpb >>= 1;
+  const dim3 grid((unsigned)((r.n + lpb - 1) / lpb));
   if (r.agent == COBEL_AGENT_DYNAQ)
-    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_DYNAQ>), grid, dim3(64), 0, st, G);
+    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_DYNAQ>), grid, dim3(lpb), 0, st, G);
   else
-    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_Q>), grid, dim3(64), 0, st, G);
+    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_Q>), grid, dim3(lpb), 0, st, G);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
