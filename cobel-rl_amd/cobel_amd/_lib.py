@@ -160,7 +160,13 @@ class TabRun(C.Structure):
         ('model_lr', C.c_double), ('seed', C.c_uint64),
         ('param_sets', C.c_void_p), ('param_index', C.c_void_p), ('n_param_sets', C.c_int32),
         ('mon_stripes', C.c_int32), ('batches_done', C.c_void_p),
+        ('scratch', C.c_void_p), ('scratch_bytes', C.c_int64),
     ]
+
+
+def tab_scratch_bytes(n: int) -> int:
+    """``COBEL_TAB_SCRATCH_BYTES(n)``."""
+    return (256 + 7 * (int(n) + 8)) * 4
 
 
 SFMA_MODES = ('default', 'reverse', 'forward', 'blend_forward', 'blend_reverse', 'interpolate',

@@ -36,6 +36,11 @@ class TabularAgent(FusedAgent):
         # planning / replay batches the kernels evaluated (cobel_tab_run_t.batches_done): a Dyna-Q
         # batch is drawn every learning step, but evaluated only if it can change a table
         self.batches_done = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # work area of a launch (cobel_tab_run_t.scratch: ticket and slice counters of the
+        # persistent-workgroup Dyna-Q kernel), one per agent: agents that share a world handle may
+        # be in flight together
+        self._scratch = torch.empty(_lib.tab_scratch_bytes(self.n_envs) // 4, dtype=torch.int32,
+                                    device=self.device)
         if self._q_host is not None:
             self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
 
@@ -103,6 +108,7 @@ class TabularAgent(FusedAgent):
         run.occupancy = _lib.ptr(mon.occupancy)
         run.steps_done = _lib.ptr(mon.steps_done)
         run.batches_done = _lib.ptr(self.batches_done)
+        run.scratch, run.scratch_bytes = _lib.ptr(self._scratch), self._scratch.numel() * 4
         run.last_exp = _lib.ptr(self._last_exp) if budget == 1 else None
         run.n, run.trial_cap = self.n_envs, mon.cap
         run.instance_base = interface.instance_base

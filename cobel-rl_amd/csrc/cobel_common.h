@@ -38,7 +38,8 @@ struct cobel_world {
   int32_t* start_off;    // [dev] [n_worlds + 1]
   int32_t* h_start_off;  // [host] copy for argument checks
   int32_t max_rewarded_states;  // max over worlds of #{s : reward[s] != 0}
-  uint32_t* queue;       // [dev] one word: instance counter of the persistent-workgroup kernel
+  uint32_t* queue;       // [dev] 256 B: ticket counters of the persistent-workgroup kernel for calls
+                         // that bring no scratch area (cobel_tab_run_t.scratch)
   cobel_rw_info* rw;     // [dev] [n_worlds] rewarded states + pairwise combine order (four-action worlds)
   // action counts other than four (cobel_world_create_n): `rec` is NULL and these hold the world
   int32_t n_actions;
@@ -85,6 +86,7 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r);
 int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipStream_t st);
 
 int cobel_fail(int code, const char* fmt, ...);
+int cobel_device_limits(int device, int* n_cu, size_t* lds_per_cu);   // world.hip (cached per device)
 // COBEL_DEBUG_LDS_PAD=<bytes> (occupancy experiments, scripts/exp_occ*.py): extra dynamic LDS per
 // workgroup.  Honoured only if it is a plain number that keeps `base + pad` within `limit`; anything
 // else (a stray or malformed variable) is ignored, so it can change occupancy, never break a launch.

@@ -36,6 +36,9 @@
 
 namespace {
 
+constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
+constexpr int kMaxGlobalWaves = 4;
+constexpr int kMaxSlices = 8;
 struct pwg_args {
   const cobel_wrec* rec;
   const uint16_t* starts;
@@ -44,13 +47,21 @@ struct pwg_args {
   cobel_tab_run_t r;
   uint64_t thr[16][3];   // integer CDF thresholds of the epsilon-greedy tie patterns
   float alpha_f, gamma_f, model_lr_f;
-  uint32_t* queue;       // eight heads, 32 B apart: next instance of each XCD's share (zeroed before the launch)
   int32_t nl, ng;        // waves per workgroup with Q in LDS / with Q in global memory
-  uint32_t reserve;      // instances per queue the global-memory waves leave to the others
+  // tickets (all counters zeroed before the launch)
+  uint32_t* queue;       // eight heads, 32 B apart: next ticket of each queue
+  uint32_t reserve;      // tickets per queue the global-memory waves leave to the others
+  // slices (n_slices > 1): an instance's steps of this call are cut into n_slices tickets
+  int32_t n_slices;
+  int32_t slice_steps[kMaxSlices];
+  uint32_t* owner;       // [8] XCD (id + 1) that serves each queue, 0 = nobody yet
+  uint32_t* tail;        // eight counters, 32 B apart: entries pushed onto each queue's ring
+  uint32_t* ring;        // eight rings of ring_stride words: the tickets after a queue's first nq
+  uint32_t ring_stride;
+  uint32_t xcc_limit;    // 7; tests: the workgroups of XCDs beyond it sit a sliced launch out, so
+                         // that their queues have no XCD of their own
 };
 
-constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
-constexpr int kMaxGlobalWaves = 4;
 #if defined(COBEL_PWG_NT)
 #define NT_LD(p) __builtin_nontemporal_load(p)
 #define NT_ST(v, p) __builtin_nontemporal_store(v, p)
@@ -80,11 +91,30 @@ __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(u
 // this wave's earlier global stores are complete before anything after this point is issued
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#if defined(COBEL_PWG_STAMPS)
+// (timing experiments, scripts/exp_pwg_stamps.py: cycles per phase of a ticket, summed per wave
+//  into the scratch area behind the counters; the previous stamp waits in a spare LDS word)
+__device__ __forceinline__ void pwg_stamp(uint32_t* stamps, uint32_t* prev, int k, int lane) {
+  if (lane == 0) {
+    const uint32_t now = (uint32_t)__builtin_readcyclecounter();
+    atomicAdd(stamps + k, now - *prev);
+    *prev = now;
+  }
+}
+#define PWG_STAMP(k) pwg_stamp(stamps, stamp_prev, k, lane)
+#else
+#define PWG_STAMP(k)
+#endif
+
 // One instance, all the steps of the call.  QG: the Q table stays in global memory.
 template <bool QG>
-__device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
+__device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, const int step_budget,
                                              unsigned char* const lds, const int lane,
-                                             const uint64_t thr_mine, const uint32_t stripe) {
+                                             const uint64_t thr_mine, const uint32_t stripe
+#if defined(COBEL_PWG_STAMPS)
+                                             , uint32_t* stamps, uint32_t* stamp_prev
+#endif
+                                             ) {
   const int S = A.S;
   float4* const Qs = reinterpret_cast<float4*>(lds);
   float* const Qf = reinterpret_cast<float*>(lds);
@@ -99,17 +129,20 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   const uint32_t* const model32 = reinterpret_cast<const uint32_t*>(model);
   const uint32_t SA = (uint32_t)S * 4u;
   uint16_t* const Mg = A.r.model_index + (size_t)i * SA;
+  // Lane constants in vector registers where the compiler would keep lane masks in scalar pairs
+  // (the step loop is short of those: masks it spilled were reloaded in every step): lane l reads
+  // successor l % 4 of a packed record pair as bfe(bfi(sel, w1, w0), sh, 16).
+  uint32_t succ_sel = (lane & 2) ? 0xffffffffu : 0u, succ_sh = (uint32_t)(lane & 1) * 16u;
+  uint32_t SAv = SA;
+  asm volatile("" : "+v"(succ_sel), "+v"(succ_sh), "+v"(SAv));
+  auto succ_of = [&](uint32_t w0, uint32_t w1) -> uint32_t {
+    return (((w1 & succ_sel) | (w0 & ~succ_sel)) >> succ_sh) & 0xffffu;
+  };
 
   // ---- stage ---------------------------------------------------------------------------------
-  uint32_t nonzero = 0u;
-  for (int s = lane; s < S; s += 64) {
-    const float4 qv = Qg[s];
-    if (!QG) Qs[s] = qv;
-    nonzero |= fbits(qv.x) | fbits(qv.y) | fbits(qv.z) | fbits(qv.w);
-  }
-  for (int b = lane; b < 128; b += 64) H[b] = 0ull;
-  __builtin_amdgcn_wave_barrier();
-
+  // (the instance's scalar state is requested first and the table in batches of eight rows per
+  //  lane, every request of a batch before the first use: staged row by row — a memory round trip
+  //  per row — the 16 rows of a 32 x 32 table were 20 us of an instance's ~500, and of every slice)
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
   int state = inst[COBEL_I_STATE];
   int step = inst[COBEL_I_STEP];
@@ -118,16 +151,50 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
   uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
   uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
-  // COBEL_IF_NONZERO (bit 1, launch-local): see k_tab_wpi
-  if (!__ballot(nonzero != 0u))
-    for (uint32_t e = (uint32_t)lane; e < SA; e += 64u) nonzero |= (uint32_t)Mg[e] & 0x8000u;
-  if (__ballot(nonzero != 0u)) iflags |= 2u;
   double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO + (lane & 0));
   asm volatile("" : "+v"(trew));
+  // The table.  LDS waves: straight into LDS (global_load_lds_dwordx4: lane l of request j
+  // supplies row 64 j + l, the 64 rows land side by side — the layout of Qs), sixteen requests in
+  // flight behind the scalar state, no register in between; read back for the all-zero test once
+  // they have landed.  Global-memory waves only look at it (eight rows per lane and trip).
+  uint32_t nonzero = 0u;
+  if (QG) {
+    for (int s0 = 0; s0 < S; s0 += 512) {
+      float4 qv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + j * 64 + lane;
+        qv[j] = Qg[s < S ? s : S - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        nonzero |= fbits(qv[j].x) | fbits(qv[j].y) | fbits(qv[j].z) | fbits(qv[j].w);
+    }
+  } else {
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      if (s < S)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(Qg + s),
+            (__attribute__((address_space(3))) void*)(Qs + s0), 16, 0, 0);
+    }
+  }
 
   const int B = A.r.batch;
-  uint64_t seed = A.r.seed;
-  asm volatile("" : "+v"(seed));
+  // The Philox key schedule (twenty values derived from the seed) is formed by the scalar unit
+  // where a block is evaluated — once in four steps — instead of living in twenty vector registers
+  // across the step loop: the seed is handed out through an opaque scalar move at every use.
+#if defined(COBEL_PWG_SSEED)
+  auto seed_now = [&]() -> uint64_t {
+    uint64_t sd = A.r.seed;
+    asm volatile("" : "+s"(sd));
+    return sd;
+  };
+#else
+  uint64_t seed_v = A.r.seed;
+  asm volatile("" : "+v"(seed_v));
+  auto seed_now = [&]() -> uint64_t { return seed_v; };
+#endif
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   double alpha = A.r.alpha, gamma = A.r.gamma;
@@ -145,25 +212,25 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   uint32_t idx_cur = 0, mg_cur = 0;
 
   auto draw_m = [&](uint32_t counter) -> uint32_t {
-    const cobel_u4 b = cobel_philox(counter >> 2, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed);
+    const cobel_u4 b = cobel_philox(counter >> 2, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed_now());
     return cobel_word(b, counter & 3u);
   };
   auto refresh_draws = [&](uint32_t pq) {
     const uint32_t mi = (cm + 1u) >> 2;
     const bool p0 = lane == 62, p1 = lane == 63;
     blk = cobel_philox(p1 ? 2u * pq + 1u : (p0 ? 2u * pq : mi), (p0 || p1) ? 0u : (uint32_t)lane,
-                       g, (p0 || p1) ? COBEL_STREAM_POLICY : COBEL_STREAM_MEMORY, seed);
+                       g, (p0 || p1) ? COBEL_STREAM_POLICY : COBEL_STREAM_MEMORY, seed_now());
   };
   auto enter_state = [&](int s) {
     const uint4 c = W4[s];
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
-    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    cand = W4[succ_of(cw0, cw1)];   // (every lane: successor lane % 4; four distinct lines)
     mdig = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)s * 4u]);
   };
   auto begin_trial = [&]() -> bool {
     if (trial >= A.r.trials_target) return false;
-    state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+    state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed_now(),
                                                              start_cnt)];
     ce += 1u;
     step = 0;
@@ -276,6 +343,17 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   };
 
   // ---- prologue -------------------------------------------------------------------------------
+  // What a launch (or a slice) has to fetch before its first step, overlapped: the state's world
+  // record and, behind it, the successors' records and the first batch's digest entries travel
+  // while the table is landing (three trips to memory in a row; row by row the table alone was
+  // sixteen).
+  // (one request per cache line of the instance's digest: the planning lanes of the first steps
+  //  gather from all over it, and an instance comes back to a wave long after its lines left the L2)
+  uint32_t warm;
+  {
+    const uint32_t off = (uint32_t)lane * 128u, last = SA * 2u - 4u;
+    warm = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(Mg) + (off < last ? off : last));
+  }
   bool live = true;
   if (iflags & 1u) enter_state(state);
   else live = begin_trial();
@@ -286,8 +364,35 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
   }
   idx_cur = lane < B ? cobel_bounded(draw_m(cm), SA) : 0u;
   mg_cur = lane < B ? (uint32_t)Mg[idx_cur] : 0u;
+  asm volatile("" ::"v"(warm));
+  if (!QG) {
+    stores_done();   // (vmcnt(0): the table has landed)
+    for (int s = lane; s < S; s += 64) {
+      const float4 qv = Qs[s];
+      nonzero |= fbits(qv.x) | fbits(qv.y) | fbits(qv.z) | fbits(qv.w);
+    }
+  }
+  for (int b = lane; b < 128; b += 64) H[b] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+  // COBEL_IF_NONZERO (bit 1, launch-local): see k_tab_wpi
+  if (!__ballot(nonzero != 0u)) {
+    // (the digest, a state's four entries per request, eight requests in flight)
+    const uint2* const M2 = reinterpret_cast<const uint2*>(Mg);
+    for (int s0 = 0; s0 < S; s0 += 512) {
+      uint2 mv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + j * 64 + lane;
+        mv[j] = M2[s < S ? s : S - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nonzero |= (mv[j].x | mv[j].y) & 0x80008000u;
+    }
+  }
+  if (__ballot(nonzero != 0u)) iflags |= 2u;
 
-  const int budget0 = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  PWG_STAMP(1);   // prologue
+  const int budget0 = step_budget > 0 ? step_budget : 0x7fffffff;
   int budget = budget0;
   uint32_t batches = 0u;
   asm volatile("" : "+v"(batches));
@@ -309,7 +414,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
     cp += 1u;
 
     // ---- everything this step reads from Q ----------------------------------------------------------
-    const uint32_t succ = next_of(cw0, cw1, lane & 3);
+    const uint32_t succ = succ_of(cw0, cw1);
     float4 qrow, srow;
     float4 prow = {0.0f, 0.0f, 0.0f, 0.0f};   // QG, lane j < B: Q[ns_j] ...
     float pq = 0.0f;                           // ... and Q[s_j][a_j] of the pair it replays
@@ -362,7 +467,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
     __builtin_amdgcn_sched_barrier(0);
     uint2 mdig_next = {0u, 0u};
     if (!trial_over) {
-      if (lane < 4) cand = W4[next_of(nw0, nw1, lane)];
+      cand = W4[succ_of(nw0, nw1)];
       mdig_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
     }
 
@@ -401,7 +506,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
       const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
       if (lane < B) {
         float rj = 0.0f;
-        idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
+        idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SAv);
         mg_next = (uint32_t)Mg[idx_next];
         if (iflags & 2u) {
           batches += 1u;
@@ -464,8 +569,22 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i,
 
   // ---- write back -------------------------------------------------------------------------------
   __builtin_amdgcn_wave_barrier();
-  if (!QG)
-    for (int s = lane; s < S; s += 64) Qg[s] = Qs[s];
+  PWG_STAMP(2);   // steps
+  if (!QG) {
+    for (int s0 = 0; s0 < S; s0 += 256) {
+      float4 qv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = s0 + j * 64 + lane;
+        qv[j] = Qs[s < S ? s : S - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = s0 + j * 64 + lane;
+        if (s < S) Qg[s] = qv[j];
+      }
+    }
+  }
   if (lane == 0) {
     inst[COBEL_I_STATE] = state;
     inst[COBEL_I_STEP] = step;
@@ -498,42 +617,138 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
   const uint64_t thr_mine = A.thr[(lane % 48) / 3][lane % 3];
   const uint32_t wave_id = (uint32_t)blockIdx.x * (uint32_t)waves + (uint32_t)wave;
   const uint32_t stripe = A.r.mon_stripes > 1 ? wave_id % (uint32_t)A.r.mon_stripes : 0u;
-  // Instances are handed out per XCD: instance i belongs to queue i % 8, and a workgroup serves the
-  // queue of the XCD it runs on first (then the others, until all eight are empty).  The world of
-  // an instance is (global id) % n_worlds, so an XCD's L2 sees an eighth of the worlds' records
-  // and the same instances launch after launch — what the round-robin placement of one workgroup
-  // per instance gives k_tab_wpi for free.  Speed only: any wave may run any instance.
+  // Work is handed out as tickets from eight queues, one per XCD: instance i belongs to queue i % 8,
+  // and a workgroup serves the queue of the XCD it runs on first.  The world of an instance is
+  // (global id) % n_worlds, so an XCD's L2 sees an eighth of the worlds' records and the same
+  // instances launch after launch — what the round-robin placement of one workgroup per instance
+  // gives k_tab_wpi for free.
+  //   * n_slices == 1: a ticket is an instance with all its steps of this call; a wave whose queue
+  //     is empty takes tickets of the others until all eight are (speed only: any wave may run any
+  //     instance — nothing an instance touches is handed from one wave to another inside a launch).
+  //   * n_slices > 1 (few instances per wave slot: the shard of a batch split over several GPUs):
+  //     an instance's steps are cut into slices — long ones first, short ones last — and a slice is
+  //     what a launch with that step budget would be: tables staged, stepped, written back.  All
+  //     instances then advance at about the same pace and the last round of the launch consists of
+  //     short tickets (an instance's 512 steps as ONE unit of work leave 8 192 instances on 3 328
+  //     wave slots with a launch of four rounds for 2.5 rounds of work).  Tickets 0 .. nq - 1 of a
+  //     queue are the first slices of its nq instances; the wave that finishes slice k of an
+  //     instance appends (instance, k + 1) to the queue's ring, and tickets nq, nq + 1, ... are the
+  //     ring's entries in that order: a ticket exists when its predecessor is done, a wave that
+  //     draws a ticket not yet written waits for the entry (somebody is running the slice that
+  //     will write it — the waiting waves hold no ticket, so there is no cycle).  The tables travel
+  //     from wave to wave through the XCD's L2 — per-XCD L2s are not coherent with each other, and
+  //     writing one back per hand-off would turn every dirty line of the model tables into HBM
+  //     traffic — so here a queue is served by the waves of ONE XCD only: the first wave to ask
+  //     claims it for its XCD (`owner`), its own XCD's queue first; an XCD whose queue is empty
+  //     claims queues nobody serves (none on a chip whose eight XCDs all run workgroups).  The
+  //     producer's stores are complete in L2 (vmcnt(0)) before the entry is written; the consumer's
+  //     CU drops its L1 (agent-scope acquire) before it reads.
+#if defined(COBEL_PWG_STAMPS)
+  uint32_t* const stamps = A.ring + (size_t)8 * A.ring_stride + (size_t)wave_id * 8u;
+  uint32_t* const stamp_prev = reinterpret_cast<uint32_t*>(
+      lds_raw + (size_t)A.nl * slice_l + (size_t)A.ng * kHashBytes + (size_t)wave * 8);
+  if (lane == 0) *stamp_prev = (uint32_t)__builtin_readcyclecounter();
+#endif
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
-  int k0 = 0;   // queues (xcc + k) % 8, k < k0, are known to be empty
+  if (A.n_slices > 1 && xcc > A.xcc_limit) return;
+  // (what the ticket loop carries across an instance — XCD, queues tried, slice — is ONE scalar
+  //  register: the step loop has none to spare, and a value it had to spill for the ticket loop's
+  //  sake was reloaded in every step)
+  uint32_t tstate = xcc << 8;   // bits 0-7: queues (xcc + k) % 8, k < k0, are empty (or another XCD's)
+  uint32_t t_next = 0xffffffffu;   // a ticket of the current queue drawn ahead (with the last append)
   // (s_setprio for either kind of wave was measured and loses: LDS waves at priority 1 / 3 12.64 ms
   //  per launch against 12.50, global-memory waves at 3 13.1 ms)
   for (;;) {
     int i = -1;
-    while (k0 < 8) {
-      const uint32_t q = (xcc + (uint32_t)k0) & 7u;
-      uint32_t t = 0u;
-      if (lane == 0) {
-        // a wave with Q in global memory needs about three times as long for an instance: it
-        // leaves the last `reserve` instances of a queue to the LDS waves, which finish them
-        // sooner than it would finish one
-        if (qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                      A.reserve >= ((uint32_t)A.r.n + 7u - q) / 8u)
+    {
+      const bool sliced = A.n_slices > 1;
+      uint32_t k0 = tstate & 0xffu;
+      const uint32_t x = (tstate >> 8) & 0xffu;
+      uint32_t sl = 0u;
+      while (k0 < 8u) {
+        const uint32_t q = (x + k0) & 7u;
+        const uint32_t nq = ((uint32_t)A.r.n + 7u - q) / 8u;
+        const uint32_t total = nq * (uint32_t)A.n_slices;
+        uint32_t t = t_next;
+        t_next = 0xffffffffu;
+        if (t == 0xffffffffu) {
           t = 0x10000000u;
-        else
-          t = atomicAdd(A.queue + q * 8u, 1u);
+          if (lane == 0 && total) {
+            bool serve = true;
+            if (sliced) {
+              uint32_t o = __hip_atomic_load(A.owner + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (o == 0u) {
+                o = atomicCAS(A.owner + q, 0u, x + 1u);
+                if (o == 0u) o = x + 1u;
+              }
+              serve = o == x + 1u;
+            }
+            // a wave with Q in global memory needs about three times as long for a ticket: it
+            // leaves the last `reserve` tickets of a queue to the LDS waves, which finish them
+            // sooner than it would finish one
+            if (serve && !(qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT) + A.reserve >= total))
+              t = atomicAdd(A.queue + q * 8u, 1u);
+          }
+          t = rfl(t);
+        }
+        if (t < total) {
+          if (t < nq) {
+            i = (int)(t * 8u + q);
+          } else {
+            const uint32_t* const slot = A.ring + (size_t)q * A.ring_stride + (t - nq);
+            uint32_t e;
+            while ((e = rfl(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == 0u)
+              __builtin_amdgcn_s_sleep(32);
+            // (this CU's L1 is dropped; the wave's own loads behind the fence need no wait for it)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sl = e >> 24;
+            i = (int)(((e & 0xffffffu) - 1u) * 8u + q);
+          }
+          break;
+        }
+        k0 += 1u;
       }
-      const uint32_t c = rfl(t) * 8u + q;
-      if (c < (uint32_t)A.r.n) {
-        i = (int)c;
-        break;
-      }
-      k0 += 1;
+      tstate = k0 | (x << 8) | (sl << 16);
     }
     if (i < 0) break;
-    if (qg) pwg_instance<true>(A, i, lds, lane, thr_mine, stripe);
-    else pwg_instance<false>(A, i, lds, lane, thr_mine, stripe);
+    int budget = A.r.step_budget;
+    if (A.n_slices > 1) {
+      const int slice = (int)(tstate >> 16);
+#pragma unroll
+      for (int j = 0; j < kMaxSlices; ++j)
+        if (j == slice) budget = A.slice_steps[j];
+    }
+#if defined(COBEL_PWG_STAMPS)
+    PWG_STAMP(0);   // ticket
+    if (lane == 0) atomicAdd(stamps + 4, 1u);
+    if (qg) pwg_instance<true>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
+    else pwg_instance<false>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
+    PWG_STAMP(3);   // write-back issued
+#else
+    if (qg) pwg_instance<true>(A, i, budget, lds, lane, thr_mine, stripe);
+    else pwg_instance<false>(A, i, budget, lds, lane, thr_mine, stripe);
+#endif
+    if (A.n_slices > 1) {
+      // the instance's next slice becomes a ticket; this wave's next ticket is drawn in the same
+      // trip to memory (an LDS wave: the global-memory waves look at the queue's length first)
+      const uint32_t q = (uint32_t)i & 7u;
+      const uint32_t sl1 = (tstate >> 16) + 1u;
+      const bool more = sl1 < (uint32_t)A.n_slices;
+      uint32_t pos = 0u, t = 0xffffffffu;
+      if (lane == 0) {
+        if (more) pos = atomicAdd(A.tail + q * 8u, 1u);
+        if (!qg) t = atomicAdd(A.queue + q * 8u, 1u);
+      }
+      stores_done();
+      if (lane == 0 && more)
+        __hip_atomic_store(A.ring + (size_t)q * A.ring_stride + pos,
+                           (((uint32_t)i >> 3) + 1u) | (sl1 << 24), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      t_next = rfl(t);
+    }
   }
 }
 
@@ -548,8 +763,12 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   if (r.agent != COBEL_AGENT_DYNAQ || !r.model_index || r.occupancy || r.param_index ||
       r.last_exp || S * 4 > 4096 || S <= 256 || r.batch < 1 || r.batch > COBEL_MAX_BATCH)
     return false;
-  if (!world->queue) return false;
-  const size_t slice_l = (size_t)S * 16 + kHashBytes, total = 160 * 1024;
+  const bool scratch = r.scratch && r.scratch_bytes >= COBEL_TAB_SCRATCH_BYTES(r.n);
+  if (!scratch && !world->queue) return false;
+  int n_cu = 0;
+  size_t total = 0;
+  if (cobel_device_limits(world->device, &n_cu, &total) != COBEL_OK) return false;
+  const size_t slice_l = (size_t)S * 16 + kHashBytes;
   int nl = (int)(total / slice_l);
   if (nl > 16) nl = 16;
   int ng = (int)((total - (size_t)nl * slice_l) / kHashBytes);
@@ -577,6 +796,46 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   return true;
 }
 
+// The slices of a launch (see k_tab_pwg): none while the instances are many rounds of the wave
+// slots; otherwise the steps of the call are halved down to a last slice whose length is a
+// twentieth or so of the launch — budget / 2, / 4, ..., / 2^m, / 2^m — so that the tickets of the
+// last round are short while an instance is staged m + 1 times, not 2^m times.
+static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, bool scratch,
+                       int32_t* steps /* [kMaxSlices] */) {
+  const char* const forced = getenv("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
+  for (int j = 0; j < kMaxSlices; ++j) steps[j] = 0;
+  steps[0] = r.step_budget;
+  if (!scratch || grid < n_cu || r.step_budget < 64) return 1;
+  if (forced) {
+    int v[kMaxSlices] = {0}, k = 0, sum = 0;
+    const char* c = forced;
+    while (k < kMaxSlices && *c) {
+      v[k] = atoi(c);
+      if (v[k] <= 0) break;
+      sum += v[k++];
+      while (*c && *c != ',') ++c;
+      if (*c == ',') ++c;
+    }
+    if (k >= 1 && sum == r.step_budget) {
+      for (int j = 0; j < k; ++j) steps[j] = v[j];
+      return k;
+    }
+    return 1;
+  }
+  const double rounds = (double)r.n / ((double)grid * waves);
+  if (rounds >= 8.0 || rounds < 1.0) return 1;
+  int m = 0;
+  while ((1 << m) * rounds < 16.0 && m < kMaxSlices - 1 && (r.step_budget >> (m + 1)) >= 32) ++m;
+  if (m == 0) return 1;
+  int left = r.step_budget;
+  for (int j = 0; j < m; ++j) {
+    steps[j] = r.step_budget >> (j + 1);
+    left -= steps[j];
+  }
+  steps[m] = left;
+  return m + 1;
+}
+
 int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st) {
   int nl = 0, ng = 0;
   size_t lds = 0;
@@ -594,18 +853,28 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
-  A.queue = world->queue;
   A.nl = nl;
   A.ng = ng;
-  static int n_cu = 0;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    COBEL_HIP_TRY(hipGetDeviceProperties(&prop, world->device));
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  int n_cu = 0;
+  size_t lds_cu = 0;
+  if (cobel_device_limits(world->device, &n_cu, &lds_cu) != COBEL_OK) return COBEL_E_HIP;
   const int waves = nl + ng;
   int grid = (r.n + waves - 1) / waves;
   if (grid > n_cu) grid = n_cu;
+  // the counters of the launch: in the caller's scratch area when there is one (any number of
+  // calls in flight), else in the 256 bytes of the world handle (one call per handle at a time)
+  const bool scratch = r.scratch && r.scratch_bytes >= COBEL_TAB_SCRATCH_BYTES(r.n);
+  uint32_t* const base = scratch ? static_cast<uint32_t*>(r.scratch) : world->queue;
+  A.queue = base;
+  A.owner = scratch ? base + 64 : base;
+  A.tail = scratch ? base + 128 : base;
+  A.ring = scratch ? base + 256 : base;
+  A.n_slices = plan_slices(r, grid, n_cu, waves, scratch, A.slice_steps);
+  A.ring_stride = (uint32_t)((r.n + 7) / 8) * (uint32_t)(A.n_slices - 1);
+  {
+    const char* const m_env = getenv("COBEL_DEBUG_PWG_XCCLIMIT");   // (tests)
+    A.xcc_limit = m_env ? (uint32_t)atoi(m_env) & 7u : 7u;
+  }
   {
     static const char* const k_env = getenv("COBEL_DEBUG_PWG_RESERVE");   // (experiments)
     // (2.0: within 0.5 % of the best at 32 768 and 65 536 instances per GPU, 3-5 % ahead of 2.5 at the
@@ -613,7 +882,13 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
     const double k = k_env ? atof(k_env) : 2.0;
     A.reserve = nl ? (uint32_t)((double)nl * grid * k / 8.0) : 0u;
   }
-  COBEL_HIP_TRY(hipMemsetAsync(world->queue, 0, 256, st));
+#if defined(COBEL_PWG_STAMPS)
+  lds += 1024;
+  COBEL_HIP_TRY(hipMemsetAsync(base, 0, (256 + (size_t)8 * A.ring_stride + (size_t)8 * grid * waves) * 4, st));
+#else
+  COBEL_HIP_TRY(hipMemsetAsync(base, 0, A.n_slices > 1 ? (256 + (size_t)8 * A.ring_stride) * 4
+                                                       : (size_t)256, st));
+#endif
   if (lds > 64 * 1024)
     COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_pwg),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

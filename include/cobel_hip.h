@@ -329,7 +329,19 @@ typedef struct {
                             reward estimates of its model are all +0.0f (every update of such a
                             batch is 0 + alpha (0 + gamma nt 0 - 0) = 0).  steps_done minus this is
                             the number of batches skipped that way (episodic replay: per trial).  */
+  void* scratch;         /* optional [dev] work area of the call, caller-owned (the library allocates
+                            nothing in a run): COBEL_TAB_SCRATCH_BYTES(n) bytes, contents undefined
+                            between calls, never shared by two calls in flight.  The
+                            persistent-workgroup Dyna-Q kernel keeps its ticket counters and the
+                            rings of its ready slices there; with it a launch of few instances
+                            per GPU (a shard of a split batch) is handed out in slices of an
+                            instance's steps instead of whole instances, so that the last round of
+                            work fills the chip.  NULL: whole instances,
+                            counters in a buffer of the world handle (one call in flight per
+                            handle).                                                           */
+  int64_t scratch_bytes;
 } cobel_tab_run_t;
+#define COBEL_TAB_SCRATCH_BYTES(n) ((256 + 7 * ((int64_t)(n) + 8)) * 4)
 
 /* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —
  * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — are planned by

@@ -1,0 +1,56 @@
+"""Where a ticket's time goes in k_tab_pwg (a library built with -DCOBEL_PWG_STAMPS, COBEL_LIB=...):
+cycles per phase — ticket draw, prologue, steps, write-back — summed per wave by the kernel into the
+scratch area, read back here and split by the two kinds of wave.
+
+    COBEL_LIB=$PWD/gpurun_ab/libcobel_stamps.so python scripts/exp_pwg_stamps.py [instances] [pretrain launches]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'cobel-rl_amd')]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    pre = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+    dev = torch.device('cuda', 0)
+    cfg = dict(bench.CONFIGS['C3'])
+    env, agent = bench.build_agent('C3', cfg, n, 0, dev)
+    run = bench.Runner(cfg, env, agent)
+    for _ in range(pre):
+        run.launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    what = run.describe()
+    waves = what['instances_per_workgroup']
+    sc = agent._scratch.cpu().numpy().view(np.uint32)
+    grid = 256
+    slices = len(os.environ.get('COBEL_DEBUG_PWG_SLICES', '512').split(','))
+    off = 256 + 8 * ((n + 7) // 8) * (slices - 1)
+    st = sc[off:off + grid * waves * 8].reshape(grid, waves, 8).astype(np.float64)
+    nl = 9 if waves == 13 else waves
+    print('launch %.3f ms, %d waves per workgroup' % (ms, waves))
+    for name, sel in (('LDS waves', st[:, :nl]), ('global-memory waves', st[:, nl:])):
+        if sel.size == 0:
+            continue
+        cnt = sel[..., 4].sum()
+        tot = sel[..., :4].sum()
+        print('%s: %.1f tickets per wave; cycles per ticket: draw %.0f, prologue %.0f, steps %.0f, '
+              'write-back %.0f; share outside the steps %.2f %%; total cycles per wave %.3g'
+              % (name, cnt / sel[..., 4].size, sel[..., 0].sum() / cnt, sel[..., 1].sum() / cnt,
+                 sel[..., 2].sum() / cnt, sel[..., 3].sum() / cnt,
+                 100 * (1 - sel[..., 2].sum() / tot), tot / sel[..., 4].size))
+
+
+if __name__ == '__main__':
+    main()

@@ -88,3 +88,46 @@ def test_global_q_waves_against_the_oracle():
         if left:
             ref.train(env, 1, left, batch, trace=tr)
         assert np.array_equal(out['q'][i], ref.Q), i
+
+
+def _sliced(monkeypatch, slices, limit=None, **args):
+    if slices is not None:
+        monkeypatch.setenv('COBEL_DEBUG_PWG_SLICES', slices)
+    if limit is not None:
+        monkeypatch.setenv('COBEL_DEBUG_PWG_XCCLIMIT', str(limit))
+    try:
+        return _run(0, **args)
+    finally:
+        monkeypatch.delenv('COBEL_DEBUG_PWG_SLICES', raising=False)
+        monkeypatch.delenv('COBEL_DEBUG_PWG_XCCLIMIT', raising=False)
+
+
+def test_slices_of_an_instances_steps_equal_whole_instances(monkeypatch):
+    """A launch of few instances per wave slot is handed out as slices of an instance's steps
+    (tickets, csrc/tabular_pwg.hip): the slices of an instance run in order on whichever waves of
+    its XCD draw them, and leave exactly what one wave running the whole launch leaves."""
+    from cobel_amd import _lib
+    # (one workgroup per CU needs >= 256 x 13 instances before the launch is sliced at all)
+    args = dict(n=3400, side=32, seeds=[1234, 1235, 1236, 1237, 1238], launches=2, steps=512, spt=90)
+    plain = _run(_lib.F_NO_PWG, **args)
+    auto = _run(0, **args)                                     # 256 + 128 + 64 + 32 + 32 by the plan
+    odd = _sliced(monkeypatch, '300,7,100,64,41', **args)      # uneven slices
+    one = _sliced(monkeypatch, '512', **args)                  # whole instances
+    assert auto['kinds'] == {_lib.TAB_KERNEL_PWG} and plain['kinds'] == {_lib.TAB_KERNEL_WPI_INDEX}
+    assert plain['q'].any() and plain['batches'] > 0 and plain['lat_cnt'].sum() > 0
+    _same(plain, auto)
+    _same(plain, odd)
+    _same(plain, one)
+
+
+def test_queues_without_an_xcd_of_their_own_are_claimed(monkeypatch):
+    """Sliced launches bind a queue to one XCD (its L2 carries an instance from slice to slice).
+    With the workgroups of XCDs 4 ... 7 (or of all but XCD 0) sitting the launch out, their queues
+    have no XCD of their own: the XCDs that finish their queue claim them."""
+    from cobel_amd import _lib
+    args = dict(n=3400, side=32, seeds=[77, 78], launches=1, steps=256, spt=70)
+    plain = _run(_lib.F_NO_PWG, **args)
+    masked = _sliced(monkeypatch, '128,64,64', limit=3, **args)
+    single = _sliced(monkeypatch, '128,64,64', limit=0, **args)
+    _same(plain, masked)
+    _same(plain, single)
