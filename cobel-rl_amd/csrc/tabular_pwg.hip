@@ -647,7 +647,10 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
   uint32_t* const stamps = A.ring + (size_t)8 * A.ring_stride + (size_t)wave_id * 8u;
   uint32_t* const stamp_prev = reinterpret_cast<uint32_t*>(
       lds_raw + (size_t)A.nl * slice_l + (size_t)A.ng * kHashBytes + (size_t)wave * 8);
-  if (lane == 0) *stamp_prev = (uint32_t)__builtin_readcyclecounter();
+  if (lane == 0) {
+    *stamp_prev = (uint32_t)__builtin_readcyclecounter();
+    stamps[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+  }
 #endif
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -713,6 +716,12 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
       }
       tstate = k0 | (x << 8) | (sl << 16);
     }
+#if defined(COBEL_PWG_STAMPS)
+    if (i < 0 && lane == 0) {
+      stamps[5] = tstate >> 8 & 0xffu;
+      stamps[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (i < 0) break;
     int budget = A.r.step_budget;
     if (A.n_slices > 1) {
@@ -796,10 +805,12 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   return true;
 }
 
-// The slices of a launch (see k_tab_pwg): none while the instances are many rounds of the wave
-// slots; otherwise the steps of the call are halved down to a last slice whose length is a
-// twentieth or so of the launch — budget / 2, / 4, ..., / 2^m, / 2^m — so that the tickets of the
-// last round are short while an instance is staged m + 1 times, not 2^m times.
+// The slices of a launch (see k_tab_pwg).  A slice boundary costs an instance ~19 us on C3 (9.6 us
+// of ticket, prologue and write-back, the rest in steps that run slower while more tables are on
+// the move; scripts/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch:
+// measured on one MI355X (ms per launch of 512 steps; unsliced / best): 8 192 instances 1.96 / 1.76
+// with 320 + 128 + 64 (256 + 128 + 64 + 64: 1.80, 384 + 64 + 32 + 32: 1.88), 16 384: 3.30 / 3.26 with
+// 384 + 128, 32 768: 6.40 / 6.33 with 448 + 64; 65 536 is not sliced.
 static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, bool scratch,
                        int32_t* steps /* [kMaxSlices] */) {
   const char* const forced = getenv("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
@@ -823,17 +834,22 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, 
     return 1;
   }
   const double rounds = (double)r.n / ((double)grid * waves);
-  if (rounds >= 8.0 || rounds < 1.0) return 1;
-  int m = 0;
-  while ((1 << m) * rounds < 16.0 && m < kMaxSlices - 1 && (r.step_budget >> (m + 1)) >= 32) ++m;
-  if (m == 0) return 1;
-  int left = r.step_budget;
-  for (int j = 0; j < m; ++j) {
-    steps[j] = r.step_budget >> (j + 1);
-    left -= steps[j];
+  const int b = r.step_budget;
+  if (rounds >= 14.0 || rounds < 1.0) return 1;
+  if (rounds >= 7.0) {
+    steps[1] = b / 8;
+    steps[0] = b - steps[1];
+    return 2;
   }
-  steps[m] = left;
-  return m + 1;
+  if (rounds >= 3.5) {
+    steps[1] = b / 4;
+    steps[0] = b - steps[1];
+    return 2;
+  }
+  steps[2] = b / 8;
+  steps[1] = b / 4;
+  steps[0] = b - steps[1] - steps[2];
+  return 3;
 }
 
 int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st) {

@@ -52,5 +52,26 @@ def main():
                  100 * (1 - sel[..., 2].sum() / tot), tot / sel[..., 4].size))
 
 
+    ss = sc[off + 26624:off + 26624 + 3].astype(np.float64)
+    if ss.any():
+        tickets = st[..., 4].sum()
+        print('cycles per step, all waves: steps 0-3 %.0f, 4-15 %.0f, 16-63 %.0f, later (LDS waves) %.0f'
+              % (ss[0] / tickets / 4, ss[1] / tickets / 12, ss[2] / tickets / 48,
+                 st[:, :nl, 2].sum() / st[:, :nl, 4].sum() / max(1, (512 // slices) - 64)))
+    # when each XCD's waves ran out of tickets (100 MHz clock), relative to the first start
+    raw = sc[off:off + grid * waves * 8].reshape(grid, waves, 8)
+    t0 = raw[..., 7].min()
+    end = (raw[..., 6] - t0).astype(np.int64) / 100.0          # us
+    xcc = raw[..., 5]
+    for kind, sl in (('LDS', slice(0, nl)), ('global', slice(nl, waves))):
+        if sl.start >= waves:
+            continue
+        print(kind, 'waves finish (us) by XCD: ' + '  '.join(
+            '%d: %.0f-%.0f (median %.0f)' % (x, end[:, sl][xcc[:, sl] == x].min(),
+                                           end[:, sl][xcc[:, sl] == x].max(),
+                                           np.median(end[:, sl][xcc[:, sl] == x]))
+            for x in range(8) if (xcc[:, sl] == x).any()))
+
+
 if __name__ == '__main__':
     main()

@@ -86,6 +86,28 @@ def test_plain_invocation_with_gpus_2_starts_its_own_ranks():
         assert a['monitors'][key] == b['monitors'][key], key
 
 
+def test_five_ranks_on_one_card_with_an_uneven_split():
+    """More ranks than two, and a total that does not divide (1 003 instances over five ranks: 201,
+    201, 201, 200, 200), on ONE card over gloo — five is what a one-GPU box admits next to this
+    process; the eight-rank split is rehearsed without a card in tests/test_host_cpu.py."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    args = ['--config', 'C3', '--instances', '1003', '--env-steps', '64'] + COMMON
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    five = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '5', '--backend',
+                           'gloo'] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert five.returncode == 0, five.stderr[-3000:]
+    a, b = _line(one.stdout), _line(five.stdout)
+    assert b['n_gpus'] == 5 and b['config']['instances_total'] == 1003
+    assert b['config']['instances_per_gpu'] == 201          # (rank 0's shard)
+    assert b['monitors']['collectives_in_timed_region'] == 1
+    for key in ('trials_finished', 'escape_latency_sum', 'trial_reward_sum'):
+        assert a['monitors'][key] == b['monitors'][key], key
+
+
 def test_two_gpus_over_rccl_report_the_same_monitors():
     """The real collective: one rank per GPU, backend "nccl" (= RCCL).  Needs two cards."""
     import torch

@@ -110,7 +110,7 @@ def test_slices_of_an_instances_steps_equal_whole_instances(monkeypatch):
     # (one workgroup per CU needs >= 256 x 13 instances before the launch is sliced at all)
     args = dict(n=3400, side=32, seeds=[1234, 1235, 1236, 1237, 1238], launches=2, steps=512, spt=90)
     plain = _run(_lib.F_NO_PWG, **args)
-    auto = _run(0, **args)                                     # 256 + 128 + 64 + 32 + 32 by the plan
+    auto = _run(0, **args)                                     # 320 + 128 + 64 by the plan
     odd = _sliced(monkeypatch, '300,7,100,64,41', **args)      # uneven slices
     one = _sliced(monkeypatch, '512', **args)                  # whole instances
     assert auto['kinds'] == {_lib.TAB_KERNEL_PWG} and plain['kinds'] == {_lib.TAB_KERNEL_WPI_INDEX}

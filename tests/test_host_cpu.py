@@ -345,6 +345,55 @@ def test_monitor_allreduce_two_ranks_gloo(tmp_path):
     assert all('ok' in o for o in outs)
 
 
+WORKER8 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'cobel-rl_amd'))
+import numpy as np, torch, torch.distributed as dist
+from cobel_amd.agent.agent import DeviceMonitors
+from cobel_amd.misc.sharding import shard_instances
+rank, world, total, trials = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), 1003, 5
+dist.init_process_group('gloo')
+# what every instance of the whole job reports (a function of its GLOBAL id), and this rank's share
+gid = np.arange(total)
+lat = (gid[:, None] * 7 + np.arange(trials)[None, :] * 3) % 41
+rew = ((gid[:, None] + np.arange(trials)[None, :]) % 5 == 0).astype(np.float64)
+base, count = shard_instances(total, world, rank)
+assert count in (total // world, total // world + 1)
+mon = DeviceMonitors(torch.device('cpu'), 1, 4, occupancy=True)
+mon.reserve(trials)
+mine = slice(base, base + count)
+mon.lat_sum += torch.as_tensor(lat[mine].sum(axis=0)); mon.lat_cnt += count
+mon.reward_sum += torch.as_tensor(rew[mine].sum(axis=0)); mon.steps_done += int(lat[mine].sum()) + count * trials
+mon.occupancy += count
+g = mon.all_reduce()
+assert g.ranks == world and mon.collectives == 1
+assert np.array_equal(g.lat_sum[:trials], lat.sum(axis=0)) and np.array_equal(g.lat_cnt[:trials], [total] * trials)
+assert np.array_equal(g.reward_sum[:trials], rew.sum(axis=0))
+assert g.steps_done == int(lat.sum()) + total * trials and int(g.occupancy.sum()) == 4 * total
+bits = torch.as_tensor(np.ascontiguousarray(g.reward_sum).view(np.int64))
+every = [torch.zeros_like(bits) for _ in range(world)]
+dist.all_gather(every, bits)
+assert all(torch.equal(every[0], e) for e in every)
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_monitor_allreduce_eight_ranks_uneven_split_gloo(tmp_path):
+    """The split BASELINE config 3 names — eight ranks — rehearsed on the CPU with a total that does
+    not divide (1 003 instances: shards of 126 and 125): every rank ends with the sums of the
+    whole job, bit-identical everywhere, after ONE collective."""
+    script = tmp_path / 'worker8.py'
+    script.write_text(WORKER8)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE='8',
+               OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)
+
+
 def test_instance_shards_are_disjoint_and_complete():
     """Global instance ids of the ranks of a node: contiguous, disjoint, complete, balanced —
     for the BASELINE split of C3's 65 536 instances over 1/2/4/8 GPUs and for ragged totals."""
