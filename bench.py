@@ -319,7 +319,12 @@ def run_grid_search(device, runs=16):
                          'the whole fit takes, the rest is the host enumerating combinations and '
                          'writing the result files as the reference does); 5x5 tables are LDS '
                          'resident' % (stats['kernel_ms'], dt))
-    return {'value': combos * runs / dt, 'unit': 'simulations/s',
+    iss = issue_roofline('grid_search', stats['env_steps'] / (stats['kernel_ms'] * 1e-3),
+                         stats['kernel_ms'], device, runs == 16)
+    if iss is not None:
+        roof['issue'] = iss
+    roof = to_issue_bound(roof)
+    return {'value': combos * runs / dt, 'unit': 'simulations/s', 'env_steps': stats['env_steps'],
             'env_steps_per_s': stats['env_steps'] / dt, 'seconds': dt,
             'env_steps_per_s_kernel': stats['env_steps'] / (stats['kernel_ms'] * 1e-3),
             'config': {'workload': 'GridSearchOptimizer.fit_vectorised: %d combinations x %d runs of '
@@ -327,6 +332,40 @@ def run_grid_search(device, runs=16):
                                    'instances of one launch, files written as the reference does'
                                    % (combos, runs, trials, steps, combos * runs)},
             'roofline': roof}
+
+
+def run_c1(device, with_cpu=True):
+    """C1, the reference's own CPU-runnable case (demo/gridworld/demo_dyna_q.py:36-56): ONE Dyna-Q
+    agent on the 5x5 open field, 500 training + 300 test trials of <= 50 steps, batch 32 — through
+    the drop-in classes (whole launches, no per-step hooks), with the reference loop's port timed
+    on the same shape beside it."""
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    world = make_open_field(5, 5, 0, 1)
+    world['starting_states'] = np.arange(1, 25)
+    env = Gridworld(world, seed=SEED, device=device)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1), learning_rate=0.99)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    agent.train(env, 500, 50, 32)
+    agent.test(env, 300, 50)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    steps = agent.env_steps()
+    r = {'value': steps / dt, 'unit': 'env-steps/s', 'seconds': dt, 'env_steps': steps, 'dtype': 'f32',
+         'config': {'workload': 'C1: one Dyna-Q agent, 5x5 open field, 500 train + 300 test trials x <= '
+                                '50 steps, batch 32 (demo/gridworld/demo_dyna_q.py) through the '
+                                'drop-in classes', 'instances_per_gpu': 1},
+         'roofline': {'bound': 'latency', 'achieved': None, 'peak': None, 'frac': None, 'unit': None,
+                      'traffic': None,
+                      'note': 'one instance is one wavefront: the reference plumbing case, not a '
+                              'throughput configuration'}}
+    if with_cpu:
+        cfg = dict(instances=1, steps_per_trial=50, batch=32, agent='dynaq')
+        r['cpu_baseline'] = cpu_baseline('C1', cfg, 4.0)
+    return r
 
 
 def run_general(device, which, n=65536, env_steps=64, launches=4):
@@ -390,6 +429,12 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
                          'latency' if what['kernel'] == _lib.TAB_KERNEL_GENERAL else 'issue',
                          '%d B per env step + %d B per replayed / planned update of the batches the '
                          'kernel evaluated (%d of %d drawn)' % (b_step, b_upd, batches, steps))
+    if which == 'dynaq_b100':
+        iss = issue_roofline('general_dynaq_b100', steps / sec, float(np.mean(ms)), device,
+                             n == 65536)
+        if iss is not None:
+            roof['issue'] = iss
+            roof = to_issue_bound(roof)
     return {'value': steps / sec, 'unit': 'env-steps/s', 'ms_per_step': float(np.mean(ms)),
             'td_updates_per_s': (steps + batch * batches) / sec, 'dtype': 'f32',
             'config': {'workload': desc, 'instances_per_gpu': n, 'env_steps_per_launch': env_steps},
@@ -398,6 +443,10 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
 
 def make_worlds(cfg_name):
     from cobel_amd.misc.gridworld_tools import make_obstacle_maze, make_open_field
+    if cfg_name == 'C1':
+        w = make_open_field(5, 5, 0, 1)
+        w['starting_states'] = np.arange(1, 25)
+        return [w]
     if cfg_name == 'C2':
         return [make_open_field(5, 5, 0, 1)]
     if cfg_name == 'C3':
@@ -466,8 +515,24 @@ class Runner:
                                           c['batch'])
 
 
+# rate of the port / rate of the real reference, one core, alternating 2-second slices in the build
+# container where both exist (scripts/calibrate_cpu_baseline.py)
+PORT_OVER_REFERENCE = {'C1': 1.11, 'C2': 1.11, 'C3': 1.13, 'C4': 1.35, 'C6': 1.08}
+
+
 def cpu_baseline(cfg_name, cfg, seconds=12.0):
     """NumPy restatement of the reference loop, 1 core, bounded sample of the same workload."""
+    r = _cpu_baseline(cfg_name, cfg, seconds)
+    r['port_over_reference'] = PORT_OVER_REFERENCE.get(cfg_name)
+    r['calibration'] = ('the port runs at %.2f x the rate of the real reference on this leg '
+                        '(measured where both exist: BASELINE.md section 4), so the reference '
+                        'itself would read ~%.0f %s here'
+                        % (r['port_over_reference'], r['value'] / r['port_over_reference'], r['unit'])
+                        if r['port_over_reference'] else None)
+    return r
+
+
+def _cpu_baseline(cfg_name, cfg, seconds=12.0):
     from oracle import philox, ref_loop
     world = make_worlds(cfg_name)[0]
     tabs = world.compact()
@@ -529,6 +594,67 @@ def pmc_traffic(cfg_name, cfg, kernel=None):
     if entry is None or (kernel is not None and not entry['kernel'].startswith(kernel.split('<')[0])):
         return None       # counters of another kernel than the one that ran
     return entry['hbm_bytes_per_launch']
+
+
+VALU_PEAK_SIMDS = 1024          # 256 CUs x 4 SIMDs; a wave64 vector instruction occupies a SIMD for 4 cycles
+VALU_CLOCK_GHZ = 2.4            # MI355X peak engine clock (MI355X_MICROARCH.md)
+
+
+def issue_roofline(key, env_steps_per_s, launch_ms, device, same_geometry):
+    """Instruction-issue view of a leg whose tables never leave the chip (LDS resident): vector
+    instructions per env step and how busy the vector ALUs are, from the committed SQ counter
+    passes (profiles/rNN_pmc_sq.json, scripts/pmc_sq.py: SQ_INSTS_* and SQ_ACTIVE_INST_VALU of the
+    leg's kernel under `rocprofv3 --pmc`, the timed launches).  `floor_ms` = what the same
+    instructions would take with the vector ALUs issuing every cycle."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_sq.json')))
+    if not files:
+        return None
+    entry = json.load(open(files[-1])).get(key)
+    if entry is None:
+        return None
+    clock_ghz = VALU_CLOCK_GHZ
+    peak = VALU_PEAK_SIMDS * clock_ghz / 4.0            # G wave-instructions / s
+    achieved = entry['valu_per_env_step'] * env_steps_per_s / 1e9
+    r = {'valu_per_step': entry['valu_per_env_step'], 'salu_per_step': entry['salu_per_env_step'],
+         'lds_per_step': entry.get('lds_per_env_step'),
+         'valu_instr_per_s': achieved * 1e9, 'valu_peak_instr_per_s': peak * 1e9,
+         'source': os.path.basename(files[-1]) + ' (' + entry['kernel'] + ')',
+         'note': 'wave-level instructions per env step (a lane-per-instance kernel serves 64 env '
+                 'steps with one); valu_busy_frac = SQ_ACTIVE_INST_VALU / (SIMDs x launch cycles): '
+                 'float64 and transcendental instructions hold a SIMD longer than 4 cycles, so it '
+                 'exceeds valu_instr_per_s / valu_peak_instr_per_s where they matter'}
+    if same_geometry:   # busy fraction and floor hold for the launch geometry of the counter pass
+        r['valu_busy_frac'] = entry['valu_busy_frac']
+        r['floor_ms'] = launch_ms * entry['valu_busy_frac']
+    return r
+
+
+def to_issue_bound(roof):
+    """Roofline object of a leg bound by instruction issue: `frac` = how busy the vector ALUs are
+    (`issue.valu_busy_frac` at the counter pass's own geometry, else vector instructions per second
+    against one wave64 instruction per SIMD and four cycles), the byte accounting of SURVEY 8d
+    moved to `hbm_accounting`."""
+    iss = roof.get('issue')
+    acct = {k: roof.pop(k) for k in ('achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_measured',
+                                     'traffic_unit', 'algorithmic_bytes_per_launch',
+                                     'algorithmic_bytes_per_env_step',
+                                     'algorithmic_bytes_per_reactivation') if k in roof}
+    acct['note'] = ('SURVEY 8d bytes per env step x env steps / launch time against the 8 TB/s HBM '
+                    'peak; these tables are LDS resident, so the bytes are accounting, not traffic '
+                    '(`traffic` = the L2 <-> fabric bytes of the PMC passes)')
+    roof['hbm_accounting'] = acct
+    roof['bound'] = 'issue'
+    roof['unit'] = 'G vector instructions/s'
+    if iss is None:
+        roof.update({'achieved': None, 'peak': None, 'frac': None,
+                     'note': 'no SQ counter pass for this kernel under profiles/'})
+        return roof
+    roof['achieved'] = iss['valu_instr_per_s'] / 1e9
+    roof['peak'] = iss['valu_peak_instr_per_s'] / 1e9
+    roof['frac'] = iss.get('valu_busy_frac', roof['achieved'] / roof['peak'])
+    roof['traffic'] = acct.get('traffic')
+    return roof
 
 
 def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
@@ -690,7 +816,7 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
         'metric': 'gridworld env-steps/sec (whole job)',
         'value': total_steps / elapsed,
         'unit': 'env-steps/s',
-        'n_gpus': world_size, 'steps': args.steps, 'warmup': warm,
+        'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -714,6 +840,17 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
                      'launch_ms_all': [round(x, 4) for x in launch_ms]},
     }
     res['roofline'].update(extra)
+    # C2 / C6 keep their tables in LDS for a whole launch (measured L2 <-> fabric traffic: 1 % / 0.3 %
+    # of the HBM peak): what bounds them is instruction issue, and that is the roofline they are held
+    # against; SURVEY 8d's byte accounting stays beside it as `hbm_accounting`.  C3 keeps the
+    # north-star's HBM accounting and carries the issue view as well.
+    iss = issue_roofline(cfg_name, steps_per_launch / mean_launch_s, mean_launch_s * 1e3, device,
+                         n == CONFIGS[cfg_name]['instances'] and args.scale == 1.0
+                         and not args.env_steps and world_size == 1)
+    if iss is not None:
+        res['roofline']['issue'] = iss
+    if cfg_name in ('C2', 'C6'):
+        res['roofline'] = to_issue_bound(res['roofline'])
     if dynaq:
         # (this rank's instances; counted by the kernel: cobel_tab_run_t.batches_done)
         drawn = steps_per_launch * args.steps
@@ -729,10 +866,12 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
             'window starts after untimed pre-training (`pretraining`) so that nearly every batch '
             'is evaluated: value / ms_per_step / frac are full-work numbers; `young_agents` is the '
             'rate of the first launches after one warm-up launch')
-        pre = {'launches': warm, 'env_steps_per_instance': warm * cfg['env_steps_per_launch'],
+        pre = {'launches': warm - args.warmup, 'untimed_launches_in_all': warm,
+               'env_steps_per_instance': warm * cfg['env_steps_per_launch'],
                'evaluated_fraction_at_start': frac_at_start,
                'train_until': None if args.no_pretrain else cfg.get('train_until'),
-               'note': 'untimed; the agents learn exactly as in the timed window'}
+               'note': 'untimed launches after the `warmup` ones; the agents learn exactly as in '
+                       'the timed window'}
         res['pretraining'] = pre
         k_young = [k for k in range(1, min(5, len(warm_ev)))]
         if k_young:
@@ -771,7 +910,7 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
         res['reactivations_per_s'] = replays * world_size / elapsed
         res['roofline']['algorithmic_bytes_per_reactivation'] = cfg['bytes_per_reactivation']
         res['roofline']['reactivations_per_launch'] = replays // args.steps
-        res['transient'] = {'first_launch_ms': first_ms, 'warmup_launches': warm,
+        res['transient'] = {'first_launch_ms': first_ms, 'untimed_launches': warm,
                             'note': 'launch time grows with the reactivations per launch while the '
                                     'agents learn; the timed window is the steady state'}
     return res, cfg
@@ -832,6 +971,9 @@ def main():
                          'go through the backend (RCCL on a one-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
+    ap.add_argument('--legs', default=None,
+                    help='comma-separated subset of the legs behind --also (C5_f64, C5_f32, dyna_dqn, '
+                         'dyna_dsr, C1, grid_search, general_hex_q, general_dynaq_b100); default: all')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -887,21 +1029,26 @@ def main():
                     others[name]['transient'] = r['transient']
                 if 'reactivations_per_s' in r:
                     others[name]['reactivations_per_s'] = r['reactivations_per_s']
-                    if rank == 0 and not args.no_cpu_baseline:
-                        others[name]['cpu_baseline'] = cpu_baseline(name, CONFIGS[name], 8.0)
+                # the reference's single-process loop on the same world, timed beside
+                # every leg that has one (C2 / C4 / C6; >= 2 000 env steps each)
+                if rank == 0 and not args.no_cpu_baseline:
+                    others[name]['cpu_baseline'] = cpu_baseline(name, CONFIGS[name], 8.0)
             except Exception as e:  # e.g. not enough HBM for C4 on a shared device
                 others[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
-        legs = [] if args.no_c5 else [
+        legs = [] if (args.no_c5 and args.legs is None) else [
             ('C5_f64', lambda: run_c5(device, 'f64', n=scaled(8192))),
             ('C5_f32', lambda: run_c5(device, 'f32', n=scaled(8192))),
             ('dyna_dqn', lambda: run_dyna_dqn(device, scaled(8192))),
             ('dyna_dsr', lambda: run_dyna_dsr(device, scaled(8192))),
+            ('C1', lambda: run_c1(device, not args.no_cpu_baseline)),
             ('grid_search', lambda: run_grid_search(device, 16 if args.scale == 1.0 else 4)),
             ('general_hex_q', lambda: run_general(device, 'hex_q', scaled(65536))),
             ('general_dynaq_b100', lambda: run_general(device, 'dynaq_b100', scaled(65536))),
         ]
+        if args.legs is not None:
+            legs = [(name, leg) for name, leg in legs if name in args.legs.split(',')]
         for name, leg in legs:
             try:
                 others[name] = leg()

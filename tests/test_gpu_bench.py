@@ -42,6 +42,7 @@ def test_two_ranks_split_the_instances_and_report_the_same_monitors(config, inst
         assert r['config']['instances_total'] == instances
         assert r['config']['instances_per_gpu'] == instances // n
         assert r['roofline']['frac'] <= 1.0 and r['roofline']['limiter'] in ('issue', 'hbm', 'latency')
+        assert r['roofline']['bound'] == 'hbm'
     assert b['monitors']['collectives_in_timed_region'] == 1
     for key in ('trials_finished', 'escape_latency_sum', 'trial_reward_sum'):
         assert a['monitors'][key] == b['monitors'][key], key
@@ -144,14 +145,28 @@ def test_every_default_leg_runs_and_carries_a_roofline():
     per_launch = r['config']['instances_per_gpu'] * r['config']['env_steps_per_launch']
     want = 78 * per_launch + 31 * 50 * roof['planning_batches_evaluated'] // r['steps']
     assert roof['algorithmic_bytes_per_launch'] == want
-    assert r['pretraining']['launches'] == r['warmup'] and 'young_agents' in r
+    # `warmup` echoes the request; the untimed pre-training is counted apart from it
+    assert r['warmup'] == 1 and 'young_agents' in r
+    assert r['pretraining']['untimed_launches_in_all'] == r['pretraining']['launches'] + 1
     legs = r['other_configs']
-    assert set(legs) >= {'C2', 'C4', 'C6', 'C5_f64', 'C5_f32', 'dyna_dqn', 'dyna_dsr', 'grid_search',
+    assert set(legs) >= {'C1', 'C2', 'C4', 'C6', 'C5_f64', 'C5_f32', 'dyna_dqn', 'dyna_dsr', 'grid_search',
                          'general_hex_q', 'general_dynaq_b100'}
     for name, leg in legs.items():
         assert 'error' not in leg, (name, leg)
-        assert leg['roofline'] is not None and leg['roofline']['frac'] > 0, name
+        assert leg['roofline'] is not None, name
+        if name != 'C1':     # (one instance = one wavefront: the plumbing case carries no fraction)
+            assert leg['roofline']['frac'] > 0, name
         assert leg['value'] > 0, name
+    # the LDS-resident legs are held against instruction issue, not against HBM bytes
+    for name in ('C2', 'C6', 'grid_search'):
+        assert legs[name]['roofline']['bound'] == 'issue', name
+        assert legs[name]['roofline']['hbm_accounting']['frac'] > 0, name
+    assert roof['bound'] == 'hbm' and roof['issue']['valu_per_step'] > 0
+    # the reference loop's port is timed beside every leg that has one
+    for name in ('C1', 'C2', 'C4', 'C6'):
+        cpu = legs[name]['cpu_baseline']
+        assert cpu['value'] > 0 and cpu['cores'] == 1 and cpu['kind'] == 'port', name
+        assert cpu['port_over_reference'] >= 1.0, name
 
 
 def test_one_rank_process_group_over_rccl():
@@ -175,6 +190,7 @@ def test_one_rank_process_group_over_rccl():
     assert rccl.stdout.strip().count('\n') == 0 and plain.stdout.strip().count('\n') == 0
     assert a['monitors']['collectives_in_timed_region'] == 0
     assert b['monitors']['collectives_in_timed_region'] == 1 and b['n_gpus'] == 1
-    assert a['warmup'] == b['warmup'] == 17
+    assert a['warmup'] == b['warmup'] == 1
+    assert a['pretraining']['untimed_launches_in_all'] == b['pretraining']['untimed_launches_in_all'] == 17
     for key in ('trials_finished', 'escape_latency_sum', 'trial_reward_sum'):
         assert a['monitors'][key] == b['monitors'][key], key
