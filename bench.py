@@ -371,7 +371,8 @@ def run_c1(device, with_cpu=True):
 def run_general(device, which, n=65536, env_steps=64, launches=4):
     """What leaving the four-action / <= 62-update wavefront kernels costs:
     `hex_q` = QAgent with a replay batch of 32 on a six-action hexagonal Topology
-    (misc/topology_tools.py:175-272) — k_tab_general, one lane per instance; `dynaq_b100` = Dyna-Q
+    (misc/topology_tools.py:175-272) — k_tab_wqn since round 4, one wavefront per instance with the
+    tables in LDS (k_tab_general, one lane per instance, before); `dynaq_b100` = Dyna-Q
     on C3's mazes with 100 planning updates per step (agent/dyna_q.py:319-330 has no limit) — the
     generic k_tab_wpi in two passes of <= 62 lanes."""
     from cobel_amd import _lib
@@ -422,13 +423,20 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
     sec = sum(ms) * 1e-3
     what = runner.describe()
     names = {_lib.TAB_KERNEL_GENERAL: 'k_tab_general', _lib.TAB_KERNEL_WPI: 'k_tab_wpi (generic, %d '
-             'passes)' % -(-batch // _lib.MAX_BATCH)}
+             'passes)' % -(-batch // _lib.MAX_BATCH), _lib.TAB_KERNEL_WQN: 'k_tab_wqn'}
     kernel = names.get(what['kernel'], 'kernel %d' % what['kernel'])
     alg = b_step * steps + b_upd * batch * batches
+    if which == 'hex_q':
+        traffic = pmc_traffic_leg('general_hex_q', kernel) if n == 65536 else None
     roof = _hbm_roofline(alg / steps, steps / sec, kernel,
                          'latency' if what['kernel'] == _lib.TAB_KERNEL_GENERAL else 'issue',
                          '%d B per env step + %d B per replayed / planned update of the batches the '
                          'kernel evaluated (%d of %d drawn)' % (b_step, b_upd, batches, steps))
+    if which == 'hex_q' and traffic is not None:
+        roof['traffic'] = traffic
+        roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC, profiles/)'
+        roof['frac_measured'] = traffic / (sec / launches) / 1e9 / HBM_PEAK_GBS
+        roof['measured_over_algorithmic'] = traffic / (alg / launches)
     if which == 'dynaq_b100':
         iss = issue_roofline('general_dynaq_b100', steps / sec, float(np.mean(ms)), device,
                              n == 65536)
@@ -655,6 +663,18 @@ def to_issue_bound(roof):
     roof['frac'] = iss.get('valu_busy_frac', roof['achieved'] / roof['peak'])
     roof['traffic'] = acct.get('traffic')
     return roof
+
+
+def pmc_traffic_leg(key, kernel):
+    """HBM bytes per launch of a leg's kernel from the newest committed PMC passes, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None
+    entry = json.load(open(files[-1])).get(key)
+    if entry is None or not entry['kernel'].startswith(kernel.split(' ')[0]):
+        return None
+    return entry['hbm_bytes_per_launch']
 
 
 def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
@@ -1016,7 +1036,7 @@ def main():
         c['instances'] = scaled(c['instances'])
     res, cfg = run_config(args.config, args, rank, world_size, device, dist, args.min_seconds)
     others = {}
-    if world_size == 1 and not args.instances and args.also:
+    if world_size == 1 and not args.instances and (args.also or args.legs):
         for name in [c for c in args.also.split(',') if c and c != args.config]:
             try:
                 gc.collect()               # (the previous leg's tables: C4 alone holds 64 GiB)

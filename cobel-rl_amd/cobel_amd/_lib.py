@@ -23,6 +23,7 @@ F_FORCE_LDS_MODEL, F_NO_PREFETCH, F_SR_STREAM_ROWS, F_TAB_GENERAL, F_NO_PWG = 64
 F_PWG_GLOBAL = 2048
 TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX, TAB_KERNEL_GENERAL = range(5)
 TAB_KERNEL_PWG = 5
+TAB_KERNEL_WQN = 6
 MAX_BATCH = 62       # largest batch of the wavefront kernels; larger ones run on the general kernel
 MAX_ACTIONS = 8
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,

@@ -350,6 +350,16 @@ class FusedAgent(Agent):
             keys = interface.observation_key_table() if hasattr(interface, 'observation_key_table') \
                 else interface.pose
             self._poses = np.asarray(keys, dtype=np.float64)
+            # The reference keys its table by the observation itself (agent/q.py:150-158): two nodes
+            # with the same observation — "manually defined observations" may repeat — SHARE one
+            # row there.  The tables here are indexed by node, so such a world would learn
+            # differently without a word; refuse it instead.
+            uniq = np.unique(self._poses.reshape(len(self._poses), -1), axis=0)
+            if len(uniq) != len(self._poses):
+                raise NotImplementedError(
+                    '%d of the %d nodes share their observation with another node: the reference '
+                    'would let them share a table row (agent/q.py:150-158), the device tables are '
+                    'indexed by node' % (len(self._poses) - len(uniq), len(self._poses)))
         else:
             assert int(interface.observation_space.n) == self.n_states
         self.inst = torch.zeros((self.n_envs, _lib.I_WORDS), dtype=torch.int32, device=self.device)

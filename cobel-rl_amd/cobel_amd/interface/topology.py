@@ -25,6 +25,14 @@ from .gridworld import WorldHandle, _as_seed
 from .interface import Interface
 
 
+def _torch_dtype(dt):
+    """torch counterpart of a NumPy dtype (float64 where torch has none)."""
+    try:
+        return torch.from_numpy(np.zeros(1, dtype=dt)).dtype
+    except TypeError:
+        return torch.float64
+
+
 class Topology(Interface):
     def __init__(self, nodes: dict, starting_nodes=None, simulator=None, widget=None, rng=None,
                  n_envs: int = 1, seed: int | None = None, device=None,
@@ -104,6 +112,10 @@ class Topology(Interface):
             for c, part in enumerate(parts(observations[pose])):
                 rows[c].append(np.asarray(part, dtype=np.float64))
         self._sim_shapes = [r[0].shape for r in rows]
+        # (the device tables are float64 — every integer and float32 value is exact in it; the
+        #  observations go back out in the dtype they were stored with, as the reference returns
+        #  the stored objects themselves: topology.py:174-193)
+        self._sim_dtypes = [np.asarray(parts(first)[c]).dtype for c in range(len(rows))]
         self._sim_tabs = [torch.as_tensor(np.stack([x.reshape(-1) for x in r]), device=self.device)
                           .contiguous() for r in rows]
         self._sim_out = [torch.zeros((self.n_envs, t.shape[1]), dtype=torch.float64,
@@ -147,10 +159,12 @@ class Topology(Interface):
                 _lib.ptr(tab), _lib.ptr(self.state), _lib.ptr(out), self.n_envs, tab.shape[1],
                 len(self.ids), self._stream()))
         if self.n_envs == 1:
-            parts = [o[0].cpu().numpy().reshape(sh) for o, sh in zip(self._sim_out, self._sim_shapes)]
+            parts = [o[0].cpu().numpy().reshape(sh).astype(dt, copy=False)
+                     for o, sh, dt in zip(self._sim_out, self._sim_shapes, self._sim_dtypes)]
         else:
-            parts = [o.reshape((self.n_envs,) + tuple(sh))
-                     for o, sh in zip(self._sim_out, self._sim_shapes)]
+            # (fresh tensors, not views of the gather buffers: the next step overwrites those)
+            parts = [o.reshape((self.n_envs,) + tuple(sh)).to(_torch_dtype(dt), copy=True)
+                     for o, sh, dt in zip(self._sim_out, self._sim_shapes, self._sim_dtypes)]
         if self._sim_kind == 'dict':
             return dict(zip(self._sim_keys, parts))
         return parts if self._sim_kind == 'list' else parts[0]

@@ -216,8 +216,17 @@ def _segment_distance(a: np.ndarray, b: np.ndarray, c: np.ndarray, d: np.ndarray
         t = 0.0 if den == 0.0 else min(1.0, max(0.0, float((p - q) @ qr) / den))
         return float(np.hypot(*(p - (q + t * qr))))
 
+    def within(p, q, r):     # r is collinear with pq: does it lie between them?
+        return (min(p[0], q[0]) <= r[0] <= max(p[0], q[0])
+                and min(p[1], q[1]) <= r[1] <= max(p[1], q[1]))
+
     o1, o2, o3, o4 = orient(a, b, c), orient(a, b, d), orient(c, d, a), orient(c, d, b)
-    if o1 * o2 < 0 and o3 * o4 < 0:   # a proper crossing (touching ends come out of the minima as 0)
+    if o1 * o2 < 0 and o3 * o4 < 0:   # a proper crossing
+        return 0.0
+    # touching: an end of one segment exactly ON the other (a zero orientation inside the other's
+    # bounding box) — decided by the orientation signs, not by a distance that has to round to 0.0
+    if ((o1 == 0 and within(a, b, c)) or (o2 == 0 and within(a, b, d))
+            or (o3 == 0 and within(c, d, a)) or (o4 == 0 and within(c, d, b))):
         return 0.0
     return min(point_segment(a, c, d), point_segment(b, c, d), point_segment(c, a, b),
                point_segment(d, a, b))

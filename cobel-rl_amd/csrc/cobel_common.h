@@ -77,6 +77,11 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
                         size_t* lds_bytes);
 int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
 
+// tabular_nact.hip: Q-learning on worlds of 1..8 (not four) actions, one wavefront per instance
+bool cobel_tab_nact_covers(const cobel_world* world, const cobel_tab_run_t& r, size_t* lds_bytes,
+                           int* instances_per_workgroup);
+int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
+
 // world.hip: the additions NumPy's pairwise sum performs on k non-zero elements at `pos` (ascending)
 // of a vector of n elements; returns the slot holding the result (-1: k == 0)
 int cobel_pairwise_schedule(int n, const int* pos, int k, uint8_t* dst, uint8_t* src);
@@ -91,6 +96,8 @@ int cobel_device_limits(int device, int* n_cu, size_t* lds_per_cu);   // world.h
 // workgroup.  Honoured only if it is a plain number that keeps `base + pad` within `limit`; anything
 // else (a stray or malformed variable) is ignored, so it can change occupancy, never break a launch.
 size_t cobel_debug_lds_pad(size_t base, size_t limit);
+// getenv(name) under the master switch COBEL_DEBUG=1, else NULL (world.hip)
+const char* cobel_debug_env(const char* name);
 // mlp.hip: the parameter-staging DQN replay kernel (cobel_dqn_replay, mlp_fit.hip, dispatches)
 size_t cobel_dqn_replay_lds_bytes(int32_t n_inputs, int32_t is_float64);
 int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st);

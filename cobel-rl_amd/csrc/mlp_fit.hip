@@ -910,7 +910,7 @@ int shape_ok(int32_t D, int32_t O, const char* who) {
 // n x 16 uint64 for the per-phase stamps.  Taken only if it parses completely and names DEVICE memory
 // of the current device; anything else is ignored, so a stray variable cannot send stores anywhere.
 unsigned long long* debug_trace_buffer() {
-  const char* const v = getenv("COBEL_DEBUG_MLP_TRACE");
+  const char* const v = cobel_debug_env("COBEL_DEBUG_MLP_TRACE");
   if (!v || !*v) return nullptr;
   char* end = nullptr;
   const unsigned long long addr = strtoull(v, &end, 0);
@@ -927,7 +927,7 @@ unsigned long long* debug_trace_buffer() {
 }
 // COBEL_DEBUG_MLP_STAGE = 1 .. 5: leave the step after that phase (phase timings; any other value: 0)
 int debug_stage_env() {
-  const char* const v = getenv("COBEL_DEBUG_MLP_STAGE");
+  const char* const v = cobel_debug_env("COBEL_DEBUG_MLP_STAGE");
   if (!v || !*v) return 0;
   char* end = nullptr;
   const long k = strtol(v, &end, 10);
@@ -1040,7 +1040,7 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
 // 1.34 -> 1.0 ms per step of 8 192 instances.  COBEL_DEBUG_DQN_KERNEL = lds | stream pins one
 // (experiments, tests).
 static bool dqn_staged(int32_t n_inputs, int32_t is_float64) {
-  if (const char* v = getenv("COBEL_DEBUG_DQN_KERNEL")) {   // exactly "lds" or "stream", else ignored
+  if (const char* v = cobel_debug_env("COBEL_DEBUG_DQN_KERNEL")) {   // exactly "lds" or "stream", else ignored
     if (!strcmp(v, "lds")) return true;
     if (!strcmp(v, "stream")) return false;
   }

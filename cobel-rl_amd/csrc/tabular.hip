@@ -1229,6 +1229,21 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                        (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ) ||
                        (r.flags & COBEL_F_TAB_GENERAL) ||
                        cobel_tab_query(world->n_states, r.agent, pass, &lds_max, nullptr) != COBEL_OK;
+  // Q-learning on worlds of other action counts whose tables fit the LDS: one wavefront per instance
+  {
+    size_t nact_lds = 0;
+    int nact_ipw = 0;
+    if (cobel_tab_nact_covers(world, r, &nact_lds, &nact_ipw)) {
+      if (describe) {
+        describe[0] = COBEL_TAB_KERNEL_WQN;
+        describe[1] = (int32_t)nact_lds;
+        describe[2] = lds_workgroups_per_cu(nact_lds);
+        describe[3] = nact_ipw;
+        return COBEL_OK;
+      }
+      return cobel_tab_nact_launch(world, r, (hipStream_t)stream);
+    }
+  }
   if (general) {
     COBEL_REQUIRE(world->n_actions == 4 || !r.model_index, COBEL_E_ARG,
                   "cobel_tab_run: the model digest exists for four-action worlds only");
@@ -1266,9 +1281,9 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
   // (debug switches are read once per process, not per launch)
-  static const bool no_exact_hash = getenv("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
+  static const bool no_exact_hash = cobel_debug_env("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
   // (per launch: scripts/exp_occupancy.py; validated against the limit below)
-  static const char* const lpw_env = getenv("COBEL_DEBUG_LPW");
+  static const char* const lpw_env = cobel_debug_env("COBEL_DEBUG_LPW");
   A.hash_exact = (world->n_states * 4 <= 4096 && !no_exact_hash) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
   const size_t lds_pad = cobel_debug_lds_pad(lds, (size_t)kLdsLimit);   // occupancy experiments

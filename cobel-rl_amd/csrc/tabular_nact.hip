@@ -1,0 +1,515 @@
+// Q-learning on worlds whose action count is not four — one WAVEFRONT per instance.
+//
+// The wavefront kernels of tabular.hip are laid out for four actions (16-byte Q rows, packed
+// world records, 48 CDF thresholds).  A Topology's action space is the neighbour count of its
+// start node (interface/topology.py:110-112): six on the hexagonal graphs of
+// misc/topology_tools.py:175-272.  Such runs used to take k_tab_general — one LANE per instance,
+// every table in HBM: each of a step's 1 + B TD updates two dependent trips to memory for 4-24
+// useful bytes of a 128-byte line (4.3e8 env-steps/s on the six-action bench leg, 7 % of the
+// byte roofline of SURVEY 8d).  Here the tables of an instance live in LDS for the whole call:
+//   * Q rows padded to eight floats (32 B; the pad cells hold -inf, so the row maximum and the tie
+//     pattern need no action count), the world as u16 next[S][8] + {reward, terminal}[S];
+//   * epsilon-greedy (policy/greedy.py:40-88) without floating point, as in k_tab_wpi: for every
+//     tie pattern of the A values the A - 1 thresholds ceil(cdf_k 2^53) of the normalised float64
+//     CDF, worked out once per launch by the workgroup itself (sequential float64 cumulative sum,
+//     correctly rounded division — what np.cumsum and Generator.choice compute) into an LDS table;
+//     a step reads its pattern's row and counts the thresholds the 53-bit draw has passed;
+//   * lane k < A evaluates successor k of the current state ahead of the action draw (next state,
+//     its reward / terminal record, the maximum of its Q row): the step pays one LDS round trip,
+//     the chosen successor is a readlane away;
+//   * the replay batch (agent/q.py:344-354: B indices into the experience log, one vector draw) is
+//     one lane per update; the logged records are gathered from HBM one step ahead (the memory
+//     stream is counter based) and patched with the two records the gather cannot have seen; the
+//     B sequential float32 TD updates run as speculative rounds over exact conflict sets (two
+//     tables of lane masks keyed by the bits of s * 8 + a), as in k_tab_wpi.
+// Same streams, counters, arithmetic and order of effects as k_tab_general: identical Q tables,
+// logs, counters and monitors (tests/test_gpu_general.py, scripts/fuzz_topology.py).
+//
+// Reference behaviour restated: agent/q.py:160-228 (train), :289-315 (update_q), :344-354 (replay);
+// interface/topology.py:126-157 (step); policy/greedy.py:40-88.
+#include <math.h>
+#include <stdlib.h>
+
+#include "cobel_common.h"
+#include "cobel_policy.h"
+
+namespace {
+
+struct nact_args {
+  const uint16_t* next_n;      // [W][S][A]
+  const float* reward_s;       // [W][S]
+  const uint8_t* terminal_s;   // [W][S]
+  const uint16_t* starts;
+  const int32_t* start_off;
+  int32_t S, n_worlds, A;
+  int32_t wpg;                 // wavefronts (instances) per workgroup
+  int32_t shared_world;        // one world: the workgroup keeps ONE copy of it
+  cobel_tab_run_t r;
+  float alpha_f, gamma_f;
+};
+
+constexpr int kHashWords = 64 + 128;   // H1: bits 0-5 of s * 8 + a; H2: bits 6-12
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float max8(const float4 a, const float4 b) {
+  return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+}
+
+// QAgent replay record of the general kernel (general.hip, log_pack_n): lo = f32 reward,
+// hi = s | ns << 14 | action << 28 | nonterminal << 30 up to four actions, << 31 beyond
+__device__ __forceinline__ uint64_t log_pack8(float r, uint32_t s, uint32_t a, uint32_t ns,
+                                              uint32_t nt, uint32_t nt_shift) {
+  return (uint64_t)fbits(r) | ((uint64_t)(s | (ns << 14) | (a << 28) | (nt << nt_shift)) << 32);
+}
+
+__host__ __device__ inline size_t nact_thr_words(int A) {
+  return A > 1 ? ((size_t)1 << A) * (size_t)(A - 1) : 1;
+}
+// LDS of a workgroup of `wpg` instances (bytes): thresholds | worlds | per instance Q + hash
+__host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool shared) {
+  const size_t thr = (nact_thr_words(A) * 8 + 15) & ~(size_t)15;
+  const size_t world = (size_t)S * 24;
+  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * 32 + kHashWords * 8);
+}
+
+__global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int S = G.S, A = G.A;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = (int)rfl(threadIdx.x >> 6);
+  const int i = (int)blockIdx.x * G.wpg + wave;
+  const bool present = i < G.r.n;
+  const uint32_t g = G.r.instance_base + (uint32_t)(present ? i : 0);
+  const int world = (int)(g % (uint32_t)G.n_worlds);
+  const size_t wbase = (size_t)world * S;
+
+  // ---- LDS carve-up ---------------------------------------------------------------------------
+  unsigned long long* const thr = reinterpret_cast<unsigned long long*>(lds_raw);
+  size_t off = (nact_thr_words(A) * 8 + 15) & ~(size_t)15;
+  const size_t wbytes = (size_t)S * 24;
+  unsigned char* const wl = lds_raw + off + (G.shared_world ? 0 : (size_t)wave * wbytes);
+  off += G.shared_world ? wbytes : wbytes * (size_t)G.wpg;
+  uint16_t* const nextL = reinterpret_cast<uint16_t*>(wl);               // [S][8]
+  uint2* const RT = reinterpret_cast<uint2*>(wl + (size_t)S * 16);       // [S] {reward bits, terminal}
+  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * 32 + kHashWords * 8);
+  float4* const Qs = reinterpret_cast<float4*>(mine);                    // [S][2]
+  float* const Qf = reinterpret_cast<float*>(mine);
+  unsigned long long* const H1 = reinterpret_cast<unsigned long long*>(mine + (size_t)S * 32);
+  unsigned long long* const H2 = H1 + 64;
+
+  // ---- the threshold table (whole workgroup) ----------------------------------------------------
+  // thr[t * (A - 1) + k] = ceil(cdf_k * 2^53) of the tie pattern t (bit a set: action a attains
+  // the maximum): probs = eps / A + ((1 - eps) * tie) / n_ties, sequential cumulative sum, divided
+  // by its last entry (greedy.py:83-86, Generator.choice) — cobel_make_eps_consts for A values.
+  if (A > 1) {
+    const double eps = G.r.epsilon;
+    for (int t = (int)threadIdx.x; t < (1 << A); t += (int)blockDim.x) {
+      const int nt = __popc((unsigned)t);
+      const double base = eps / (double)A;
+      const double bonus = nt ? ((1.0 - eps) * 1.0) / (double)nt : 0.0;
+      double cum[8];
+      double run = 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const double p = a < A ? base + (((t >> a) & 1) ? bonus : 0.0) : 0.0;
+        run = a == 0 ? p : run + p;
+        cum[a] = run;
+      }
+      double total = cum[0];
+#pragma unroll
+      for (int a = 1; a < 8; ++a) total = a == A - 1 ? cum[a] : total;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (k < A - 1) {
+          const double cdf = nt ? cum[k] / total : 2.0;   // t = 0 cannot occur
+          const double scaled = ceil(ldexp(cdf, 53));
+          thr[(size_t)t * (A - 1) + k] =
+              scaled >= 18446744073709551615.0 ? ~0ull : (unsigned long long)scaled;
+        }
+      }
+    }
+  }
+  // ---- the world(s) ---------------------------------------------------------------------------
+  {
+    const int nthr = G.shared_world ? (int)blockDim.x : 64;
+    const int tid = G.shared_world ? (int)threadIdx.x : lane;
+    if (G.shared_world || present) {
+      for (int e = tid; e < S * 8; e += nthr) {
+        const int s = e >> 3, a = e & 7;
+        nextL[e] = a < A ? G.next_n[(wbase + s) * A + a] : (uint16_t)s;
+      }
+      for (int s = tid; s < S; s += nthr)
+        RT[s] = make_uint2(fbits(G.reward_s[wbase + s]), (uint32_t)G.terminal_s[wbase + s]);
+    }
+  }
+  // ---- this instance's Q table (pad cells: -inf) and conflict tables ----------------------------
+  float* const Qg = G.r.q + (size_t)(present ? i : 0) * S * A;
+  if (present) {
+    for (int e0 = 0; e0 < S * 8; e0 += 512) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * 64 + lane;
+        const int s = e >> 3, a = e & 7;
+        const bool ok = e < S * 8 && a < A;
+        v[j] = Qg[ok ? (size_t)s * A + a : 0];
+        if (!ok) v[j] = -__builtin_huge_valf();
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * 64 + lane;
+        if (e < S * 8) Qf[e] = v[j];
+      }
+    }
+    for (int b = lane; b < kHashWords; b += 64) H1[b] = 0ull;
+  }
+  __syncthreads();
+  if (!present) return;
+
+  // ---- scalar state -----------------------------------------------------------------------------
+  int32_t* const inst = G.r.inst + (size_t)i * COBEL_I_WORDS;
+  int state = inst[COBEL_I_STATE];
+  int step = inst[COBEL_I_STEP];
+  int trial = inst[COBEL_I_TRIAL];
+  uint32_t ce = (uint32_t)inst[COBEL_I_CTR_ENV];
+  uint32_t cp = (uint32_t)inst[COBEL_I_CTR_POLICY];
+  uint32_t cm = (uint32_t)inst[COBEL_I_CTR_MEMORY];
+  uint32_t loglen = (uint32_t)inst[COBEL_I_LOG_LEN];
+  uint32_t iflags = (uint32_t)inst[COBEL_I_FLAGS];
+  double trew = *reinterpret_cast<const double*>(inst + COBEL_I_REWARD_LO + (lane & 0));
+  asm volatile("" : "+v"(trew));
+
+  const uint32_t flags = G.r.flags;
+  const bool learn = (flags & COBEL_F_LEARN) != 0;
+  uint64_t* const rlog = G.r.replay_log ? G.r.replay_log + (size_t)i * G.r.log_cap : nullptr;
+  const uint32_t cap = rlog ? (uint32_t)G.r.log_cap : 0u;
+  const int B = (learn && !(flags & COBEL_F_NO_REPLAY) && rlog) ? G.r.batch : 0;
+  const uint32_t pol_stream =
+      (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
+  uint64_t seed = G.r.seed;
+  asm volatile("" : "+v"(seed));
+  const int start_lo = G.start_off[world];
+  const uint32_t start_cnt = (uint32_t)(G.start_off[world + 1] - start_lo);
+  float alpha_f = G.alpha_f, gamma_f = G.gamma_f;
+  asm volatile("" : "+v"(alpha_f), "+v"(gamma_f));
+  const uint32_t nt_shift = A <= 4 ? 30u : 31u, a_mask = A <= 4 ? 3u : 7u;
+
+  // Cached Philox output: lanes < B hold memory block mb_idx (four consecutive batches), lanes 62
+  // and 63 the policy blocks 2 pb_idx and 2 pb_idx + 1 (action draws 4 pb_idx .. 4 pb_idx + 3).
+  // The memory block is the one of the NEXT batch (cm + 1): its records are gathered a step ahead.
+  cobel_u4 blk = {0, 0, 0, 0};
+  uint32_t mb_idx = ~0u, pb_idx = ~0u;
+  auto refresh = [&]() {
+    const uint32_t pq = cp >> 2, mi = (cm + 1u) >> 2;
+    if (__builtin_expect(pq == pb_idx && (B == 0 || mi == mb_idx), 1)) return;
+    const bool p0 = lane == 62, p1 = lane == 63;
+    blk = cobel_philox(p1 ? 2u * pq + 1u : (p0 ? 2u * pq : mi), (p0 || p1) ? 0u : (uint32_t)lane,
+                       g, (p0 || p1) ? pol_stream : COBEL_STREAM_MEMORY, seed);
+    pb_idx = pq;
+    mb_idx = mi;
+  };
+  // the record batch `c` replays in lane j from a log of `len` entries, or 0 (gather: entries that
+  // exist in memory now, i.e. below `have`)
+  auto gather = [&](uint32_t word, uint32_t len, uint32_t have, uint32_t& idx) -> uint64_t {
+    uint64_t rec = 0;
+    idx = 0u;
+    if (lane < B && len > 0u) {
+      idx = cobel_bounded(word, len);
+      if (idx < have) rec = rlog[idx];
+    }
+    return rec;
+  };
+
+  // ---- B sequential float32 TD updates (q.py:305-313), speculative rounds ------------------------
+  auto run_batch = [&](uint64_t rec) {
+    const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+    const uint32_t s = hi & 0x3fffu, ns = (hi >> 14) & 0x3fffu, a = (hi >> 28) & a_mask,
+                   nt = (hi >> nt_shift) & 1u;
+    const float r = __builtin_bit_cast(float, lo);
+    const uint32_t p = s * 8u + a;
+    const bool on = lane < B;
+    int first = 0;
+    bool have_conf = false;
+    unsigned long long conf = 0ull;
+    do {
+      const bool act = on && lane >= first;
+      float q = 0.0f, qn = 0.0f;
+      if (act) {
+        const float m = max8(Qs[ns * 2u], Qs[ns * 2u + 1u]);
+        q = Qf[p];
+        const float gnt = nt ? gamma_f : 0.0f;
+        float td = r + gnt * m;
+        td = td - q;
+        qn = q + alpha_f * td;
+      }
+      const bool ch = act && fbits(qn) != fbits(q);
+      const unsigned long long changed = __ballot(ch);
+      int stop = B;
+      if (changed) {
+        if (!have_conf) {
+          // exact conflict sets: all EARLIER lanes that write a cell this lane reads — its own
+          // cell (both buckets of p) or a cell of row ns (the eight H1 buckets of ns % 8, the H2
+          // bucket of ns / 8)
+          const uint32_t h1 = p & 63u, h2 = p >> 6;
+          const unsigned long long bit = 1ull << lane;
+          if (on) {
+            atomicOr(&H1[h1], bit);
+            atomicOr(&H2[h2], bit);
+          }
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long cnd = 0ull;
+          if (on) {
+            const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 7u) * 8u]);
+            const ulonglong2 ra = r8[0], rb = r8[1], rc = r8[2], rd = r8[3];
+            const unsigned long long cell = H1[h1] & H2[h2];
+            const unsigned long long row =
+                (((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y))) & H2[ns >> 3];
+            cnd = (cell | row) & (bit - 1ull);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (on) {
+            H1[h1] = 0ull;
+            H2[h2] = 0ull;
+          }
+          conf = cnd;
+          have_conf = true;
+        }
+        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
+        if (blocked) stop = __ffsll((long long)blocked) - 1;
+        if (ch && lane < stop) Qf[p] = qn;
+        __builtin_amdgcn_wave_barrier();
+      }
+      first = stop;
+    } while (first < B);
+  };
+
+  // what depends only on the state being entered: lane k < 8 evaluates successor k
+  uint32_t sn = 0, srw = 0, ste = 0;
+  float smax = 0.0f;
+  auto enter_state = [&](int s) {
+    sn = nextL[(uint32_t)s * 8u + (uint32_t)(lane & 7)];
+    const uint2 rt = RT[sn];
+    srw = rt.x;
+    ste = rt.y;
+  };
+  auto begin_trial = [&]() -> bool {
+    if (trial >= G.r.trials_target) return false;
+    state = (int)G.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed,
+                                                             start_cnt)];
+    ce += 1u;
+    step = 0;
+    trew = 0.0;
+    asm volatile("" : "+v"(trew));
+    iflags |= 1u;
+    return true;
+  };
+
+  // ---- prologue -----------------------------------------------------------------------------------
+  bool live = (iflags & 1u) ? true : begin_trial();
+  // the batch of the first step: drawn over the log as it will be after that step's append
+  uint32_t idx_cur = 0u;
+  uint64_t rec_cur = 0;
+  uint64_t fresh_prev = 0;          // the latest record this launch appended before the current step
+  bool have_prev = false;
+  if (B > 0 && live) {
+    const uint32_t len1 = loglen + ((learn && loglen < cap) ? 1u : 0u);
+    const cobel_u4 b0 = cobel_philox(cm >> 2, (uint32_t)lane, g, COBEL_STREAM_MEMORY, seed);
+    rec_cur = gather(cobel_word(b0, cm & 3u), len1, loglen, idx_cur);
+  }
+  const size_t mstripe = cobel_mon_offset(G.r.mon_stripes, G.r.trial_cap);
+  int budget = G.r.step_budget > 0 ? G.r.step_budget : 0x7fffffff;
+  unsigned long long executed = 0ull;
+  uint32_t batches = 0u;
+
+  while (live) {
+    if (budget == 0) break;
+    budget -= 1;
+    refresh();
+    // ---- successors of the current state, and its own row -------------------------------------------
+    enter_state(state);
+    const float4 qa = Qs[(uint32_t)state * 2u], qb = Qs[(uint32_t)state * 2u + 1u];
+    smax = max8(Qs[sn * 2u], Qs[sn * 2u + 1u]);
+    // ---- select --------------------------------------------------------------------------------------
+    const int src_lane = 62 + (int)((cp >> 1) & 1u);
+    const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
+    const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
+    cp += 1u;
+    int a = 0;
+    if (A > 1) {
+      const float m = max8(qa, qb);
+      const uint32_t t = ((uint32_t)__ballot(qa.x == m) & 1u) | ((uint32_t)__ballot(qa.y == m) & 2u) |
+                         ((uint32_t)__ballot(qa.z == m) & 4u) | ((uint32_t)__ballot(qa.w == m) & 8u) |
+                         ((uint32_t)__ballot(qb.x == m) & 16u) | ((uint32_t)__ballot(qb.y == m) & 32u) |
+                         ((uint32_t)__ballot(qb.z == m) & 64u) | ((uint32_t)__ballot(qb.w == m) & 128u);
+      const uint64_t K = cobel_u53(w0, w1);
+      const unsigned long long T = lane < A - 1 ? thr[(size_t)t * (A - 1) + lane] : ~0ull;
+      a = __popcll(__ballot(lane < A - 1 && T <= K));
+    }
+    // ---- env.step (interface/topology.py:126-157) ------------------------------------------------------
+    const int ns = (int)rl(sn, a);
+    const uint32_t r_bits = rl(srw, a);
+    const float r = __builtin_bit_cast(float, r_bits);
+    const uint32_t end = rl(ste, a);
+    const uint32_t nt = 1u - end;
+    const float ns_max = __builtin_bit_cast(float, rl(fbits(smax), a));
+    const uint32_t p_sa = (uint32_t)state * 8u + (uint32_t)a;
+    const bool trial_over = end || (step + 1 >= G.r.steps_per_trial);
+    // ---- online TD (q.py:305-313, float32) and the log (q.py:213) ----------------------------------------
+    uint64_t fresh_cur = 0;
+    bool appended = false;
+    if (learn) {
+      const float qrow[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+      float q_sa = qrow[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) q_sa = a == k ? qrow[k] : q_sa;
+      const float gnt = nt ? gamma_f : 0.0f;
+      float td = r + gnt * ns_max;
+      td = td - q_sa;
+      const float qn = q_sa + alpha_f * td;
+      fresh_cur = log_pack8(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt, nt_shift);
+      appended = loglen < cap;      // (a full log takes no record)
+      if (lane == 0) {
+        Qf[p_sa] = qn;
+        if (appended) rlog[loglen] = fresh_cur;
+      }
+      if (appended) loglen += 1u;
+      __builtin_amdgcn_wave_barrier();
+    }
+    trew += (double)r;
+    executed += 1ull;
+    state = ns;
+    // ---- replay: this step's batch (gathered a step ago), the next one's gather ----------------------------
+    if (B > 0) {
+      uint64_t rec_next = 0;
+      uint32_t idx_next = 0u;
+      {
+        const uint32_t len2 = loglen + ((loglen < cap) ? 1u : 0u);
+        rec_next = gather(cobel_word(blk, (cm + 1u) & 3u), len2, loglen, idx_next);
+      }
+      if (loglen > 0u) {
+        batches += 1u;
+        // what the gather of a step ago cannot have seen: the record this step appended (index
+        // loglen - 1) and, its store possibly still in flight then, the one before it
+        uint64_t rec = rec_cur;
+        if (appended) {
+          if (idx_cur + 1u == loglen) rec = fresh_cur;
+          else if (idx_cur + 2u == loglen && have_prev) rec = fresh_prev;
+        } else if (idx_cur + 1u == loglen && have_prev) {
+          rec = fresh_prev;
+        }
+        run_batch(rec);
+      }
+      cm += 1u;
+      rec_cur = rec_next;
+      idx_cur = idx_next;
+      if (appended) {
+        fresh_prev = fresh_cur;
+        have_prev = true;
+      }
+    }
+    if (__builtin_expect(trial_over, 0)) {
+      if (lane == 0 && trial >= 0 && trial < G.r.trial_cap) {
+        const size_t mo = mstripe + (size_t)trial;
+        if (G.r.lat_sum) atomicAdd(G.r.lat_sum + mo, (unsigned long long)step);
+        if (G.r.lat_cnt) atomicAdd(G.r.lat_cnt + mo, 1ull);
+        if (G.r.reward_sum) atomicAdd(G.r.reward_sum + mo, trew);
+        if (G.r.resp_cnt && trew > 0.0) atomicAdd(G.r.resp_cnt + mo, 1ull);
+        if (G.r.lat_trace) G.r.lat_trace[(size_t)i * G.r.trial_cap + trial] = step;
+      }
+      trial += 1;
+      iflags &= ~1u;
+      if (!begin_trial()) break;
+    } else {
+      step += 1;
+    }
+  }
+
+  // ---- write back ---------------------------------------------------------------------------------
+  __builtin_amdgcn_wave_barrier();
+  for (int e = lane; e < S * 8; e += 64) {
+    const int s = e >> 3, a = e & 7;
+    if (a < A) Qg[(size_t)s * A + a] = Qf[e];
+  }
+  if (lane == 0) {
+    inst[COBEL_I_STATE] = state;
+    inst[COBEL_I_STEP] = step;
+    inst[COBEL_I_TRIAL] = trial;
+    inst[COBEL_I_CTR_ENV] = (int32_t)ce;
+    inst[COBEL_I_CTR_POLICY] = (int32_t)cp;
+    inst[COBEL_I_CTR_MEMORY] = (int32_t)cm;
+    inst[COBEL_I_LOG_LEN] = (int32_t)loglen;
+    inst[COBEL_I_FLAGS] = (int32_t)iflags;
+    *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
+    if (G.r.steps_done && executed) atomicAdd(G.r.steps_done, executed);
+    if (G.r.batches_done && batches) atomicAdd(G.r.batches_done, (unsigned long long)batches);
+  }
+}
+
+// waves per workgroup and the LDS they take; false: the run is not covered
+bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out, size_t* lds_out) {
+  const int S = world->n_states, A = world->n_actions;
+  if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 8 || !world->next_n || world->succ_off ||
+      r.param_index || r.occupancy || r.last_exp || (r.flags & COBEL_F_MASK_ACTIONS) ||
+      (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
+      S > 1024 || r.n < 1)
+    return false;
+  const bool shared = world->n_worlds == 1;
+  int n_cu = 0;
+  size_t lds_cu = 0;
+  if (cobel_device_limits(world->device, &n_cu, &lds_cu) != COBEL_OK) return false;
+  // four instances per workgroup where they share the world's copy; as many workgroups per CU as
+  // LDS allows (the limit: 64 KiB of dynamic LDS need no opt-in, the rest of the 160 KiB does)
+  int wpg = shared ? 4 : 1;
+  while (wpg > 1 && nact_lds_bytes(S, A, wpg, shared) > lds_cu / 2) wpg >>= 1;
+  const size_t lds = nact_lds_bytes(S, A, wpg, shared);
+  if (lds > lds_cu) return false;
+  *wpg_out = wpg;
+  *lds_out = lds;
+  return true;
+}
+
+}  // namespace
+
+bool cobel_tab_nact_covers(const cobel_world* world, const cobel_tab_run_t& r, size_t* lds_bytes,
+                           int* instances_per_workgroup) {
+  int wpg = 0;
+  size_t lds = 0;
+  if (!nact_plan(world, r, &wpg, &lds)) return false;
+  if (lds_bytes) *lds_bytes = lds;
+  if (instances_per_workgroup) *instances_per_workgroup = wpg;
+  return true;
+}
+
+int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st) {
+  int wpg = 0;
+  size_t lds = 0;
+  if (!nact_plan(world, r, &wpg, &lds))
+    return cobel_fail(COBEL_E_UNSUPPORTED, "cobel_tab_nact_launch: run not covered");
+  nact_args G;
+  G.next_n = world->next_n;
+  G.reward_s = world->reward_s;
+  G.terminal_s = world->terminal_s;
+  G.starts = world->starts;
+  G.start_off = world->start_off;
+  G.S = world->n_states;
+  G.n_worlds = world->n_worlds;
+  G.A = world->n_actions;
+  G.wpg = wpg;
+  G.shared_world = world->n_worlds == 1 ? 1 : 0;
+  G.r = r;
+  G.alpha_f = (float)r.alpha;
+  G.gamma_f = (float)r.gamma;
+  if (lds > 64 * 1024)
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wqn),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_tab_wqn, dim3((unsigned)((r.n + wpg - 1) / wpg)), dim3(64 * wpg), lds, st, G);
+  COBEL_HIP_TRY(hipGetLastError());
+  return COBEL_OK;
+}

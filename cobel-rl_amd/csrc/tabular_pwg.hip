@@ -767,7 +767,7 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
 // digest in HBM, exact dependency lookup, no visit counters, no parameter sets)
 bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int* nl_out, int* ng_out,
                         size_t* lds_out) {
-  static const char* const force = getenv("COBEL_DEBUG_PWG");   // "nl,ng" (experiments)
+  static const char* const force = cobel_debug_env("COBEL_DEBUG_PWG");   // "nl,ng" (experiments)
   const int S = world->n_states;
   if (r.agent != COBEL_AGENT_DYNAQ || !r.model_index || r.occupancy || r.param_index ||
       r.last_exp || S * 4 > 4096 || S <= 256 || r.batch < 1 || r.batch > COBEL_MAX_BATCH)
@@ -813,7 +813,7 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
 // 384 + 128, 32 768: 6.40 / 6.33 with 448 + 64; 65 536 is not sliced.
 static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, bool scratch,
                        int32_t* steps /* [kMaxSlices] */) {
-  const char* const forced = getenv("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
+  const char* const forced = cobel_debug_env("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
   for (int j = 0; j < kMaxSlices; ++j) steps[j] = 0;
   steps[0] = r.step_budget;
   if (!scratch || grid < n_cu || r.step_budget < 64) return 1;
@@ -888,11 +888,11 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   A.n_slices = plan_slices(r, grid, n_cu, waves, scratch, A.slice_steps);
   A.ring_stride = (uint32_t)((r.n + 7) / 8) * (uint32_t)(A.n_slices - 1);
   {
-    const char* const m_env = getenv("COBEL_DEBUG_PWG_XCCLIMIT");   // (tests)
+    const char* const m_env = cobel_debug_env("COBEL_DEBUG_PWG_XCCLIMIT");   // (tests)
     A.xcc_limit = m_env ? (uint32_t)atoi(m_env) & 7u : 7u;
   }
   {
-    static const char* const k_env = getenv("COBEL_DEBUG_PWG_RESERVE");   // (experiments)
+    static const char* const k_env = cobel_debug_env("COBEL_DEBUG_PWG_RESERVE");   // (experiments)
     // (2.0: within 0.5 % of the best at 32 768 and 65 536 instances per GPU, 3-5 % ahead of 2.5 at the
     //  8 192 / 16 384 an eight- / four-way split leaves each GPU)
     const double k = k_env ? atof(k_env) : 2.0;

@@ -22,8 +22,17 @@ int cobel_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// The experiment switches (COBEL_DEBUG_*: occupancy padding, kernel choice, phase cuts, slice plans)
+// are honoured only under the master switch COBEL_DEBUG=1: a stray variable in a production
+// environment changes nothing.
+const char* cobel_debug_env(const char* name) {
+  const char* const on = getenv("COBEL_DEBUG");
+  if (!on || on[0] != '1' || on[1] != '\0') return nullptr;
+  return getenv(name);
+}
+
 size_t cobel_debug_lds_pad(size_t base, size_t limit) {
-  const char* const v = getenv("COBEL_DEBUG_LDS_PAD");
+  const char* const v = cobel_debug_env("COBEL_DEBUG_LDS_PAD");
   if (!v || !*v) return 0;
   char* end = nullptr;
   const long pad = strtol(v, &end, 10);

@@ -369,6 +369,9 @@ enum {
   COBEL_TAB_KERNEL_PWG = 5,       /* plain Dyna-Q training, one persistent workgroup of 16 wavefronts
                                      per CU: some keep Q in LDS, the others work on it in L2; out[1]
                                      = LDS of the workgroup, out[2] = 1, out[3] = its wavefronts    */
+  COBEL_TAB_KERNEL_WQN = 6,       /* Q-learning on worlds of 1..8 (not four) actions whose tables fit
+                                     the LDS: one wavefront per instance, Q rows padded to eight
+                                     values; out[3] = instances per workgroup                      */
   COBEL_TAB_KERNEL_GENERAL = 4    /* one lane per instance, tables in HBM: any action count, batch
                                      size and state count                                        */
 };

@@ -1,3 +1,4 @@
+export COBEL_DEBUG=1
 mkdir -p gpurun_out
 run() { # name, env..., args
   name=$1; shift

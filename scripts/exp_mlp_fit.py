@@ -3,6 +3,7 @@ agents): launch time of the full step and of variants that leave parts out."""
 import ctypes as C
 import json
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,7 @@ every workgroup stamps wall_clock64() (100 MHz) at the phase boundaries of its s
     python scripts/exp_mlp_trace.py c5|dsr [f64|f32]"""
 import json
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

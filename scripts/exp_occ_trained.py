@@ -3,6 +3,7 @@ agents.  24x24 mazes need 10 240 B of LDS (8 blocks of 1 280 B: 16 instances per
 limit); COBEL_DEBUG_LDS_PAD pads them down to 14 / 12 / 11 / 10 / 9 per CU — same work, different
 occupancy."""
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

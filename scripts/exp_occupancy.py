@@ -1,6 +1,8 @@
 """Scratch: what one or two more resident instances per CU buy the Dyna-Q kernel (k_tab_wpi MIDX).
 Worlds of 30x30 / 28x28 states need 16 / 14 KiB of LDS (10 / 11 instances per CU); COBEL_DEBUG_LDS_PAD
 pads them back to the 17 KiB (9 per CU) of a 32x32 world — same work, different occupancy."""
+import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))

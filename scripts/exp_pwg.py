@@ -2,6 +2,7 @@
 LDS / global-memory waves (COBEL_DEBUG_PWG="nl,ng", read once per process) on trained agents.
 `python scripts/exp_pwg.py [pretrain launches] [nopwg]`"""
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

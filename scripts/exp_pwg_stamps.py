@@ -5,6 +5,7 @@ scratch area, read back here and split by the two kinds of wave.
     COBEL_LIB=$PWD/gpurun_ab/libcobel_stamps.so python scripts/exp_pwg_stamps.py [instances] [pretrain launches]
 """
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -24,7 +24,8 @@ import json
 import os
 import sys
 
-KERNELS = {'C3': 'k_tab_pwg', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma'}
+KERNELS = {'C3': 'k_tab_pwg', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma',
+           'general_hex_q': 'k_tab_wqn'}
 # bench.py times the LAST `--steps` (4) launches of each kernel; everything before them is untimed
 # warm-up (C3: the pre-training that takes the agents to the full-work state, C6: 40 launches)
 TIMED = 4
@@ -82,6 +83,8 @@ def main():
            'fetch_factor': factor, 'calibration': cal}
     for cfg, tag in KERNELS.items():
         names = [k for k in fetch if tag in k]
+        if cfg == 'general_hex_q' and not names:
+            continue          # (passes made without that leg)
         assert len(names) == 1 and names[0] in write, (cfg, names)
         f, w = fetch[names[0]][-TIMED:], write[names[0]][-TIMED:]   # the timed launches
         fk, wk = sum(f) / len(f), sum(w) / len(w)

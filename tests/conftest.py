@@ -1,6 +1,7 @@
 """Shared fixtures.  ``-m gpu`` tests need an MI355X and run the HIP library through its C ABI;
 everything else runs on CPU (oracle vs golden vectors, host logic, symbol checks)."""
 import os
+os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
 import numpy as np

@@ -529,3 +529,37 @@ def test_qagent_on_dictionary_observations_matches_reference(cobel, golden, name
     assert np.array_equal(agent.predict_on_batch(probe).astype(np.float64), g('probe_q'))
     assert len(agent.M) == int(g('log_len'))
     assert all(len(k) == 12 for k in agent.Q_dict)
+
+
+def test_prerendered_observations_keep_their_dtype_and_aliases_are_refused(cobel):
+    """interface/topology.py:174-193 hands out the stored observation objects themselves: uint8
+    images come back as uint8, float32 vectors as float32 (one env: NumPy, several: fresh device
+    tensors).  Two nodes with the SAME observation would share a table row in the reference
+    (agent/q.py:150-158 keys Q by the observation): refused, not silently learned per node."""
+    import torch
+    from cobel.agent import QAgent
+    from cobel.interface import OfflineSimulator, Topology
+    from cobel.misc.topology_tools import linear_track
+    from cobel.policy import EpsilonGreedy
+    from cobel.spaces import Box, Dict
+    nodes, starts = linear_track(4, 2, 1., 5., 'right')
+    obs = {n['pose']: {'image': np.full((3, 3), k, dtype=np.uint8),
+                       'vec': np.array(n['pose'], dtype=np.float32)}
+           for k, n in enumerate(nodes.values())}
+    space = Dict({'image': Box(0, 255, (3, 3), np.uint8), 'vec': Box(-np.inf, np.inf, (6,), np.float32)})
+    env = Topology(nodes, starts, OfflineSimulator(obs, space), seed=5)
+    o, _ = env.reset()
+    assert o['image'].dtype == np.uint8 and o['vec'].dtype == np.float32 and o['image'].shape == (3, 3)
+    many = Topology(nodes, starts, OfflineSimulator(obs, space), n_envs=5, seed=5)
+    first, _ = many.reset()
+    assert first['image'].dtype == torch.uint8 and first['vec'].dtype == torch.float32
+    kept = first['vec'].clone()
+    many.step(torch.zeros(5, dtype=torch.int64, device=first['vec'].device))
+    assert torch.equal(first['vec'], kept)            # not a view of the gather buffer
+    QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1)).train(env, 2, 5, 0)
+    # node 1 renders like node 0
+    poses = [n['pose'] for n in nodes.values()]
+    obs[poses[1]] = obs[poses[0]]
+    aliased = Topology(nodes, starts, OfflineSimulator(obs, space), seed=5)
+    with pytest.raises(NotImplementedError, match='share their observation'):
+        QAgent(aliased.observation_space, aliased.action_space, EpsilonGreedy(0.1)).train(aliased, 1, 5, 0)

@@ -118,7 +118,8 @@ def _same_tab(torch, a, b):
     for name in ('lat_sum', 'lat_cnt', 'resp_cnt', 'reward_sum'):
         assert torch.equal(getattr(a.monitors, name), getattr(b.monitors, name)), name
     assert torch.equal(a.monitors.lat_trace, b.monitors.lat_trace)
-    assert torch.equal(a.monitors.occupancy, b.monitors.occupancy)
+    if a.monitors.occupancy is not None or b.monitors.occupancy is not None:
+        assert torch.equal(a.monitors.occupancy, b.monitors.occupancy)
 
 
 def test_general_kernel_equals_wavefront_kernels(torch_cuda, golden_worlds):
@@ -308,3 +309,64 @@ def test_batches_done_counts_what_planning_evaluates(torch_cuda):
     qa = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.3))
     qa.train(env, 2, 10, 8)
     assert int(qa.batches_done.item()) == int(qa.monitors.steps_done.item())
+
+
+@pytest.mark.parametrize('A,n_worlds,batch', [(6, 1, 32), (6, 1, 0), (6, 3, 62), (5, 1, 8), (7, 2, 24),
+                                              (8, 1, 32), (3, 1, 16), (2, 2, 5), (1, 1, 4)])
+def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch):
+    """Q-learning on worlds of 1..8 (not four) actions runs one wavefront per instance with its
+    tables in LDS (csrc/tabular_nact.hip); the lane-per-instance general kernel executes the
+    reference's loop literally: same Q, logs, counters, monitors — training in two sessions with a
+    test phase in between, launches cut at odd step counts."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Topology
+    from cobel_amd.policy import EpsilonGreedy
+    rng = np.random.default_rng(100 * A + n_worlds)
+    S = 37
+
+    def graph(k):
+        nbr = rng.integers(0, S, (S, A))
+        nbr = np.where(rng.random((S, A)) < 0.2, np.arange(S)[:, None], nbr)
+        term = rng.random(S) < 0.08
+        term[0] = False
+        rew = np.where(rng.random(S) < 0.2, rng.choice([1.0, -1.0, 0.5], S), 0.0)
+        rew[term] = 2.0
+        nodes = {str(i): {'id': str(i), 'pose': np.array([float(i), float(k), 0., 0., 0., 0.]),
+                          'neighbors': [str(int(j)) for j in nbr[i]], 'reward': float(rew[i]),
+                          'terminal': bool(term[i])} for i in range(S)}
+        return nodes
+    worlds = [graph(k) for k in range(n_worlds)]
+    outs = []
+    for general in (False, True):
+        env = Topology(worlds[0], None, n_envs=150, seed=SEED, instance_base=5)
+        if n_worlds > 1:    # (several graphs in one handle: instance g walks graph g % n_worlds)
+            from cobel_amd.interface.gridworld import WorldHandle
+            env.handle = WorldHandle([Topology(w, None, seed=1).world for w in worlds], env.device)
+        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2), learning_rate=0.7,
+                    gamma=0.9)
+        ag.force_general = general
+        ag.track_instances = True
+        ag.track_responses = True
+        ag._bind(env)
+        ag._env_in(env)
+        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False)
+        ag.monitors.reserve(64, 150, True)
+        if batch:
+            ag.reserve_replay(400)
+        kinds = set()
+        for steps in (2, 7, 33, 64, 5):      # (a one-step launch carries per-step host logs: general kernel)
+            kinds.add(ag.describe_launch(env, ag.policy, flags, 40, 11, steps, batch)['kernel'])
+            ag._launch(env, ag.policy, flags, 40, 11, steps, batch)
+        ag.test(env, 3, 9)
+        ag.train(env, 4, 13, batch)
+        torch.cuda.synchronize()
+        outs.append((ag, kinds))
+    (a, ka), (b, kb) = outs
+    assert ka == {_lib.TAB_KERNEL_WQN} and kb == {_lib.TAB_KERNEL_GENERAL}
+    assert a._q.abs().sum() > 0 and int(a.inst[:, _lib.I_LOG_LEN].sum()) > 0
+    _same_tab(torch, a, b)
+    if batch:
+        assert torch.equal(a._log, b._log)
+    assert int(a.batches_done.item()) == int(b.batches_done.item())
