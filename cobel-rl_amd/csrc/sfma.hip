@@ -34,6 +34,12 @@ struct sfma_args {
   cobel_eps_bb eps;
   uint64_t eps_thr[16][3];   // integer CDF thresholds of the unmasked selection (cobel_policy.h)
   float alpha_f, gamma_f, model_lr_f;
+  // transition rows that are distributions (cobel_world_set_transitions), else NULL: SFMA.train
+  // steps the interface (agent/sfma.py:262-264), whose step() then DRAWS the successor
+  // (interface/gridworld.py:119-123) — one double of the env stream per step
+  const uint32_t* succ_off;
+  const uint16_t* succ_state;
+  const double* succ_cdf;
 };
 
 struct sfma_lds {
@@ -801,8 +807,16 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
                       ? (int)rfl((uint32_t)cobel_eps_greedy_select_thr(q.x, q.y, q.z, q.w,
                                                                         cobel_u53(w0, w1), L.thr, lane))
                       : (int)rfl((uint32_t)select_action(q, mask_cur, cobel_u01(w0, w1)));
-    const uint4 wc = W4[state];
-    const int ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
+    int ns;
+    if (!FAST && A.succ_off) {
+      const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      ns = (int)rfl((uint32_t)cobel_draw_successor(
+          A.succ_off, A.succ_state, A.succ_cdf, ((size_t)world * S + (size_t)state) * 4 + a, ue));
+    } else {
+      const uint4 wc = W4[state];
+      ns = (int)next_of(rfl(wc.x), rfl(wc.y), a);
+    }
     const uint4 wn = W4[ns];
     const float r = __builtin_bit_cast(float, rfl(wn.z));
     const uint32_t end = rfl(wn.w);
@@ -1031,7 +1045,10 @@ extern "C" int cobel_sfma_exp_check(const double* x, double* in_range, double* l
 
 extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t* run,
                               void* stream) {
-  if (int rc = cobel_world_check4(world, "cobel_sfma_run")) return rc;
+  if (int rc = cobel_world_check(world, "cobel_sfma_run")) return rc;
+  COBEL_REQUIRE(world->n_actions == 4, COBEL_E_UNSUPPORTED,
+                "cobel_sfma_run: the world has %d actions, this entry point serves four-action worlds",
+                world->n_actions);
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sfma_run: NULL world/run");
   const cobel_sfma_run_t& r = *run;
   COBEL_REQUIRE(r.q && r.model && r.strength && r.stamp && r.inst && r.sfma_inst && r.metric,
@@ -1078,6 +1095,9 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
+  A.succ_off = world->succ_off;
+  A.succ_state = world->succ_state;
+  A.succ_cdf = world->succ_cdf;
   const uint32_t special = COBEL_SF_RECENCY | COBEL_SF_C_NORMALIZE | COBEL_SF_D_NORMALIZE |
                            COBEL_SF_DETERMINISTIC;
   const bool plain = !(r.sfma_flags & special) && (r.sfma_flags & COBEL_SF_R_NORMALIZE) &&
@@ -1091,7 +1111,8 @@ extern "C" int cobel_sfma_run(const cobel_world_t* world, const cobel_sfma_run_t
                       !(r.flags & (COBEL_F_NO_REPLAY | COBEL_F_TEST_STREAM)) &&
                       !(r.sfma_flags & slow_sf) && r.nb_replays == 1 && r.decay_strength == 1.0 &&
                       r.beta >= 0.0 && r.beta <= 700.0 && r.r_threshold >= 0.0 &&
-                      !r.last_exp && !r.occupancy && !r.replay_trace && !r.lat_trace;
+                      !r.last_exp && !r.occupancy && !r.replay_trace && !r.lat_trace &&
+                      !world->succ_off;
     if (fast) {
       hipLaunchKernelGGL(k_sfma_2_fast, dim3(A.r.n), dim3(64), sfma_lds_bytes(kFastStates), st, A);
       COBEL_HIP_TRY(hipGetLastError());

@@ -38,6 +38,10 @@ struct sr_args {
   cobel_sr_run_t r;
   cobel_eps_consts eps;
   float alpha_f, gamma_f;
+  // transition rows that are distributions (cobel_world_set_transitions), STOCH kernels only
+  const uint32_t* succ_off;
+  const uint16_t* succ_state;
+  const double* succ_cdf;
 };
 
 // Padded LDS position of row element e: 8 floats of padding per 128 keep the four leaves a
@@ -251,7 +255,13 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
 // PSETS: hyper-parameters from per-instance parameter sets (run.param_index).
 // Five waves per SIMD = five workgroups per CU (96 registers; the allocator's own choice of 98
 // stops at four, and six — 80 registers — spills: 10.0 / 8.9 / 9.3 ms per launch on C4).
-template <bool VEC, bool OCC, bool PRE, bool PSETS>
+// STOCH: the world's transition rows are distributions — SR.train simply calls interface.step
+// (agent/sr.py:170-182), and Gridworld.step draws the successor from the row (interface/
+// gridworld.py:119-123): one double of the env stream per step (sub-stream 1 of the counter the
+// trial starts share, as cobel_env_step_draw and the general tabular kernel), first successor whose
+// cumulative probability exceeds it; the record of the state entered is then fetched, not taken
+// from the prefetched four.
+template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sr(
     const sr_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const uint4 c = W4[s];
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
-    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    if (!STOCH && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
     tcur = load_trow(s);
     left_state = -1;
@@ -410,10 +420,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                                         cobel_u53(w0, w1), L.thr, lane))
                       : (int)rfl((uint32_t)cobel_eps_greedy_select_wave(
                             q.x, q.y, q.z, q.w, mask_cur, cobel_u01(w0, w1), ebb, lane));
-    const int ns = (int)next_of(cw0, cw1, a);
-    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
-    const float r = __builtin_bit_cast(float, rl(cand.z, a));
-    const uint32_t end = rl(cand.w, a);
+    int ns;
+    uint32_t nw0, nw1, end;
+    float r;
+    if (STOCH) {
+      const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      ns = (int)rfl((uint32_t)cobel_draw_successor(
+          A.succ_off, A.succ_state, A.succ_cdf, ((size_t)world * S + (size_t)state) * 4 + a, ue));
+      const uint4 c = W4[ns];
+      nw0 = rfl(c.x);
+      nw1 = rfl(c.y);
+      r = __builtin_bit_cast(float, rfl(c.z));
+      end = rfl(c.w);
+    } else {
+      ns = (int)next_of(cw0, cw1, a);
+      nw0 = rl(cand.x, a);
+      nw1 = rl(cand.y, a);
+      r = __builtin_bit_cast(float, rl(cand.z, a));
+      end = rl(cand.w, a);
+    }
     const uint32_t nt = 1u - end;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     // T[ns][.] as it stands before this step's write (one 8-byte load, the same for all threads)
@@ -528,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     cw0 = nw0;
     cw1 = nw1;
     if (!trial_over) {
-      if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+      if (!STOCH && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
       mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
       step += 1;
     } else {
@@ -611,13 +637,14 @@ __global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
   }
 }
 
-template <bool VEC, bool OCC, bool PRE, bool PSETS>
+template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false>
 int launch_sr(const sr_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE, PSETS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    COBEL_HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE, PSETS, STOCH>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE, PSETS>), dim3(A.r.n), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE, PSETS, STOCH>), dim3(A.r.n), dim3(256), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -639,9 +666,15 @@ extern "C" int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t
 }
 
 extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* run, void* stream) {
-  if (int rc = cobel_world_check4(world, "cobel_sr_run")) return rc;
+  if (int rc = cobel_world_check(world, "cobel_sr_run")) return rc;
+  COBEL_REQUIRE(world->n_actions == 4, COBEL_E_UNSUPPORTED,
+                "cobel_sr_run: the world has %d actions, this entry point serves four-action worlds",
+                world->n_actions);
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sr_run: NULL world/run");
   const cobel_sr_run_t& r = *run;
+  COBEL_REQUIRE(!world->succ_off || !r.param_index, COBEL_E_UNSUPPORTED,
+                "cobel_sr_run: per-instance parameter sets on a world whose transition rows are "
+                "distributions");
   COBEL_REQUIRE(r.sr && r.trans && r.rewards && r.inst, COBEL_E_ARG,
                 "cobel_sr_run: sr, trans, rewards and inst are required");
   COBEL_REQUIRE(((uintptr_t)r.sr & 15u) == 0 && ((uintptr_t)r.inst & 7u) == 0, COBEL_E_ARG,
@@ -666,7 +699,7 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   if (r.n == 0) return COBEL_OK;
   // Worlds with at most eight rewarded states and up to 1 024 states (every builder of the reference):
   // the value rows collapse to a few elements each, see sr_wave.hip.
-  if (((uintptr_t)r.rewards & 15u) == 0 && cobel_sr_wave_covers(world, r))
+  if (!world->succ_off && ((uintptr_t)r.rewards & 15u) == 0 && cobel_sr_wave_covers(world, r))
     return cobel_sr_wave_launch(world, r, (hipStream_t)stream);
   sr_args A;
   A.rec = world->rec;
@@ -679,8 +712,17 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   A.eps = cobel_make_eps_consts(r.epsilon);
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
+  A.succ_off = world->succ_off;
+  A.succ_state = world->succ_state;
+  A.succ_cdf = world->succ_cdf;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (S % 4) == 0;
+  if (world->succ_off) {   // the successor is drawn: the row-streaming kernel without its prefetch
+    if (vec) return occ ? launch_sr<true, true, false, false, true>(A, lds, st)
+                        : launch_sr<true, false, false, false, true>(A, lds, st);
+    return occ ? launch_sr<false, true, false, false, true>(A, lds, st)
+               : launch_sr<false, false, false, false, true>(A, lds, st);
+  }
   const bool pre = vec && S <= 1024 && !(r.flags & COBEL_F_NO_PREFETCH);
 #define COBEL_SR(V, PF)                                                                   \
   do {                                                                                    \

@@ -337,7 +337,9 @@ def run_case(world: dict, D, seed: int, inst: int, f32: bool, mode: str, opts: d
     from .philox import (STREAM_AGENT, STREAM_AUX, STREAM_ENV, STREAM_MEMORY, STREAM_POLICY,
                          TapeRNG)
     dt = np.float32 if f32 else np.float64
-    env = RefGridworld(world, TapeRNG(seed, inst, STREAM_ENV))
+    # (double_sub: a world whose rows are distributions draws one double per step from sub-stream 1
+    #  of the env stream; a table world never asks for one)
+    env = RefGridworld(world, TapeRNG(seed, inst, STREAM_ENV, double_sub=1))
     S = env.n_states
     mem = RefSFMAMemory(D, S, 4, TapeRNG(seed, inst, STREAM_MEMORY, double_sub=1), dtype=dt)
     pol = RefEpsilonGreedy(eps, TapeRNG(seed, inst, STREAM_POLICY))

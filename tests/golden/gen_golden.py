@@ -426,12 +426,19 @@ def gen_stochastic():
         'slip4_q_b4': ('slip_4x4', 'q', 2, 30, 40, 4),
         'slip4_q_b0': ('slip_4x4', 'q', 3, 20, 40, 0),
         'slip56_dynaq_b70': ('slip_5x6_wind', 'dynaq', 1, 20, 60, 70),
+        # SR.train only ever calls interface.step (agent/sr.py:170-182): the successor is drawn
+        'slip4_sr': ('slip_4x4', 'sr', 1, 25, 40, 0),
+        'slip56_sr': ('slip_5x6_wind', 'sr', 2, 15, 50, 0),
     }
     for name, (wname, kind, inst, trials, steps, B) in cases.items():
         world = worlds[wname]
         env = Gridworld(world, rng=TapeRNG(SEED, inst, STREAM_ENV, double_sub=1))
         pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
-        if kind == 'dynaq':
+        if kind == 'sr':
+            ag = SR(env.observation_space, env.action_space, pol)
+            ag.SR = ag.SR.astype(np.float32)
+            ag.rewards = ag.rewards.astype(np.float32)
+        elif kind == 'dynaq':
             ag = DynaQ(env.observation_space, env.action_space, pol)
             ag.M.rng = TapeRNG(SEED, inst, STREAM_MEMORY)
             ag.Q = ag.Q.astype(np.float32)
@@ -445,10 +452,17 @@ def gen_stochastic():
         ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
         for k in ('on_trial_begin', 'on_step_begin'):
             ag.callbacks.custom_callbacks.setdefault(k, [])
-        ag.train(env, trials, steps, B)
+        if kind == 'sr':
+            ag.train(env, trials, steps)
+        else:
+            ag.train(env, trials, steps, B)
         d = tr.pack()
         d.pop('Q_trial', None)
-        if kind == 'dynaq':
+        if kind == 'sr':
+            d.pop('td', None)
+            d.update(SR=np.array(ag.SR, dtype=np.float64), rewards=np.array(ag.rewards, dtype=np.float64),
+                     T=np.argmax(ag.transitions, axis=-1).astype(np.int16))
+        elif kind == 'dynaq':
             d.update(Q=np.array(ag.Q, dtype=np.float64),
                      M_rewards=np.array(ag.M.rewards, dtype=np.float64),
                      M_states=ag.M.states.astype(np.int16), M_terminals=ag.M.terminals.astype(np.int8))

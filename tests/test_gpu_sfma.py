@@ -27,12 +27,12 @@ def Z(golden):
     return golden('sfma_traces')
 
 
-def build(world, D, opts, n_envs, base, callbacks=None, eps=0.1):
+def build(world, D, opts, n_envs, base, callbacks=None, eps=0.1, made=False):
     from cobel_amd.agent import SFMA
     from cobel_amd.interface import Gridworld
     from cobel_amd.memory import SFMAMemory
     from cobel_amd.policy import EpsilonGreedy
-    env = Gridworld(as_world(world), n_envs=n_envs, seed=SEED, instance_base=base)
+    env = Gridworld(world if made else as_world(world), n_envs=n_envs, seed=SEED, instance_base=base)
     mem = SFMAMemory(D, env.observation_space.n, 4)
     for k in MEM_KEYS:
         if k in opts:

@@ -118,6 +118,82 @@ def test_stochastic_world_runs_match_reference(Z, name):
     assert what['kernel'] == _lib.TAB_KERNEL_GENERAL
 
 
+@pytest.mark.parametrize('name', ['slip4_sr', 'slip56_sr'])
+def test_sr_on_stochastic_worlds_matches_reference(Z, name):
+    """SR.train only calls interface.step (agent/sr.py:170-182), so on a world whose rows are
+    distributions the successor is drawn (gridworld.py:119-123): SR matrix, learned transitions,
+    reward estimates, escape latencies and the env stream's draw count of the reference's float32
+    run — one instance alone with per-step logs, and inside a vectorised launch with visit counts."""
+    import torch
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    inst, trials, steps, _ = [int(x) for x in Z[name + '/cfg']]
+    world = slippery_world(Z, str(Z[name + '/world']))
+    g = lambda k: Z['%s/%s' % (name, k)]     # noqa: E731
+    sarsn, steps_log = [], []
+    cbs = {'on_step_end': [lambda l: sarsn.append((l['state'], l['action'], l['reward'],
+                                                   l['next_state'], l['terminal']))],
+           'on_trial_end': [lambda l: steps_log.append(l['steps'])]}
+    env = Gridworld(world, seed=SEED, instance_base=inst)
+    ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1), custom_callbacks=cbs)
+    ag.train(env, trials, steps)
+    arr = np.array(sarsn, dtype=np.float64)
+    for col, key in enumerate(('state', 'action', 'reward', 'next_state', 'nonterminal')):
+        assert np.array_equal(arr[:, col], g(key)), key
+    assert np.array_equal(steps_log, g('steps'))
+    assert int(env.env_ctr[0].item()) == int(g('env_draws'))
+
+    def tables(a, i):
+        assert np.array_equal(a._T[i].cpu().numpy(), g('T'))
+        assert np.array_equal(a._rw[i].cpu().numpy().astype(np.float64), g('rewards'))
+        assert np.array_equal(a._sr[i].cpu().numpy().astype(np.float64), g('SR'))
+    tables(ag, 0)
+    env = Gridworld(world, n_envs=inst + 40, seed=SEED)
+    ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    ag.track_instances = True
+    ag.track_occupancy = True
+    ag.train(env, trials, steps)
+    torch.cuda.synchronize()
+    assert np.array_equal(ag.monitors.lat_trace[inst].cpu().numpy()[:trials], g('steps'))
+    tables(ag, inst)
+    assert int(env.env_ctr[inst].item()) == int(g('env_draws'))
+    assert int(ag.monitors.occupancy.sum().item()) == ag.env_steps()
+
+
+@pytest.mark.parametrize('opts,mode,B', [({}, 'reverse', 16), ({'recency': True, 'dynamic': True}, 'default', 24)])
+def test_sfma_on_a_stochastic_world_vs_oracle(Z, opts, mode, B):
+    """SFMA.train steps the interface (agent/sfma.py:262-264): on a world of distributions the
+    successor is drawn.  Latencies, every reactivation, Q and the memory's tables against the NumPy
+    restatement of the reference's SFMA (oracle/sfma_loop.py) walking the same slippery world
+    (its env is the restatement pinned by the stochastic Dyna-Q / SR fixtures above)."""
+    import test_gpu_sfma as ts
+    from cobel_amd.memory.utils import SR as SRMetric
+    from oracle import sfma_loop
+    world = slippery_world(Z, 'slip_5x6_wind')
+    D = SRMetric(np.asarray(world['next']), 0.9).D
+    o = dict(opts, mode=mode)
+    env, agent = ts.build(world, D, o, 24, 500, made=True)
+    assert env.handle.stochastic
+    trials, steps = 6, 30
+    ts.run_schedule(env, agent, o, trials, steps, B)
+    ow = dict(next=np.asarray(world['next']), reward=np.asarray(world['rewards'], dtype=np.float64),
+              terminal=np.asarray(world['terminals']), starts=np.asarray(world['starting_states']),
+              sas=np.asarray(world['sas']))
+    moved = 0
+    for i in (0, 7, 23):
+        ag, oenv = sfma_loop.run_case(ow, D, SEED, 500 + i, True, mode, o, trials, steps, B)
+        assert np.array_equal(agent.monitors.lat_trace[i].cpu().numpy()[:trials], ag.steps), i
+        rp = np.array(ag.replayed, dtype=np.float64).reshape(-1, 8)
+        ts.check_events(ts.events_of(agent, i), rp)
+        assert np.array_equal(agent.Q[i].cpu().numpy(), ag.Q), i
+        assert np.array_equal(agent.M.states[i], ag.M.states), i
+        assert np.array_equal(agent.M.C[i], ag.M.C), i
+        assert int(env.env_ctr[i].item()) == oenv.rng.index
+        moved += int((np.asarray(ag.M.states) != np.asarray(world['next'])).sum())
+    assert moved > 0         # (the model learned successors the argmax table does not hold)
+
+
 def test_stochastic_worlds_and_the_other_entry_points(Z):
     """The kernels that step transition tables refuse a world of distributions loudly; the network
     agents run it through their PyTorch loops (env.step draws); a world of the same rows with the
@@ -132,8 +208,7 @@ def test_stochastic_worlds_and_the_other_entry_points(Z):
     world = slippery_world(Z, 'slip_4x4')
     env = Gridworld(world, n_envs=8, seed=3)
     sr = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1))
-    with pytest.raises(NotImplementedError):
-        sr.train(env, 1, 5)
+    sr.train(env, 1, 5)          # (served since round 4: test_sr_on_stochastic_worlds below)
     state = torch.zeros(8, dtype=torch.int32, device='cuda')
     act = torch.zeros(8, dtype=torch.uint8, device='cuda')
     with pytest.raises(NotImplementedError):     # the counter-less entry cannot draw
