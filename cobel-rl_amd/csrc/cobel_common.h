@@ -17,19 +17,18 @@ struct __attribute__((aligned(16))) cobel_wrec {
 };
 static_assert(sizeof(cobel_wrec) == 16, "world record must be 16 bytes");
 
-// The rewarded states of one world (reward != 0), at most eight of them, and the order in which
+// The rewarded states of one world (reward != 0), at most 32 of them, and the order in which
 // NumPy's pairwise summation (numpy/core/src/umath/loops_utils.h) adds the products of a row with a
 // vector that is zero everywhere else: a sum over S elements of which all but k are zero is the sum
 // of those k in the grouping the summation tree gives them (an addition of zero changes nothing),
 // so k - 1 additions in this order return np.sum(row * R) bit for bit (up to the sign of a zero).
 struct cobel_rw_info {
-  uint16_t pos[8];      // ascending states
-  uint8_t k;            // how many (0 .. 8); 255: more than eight
+  uint16_t pos[32];     // ascending states
+  uint8_t k;            // how many (0 .. 32); 255: more
   uint8_t root;         // slot that holds the sum after the last step
-  uint8_t dst[7], src[7];   // step t: value[dst[t]] += value[src[t]]
-  uint8_t pad_[8];
+  uint8_t dst[31], src[31];   // step t: value[dst[t]] += value[src[t]]
 };
-static_assert(sizeof(cobel_rw_info) == 40, "cobel_rw_info layout");
+static_assert(sizeof(cobel_rw_info) == 128, "cobel_rw_info layout");
 
 struct cobel_world {
   int32_t n_states, n_worlds, device;

@@ -180,7 +180,7 @@ __device__ __forceinline__ const srw_args* rare_args() {
 // Lane 8a + n gathers element pos[n] of value row a, holds R[pos[n]] and its product; the k - 1
 // additions run as shuffles inside the groups of eight lanes.  The values of the row a step
 // rewrites are read back from an LDS copy of the new row.
-template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX, bool ODD>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // that row (value gathers) come from here instead of waiting for the store to reach L2, and the
   // values of the row a step rewrites are read back from it.
   __shared__ __attribute__((aligned(16))) float frow[NV * 256];
+  __shared__ uint8_t sched32[64];   // KX == 32: dst[31] | src[31] of the world's combine order
   extern __shared__ __attribute__((aligned(16))) uint32_t occ[];   // [S] if OCC
   const int S = ANY_S ? A.S : NV * 256;
   const int quads = S >> 2;
@@ -221,22 +222,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   int nz = 0, e0 = 0, e1 = 0;
   float r0 = 0.0f, r1 = 0.0f;
   bool dense = false;
-  // KX: slot n = lane & 7 of each group of eight lanes
+  // KX == 8: slot n = lane & 7 of each group of eight lanes (lane 8a + n: row a)
+  // KX == 32 (nine to 32 rewarded states): groups of sixteen lanes, lane 16a + n holds slots n and
+  // n + 16 of row a; the combine order (up to 31 additions) is read from LDS step by step
   int Kw = 0, kroot = 0;
-  uint32_t sched_d = 0u, sched_s = 0u;   // 3 bits per step
-  uint32_t elane = 0u;
-  float rlane = 0.0f;
+  uint32_t sched_d = 0u, sched_s = 0u;   // KX == 8: 3 bits per step
+  uint32_t elane = 0u, elane_hi = 0u;
+  float rlane = 0.0f, rlane_hi = 0.0f;
+  float gv_hi = 0.0f;                    // KX == 32: the gathered value of the lane's second slot
   int nzc = 0;
+  constexpr int GW = KX == 32 ? 16 : 8;  // lanes per row group
   if (KX) {
     const cobel_rw_info* const I = A.rw + world;
     Kw = (int)I->k;
     kroot = (int)I->root;
+    if (KX == 32) {
+      if (lane < 31) {
+        sched32[lane] = I->dst[lane];
+        sched32[32 + lane] = I->src[lane];
+      }
+      if ((lane & 15) + 16 < Kw) elane_hi = (uint32_t)I->pos[(lane & 15) + 16];
+    } else {
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      sched_d |= (uint32_t)I->dst[t] << (3 * t);
-      sched_s |= (uint32_t)I->src[t] << (3 * t);
+      for (int t = 0; t < 7; ++t) {
+        sched_d |= (uint32_t)I->dst[t] << (3 * t);
+        sched_s |= (uint32_t)I->src[t] << (3 * t);
+      }
     }
-    if ((lane & 7) < Kw) elane = (uint32_t)I->pos[lane & 7];
+    if ((lane & (GW - 1)) < Kw) elane = (uint32_t)I->pos[lane & (GW - 1)];
   }
   {
     const float4* const R4 = reinterpret_cast<const float4*>(Rg) + lane;
@@ -276,8 +289,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     if (KX) {
       // every non-zero estimate must sit at one of the world's rewarded states (only a caller's
       // edit of `rewards` can break that): otherwise the full sums from memory
-      if ((lane & 7) < Kw) rlane = Rg[elane];
-      const int listed = __popcll(__ballot(lane < 8 && rlane != 0.0f));
+      if ((lane & (GW - 1)) < Kw) rlane = Rg[elane];
+      int listed = __popcll(__ballot(lane < GW && rlane != 0.0f));
+      if (KX == 32) {
+        if ((lane & 15) + 16 < Kw) rlane_hi = Rg[elane_hi];
+        listed += __popcll(__ballot(lane < 16 && rlane_hi != 0.0f));
+      }
       dense = nzc != listed;
     }
   }
@@ -356,6 +373,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   // KX: lane 8a + n reads element pos[n] of row tq[a]
   auto issue_gathers_x = [&](uint64_t tq, int fresh) -> float {
     float gv = 0.0f;
+    if (KX == 32) {
+      const int j = t_of(tq, lane >> 4);
+      gv_hi = 0.0f;
+      if (j != fresh) {
+        if ((lane & 15) < Kw)
+          gv = j == lds_row ? frow[fpos((int)elane)]
+                            : ld_l2(SRg + ((uint32_t)j * (uint32_t)S + elane));
+        if ((lane & 15) + 16 < Kw)
+          gv_hi = j == lds_row ? frow[fpos((int)elane_hi)]
+                               : ld_l2(SRg + ((uint32_t)j * (uint32_t)S + elane_hi));
+      }
+      gathers += (uint32_t)(4 * Kw);
+      return gv;
+    }
     const int j = t_of(tq, (lane >> 3) & 3);
     if (lane < 32 && (lane & 7) < Kw && j != fresh) {
       if (j == lds_row) gv = frow[fpos((int)elane)];
@@ -368,6 +399,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     return gv;
   };
   auto assemble_x = [&](uint64_t tq, int fresh, float gv) {
+    if (KX == 32) {
+      const bool is_fresh = t_of(tq, lane >> 4) == fresh;
+      float f0 = 0.0f, f1 = 0.0f;
+      if (is_fresh) {
+        if ((lane & 15) < Kw) f0 = frow[fpos((int)elane)];
+        if ((lane & 15) + 16 < Kw) f1 = frow[fpos((int)elane_hi)];
+      }
+      float p0 = (is_fresh ? f0 : gv) * rlane;
+      float p1 = (is_fresh ? f1 : gv_hi) * rlane_hi;
+      for (int t = 0; t + 1 < Kw; ++t) {
+        const int dst = (int)rfl((uint32_t)sched32[t]), src = (int)rfl((uint32_t)sched32[32 + t]);
+        const int from = (lane & ~15) | (src & 15);
+        const float o0 = __shfl(p0, from), o1 = __shfl(p1, from);
+        const float other = (src & 16) ? o1 : o0;
+        if ((lane & 15) == (dst & 15)) {
+          if (dst & 16) p1 = p1 + other;
+          else p0 = p0 + other;
+        }
+      }
+      const float pr = (kroot & 16) ? p1 : p0;
+      q0 = rlf(pr, kroot & 15);
+      q1 = rlf(pr, 16 + (kroot & 15));
+      q2 = rlf(pr, 32 + (kroot & 15));
+      q3 = rlf(pr, 48 + (kroot & 15));
+      return;
+    }
     const bool is_fresh = t_of(tq, (lane >> 3) & 3) == fresh;
     float fv = 0.0f;
     if (is_fresh && lane < 32 && (lane & 7) < Kw) fv = frow[fpos((int)elane)];
@@ -566,8 +623,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     if (learn) {
       // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
       float old;
-      unsigned long long slot_m = 0ull;
+      unsigned long long slot_m = 0ull, slot_hi = 0ull;
       if (dense) old = rflf(ld_l2(Rg + ns));
+      else if (KX == 32) {
+        slot_m = __ballot(lane < 16 && lane < Kw && elane == (uint32_t)ns);
+        slot_hi = __ballot(lane < 16 && lane + 16 < Kw && elane_hi == (uint32_t)ns);
+        old = slot_m ? rlf(rlane, __builtin_ctzll(slot_m))
+                     : (slot_hi ? rlf(rlane_hi, __builtin_ctzll(slot_hi)) : 0.0f);
+      }
       else if (KX) {
         slot_m = __ballot((lane & 7) < Kw && elane == (uint32_t)ns);
         old = slot_m ? rlf(rlane, __builtin_ctzll(slot_m)) : 0.0f;
@@ -581,7 +644,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       }
       if (KX) {
         if (!dense) {
-          if (slot_m) {
+          if (KX == 32 && (slot_m || slot_hi)) {
+            if ((lane & 15) < Kw && elane == (uint32_t)ns) rlane = upd;
+            if ((lane & 15) + 16 < Kw && elane_hi == (uint32_t)ns) rlane_hi = upd;
+          } else if (KX != 32 && slot_m) {
             if ((lane & 7) < Kw && elane == (uint32_t)ns) rlane = upd;
           } else if (upd != 0.0f) {
             dense = true;   // (a non-zero estimate outside the world's rewarded states)
@@ -729,7 +795,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   }
 }
 
-template <int NV, bool OCC, bool PSETS, bool ANY_S, bool KX, bool ODD>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
   if (const size_t pad = cobel_debug_lds_pad(lds + 8 * 1024, 160 * 1024)) {   // (occupancy experiments)
@@ -745,15 +811,18 @@ int launch(const srw_args& A, hipStream_t st) {
 }
 
 template <int NV, bool ANY_S, bool ODD = false>
-int launch_nv(const srw_args& A, bool occ, bool psets, bool kx, hipStream_t st) {
+int launch_nv(const srw_args& A, bool occ, bool psets, int kx, hipStream_t st) {
+  if (kx == 32)   // (nine to 32 rewarded states; launch-wide hyper-parameters only)
+    return occ ? launch<NV, true, false, ANY_S, 32, ODD>(A, st)
+               : launch<NV, false, false, ANY_S, 32, ODD>(A, st);
   if (kx)   // (three to eight rewarded states; launch-wide hyper-parameters only)
-    return occ ? launch<NV, true, false, ANY_S, true, ODD>(A, st)
-               : launch<NV, false, false, ANY_S, true, ODD>(A, st);
+    return occ ? launch<NV, true, false, ANY_S, 8, ODD>(A, st)
+               : launch<NV, false, false, ANY_S, 8, ODD>(A, st);
   if (psets)
-    return occ ? launch<NV, true, true, ANY_S, false, ODD>(A, st)
-               : launch<NV, false, true, ANY_S, false, ODD>(A, st);
-  return occ ? launch<NV, true, false, ANY_S, false, ODD>(A, st)
-             : launch<NV, false, false, ANY_S, false, ODD>(A, st);
+    return occ ? launch<NV, true, true, ANY_S, 0, ODD>(A, st)
+               : launch<NV, false, true, ANY_S, 0, ODD>(A, st);
+  return occ ? launch<NV, true, false, ANY_S, 0, ODD>(A, st)
+             : launch<NV, false, false, ANY_S, 0, ODD>(A, st);
 }
 
 }  // namespace
@@ -768,7 +837,7 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   // at most two rewarded states (every maze / open field builder of the reference), or up to eight
   // with launch-wide hyper-parameters (the KX kernels)
   const bool rewards_ok = world->max_rewarded_states <= 2 ||
-                          (world->max_rewarded_states <= 8 && world->rw && !r.param_index);
+                          (world->max_rewarded_states <= 32 && world->rw && !r.param_index);
   return S >= 2 && S <= 1024 && rewards_ok &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
@@ -793,7 +862,7 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   COBEL_REQUIRE(A.n_leaves <= 16 && plan.n_comb == A.n_leaves - 1, COBEL_E_ARG,
                 "cobel_sr_run: pairwise plan out of range");
   const bool occ = r.occupancy != nullptr, psets = r.param_index != nullptr;
-  const bool kx = world->max_rewarded_states > 2;
+  const int kx = world->max_rewarded_states > 8 ? 32 : (world->max_rewarded_states > 2 ? 8 : 0);
   const int S = world->n_states;
   if (S == 256) return launch_nv<1, false>(A, occ, psets, kx, st);
   if (S == 512) return launch_nv<2, false>(A, occ, psets, kx, st);

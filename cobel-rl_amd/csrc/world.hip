@@ -159,12 +159,12 @@ int cobel_pairwise_schedule(int n, const int* pos, int k, uint8_t* dst, uint8_t*
 // exported for tests: evaluates nothing on the device
 extern "C" int cobel_pairwise_order(int32_t n, const int32_t* pos, int32_t k, uint8_t* dst,
                                     uint8_t* src, int32_t* root) {
-  COBEL_REQUIRE(n > 0 && pos && dst && src && root && k >= 0 && k <= 8, COBEL_E_ARG,
+  COBEL_REQUIRE(n > 0 && pos && dst && src && root && k >= 0 && k <= 32, COBEL_E_ARG,
                 "cobel_pairwise_order: bad arguments");
   for (int j = 0; j < k; ++j)
     COBEL_REQUIRE(pos[j] >= 0 && pos[j] < n && (j == 0 || pos[j] > pos[j - 1]), COBEL_E_RANGE,
                   "cobel_pairwise_order: positions must ascend inside [0, n)");
-  int p[8];
+  int p[32];
   for (int j = 0; j < k; ++j) p[j] = pos[j];
   *root = cobel_pairwise_schedule(n, p, k, dst, src);
   return COBEL_OK;
@@ -211,17 +211,17 @@ extern "C" int cobel_world_create(const uint16_t* next, const float* reward,
   std::vector<cobel_rw_info> rw((size_t)n_worlds);
   for (int k = 0; k < n_worlds; ++k) {
     int32_t rewarded = 0;
-    int pos[8];
+    int pos[32];
     for (int32_t s = 0; s < n_states; ++s)
       if (reward[(size_t)k * n_states + s] != 0.0f) {
-        if (rewarded < 8) pos[rewarded] = s;
+        if (rewarded < 32) pos[rewarded] = s;
         rewarded += 1;
       }
     if (rewarded > w->max_rewarded_states) w->max_rewarded_states = rewarded;
     cobel_rw_info& info = rw[(size_t)k];
     memset(&info, 0, sizeof(info));
-    info.k = rewarded <= 8 ? (uint8_t)rewarded : (uint8_t)255;
-    if (rewarded <= 8) {
+    info.k = rewarded <= 32 ? (uint8_t)rewarded : (uint8_t)255;
+    if (rewarded <= 32) {
       for (int j = 0; j < rewarded; ++j) info.pos[j] = (uint16_t)pos[j];
       const int root = cobel_pairwise_schedule(n_states, pos, rewarded, info.dst, info.src);
       info.root = (uint8_t)(root < 0 ? 0 : root);

@@ -379,12 +379,12 @@ COBEL_API int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run
                                  int32_t* out /* [host] [4] */);
 
 /* The additions NumPy's pairwise summation (np.sum over a contiguous float32 vector, agent/sr.py:
- * 302-306 `np.sum(SR[j] * rewards)`) performs on a vector of n elements of which only the k <= 8 at
+ * 302-306 `np.sum(SR[j] * rewards)`) performs on a vector of n elements of which only the k <= 32 at
  * `pos` (ascending) are not zero: step t is value[dst[t]] += value[src[t]] on slots 0..k-1, k - 1
  * steps (fewer never: every non-zero element is added once), *root = the slot holding the sum (-1
  * for k = 0).  Pure host function: the SR kernel's sparse-reward form takes its order from it. */
-COBEL_API int cobel_pairwise_order(int32_t n, const int32_t* pos, int32_t k, uint8_t* dst /* [7] */,
-                                   uint8_t* src /* [7] */, int32_t* root);
+COBEL_API int cobel_pairwise_order(int32_t n, const int32_t* pos, int32_t k, uint8_t* dst /* [31] */,
+                                   uint8_t* src /* [31] */, int32_t* root);
 
 /* Host helpers for the packed 8-byte records (so bindings never re-derive the layout). */
 COBEL_API uint64_t cobel_pack_model(float reward, uint16_t next_state, uint8_t nonterminal);

@@ -1,5 +1,6 @@
-"""Round 3: SR on 32x32 worlds with 1 / 4 / 8 rewarded states — the sparse-reward wave kernel
-(KX form for three to eight) against the row-streaming kernel.  `python scripts/exp_sr_rewards.py`"""
+"""SR on 32x32 worlds with 1 ... 32 rewarded states — the sparse-reward wave kernel (KX form for
+three to eight, the 32-slot form for nine to 32: round 4) against the row-streaming kernel.
+`python scripts/exp_sr_rewards.py`"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +16,10 @@ from cobel_amd.policy import EpsilonGreedy  # noqa: E402
 
 dev = torch.device('cuda', 0)
 n, steps, spt = 16384, 128, 200
-pos = [0, 1023, 517, 130, 300, 777, 40, 900]
-for k in (1, 2, 4, 8):
+rng = np.random.default_rng(4)
+pos = [0, 1023, 517, 130, 300, 777, 40, 900] + [int(x) for x in rng.permutation(np.arange(2, 1020))[:40]]
+pos = list(dict.fromkeys(pos))
+for k in (1, 2, 4, 8, 9, 16, 24, 32):
     rw = np.array([[p, 1.0 / (j + 1)] for j, p in enumerate(pos[:k])])
     world = make_gridworld(32, 32, terminals=[0], goals=[0], rewards=rw)
     for stream in (False, True):

@@ -323,8 +323,27 @@ def _multi_reward_worlds():
     three_29 = make_gridworld(29, 29, terminals=[5], goals=[5],
                               rewards=np.array([[5, 1.0], [6, -0.5], [34, 0.25]]),
                               starting_states=[4, 7, 33, 35, 64])
+    # nine to 32 rewarded states (the 32-slot form of the sparse-reward kernel): clusters around the
+    # starts so that a short run meets many of them
+    def cluster(w, cells, term):
+        vals = [1.0, 0.5, -0.25, 0.125, 2.0, 0.75, -1.5, 0.3, 0.0625, -0.5, 1.25, 0.2]
+        return np.array([[c, 3.0 if c == term else vals[k % len(vals)]] for k, c in enumerate(cells)])
+    c16 = [5, 6, 37, 38, 70, 100, 101, 133, 165, 166, 198, 230, 255, 256, 600, 900]
+    sixteen = make_gridworld(32, 32, terminals=[5], goals=[5], rewards=cluster(32, c16, 5),
+                             starting_states=[4, 7, 36, 39, 69, 102, 134, 167, 199])
+    c32 = sorted(set(c16 + [8, 9, 40, 41, 72, 73, 104, 136, 168, 200, 231, 232, 263, 264, 295, 1000]))
+    thirtytwo = make_gridworld(32, 32, terminals=[5], goals=[5], rewards=cluster(32, c32, 5),
+                               starting_states=[4, 7, 36, 39, 69, 102, 134, 167, 199, 10, 42])
+    c12 = [0, 1, 18, 19, 35, 36, 52, 53, 69, 70, 100, 220]
+    twelve_odd = make_gridworld(13, 17, terminals=[0], goals=[0], rewards=cluster(17, c12, 0),
+                                starting_states=[2, 20, 37, 54, 71])
+    c20 = [10, 11, 34, 35, 58, 59, 82, 83, 106, 107, 130, 131, 154, 155, 178, 179, 202, 203, 300, 479]
+    twenty_any = make_gridworld(20, 24, terminals=[10], goals=[10], rewards=cluster(24, c20, 10),
+                                starting_states=[9, 12, 33, 36, 60, 84, 108, 132])
     return {'four_32x32': four, 'eight_32x32': eight, 'three_13x17': three_odd,
-            'five_20x24': five_any, 'one_31x31': one_31, 'three_29x29': three_29}
+            'five_20x24': five_any, 'one_31x31': one_31, 'three_29x29': three_29,
+            'sixteen_32x32': sixteen, 'thirtytwo_32x32': thirtytwo, 'twelve_13x17': twelve_odd,
+            'twenty_20x24': twenty_any}
 
 
 @pytest.mark.parametrize('name,n,budgets,spt', [
@@ -334,10 +353,15 @@ def _multi_reward_worlds():
     ('five_20x24', 16, (128, 128), 35),
     ('one_31x31', 10, (100, 77), 40),
     ('three_29x29', 12, (90, 90), 30),
+    ('sixteen_32x32', 16, (150, 150, 9), 40),
+    ('thirtytwo_32x32', 16, (160, 140), 40),
+    ('twelve_13x17', 16, (90, 111), 30),
+    ('twenty_20x24', 16, (128, 128), 35),
 ])
 def test_three_to_eight_rewarded_states_take_the_wave_kernel(torch_cuda, name, n, budgets, spt):
-    """Worlds with three to eight rewarded states (make_gridworld(rewards=...)): the sparse-reward
-    kernel adds the up-to-eight products of a value row in NumPy's pairwise grouping
+    """Worlds with three to 32 rewarded states (make_gridworld(rewards=...)): the sparse-reward
+    kernel adds the up-to-eight (one lane each in groups of eight) or up-to-32 (two per lane in
+    groups of sixteen) products of a value row in NumPy's pairwise grouping
     (cobel_pairwise_order) — SR, transition tables, reward estimates, counters and monitors equal
     the row-streaming kernel's and the C oracle's full row sums, bit for bit."""
     torch = torch_cuda

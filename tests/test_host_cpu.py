@@ -723,7 +723,7 @@ def test_deterministic_flag_and_stochastic_rows():
 
 
 def test_pairwise_order_reproduces_numpy_sums_of_sparse_vectors():
-    """cobel_pairwise_order (host function of the library): adding the k <= 8 non-zero elements of a
+    """cobel_pairwise_order (host function of the library): adding the k <= 32 non-zero elements of a
     float32 vector in the order it returns gives np.sum of the whole vector bit for bit — the
     grouping NumPy's pairwise summation applies to those positions (agent/sr.py:302-306)."""
     import ctypes as C
@@ -732,12 +732,12 @@ def test_pairwise_order_reproduces_numpy_sums_of_sparse_vectors():
     rng = np.random.default_rng(12)
     for trial in range(400):
         n = int(rng.choice([5, 7, 8, 25, 100, 128, 129, 221, 256, 400, 480, 512, 640, 961, 1024]))
-        k = int(rng.integers(0, min(8, n) + 1))
+        k = int(rng.integers(0, min(32 if trial % 2 else 8, n) + 1))
         pos = np.sort(rng.choice(n, size=k, replace=False)).astype(np.int32)
         vals = (rng.standard_normal(k) * 10.0 ** rng.integers(-6, 6, k)).astype(np.float32)
         vec = np.zeros(n, dtype=np.float32)
         vec[pos] = vals
-        dst, src = (C.c_uint8 * 7)(), (C.c_uint8 * 7)()
+        dst, src = (C.c_uint8 * 31)(), (C.c_uint8 * 31)()
         root = C.c_int32(-2)
         rc = lib.cobel_pairwise_order(n, pos.ctypes.data_as(C.c_void_p), k, dst, src, C.byref(root))
         assert rc == 0
