@@ -48,5 +48,24 @@ def test_every_fixture_regenerates_bit_identically(tmp_path):
             assert _same(old[key], new[key]), '%s: %s differs' % (os.path.basename(path), key)
             n_arrays += 1
     assert n_arrays > 1500
+    # the pickled WorldDicts (what the reference's gridworld editor writes, misc/gridworld_gui.py:
+    # 203-239): unpickled and compared entry by entry
+    import pickle
+    pickles = sorted(glob.glob(os.path.join(GOLDEN, '*.pkl')))
+    assert pickles
+    for path in pickles:
+        fresh_path = os.path.join(str(tmp_path), os.path.basename(path))
+        assert os.path.exists(fresh_path), 'generator no longer writes %s' % os.path.basename(path)
+        with open(path, 'rb') as fh:
+            old = pickle.load(fh)
+        with open(fresh_path, 'rb') as fh:
+            new = pickle.load(fh)
+        assert set(old) == set(new), os.path.basename(path)
+        for key in old:
+            a, b = old[key], new[key]
+            if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+                assert _same(np.asarray(a), np.asarray(b)), '%s: %s differs' % (os.path.basename(path), key)
+            else:
+                assert a == b, '%s: %s differs' % (os.path.basename(path), key)
     # nothing may be written next to the committed files when an output directory is given
     assert not [f for f in os.listdir(str(tmp_path)) if f.endswith('.py')]

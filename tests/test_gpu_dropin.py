@@ -563,3 +563,51 @@ def test_prerendered_observations_keep_their_dtype_and_aliases_are_refused(cobel
     aliased = Topology(nodes, starts, OfflineSimulator(obs, space), seed=5)
     with pytest.raises(NotImplementedError, match='share their observation'):
         QAgent(aliased.observation_space, aliased.action_space, EpsilonGreedy(0.1)).train(aliased, 1, 5, 0)
+
+
+def test_pickled_worlddict_steps_and_learns_like_the_oracle(cobel):
+    """A WorldDict as the reference's gridworld editor pickles it (misc/gridworld_gui.py:203-239),
+    loaded with load_world: cobel_env_step walks its transition table (every (state, action) pair
+    against the pickled dense `sas`), and a vectorised Dyna-Q run on it leaves the Q tables and escape
+    latencies of the NumPy oracle driven by the same streams."""
+    import os
+    import pickle
+    import torch
+    from conftest import GOLDEN, SEED
+    from cobel.agent import DynaQ
+    from cobel.interface import Gridworld
+    from cobel.misc.gridworld_tools import load_world
+    from cobel.policy import EpsilonGreedy
+    from oracle import philox, ref_loop
+    path = os.path.join(GOLDEN, 'double_t_maze_2_1.pkl')
+    world = load_world(path)
+    with open(path, 'rb') as fh:
+        raw = pickle.load(fh)
+    S = int(raw['states'])
+    sas = np.asarray(raw['sas'])
+    # env.step over every pair
+    env = Gridworld(world, n_envs=S * 4, seed=3)
+    pairs = np.stack(np.meshgrid(np.arange(S), np.arange(4), indexing='ij'), -1).reshape(-1, 2)
+    env.state.copy_(torch.as_tensor(pairs[:, 0], device=env.device).to(torch.int32))
+    ns, r, done, _, _ = env.step(torch.as_tensor(pairs[:, 1], device=env.device))
+    want = sas[pairs[:, 0], pairs[:, 1]].argmax(axis=1)
+    assert np.array_equal(env.state.cpu().numpy(), want)
+    assert np.array_equal(r.cpu().numpy(), np.asarray(raw['rewards'])[want].astype(np.float32))
+    assert np.array_equal(done.cpu().numpy(), np.asarray(raw['terminals'])[want].astype(bool))
+    # Dyna-Q on it against the oracle
+    n, trials, steps, batch = 48, 5, 40, 16
+    env = Gridworld(world, n_envs=n, seed=SEED)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.2))
+    agent.track_instances = True
+    agent.train(env, trials, steps, batch)
+    torch.cuda.synchronize()
+    q, lat = agent.Q.cpu().numpy(), agent.monitors.lat_trace.cpu().numpy()
+    tabs = world.compact()
+    for i in (0, 11, 47):
+        renv = ref_loop.RefGridworld(tabs, philox.TapeRNG(SEED, i, philox.STREAM_ENV))
+        pol = ref_loop.RefEpsilonGreedy(0.2, philox.TapeRNG(SEED, i, philox.STREAM_POLICY))
+        ref = ref_loop.RefDynaQ(S, 4, pol, philox.TapeRNG(SEED, i, philox.STREAM_MEMORY), dtype=np.float32)
+        tr = ref_loop.new_trace()
+        ref.train(renv, trials, steps, batch, trace=tr)
+        assert np.array_equal(lat[i, :trials], np.array(tr['steps'])), i
+        assert np.array_equal(q[i], ref.Q), i
