@@ -106,6 +106,24 @@ __device__ __forceinline__ void pwg_stamp(uint32_t* stamps, uint32_t* prev, int 
 #define PWG_STAMP(k)
 #endif
 
+// The kernel arguments as they lie in the kernarg segment, through a pointer the optimizer cannot
+// see through: what only trial ends and the final save read through it (monitor arrays, trial
+// counts, start lists) is loaded where it is used instead of being held — and spilled — in scalar
+// registers across the step loop.
+// (kept in the constant address space: what is read through it is a scalar load and wave-uniform
+//  by construction — through a generic pointer the loads are per-lane to the compiler, and a loop
+//  whose exit depends on one runs under an exec mask)
+typedef const __attribute__((address_space(4))) pwg_args* pwg_kargs;
+__device__ __forceinline__ pwg_kargs rare_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  pwg_kargs p = (pwg_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+#else
+  return nullptr;
+#endif
+}
+
 // One instance, all the steps of the call.  QG: the Q table stays in global memory.
 template <bool QG>
 __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, const int step_budget,
@@ -195,8 +213,6 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   asm volatile("" : "+v"(seed_v));
   auto seed_now = [&]() -> uint64_t { return seed_v; };
 #endif
-  const int start_lo = A.start_off[world];
-  const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   double alpha = A.r.alpha, gamma = A.r.gamma;
   float alpha_f = A.alpha_f, gamma_f = A.gamma_f, mlr_f = A.model_lr_f;
   asm volatile("" : "+v"(alpha), "+v"(gamma), "+v"(alpha_f), "+v"(gamma_f), "+v"(mlr_f));
@@ -229,9 +245,12 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     mdig = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)s * 4u]);
   };
   auto begin_trial = [&]() -> bool {
-    if (trial >= A.r.trials_target) return false;
-    state = (int)A.starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed_now(),
-                                                             start_cnt)];
+    const pwg_kargs R = rare_args();
+    if (trial >= R->r.trials_target) return false;
+    const int start_lo = R->start_off[world];
+    const uint32_t start_cnt = (uint32_t)(R->start_off[world + 1] - start_lo);
+    state = (int)R->starts[start_lo + (int)cobel_draw_bounded(ce, 0u, g, COBEL_STREAM_ENV, seed_now(),
+                                                              start_cnt)];
     ce += 1u;
     step = 0;
     trew = 0.0;
@@ -551,14 +570,17 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
 
     if (__builtin_expect(trial_over, 0)) {
       // agent/dyna_q.py:207-212: current_trial += 1; logs['steps'] = step (0-based)
-      if (lane == 0 && trial >= 0 && trial < A.r.trial_cap) {
-        const size_t mo = (size_t)stripe * (size_t)A.r.trial_cap + (size_t)trial;
-        if (A.r.lat_sum) atomicAdd(A.r.lat_sum + mo, (unsigned long long)step);
-        if (A.r.lat_cnt) atomicAdd(A.r.lat_cnt + mo, 1ull);
-        if (A.r.reward_sum) atomicAdd(A.r.reward_sum + mo, trew);
-        if (A.r.resp_cnt && trew > 0.0) atomicAdd(A.r.resp_cnt + mo, 1ull);
-        if (A.r.lat_trace) A.r.lat_trace[(size_t)i * A.r.trial_cap + trial] = step;
+      const pwg_kargs R = rare_args();
+#define rr (R->r)
+      if (lane == 0 && trial >= 0 && trial < rr.trial_cap) {
+        const size_t mo = (size_t)stripe * (size_t)rr.trial_cap + (size_t)trial;
+        if (rr.lat_sum) atomicAdd(rr.lat_sum + mo, (unsigned long long)step);
+        if (rr.lat_cnt) atomicAdd(rr.lat_cnt + mo, 1ull);
+        if (rr.reward_sum) atomicAdd(rr.reward_sum + mo, trew);
+        if (rr.resp_cnt && trew > 0.0) atomicAdd(rr.resp_cnt + mo, 1ull);
+        if (rr.lat_trace) rr.lat_trace[(size_t)i * rr.trial_cap + trial] = step;
       }
+#undef rr
       trial += 1;
       iflags &= ~1u;
       if (!begin_trial()) break;
@@ -596,8 +618,9 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     const unsigned long long executed = (unsigned long long)(budget0 - budget);
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
     *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) += executed;
-    if (A.r.steps_done && executed) atomicAdd(A.r.steps_done, executed);
-    if (A.r.batches_done && batches) atomicAdd(A.r.batches_done, (unsigned long long)batches);
+    const pwg_kargs R = rare_args();
+    if (R->r.steps_done && executed) atomicAdd(R->r.steps_done, executed);
+    if (R->r.batches_done && batches) atomicAdd(R->r.batches_done, (unsigned long long)batches);
   }
   // (the next instance of this wave reuses the LDS slice: its staging stores follow these loads in
   //  the wave's own program order)
