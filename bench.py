@@ -437,6 +437,12 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
         roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC, profiles/)'
         roof['frac_measured'] = traffic / (sec / launches) / 1e9 / HBM_PEAK_GBS
         roof['measured_over_algorithmic'] = traffic / (alg / launches)
+    if which == 'hex_q' and what['kernel'] == _lib.TAB_KERNEL_WQN:
+        # (tables in LDS for the whole launch: held against instruction issue, as C2 / C6)
+        iss = issue_roofline('general_hex_q', steps / sec, float(np.mean(ms)), device, n == 65536)
+        if iss is not None:
+            roof['issue'] = iss
+            roof = to_issue_bound(roof)
     if which == 'dynaq_b100':
         iss = issue_roofline('general_dynaq_b100', steps / sec, float(np.mean(ms)), device,
                              n == 65536)
