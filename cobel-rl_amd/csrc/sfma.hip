@@ -762,14 +762,17 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
 
   // Replays are requested (trial start: one without TD updates; trial end: nb_replays with) and
   // served at ONE place at the top of the loop, so the reactivation code exists once.
+  // (Round 4: the replays and the online steps of a trial are inner loops of their own.  As ONE loop
+  //  with `continue`s every scalar of either phase was live across every iteration: the online step
+  //  reloaded ~140 spilled scalars — v_readlane, a vector instruction on a kernel bound by vector
+  //  issue.)
   int req_count = 0, req_start = -1, req_kind = 0, req_trial = 0;
   while (true) {
-    if (req_count > 0) {
+    while (req_count > 0) {
       req_count -= 1;
       if (!FAST && req_kind == 0 && (sf & COBEL_SF_RANDOM)) random_replay(req_trial);
       else sfma_replay(req_start, req_kind == 0, req_kind, req_trial);
       if (req_count == 0 && req_kind == 0) epoch = clock;  // M.T.fill(0) after a trial's replays
-      continue;
     }
     if (!(iflags & 1u)) {
       if (trial >= A.r.trials_target) break;
@@ -788,7 +791,15 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
         continue;
       }
     }
-    if (budget == 0) break;
+    // ---- the online steps of the running trial ---------------------------------------------------
+    bool out_of_budget = false;
+    int ns = state;
+    uint32_t end = 0u;
+    for (;;) {
+    if (budget == 0) {
+      out_of_budget = true;
+      break;
+    }
     budget -= 1;
 
     // ---- select + env.step ---------------------------------------------------------------------
@@ -807,7 +818,6 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
                       ? (int)rfl((uint32_t)cobel_eps_greedy_select_thr(q.x, q.y, q.z, q.w,
                                                                         cobel_u53(w0, w1), L.thr, lane))
                       : (int)rfl((uint32_t)select_action(q, mask_cur, cobel_u01(w0, w1)));
-    int ns;
     if (!FAST && A.succ_off) {
       const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
       ce += 1u;
@@ -819,7 +829,7 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     }
     const uint4 wn = W4[ns];
     const float r = __builtin_bit_cast(float, rfl(wn.z));
-    const uint32_t end = rfl(wn.w);
+    end = rfl(wn.w);
     const uint32_t nt = 1u - end;
     float td_online = 0.0f;
 
@@ -886,10 +896,11 @@ __device__ __forceinline__ void sfma_body(const sfma_args A) {
     executed += 1ull;
     if (!FAST && A.r.occupancy && t == 0) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
     state = ns;
-    const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
-    if (!trial_over) {
-      step += 1;
-    } else {
+    if (end || (step + 1 >= A.r.steps_per_trial)) break;
+    step += 1;
+    }
+    if (out_of_budget) break;
+    {
       if (t == 0 && trial >= 0 && trial < A.r.trial_cap) {
         const size_t m = cobel_mon_offset(A.r.mon_stripes, A.r.trial_cap) + (size_t)trial;
         if (A.r.lat_sum) atomicAdd(A.r.lat_sum + m, (unsigned long long)step);
