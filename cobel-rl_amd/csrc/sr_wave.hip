@@ -157,11 +157,15 @@ __device__ __forceinline__ float row_element(const row_regs<NV>& r, int e) {
 // see through: what is read through it is loaded where it is used (trial ends, masked selection,
 // the final save) instead of being held in scalar registers across the step loop, which is short
 // of them (about sixty wave-uniform values are live in it).
-__device__ __forceinline__ const srw_args* rare_args() {
+// (in the CONSTANT address space — round 4: what is read through it is a scalar load and
+//  wave-uniform to the compiler; through a generic pointer the loads were flat loads into vector
+//  registers, per-lane as far as the compiler knows)
+typedef const __attribute__((address_space(4))) srw_args* srw_kargs;
+__device__ __forceinline__ srw_kargs rare_args() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const void* p = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  srw_kargs p = (srw_kargs)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
-  return static_cast<const srw_args*>(p);
+  return p;
 #else
   return nullptr;
 #endif
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       // Leaf L (of at most 16) belongs to the eight lanes 8 (L & 7) .. + 7 in pass L >> 3, one
       // accumulator each; its sum is then kept by lane 8 (L & 7) + (L >> 3), and the sums combine
       // in the order of the plan (the result ends up with leaf 0 = lane 0).
-      const srw_args* const R = rare_args();
+      const srw_kargs R = rare_args();
       const int nl = R->n_leaves;
       const int k = lane & 7;
       for (int a = 0; a < 4; ++a) {
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                                                           lane));
     } else {
       cobel_eps_bb ebb;
-      const srw_args* const R = rare_args();
+      const srw_kargs R = rare_args();
       ebb.base[0] = ebb.bonus[0] = 0.0;
 #pragma unroll
       for (int n = 1; n <= 4; ++n) {
@@ -754,7 +758,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
       else if (KX) assemble_x(tq, fresh, gv);
       else assemble(tq, fresh, f0, f1, gv);
     } else {
-      const cobel_sr_run_t& rr = rare_args()->r;
+      const srw_kargs RR = rare_args();
+#define rr (RR->r)
       if (lane == 0 && trial >= 0 && trial < rr.trial_cap) {
         const size_t m = cobel_mon_offset(rr.mon_stripes, rr.trial_cap) + (size_t)trial;
         if (rr.lat_sum) atomicAdd(rr.lat_sum + m, (unsigned long long)step);
@@ -763,12 +768,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         if (rr.resp_cnt && trew > 0.0) atomicAdd(rr.resp_cnt + m, 1ull);
         if (rr.lat_trace) rr.lat_trace[(size_t)i * rr.trial_cap + trial] = step;
       }
+#undef rr
       trial += 1;
       iflags &= ~1u;
     }
   }
 
-  const cobel_sr_run_t& rr = rare_args()->r;
+  const srw_kargs RR = rare_args();
+#define rr (RR->r)
   if (OCC) {
     __syncthreads();
     for (int e = lane; e < S; e += 64) {
@@ -795,6 +802,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
   }
 }
 
+#undef rr
 template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
