@@ -99,7 +99,8 @@ size_t cobel_debug_lds_pad(size_t base, size_t limit);
 const char* cobel_debug_env(const char* name);
 // mlp.hip: the parameter-staging DQN replay kernel (cobel_dqn_replay, mlp_fit.hip, dispatches)
 size_t cobel_dqn_replay_lds_bytes(int32_t n_inputs, int32_t is_float64);
-int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st);
+int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st,
+                                unsigned long long* trace /* experiments, or NULL */);
 int cobel_world_check(const cobel_world* w, const char* who);   // non-NULL, on the current device
 int cobel_world_check4(const cobel_world* w, const char* who);  // ... and a four-action world
 

@@ -53,6 +53,7 @@ static_assert(kMaxW1Iters == 8, "three instantiations: 2, 4, 8");
 
 struct mlp_args {
   cobel_dqn_replay_t r;
+  unsigned long long* trace;   // experiments: [n][16] wall-clock stamps of thread 0 (or NULL)
 };
 
 template <typename T>
@@ -169,18 +170,36 @@ __device__ __forceinline__ T adam_apply(T* __restrict__ p, T* __restrict__ m,
 // matrix, the output layer and the biases are loaded into registers (the online network's while
 // the target network's forward pass runs) and written to LDS when the buffer is free; the small
 // first layer goes straight from memory to LDS at that point.
-template <typename T>
-struct param_regs {
-  T w2[16], w3, b1, b2, b3;
+// Float32 at more than eight inputs keeps the LATE form of the small requests (first layer of a
+// network, second batch of rows, first layer's optimizer state: each where it is used): the early
+// form holds them in registers across the forward passes, and the 128 registers of the
+// four-workgroups-per-CU build do not have that room (measured at 12 / 25 inputs: 0.41 / 0.52 ms per
+// Dyna-DQN step late, 0.45 / 0.64 early with spills; at 6 inputs early wins, 0.323 -> 0.310).
+template <typename T, int DI>
+struct early_requests {
+  static constexpr bool value = sizeof(T) == 8 || DI == 2;
 };
 
-template <typename T>
-__device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restrict__ w1,
+template <typename T, int DI>
+struct param_regs {
+  T w2[16], w1[early_requests<T, DI>::value ? DI : 1], w3, b1, b2, b3;
+};
+
+template <typename T, int DI>
+__device__ __forceinline__ void params_load(param_regs<T, DI>& P, const T* __restrict__ w1,
                                             const T* __restrict__ b1, const T* __restrict__ w2,
                                             const T* __restrict__ b2, const T* __restrict__ w3,
                                             const T* __restrict__ b3, int D, int t) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) P.w2[u] = __builtin_nontemporal_load(w2 + t + 256 * u);   // coalesced along k
+  if (early_requests<T, DI>::value) {
+#pragma unroll
+    for (int u = 0; u < DI; ++u) {
+      const int e = t + 256 * u;
+      P.w1[u] = w1[e < kH * D ? e : kH * D - 1];   // (unconditional: a load under a condition is a
+                                                   //  branch and a wait for every load before it)
+    }
+  }
   P.w3 = w3[t];   // 4 * 64 = 256 elements
   P.b1 = t < kH ? b1[t] : (T)0;
   P.b2 = t < kH ? b2[t] : (T)0;
@@ -188,31 +207,20 @@ __device__ __forceinline__ void params_load(param_regs<T>& P, const T* __restric
 }
 
 template <typename T, int DI>
-__device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T>& P,
+__device__ __forceinline__ void params_store(const mlp_lds<T>& L, const param_regs<T, DI>& P,
                                              const T* __restrict__ w1, int D, int t) {
 #pragma unroll
   for (int u = 0; u < 16; ++u) {   // transposed write
     const int e = t + 256 * u;
     L.wt2[(e & 63) * kRow + (e >> 6)] = P.w2[u];
   }
-  // (float64: all of the thread's loads in flight, then their LDS writes.  Written as one plain
-  //  loop every element waits for its own trip to memory — `s_waitcnt vmcnt(0)` per iteration,
-  //  seven of them at 25 inputs.  The float32 instantiation runs under a 128-register cap with four
-  //  workgroups per CU to cover that latency and keeps the plain loop: the staged form spills.)
-  if (sizeof(T) == 8) {
-    T r1[DI];
-#pragma unroll
-    for (int u = 0; u < DI; ++u) {
-      const int e = t + 256 * u;
-      r1[u] = w1[e < kH * D ? e : kH * D - 1];   // (unconditional: a load under a condition is a
-                                                 //  branch and a wait for every load before it)
-    }
+  if (early_requests<T, DI>::value) {
 #pragma unroll
     for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
       if (e < kH * D) {
         const int j = e / D, d = e - j * D;
-        L.wt1[d * kH + j] = r1[u];
+        L.wt1[d * kH + j] = P.w1[u];
       }
     }
   } else {
@@ -289,52 +297,44 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
   lds_barrier();
 }
 
+// The 32 rows of a batch (rows `slot[s]` of the instance's ring / gathered batch, or rows
+// `index[s]` of the observation table in world-model mode): requested into registers, written to
+// LDS when L.x is free — both batches of a step are requested together, right behind the
+// parameters.
 template <typename T, int DI>
-__device__ void load_rows_table(T* dst, const double* table, const int32_t* index, int D, int t) {
-  // (`index`: the 32 row numbers, staged in LDS; float64: the thread's loads in flight together)
-  if (sizeof(T) == 8) {
-    double r[(DI / 2)];
-#pragma unroll
-    for (int u = 0; u < (DI / 2); ++u) {
-      const int e = t + 256 * u;
-      const int ec = e < kB * D ? e : kB * D - 1;   // (unconditional loads, see params_store)
-      const int s = ec / D, d = ec - s * D;
-      r[u] = table[(size_t)index[s] * D + d];
-    }
-#pragma unroll
-    for (int u = 0; u < (DI / 2); ++u) {
-      const int e = t + 256 * u;
-      if (e < kB * D) dst[e] = (T)r[u];
-    }
-  } else {
-    for (int e = t; e < kB * D; e += 256) {
-      const int s = e / D, d = e - s * D;
-      dst[e] = (T)table[(size_t)index[s] * D + d];
-    }
-  }
-}
+struct row_regs {
+  T r[DI / 2];
+};
 
 template <typename T, int DI>
-__device__ void load_rows(T* dst, const T* src, const int* slot, int D, int t) {
-  if (sizeof(T) == 8) {
-    T r[(DI / 2)];
+__device__ __forceinline__ void rows_request(row_regs<T, DI>& X, const T* src, const int* slot,
+                                             const double* table, const int32_t* index, int D,
+                                             int t) {
+  if (table) {
+#pragma unroll
+    for (int u = 0; u < (DI / 2); ++u) {
+      const int e = t + 256 * u;
+      const int ec = e < kB * D ? e : kB * D - 1;   // (unconditional loads, see params_load)
+      const int s = ec / D, d = ec - s * D;
+      X.r[u] = (T)table[(size_t)index[s] * D + d];
+    }
+  } else {
 #pragma unroll
     for (int u = 0; u < (DI / 2); ++u) {
       const int e = t + 256 * u;
       const int ec = e < kB * D ? e : kB * D - 1;
       const int s = ec / D, d = ec - s * D;
-      r[u] = src[(size_t)slot[s] * D + d];
+      X.r[u] = src[(size_t)slot[s] * D + d];
     }
+  }
+}
+
+template <typename T, int DI>
+__device__ __forceinline__ void rows_store(T* dst, const row_regs<T, DI>& X, int D, int t) {
 #pragma unroll
-    for (int u = 0; u < (DI / 2); ++u) {
-      const int e = t + 256 * u;
-      if (e < kB * D) dst[e] = r[u];
-    }
-  } else {
-    for (int e = t; e < kB * D; e += 256) {
-      const int s = e / D, d = e - s * D;
-      dst[e] = src[(size_t)slot[s] * D + d];
-    }
+  for (int u = 0; u < (DI / 2); ++u) {
+    const int e = t + 256 * u;
+    if (e < kB * D) dst[e] = X.r[u];
   }
 }
 
@@ -346,6 +346,10 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   if (R.active && !R.active[i]) return;
   const int t = (int)threadIdx.x;
   const int D = R.n_inputs;
+  auto stamp = [&](int k) {   // (scripts/exp_mlp_trace.py)
+    if (A.trace && t == 0) A.trace[(size_t)i * 16 + k] = wall_clock64();
+  };
+  stamp(0);
   mlp_lds<T> L;
   {
     T* p = reinterpret_cast<T*>(lds_raw);
@@ -383,15 +387,21 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   const size_t rows = R.batch_slots ? (size_t)R.ring_slots : (size_t)kB;
   const T* const xs = (const T*)R.states + (size_t)i * rows * D;
   const T* const xn = (const T*)R.next_states + (size_t)i * rows * D;
+  // Requests go out in the order their answers are needed, and nothing waits for an answer before
+  // everything that does not depend on it has been requested: the batch's slots first, then both
+  // networks' parameters, then (once the slots are there) both batches' rows, rewards, flags and
+  // actions — one trip to memory where the first version of this kernel made five, each behind a
+  // barrier.
+  constexpr bool kEarly = early_requests<T, DI>::value;
+  int my_slot = t, my_is = 0, my_in = 0;
   if (t < kB) {
-    L.slot[t] = R.batch_slots ? R.batch_slots[(size_t)i * kB + t] : t;
+    if (R.batch_slots) my_slot = R.batch_slots[(size_t)i * kB + t];
     if (R.state_index) {   // world-model mode: the batch's observations are rows of a table
-      L.idx_s[t] = R.state_index[(size_t)i * kB + t];
-      L.idx_n[t] = R.next_index[(size_t)i * kB + t];
+      my_is = R.state_index[(size_t)i * kB + t];
+      my_in = R.next_index[(size_t)i * kB + t];
     }
   }
-  lds_barrier();
-
+  const int my_obs = R.q_out ? R.obs_index[i] : 0;
   T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
   T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
   T* const m_w3 = (T*)R.m_w[2] + (size_t)i * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)i * n3;
@@ -412,9 +422,24 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // Both networks' parameters are requested at once (the online network's stay in registers until
   // the target network's forward pass has released the LDS buffer): twice the bytes in flight while
   // the workgroup has nothing to compute.
-  param_regs<T> P, PT;
-  params_load<T>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
-  params_load<T>(P, w1, b1, w2, b2, w3, b3, D, t);
+  param_regs<T, DI> P, PT;
+  params_load<T, DI>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
+  params_load<T, DI>(P, w1, b1, w2, b2, w3, b3, D, t);
+  if (t < kB) {
+    L.slot[t] = my_slot;
+    L.idx_s[t] = my_is;
+    L.idx_n[t] = my_in;
+  }
+  lds_barrier();
+  stamp(1);
+  row_regs<T, DI> XN, XS;
+  rows_request<T, DI>(XN, xn, L.slot, R.state_index ? R.obs_table : nullptr, L.idx_n, D, t);
+  if (kEarly) rows_request<T, DI>(XS, xs, L.slot, R.state_index ? R.obs_table : nullptr, L.idx_s, D, t);
+  // (thread t < 32: reward and flag of sample t; thread t < 128: the action of sample t / 4)
+  const size_t my_row = (size_t)i * rows + L.slot[t < kB ? t : 0];
+  const T my_r = ((const T*)R.rewards)[my_row];
+  const T my_nt = ((const T*)R.nonterminal)[my_row];
+  const int my_act = (int)R.actions[(size_t)i * rows + L.slot[t < kB * kA ? t >> 2 : 0]];
   // Adam's bias corrections (two float64 pow() and a sqrt: ~300 float64 instructions) by ONE wave
   // while the parameter loads are in flight, through two spare LDS words behind b3 — every wave
   // used to evaluate them in front of the backward pass: 9 % of a C5 step in float32.
@@ -428,9 +453,9 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   params_store<T, DI>(L, PT, tw1, D, t);
-  if (R.state_index) load_rows_table<T, DI>(L.x, R.obs_table, L.idx_n, D, t);
-  else load_rows<T, DI>(L.x, xn, L.slot, D, t);
+  rows_store<T, DI>(L.x, XN, D, t);
   lds_barrier();
+  stamp(2);
   // the target network's copies of this thread's tile of the 64 x 64 matrix, for the blend at the
   // end (the other, small tensors are read again with their moments in the backward pass)
 #pragma unroll
@@ -439,8 +464,26 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     for (int b = 0; b < 4; ++b)
       s2[a][b].target = L.wt2[(16 * a + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, b)];
   forward<T>(L, L.qt, D, t);
+  stamp(3);
+  // Optimizer state is requested in the order the backward pass consumes it, each group early
+  // enough to have arrived: the output layer's and the small tensors' here (a dozen registers over
+  // the online pass), the 64 x 64 tensor's after that pass (32 registers: requested any earlier
+  // they crowd the forward passes out of the register file), the first layer's behind it.
+  s3.m = m_w3[t];
+  s3.v = v_w3[t];
+  s3.target = tw3[t];
+  sb2.m = sb2.v = sb2.target = (T)0;
+  sb3.m = sb3.v = sb3.target = (T)0;
+  if (t < kH) {
+    sb2.m = m_b2[t]; sb2.v = v_b2[t]; sb2.target = tb2[t];
+  }
+  if (t < kA) {
+    sb3.m = m_b3[t]; sb3.v = v_b3[t]; sb3.target = tb3[t];
+  }
   // ---- online network -------------------------------------------------------------------------
   params_store<T, DI>(L, P, w1, D, t);
+  if (!kEarly) rows_request<T, DI>(XS, xs, L.slot, R.state_index ? R.obs_table : nullptr, L.idx_s, D, t);
+  if (!R.ddqn) rows_store<T, DI>(L.x, XS, D, t);   // (DDQN: the online pass on s' comes first)
   lds_barrier();
   if (R.ddqn) {   // agent/dqn.py:352-355: the online network picks the action, the target rates it
     forward<T>(L, L.q, D, t);
@@ -455,12 +498,19 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
         }
       L.pick[t] = best;
     }
+    rows_store<T, DI>(L.x, XS, D, t);
     lds_barrier();
   }
-  if (R.state_index) load_rows_table<T, DI>(L.x, R.obs_table, L.idx_s, D, t);
-  else load_rows<T, DI>(L.x, xs, L.slot, D, t);
-  lds_barrier();
   forward<T>(L, L.q, D, t);
+  stamp(4);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)   // (16 lanes read 16 consecutive elements of a row)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const size_t e = (size_t)(jt2 + mfma_acc<T>::row(lane2, b)) * kH + 16 * a + li2;
+      s2[a][b].m = __builtin_nontemporal_load(m_w2 + e);
+      s2[a][b].v = __builtin_nontemporal_load(v_w2 + e);
+    }
 
   // ---- targets and the loss gradient at the output ----------------------------------------------
   // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the 32 x 4
@@ -475,20 +525,18 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
 #pragma unroll
       for (int a = 1; a < kA; ++a) boot = L.qt[t * kA + a] > boot ? L.qt[t * kA + a] : boot;
     }
-    const size_t row = (size_t)i * rows + L.slot[t];
-    const T r = ((const T*)R.rewards)[row];
-    const T nt = ((const T*)R.nonterminal)[row];
-    L.boot[t] = r + (boot * nt) * (T)R.gamma;
+    L.boot[t] = my_r + (boot * my_nt) * (T)R.gamma;
   }
   lds_barrier();
   if (t < kB * kA) {
     const int s = t >> 2, a = t & 3;
-    const int act = (int)R.actions[(size_t)i * rows + L.slot[s]];
+    const int act = my_act;
     const T d = L.q[t] - L.boot[s];
     const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
     L.q[t] = (a == act) ? g : (T)0;   // delta3
   }
   lds_barrier();
+  stamp(5);
 
   // ---- Adam constants of this instance ----------------------------------------------------------
   adam_consts<T> c;
@@ -504,25 +552,27 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     c.tau = (T)R.tau;
     c.blend = R.tau != 0.0;
   }
+  // ... and what the END of the step needs — the first layer's optimizer state and the instance's
+  // next observation (they used to be requested where they are used: three more trips to memory,
+  // one after the other, with the workgroup waiting)
+  adam_slot<T> s1[DI];
+  auto request_s1 = [&]() {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)   // (16 lanes read 16 consecutive elements of a row)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const size_t e = (size_t)(jt2 + mfma_acc<T>::row(lane2, b)) * kH + 16 * a + li2;
-      s2[a][b].m = __builtin_nontemporal_load(m_w2 + e);
-      s2[a][b].v = __builtin_nontemporal_load(v_w2 + e);
+    for (int u = 0; u < DI; ++u) {
+      const int e = t + 256 * u;
+      const int ec = e < kH * D ? e : kH * D - 1;   // (unconditional loads, see params_load)
+      s1[u].m = m_w1[ec];
+      s1[u].v = v_w1[ec];
+      s1[u].target = tw1[ec];
     }
-  s3.m = m_w3[t];
-  s3.v = v_w3[t];
-  s3.target = tw3[t];
-  sb2.m = sb2.v = sb2.target = (T)0;
-  sb3.m = sb3.v = sb3.target = (T)0;
+  };
+  if (kEarly) request_s1();
+  sb1.m = sb1.v = sb1.target = (T)0;
   if (t < kH) {
-    sb2.m = m_b2[t]; sb2.v = v_b2[t]; sb2.target = tb2[t];
+    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
   }
-  if (t < kA) {
-    sb3.m = m_b3[t]; sb3.v = v_b3[t]; sb3.target = tb3[t];
-  }
+  T my_x = (T)0;   // (no next observation asked for: obs_table may be absent)
+  if (R.q_out) my_x = (T)R.obs_table[(size_t)my_obs * D + (t < D ? t : 0)];
 
   // The updated parameters also replace the old ones in LDS as soon as the backward pass no longer
   // needs those (the output layer's after delta2, the second layer's after delta1): the Q-values of
@@ -542,6 +592,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   lds_barrier();
+  stamp(6);
   // delta2[s][k] = (sum_a W3[a][k] delta3[s][a]) * (h2[s][k] > 0), in place over h2
   for (int e = t; e < kB * kH; e += 256) {
     const int s = e >> 6, k = e & 63;
@@ -552,6 +603,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     L.h2[s * kRow + k] = h > (T)0 ? d : (T)0;
   }
   lds_barrier();
+  stamp(7);
   L.w3[t] = new_w3;
 
   // ---- second layer: dW2[j][k] = sum_s delta2[s][j] h1[s][k] ------------------------------------
@@ -591,6 +643,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   lds_barrier();
+  stamp(8);
   // delta1[s][k] = (sum_j delta2[s][j] W2[j][k]) * (h1[s][k] > 0), in place over h1, from the
   // weights this step started from (LDS still holds them: the update above went to memory only).
   // M = s (two tiles), N = k (wave w takes columns 16 w ..), K = j.  A = delta2 (in h2), B = W2
@@ -614,10 +667,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   lds_barrier();   // every read of the old second-layer weights is done
-  sb1.m = sb1.v = sb1.target = (T)0;
-  if (t < kH) {   // (state of the first layer's bias: used at the very end)
-    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
-  }
+  stamp(9);
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -625,44 +675,17 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       L.wt2[(16 * kt + li2) * kRow + jt2 + mfma_acc<T>::row(lane2, v)] = new_w2[kt][v];
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
-  // (a small tensor: its optimizer state is loaded here — in float64 for all of the thread's
-  //  elements at once: the registers of the second layer's tile are free by now, and one element
-  //  per trip to memory, as the plain loop of the float32 instantiation does it, was seven exposed
-  //  trips at 25 inputs)
-  if (sizeof(T) == 8) {
-    adam_slot<T> s1[DI];
+  if (!kEarly) request_s1();
 #pragma unroll
-    for (int u = 0; u < DI; ++u) {
-      const int e = t + 256 * u;
-      const int ec = e < kH * D ? e : kH * D - 1;   // (unconditional loads, see params_store)
-      s1[u].m = m_w1[ec];
-      s1[u].v = v_w1[ec];
-      s1[u].target = tw1[ec];
-    }
-#pragma unroll
-    for (int u = 0; u < DI; ++u) {
-      const int e = t + 256 * u;
-      if (e < kH * D) {
-        const int j = e / D, d = e - j * D;
-        T g = (T)0;
-#pragma unroll 8
-        for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
-        L.wt1[d * kH + j] =
-            adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
-      }
-    }
-  } else {
-    for (int e = t; e < kH * D; e += 256) {
-      adam_slot<T> s1;
-      s1.m = m_w1[e];
-      s1.v = v_w1[e];
-      s1.target = tw1[e];
+  for (int u = 0; u < DI; ++u) {
+    const int e = t + 256 * u;
+    if (e < kH * D) {
       const int j = e / D, d = e - j * D;
       T g = (T)0;
 #pragma unroll 8
       for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
       L.wt1[d * kH + j] =
-          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1, c);
+          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
     }
   }
   if (t < kH) {
@@ -672,11 +695,12 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     L.b1[t] = nb;
   }
 
+  stamp(10);
   // ---- Q-values of the next observation with the updated online network ------------------------
   // (what the next step's action selection needs: agent/dqn.py:174 -> retrieve_q)
   if (R.q_out) {
     lds_barrier();   // LDS holds the updated parameters; h1 / h2 / x are free
-    if (t < D) L.x[t] = (T)R.obs_table[(size_t)R.obs_index[i] * D + t];
+    if (t < D) L.x[t] = my_x;
     lds_barrier();
     if (t < kH) {
       T acc = L.b1[t];
@@ -698,6 +722,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       ((T*)R.q_out)[(size_t)i * kA + t] = acc;
     }
   }
+  stamp(11);
 }
 
 // float64: 78 KB of LDS allow two workgroups per CU, so the kernel may use 256 registers.
@@ -748,10 +773,12 @@ size_t cobel_dqn_replay_lds_bytes(int32_t n_inputs, int32_t is_float64) {
 
 // The launch (arguments checked by cobel_dqn_replay, mlp_fit.hip, which picks between this kernel
 // and the one that streams its weight operands from memory).
-int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st) {
+int cobel_dqn_replay_lds_launch(const cobel_dqn_replay_t& r, hipStream_t st,
+                                unsigned long long* trace) {
   const int32_t lds = (int32_t)cobel_dqn_replay_lds_bytes(r.n_inputs, r.is_float64);
   mlp_args A;
   A.r = r;
+  A.trace = trace;
   if (r.n_inputs <= 8) return launch_lds<2>(A, lds, st);
   if (r.n_inputs <= 16) return launch_lds<4>(A, lds, st);
   return launch_lds<8>(A, lds, st);

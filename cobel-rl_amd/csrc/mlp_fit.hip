@@ -1090,7 +1090,8 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
                 COBEL_E_ARG, "cobel_dqn_replay: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (dqn_staged(r.n_inputs, r.is_float64)) return cobel_dqn_replay_lds_launch(r, st);
+  if (dqn_staged(r.n_inputs, r.is_float64))
+    return cobel_dqn_replay_lds_launch(r, st, debug_trace_buffer());
   // the optimisation step of cobel_mlp_fit towards the Q-learning targets
   fit_args A;
   memset(&A, 0, sizeof A);
