@@ -184,8 +184,15 @@ __device__ __forceinline__ srw_kargs rare_args() {
 // Lane 8a + n gathers element pos[n] of value row a, holds R[pos[n]] and its product; the k - 1
 // additions run as shuffles inside the groups of eight lanes.  The values of the row a step
 // rewrites are read back from an LDS copy of the new row.
+// Registers: 80 (six waves per SIMD) everywhere except the instantiation that spilled most at that
+// cap — rows of 769 .. 1 023 states (ANY_S) with the three-to-eight-rewards form: 44 B of scratch,
+// 18 scratch accesses inside the step loop.  At 96 registers it has none; measured on 31 x 31 and
+// 30 x 31 worlds with three rewarded states 3.22 -> 2.88 and 3.15 -> 2.81 ms per launch (16 384
+// instances x 128 steps).  The 32-slot form and the narrower rows measured 4-7 % SLOWER at five
+// waves (scripts/exp_sr_small.py) and keep six.
 template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sr_wave(
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) void k_sr_wave(
     const srw_args A) {
   __shared__ uint64_t thr[48];
   // The row written in the previous step, kept on chip (4 KiB at 32 x 32): a step straight back — a
