@@ -338,6 +338,22 @@ __device__ __forceinline__ void rows_store(T* dst, const row_regs<T, DI>& X, int
   }
 }
 
+// The kernel arguments as they lie in the kernarg segment, through a pointer the optimizer cannot
+// see through (constant address space: scalar loads).  The thirty tensor pointers of a step are
+// formed where they are used — two scalar loads and a multiply-add each — instead of at the top
+// of the kernel, from where they lived (and were spilled: ~240 v_readlane / v_writelane of ~2 600
+// vector instructions per wave) across the whole step.
+typedef const __attribute__((address_space(4))) mlp_args* mlp_kargs;
+__device__ __forceinline__ mlp_kargs kr() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  mlp_kargs p = (mlp_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+#else
+  return nullptr;
+#endif
+}
+
 template <typename T, int DI>
 __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -371,18 +387,18 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     L.idx_n = reinterpret_cast<int*>(p);
   }
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)kA * kH;
-  T* const w1 = (T*)R.w[0] + (size_t)i * n1;
-  T* const b1 = (T*)R.b[0] + (size_t)i * kH;
-  T* const w2 = (T*)R.w[1] + (size_t)i * n2;
-  T* const b2 = (T*)R.b[1] + (size_t)i * kH;
-  T* const w3 = (T*)R.w[2] + (size_t)i * n3;
-  T* const b3 = (T*)R.b[2] + (size_t)i * kA;
-  T* const tw1 = (T*)R.w_target[0] + (size_t)i * n1;
-  T* const tb1 = (T*)R.b_target[0] + (size_t)i * kH;
-  T* const tw2 = (T*)R.w_target[1] + (size_t)i * n2;
-  T* const tb2 = (T*)R.b_target[1] + (size_t)i * kH;
-  T* const tw3 = (T*)R.w_target[2] + (size_t)i * n3;
-  T* const tb3 = (T*)R.b_target[2] + (size_t)i * kA;
+  auto w1 = [&]() -> T* { return (T*)kr()->r.w[0] + (size_t)i * n1; };
+  auto b1 = [&]() -> T* { return (T*)kr()->r.b[0] + (size_t)i * kH; };
+  auto w2 = [&]() -> T* { return (T*)kr()->r.w[1] + (size_t)i * n2; };
+  auto b2 = [&]() -> T* { return (T*)kr()->r.b[1] + (size_t)i * kH; };
+  auto w3 = [&]() -> T* { return (T*)kr()->r.w[2] + (size_t)i * n3; };
+  auto b3 = [&]() -> T* { return (T*)kr()->r.b[2] + (size_t)i * kA; };
+  auto tw1 = [&]() -> T* { return (T*)kr()->r.w_target[0] + (size_t)i * n1; };
+  auto tb1 = [&]() -> T* { return (T*)kr()->r.b_target[0] + (size_t)i * kH; };
+  auto tw2 = [&]() -> T* { return (T*)kr()->r.w_target[1] + (size_t)i * n2; };
+  auto tb2 = [&]() -> T* { return (T*)kr()->r.b_target[1] + (size_t)i * kH; };
+  auto tw3 = [&]() -> T* { return (T*)kr()->r.w_target[2] + (size_t)i * n3; };
+  auto tb3 = [&]() -> T* { return (T*)kr()->r.b_target[2] + (size_t)i * kA; };
   // the batch: gathered tensors [N][32][..], or rows batch_slots[i][s] of the replay rings
   const size_t rows = R.batch_slots ? (size_t)R.ring_slots : (size_t)kB;
   const T* const xs = (const T*)R.states + (size_t)i * rows * D;
@@ -402,12 +418,12 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     }
   }
   const int my_obs = R.q_out ? R.obs_index[i] : 0;
-  T* const m_w1 = (T*)R.m_w[0] + (size_t)i * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)i * n1;
-  T* const m_w2 = (T*)R.m_w[1] + (size_t)i * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)i * n2;
-  T* const m_w3 = (T*)R.m_w[2] + (size_t)i * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)i * n3;
-  T* const m_b1 = (T*)R.m_b[0] + (size_t)i * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)i * kH;
-  T* const m_b2 = (T*)R.m_b[1] + (size_t)i * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)i * kH;
-  T* const m_b3 = (T*)R.m_b[2] + (size_t)i * kA; T* const v_b3 = (T*)R.v_b[2] + (size_t)i * kA;
+  auto m_w1 = [&]() -> T* { return (T*)kr()->r.m_w[0] + (size_t)i * n1; }; auto v_w1 = [&]() -> T* { return (T*)kr()->r.v_w[0] + (size_t)i * n1; };
+  auto m_w2 = [&]() -> T* { return (T*)kr()->r.m_w[1] + (size_t)i * n2; }; auto v_w2 = [&]() -> T* { return (T*)kr()->r.v_w[1] + (size_t)i * n2; };
+  auto m_w3 = [&]() -> T* { return (T*)kr()->r.m_w[2] + (size_t)i * n3; }; auto v_w3 = [&]() -> T* { return (T*)kr()->r.v_w[2] + (size_t)i * n3; };
+  auto m_b1 = [&]() -> T* { return (T*)kr()->r.m_b[0] + (size_t)i * kH; }; auto v_b1 = [&]() -> T* { return (T*)kr()->r.v_b[0] + (size_t)i * kH; };
+  auto m_b2 = [&]() -> T* { return (T*)kr()->r.m_b[1] + (size_t)i * kH; }; auto v_b2 = [&]() -> T* { return (T*)kr()->r.v_b[1] + (size_t)i * kH; };
+  auto m_b3 = [&]() -> T* { return (T*)kr()->r.m_b[2] + (size_t)i * kA; }; auto v_b3 = [&]() -> T* { return (T*)kr()->r.v_b[2] + (size_t)i * kA; };
 
   // ---- the elements this thread will update (see adam_slot) -----------------------------------
   // second layer: the 4 x 4 tile (j0 .., k0 ..) of the backward pass; first layer: elements
@@ -423,8 +439,8 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // the target network's forward pass has released the LDS buffer): twice the bytes in flight while
   // the workgroup has nothing to compute.
   param_regs<T, DI> P, PT;
-  params_load<T, DI>(PT, tw1, tb1, tw2, tb2, tw3, tb3, D, t);
-  params_load<T, DI>(P, w1, b1, w2, b2, w3, b3, D, t);
+  params_load<T, DI>(PT, tw1(), tb1(), tw2(), tb2(), tw3(), tb3(), D, t);
+  params_load<T, DI>(P, w1(), b1(), w2(), b2(), w3(), b3(), D, t);
   if (t < kB) {
     L.slot[t] = my_slot;
     L.idx_s[t] = my_is;
@@ -441,7 +457,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   const T my_nt = ((const T*)R.nonterminal)[my_row];
   const int my_act = (int)R.actions[(size_t)i * rows + L.slot[t < kB * kA ? t >> 2 : 0]];
   // Adam's bias corrections (two float64 pow() and a sqrt: ~300 float64 instructions) by ONE wave
-  // while the parameter loads are in flight, through two spare LDS words behind b3 — every wave
+  // while the parameter loads are in flight, through two spare LDS words behind b3() — every wave
   // used to evaluate them in front of the backward pass: 9 % of a C5 step in float32.
   if (t < 64) {
     const double st = R.steps[i];
@@ -452,7 +468,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       L.b3[5] = bc2_sqrt;
     }
   }
-  params_store<T, DI>(L, PT, tw1, D, t);
+  params_store<T, DI>(L, PT, tw1(), D, t);
   rows_store<T, DI>(L.x, XN, D, t);
   lds_barrier();
   stamp(2);
@@ -469,19 +485,19 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // enough to have arrived: the output layer's and the small tensors' here (a dozen registers over
   // the online pass), the 64 x 64 tensor's after that pass (32 registers: requested any earlier
   // they crowd the forward passes out of the register file), the first layer's behind it.
-  s3.m = m_w3[t];
-  s3.v = v_w3[t];
-  s3.target = tw3[t];
+  s3.m = m_w3()[t];
+  s3.v = v_w3()[t];
+  s3.target = tw3()[t];
   sb2.m = sb2.v = sb2.target = (T)0;
   sb3.m = sb3.v = sb3.target = (T)0;
   if (t < kH) {
-    sb2.m = m_b2[t]; sb2.v = v_b2[t]; sb2.target = tb2[t];
+    sb2.m = m_b2()[t]; sb2.v = v_b2()[t]; sb2.target = tb2()[t];
   }
   if (t < kA) {
-    sb3.m = m_b3[t]; sb3.v = v_b3[t]; sb3.target = tb3[t];
+    sb3.m = m_b3()[t]; sb3.v = v_b3()[t]; sb3.target = tb3()[t];
   }
   // ---- online network -------------------------------------------------------------------------
-  params_store<T, DI>(L, P, w1, D, t);
+  params_store<T, DI>(L, P, w1(), D, t);
   if (!kEarly) rows_request<T, DI>(XS, xs, L.slot, R.state_index ? R.obs_table : nullptr, L.idx_s, D, t);
   if (!R.ddqn) rows_store<T, DI>(L.x, XS, D, t);   // (DDQN: the online pass on s' comes first)
   lds_barrier();
@@ -503,13 +519,15 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   }
   forward<T>(L, L.q, D, t);
   stamp(4);
+  T* const pm2 = m_w2();
+  T* const pv2 = v_w2();
 #pragma unroll
   for (int a = 0; a < 4; ++a)   // (16 lanes read 16 consecutive elements of a row)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const size_t e = (size_t)(jt2 + mfma_acc<T>::row(lane2, b)) * kH + 16 * a + li2;
-      s2[a][b].m = __builtin_nontemporal_load(m_w2 + e);
-      s2[a][b].v = __builtin_nontemporal_load(v_w2 + e);
+      s2[a][b].m = __builtin_nontemporal_load(pm2 + e);
+      s2[a][b].v = __builtin_nontemporal_load(pv2 + e);
     }
 
   // ---- targets and the loss gradient at the output ----------------------------------------------
@@ -557,19 +575,22 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   // one after the other, with the workgroup waiting)
   adam_slot<T> s1[DI];
   auto request_s1 = [&]() {
+    const T* const pm = m_w1();
+    const T* const pv = v_w1();
+    const T* const pt = tw1();
 #pragma unroll
     for (int u = 0; u < DI; ++u) {
       const int e = t + 256 * u;
       const int ec = e < kH * D ? e : kH * D - 1;   // (unconditional loads, see params_load)
-      s1[u].m = m_w1[ec];
-      s1[u].v = v_w1[ec];
-      s1[u].target = tw1[ec];
+      s1[u].m = pm[ec];
+      s1[u].v = pv[ec];
+      s1[u].target = pt[ec];
     }
   };
   if (kEarly) request_s1();
   sb1.m = sb1.v = sb1.target = (T)0;
   if (t < kH) {
-    sb1.m = m_b1[t]; sb1.v = v_b1[t]; sb1.target = tb1[t];
+    sb1.m = m_b1()[t]; sb1.v = v_b1()[t]; sb1.target = tb1()[t];
   }
   T my_x = (T)0;   // (no next observation asked for: obs_table may be absent)
   if (R.q_out) my_x = (T)R.obs_table[(size_t)my_obs * D + (t < D ? t : 0)];
@@ -584,11 +605,11 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     T g = (T)0;
 #pragma unroll 8
     for (int s = 0; s < kB; ++s) g = fma_t<T>(L.q[s * kA + a], L.h2[s * kRow + k], g);
-    new_w3 = adam_apply<T>(w3, m_w3, v_w3, tw3, (size_t)t, L.w3[t], g, s3, c);
+    new_w3 = adam_apply<T>(w3(), m_w3(), v_w3(), tw3(), (size_t)t, L.w3[t], g, s3, c);
     if (t < kA) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kA + t];
-      L.b3[t] = adam_apply<T>(b3, m_b3, v_b3, tb3, (size_t)t, L.b3[t], gb, sb3, c);
+      L.b3[t] = adam_apply<T>(b3(), m_b3(), v_b3(), tb3(), (size_t)t, L.b3[t], gb, sb3, c);
     }
   }
   lds_barrier();
@@ -613,6 +634,10 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
     typedef typename mfma_acc<T>::type acc_t;
     const int lq = lane2 >> 4;
     acc_t g2[4];
+    T* const qm2 = m_w2();
+    T* const qv2 = v_w2();
+    T* const qw2 = w2();
+    T* const qt2 = tw2();
 #pragma unroll
     for (int a = 0; a < 4; ++a) g2[a] = acc_t{(T)0, (T)0, (T)0, (T)0};
 #pragma unroll 2
@@ -631,15 +656,15 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
         adam_update<T>(L.wt2[k * kRow + j], g2[kt][v], s2[kt][v], c, pn, mn, vn, tn);
         new_w2[kt][v] = pn;
         const size_t e = (size_t)j * kH + k;
-        __builtin_nontemporal_store(mn, m_w2 + e);
-        __builtin_nontemporal_store(vn, v_w2 + e);
-        __builtin_nontemporal_store(pn, w2 + e);
-        if (c.blend) __builtin_nontemporal_store(tn, tw2 + e);
+        __builtin_nontemporal_store(mn, qm2 + e);
+        __builtin_nontemporal_store(vn, qv2 + e);
+        __builtin_nontemporal_store(pn, qw2 + e);
+        if (c.blend) __builtin_nontemporal_store(tn, qt2 + e);
       }
     if (t < kH) {
       T gb = (T)0;
       for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
-      L.b2[t] = adam_apply<T>(b2, m_b2, v_b2, tb2, (size_t)t, L.b2[t], gb, sb2, c);
+      L.b2[t] = adam_apply<T>(b2(), m_b2(), v_b2(), tb2(), (size_t)t, L.b2[t], gb, sb2, c);
     }
   }
   lds_barrier();
@@ -676,6 +701,10 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
 
   // ---- first layer: dW1[j][d] = sum_s delta1[s][j] x[s][d] -----------------------------------------
   if (!kEarly) request_s1();
+  T* const qw1 = w1();
+  T* const qm1 = m_w1();
+  T* const qv1 = v_w1();
+  T* const qt1 = tw1();
 #pragma unroll
   for (int u = 0; u < DI; ++u) {
     const int e = t + 256 * u;
@@ -685,13 +714,13 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
 #pragma unroll 8
       for (int s = 0; s < kB; ++s) g = fma_t<T>(L.h1[s * kRow + j], L.x[s * D + d], g);
       L.wt1[d * kH + j] =
-          adam_apply<T>(w1, m_w1, v_w1, tw1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
+          adam_apply<T>(qw1, qm1, qv1, qt1, (size_t)e, L.wt1[d * kH + j], g, s1[u], c);
     }
   }
   if (t < kH) {
     T gb = (T)0;
     for (int s = 0; s < kB; ++s) gb = gb + L.h1[s * kRow + t];
-    const T nb = adam_apply<T>(b1, m_b1, v_b1, tb1, (size_t)t, L.b1[t], gb, sb1, c);
+    const T nb = adam_apply<T>(b1(), m_b1(), v_b1(), tb1(), (size_t)t, L.b1[t], gb, sb1, c);
     L.b1[t] = nb;
   }
 
