@@ -202,6 +202,15 @@ template <typename T, int NT, bool BATCH = false>
 struct input_rows {
   static constexpr int U = kB * 32 / NT;
   T r[U];
+  int row_ahead[U];
+  bool ahead = false;
+  // (the row numbers of a table-fed batch, requested before anything else of the step: what they
+  //  gate — the gather of the rows — is then one trip to memory behind the kernel's first one)
+  __device__ __forceinline__ void request_index(const int32_t* index, int t) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) row_ahead[u] = index[(t + NT * u) >> 5];
+    ahead = true;
+  }
   __device__ __forceinline__ void request(const double* table, const int32_t* index, const T* dense,
                                           const int* slot, int D, int t) {
     if (BATCH) {
@@ -229,7 +238,7 @@ struct input_rows {
     if (table) {
       int row[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) row[u] = index[(t + NT * u) >> 5];
+      for (int u = 0; u < U; ++u) row[u] = ahead ? row_ahead[u] : index[(t + NT * u) >> 5];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int d = (t + NT * u) & 31;
@@ -466,7 +475,15 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const cobel_mlp_fit_t& R = A.r;
   const int j = (int)blockIdx.x, t = (int)threadIdx.x;
-  if (R.active && !R.active[j / R.act_div]) return;
+  // The first trip to memory carries everything that depends on nothing: the two flags that decide
+  // whether this network does anything in this step, and the row numbers of its batch.  (They used
+  // to be three trips in a row — flag, flag, row numbers behind the weight requests — before the
+  // gather of the rows could start: 15.6 of a workgroup's 53.5 us, exp_mlp_trace.py dsr.)
+  input_rows<T, kFitThreads, DQN> xin;   // (DQN: batched requests — its prologue has four row sets to fetch)
+  if (!DQN && R.in_table) xin.request_index(R.in_index + (size_t)(j / R.in_div) * kB, t);
+  const bool is_active = !R.active || R.active[j / R.act_div] != 0;
+  const bool is_training = DQN || !R.train || R.train[j] != 0;
+  if (!is_active) return;
   const int D = R.n_inputs, O = DQN ? kA : R.n_outputs;
   const act_lds<T> L = carve_fit<T>(lds_raw);
   const int lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
@@ -475,7 +492,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     if (A.trace && t == 0) A.trace[(size_t)j * 16 + k] = wall_clock64();
   };
   stamp(0);
-  const bool train = DQN || !R.train || R.train[j];
+  const bool train = is_training;
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)O * kH;
   T* const w1 = (T*)R.w[0] + (size_t)j * n1;
   T* const b1 = (T*)R.b[0] + (size_t)j * kH;
@@ -528,7 +545,6 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     const T* const in_dense =
         R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * rows * D;
     for (int e = t; e < kB * kXRow; e += NT) L.q[e] = (T)0;
-    input_rows<T, NT, DQN> xin;   // (DQN: batched requests — its prologue has four row sets to fetch)
 
     if (DQN) {
       // ---- Q_target(s') [and the online network's choice among the next actions] ---------------
