@@ -699,7 +699,7 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     # C6: the work per launch grows while the agents learn (trials get shorter, so more of them
     # end — each with its 32 reactivations — inside a launch of 200 env steps): 9.8e6 reactivations
     # and 12 ms in the first launch, 4.66e7 and 28.7 ms from the ~30th on
-    # (scripts/exp_c6_trend.py).  The timed window starts in that steady state.
+    # (scripts/experiments/exp_c6_trend.py).  The timed window starts in that steady state.
     warm = max(args.warmup, cfg.get('min_warmup', 0))
     dynaq = cfg['agent'] == 'dynaq'
     per_launch = n * cfg['env_steps_per_launch']          # env steps = planning batches drawn

@@ -91,7 +91,7 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
 
 int cobel_fail(int code, const char* fmt, ...);
 int cobel_device_limits(int device, int* n_cu, size_t* lds_per_cu);   // world.hip (cached per device)
-// COBEL_DEBUG_LDS_PAD=<bytes> (occupancy experiments, scripts/exp_occ*.py): extra dynamic LDS per
+// COBEL_DEBUG_LDS_PAD=<bytes> (occupancy experiments, scripts/experiments/exp_occ*.py): extra dynamic LDS per
 // workgroup.  Honoured only if it is a plain number that keeps `base + pad` within `limit`; anything
 // else (a stray or malformed variable) is ignored, so it can change occupancy, never break a launch.
 size_t cobel_debug_lds_pad(size_t base, size_t limit);

@@ -362,7 +362,7 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
   if (R.active && !R.active[i]) return;
   const int t = (int)threadIdx.x;
   const int D = R.n_inputs;
-  auto stamp = [&](int k) {   // (scripts/exp_mlp_trace.py)
+  auto stamp = [&](int k) {   // (scripts/experiments/exp_mlp_trace.py)
     if (A.trace && t == 0) A.trace[(size_t)i * 16 + k] = wall_clock64();
   };
   stamp(0);

@@ -922,7 +922,7 @@ int shape_ok(int32_t D, int32_t O, const char* who) {
   return COBEL_OK;
 }
 
-// Experiments only (scripts/exp_mlp_trace.py): COBEL_DEBUG_MLP_TRACE = address of a device buffer of
+// Experiments only (scripts/experiments/exp_mlp_trace.py): COBEL_DEBUG_MLP_TRACE = address of a device buffer of
 // n x 16 uint64 for the per-phase stamps.  Taken only if it parses completely and names DEVICE memory
 // of the current device; anything else is ignored, so a stray variable cannot send stores anywhere.
 unsigned long long* debug_trace_buffer() {

@@ -189,7 +189,7 @@ __device__ __forceinline__ srw_kargs rare_args() {
 // 18 scratch accesses inside the step loop.  At 96 registers it has none; measured on 31 x 31 and
 // 30 x 31 worlds with three rewarded states 3.22 -> 2.88 and 3.15 -> 2.81 ms per launch (16 384
 // instances x 128 steps).  The 32-slot form and the narrower rows measured 4-7 % SLOWER at five
-// waves (scripts/exp_sr_small.py) and keep six.
+// waves (scripts/experiments/exp_sr_small.py) and keep six.
 template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) void k_sr_wave(
@@ -848,7 +848,7 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   // 1 024 fill the register layout exactly and take instantiations without bounds checks)
   // (state counts that are not multiples of four: rows move one element per lane and instruction,
   //  the ODD instantiations: 17x17 1.26e9 env-steps/s, 25x25 8.7e8, 31x31 7.2e8 against 3.0 / 2.8 /
-  //  2.5e8 of the row-streaming kernel — scripts/exp_sr_sizes.py)
+  //  2.5e8 of the row-streaming kernel — scripts/experiments/exp_sr_sizes.py)
   // at most two rewarded states (every maze / open field builder of the reference), or up to eight
   // with launch-wide hyper-parameters (the KX kernels)
   const bool rewards_ok = world->max_rewarded_states <= 2 ||

@@ -84,7 +84,7 @@ constexpr int kHashBuckets = 256;
 constexpr int kHashBucketsSmall = 128;   // with MIDX: keeps the footprint at 17 KiB (nine per CU)
 
 // LDS is handed out in blocks of 1 280 bytes, 128 per CU — not in KiB (measured on MI355X with
-// scripts/exp_occupancy.py: the launch time of k_tab_wpi steps down at 15 360 and at 14 080 bytes
+// scripts/experiments/exp_occupancy.py: the launch time of k_tab_wpi steps down at 15 360 and at 14 080 bytes
 // per workgroup and is flat in between; 17 408 B, a 32 x 32 world, are 14 blocks: nine per CU).
 inline int lds_workgroups_per_cu(size_t bytes) {
   const size_t blocks = (bytes + 1279) / 1280;
@@ -1282,7 +1282,7 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
   // (debug switches are read once per process, not per launch)
   static const bool no_exact_hash = cobel_debug_env("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
-  // (per launch: scripts/exp_occupancy.py; validated against the limit below)
+  // (per launch: scripts/experiments/exp_occupancy.py; validated against the limit below)
   static const char* const lpw_env = cobel_debug_env("COBEL_DEBUG_LPW");
   A.hash_exact = (world->n_states * 4 <= 4096 && !no_exact_hash) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);

@@ -6,7 +6,7 @@
 // instances fit on a CU (17 408 B each).  The step is a chain of dependent work, not a stream:
 // measured on trained agents, the same kernel on 24 x 24 mazes padded to 9 / 10 / 11 / 12 / 14 / 16
 // instances per CU takes 16.75 / 15.45 / 14.37 / 13.43 / 12.05 / 11.03 ms per launch
-// (scripts/exp_occ_trained.py) — every further resident wave is throughput.  LDS is full at nine;
+// (scripts/experiments/exp_occ_trained.py) — every further resident wave is throughput.  LDS is full at nine;
 // registers allow sixteen.  So here ONE workgroup of sixteen wavefronts owns a CU for the whole
 // launch: `nl` of its waves keep their instance's Q table in LDS exactly as k_tab_wpi does, the
 // other `ng` waves work on the caller's Q table where it lies, in global memory (L2 resident while
@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(u
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #if defined(COBEL_PWG_STAMPS)
-// (timing experiments, scripts/exp_pwg_stamps.py: cycles per phase of a ticket, summed per wave
+// (timing experiments, scripts/experiments/exp_pwg_stamps.py: cycles per phase of a ticket, summed per wave
 //  into the scratch area behind the counters; the previous stamp waits in a spare LDS word)
 __device__ __forceinline__ void pwg_stamp(uint32_t* stamps, uint32_t* prev, int k, int lane) {
   if (lane == 0) {
@@ -805,7 +805,7 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   if (nl > 16) nl = 16;
   int ng = (int)((total - (size_t)nl * slice_l) / kHashBytes);
   if (ng > 16 - nl) ng = 16 - nl;
-  // Measured on C3 (32 x 32, trained agents, scripts/exp_pwg.py): 9 + 0 / 3 / 4 / 5 / 6 / 7 waves take
+  // Measured on C3 (32 x 32, trained agents, scripts/experiments/exp_pwg.py): 9 + 0 / 3 / 4 / 5 / 6 / 7 waves take
   // 14.1 / 12.9 / 12.75 / 12.8 / 14.7 / 17.2 ms per launch — the Q tables of the global-memory waves
   // compete for the XCD's 4 MiB of L2 with the digests and model records of all of them.
   if (ng > kMaxGlobalWaves) ng = kMaxGlobalWaves;
@@ -830,7 +830,7 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
 
 // The slices of a launch (see k_tab_pwg).  A slice boundary costs an instance ~19 us on C3 (9.6 us
 // of ticket, prologue and write-back, the rest in steps that run slower while more tables are on
-// the move; scripts/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch:
+// the move; scripts/experiments/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch:
 // measured on one MI355X (ms per launch of 512 steps; unsliced / best): 8 192 instances 1.96 / 1.76
 // with 320 + 128 + 64 (256 + 128 + 64 + 64: 1.80, 384 + 64 + 32 + 32: 1.88), 16 384: 3.30 / 3.26 with
 // 384 + 128, 32 768: 6.40 / 6.33 with 448 + 64; 65 536 is not sliced.

@@ -1,7 +1,7 @@
 """C3: share of instances whose Q table is still all zero (no reward seen yet) after k launches of
 512 steps — what a 'nothing to plan yet' shortcut could skip."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch
 import bench

@@ -3,14 +3,14 @@ successor networks 1024-64-64-1024 and a reward network 1024-64-64-1 in float64 
 Networks of that width are outside the fused MLP kernels (inputs / outputs <= 32): the agent runs
 its PyTorch-ROCm loop — stacked parameters through batched GEMMs (the library GEMM is the right
 tool for 1024-wide layers), the fused Adam kernel, one step replayed from a HIP graph.
-    python scripts/exp_dsr_32.py [instances]"""
+    python scripts/experiments/exp_dsr_32.py [instances]"""
 import gc
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch  # noqa: E402

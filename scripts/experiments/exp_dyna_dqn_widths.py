@@ -1,9 +1,9 @@
 """Dyna-DQN step time over input widths and dtypes (the staging kernel's DI = 2 / 4 / 8
-instantiations): python scripts/exp_dyna_dqn_widths.py [n]"""
+instantiations): python scripts/experiments/exp_dyna_dqn_widths.py [n]"""
 import os
 import sys
 os.environ.setdefault('COBEL_DEBUG', '1')
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

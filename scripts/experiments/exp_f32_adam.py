@@ -1,5 +1,5 @@
 import sys
-import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'cobel-rl_amd'))
+import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'cobel-rl_amd'))
 import torch, bench
 from cobel_amd.network import TorchNetwork
 n_in=int(sys.argv[1]); n,B,gamma,tau=23,32,0.8,0.01

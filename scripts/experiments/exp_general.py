@@ -1,11 +1,11 @@
 """Throughput of the general tabular kernel (csrc/general.hip) beside the wavefront kernels:
 C3's mazes with Dyna-Q at B = 50 (both kernels) and B = 100 (general only), QAgent on a hexagonal
-Topology.  `python scripts/exp_general.py`"""
+Topology.  `python scripts/experiments/exp_general.py`"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import numpy as np  # noqa: E402

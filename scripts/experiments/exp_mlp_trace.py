@@ -1,12 +1,12 @@
 """Per-phase wall-clock stamps of k_dqn_replay / k_mlp_fit (COBEL_DEBUG_MLP_TRACE): thread 0 of
 every workgroup stamps wall_clock64() (100 MHz) at the phase boundaries of its step.
-    python scripts/exp_mlp_trace.py c5|dsr [f64|f32] [stream|lds]"""
+    python scripts/experiments/exp_mlp_trace.py c5|dsr [f64|f32] [stream|lds]"""
 import json
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

@@ -4,7 +4,7 @@ pads them back to the 17 KiB (9 per CU) of a 32x32 world — same work, differen
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch, bench
 from cobel_amd.misc.gridworld_tools import make_obstacle_maze

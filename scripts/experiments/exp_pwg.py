@@ -1,10 +1,10 @@
 """Scratch (round 3): launch time of the persistent-workgroup Dyna-Q kernel on C3 for one mix of
 LDS / global-memory waves (COBEL_DEBUG_PWG="nl,ng", read once per process) on trained agents.
-`python scripts/exp_pwg.py [pretrain launches] [nopwg]`"""
+`python scripts/experiments/exp_pwg.py [pretrain launches] [nopwg]`"""
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch  # noqa: E402

@@ -2,13 +2,13 @@
 cycles per phase — ticket draw, prologue, steps, write-back — summed per wave by the kernel into the
 scratch area, read back here and split by the two kinds of wave.
 
-    COBEL_LIB=$PWD/gpurun_ab/libcobel_stamps.so python scripts/exp_pwg_stamps.py [instances] [pretrain launches]
+    COBEL_LIB=$PWD/gpurun_ab/libcobel_stamps.so python scripts/experiments/exp_pwg_stamps.py [instances] [pretrain launches]
 """
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'cobel-rl_amd')]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -1,9 +1,9 @@
 """SR on 32x32 worlds with 1 ... 32 rewarded states — the sparse-reward wave kernel (KX form for
 three to eight, the 32-slot form for nine to 32: round 4) against the row-streaming kernel.
-`python scripts/exp_sr_rewards.py`"""
+`python scripts/experiments/exp_sr_rewards.py`"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import numpy as np  # noqa: E402

@@ -1,7 +1,7 @@
 """SR agent throughput against the world size (open fields with one rewarded goal): which kernel
-cobel_sr_run takes and what it delivers.  python scripts/exp_sr_sizes.py"""
+cobel_sr_run takes and what it delivers.  python scripts/experiments/exp_sr_sizes.py"""
 import gc, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch
 from cobel_amd.agent import SR
@@ -9,7 +9,7 @@ from cobel_amd.interface import Gridworld
 from cobel_amd.misc.gridworld_tools import make_open_field
 from cobel_amd.policy import EpsilonGreedy
 SIZES = ((5, 65536), (6, 65536), (8, 65536), (10, 65536), (16, 65536), (20, 32768), (24, 16384), (28, 16384), (32, 16384), (17, 32768), (25, 16384), (27, 16384), (29, 16384), (31, 16384))
-if len(sys.argv) > 1:      # python scripts/exp_sr_sizes.py 25 27 31 [stream]
+if len(sys.argv) > 1:      # python scripts/experiments/exp_sr_sizes.py 25 27 31 [stream]
     SIZES = tuple((int(a), 16384) for a in sys.argv[1:] if a.isdigit())
 for side, n in SIZES:
     env = Gridworld(make_open_field(side, side, 0, 1), n_envs=n, seed=1)

@@ -1,9 +1,9 @@
 """SR on small worlds (S not a multiple of 64: the ANY_S instantiations of k_sr_wave), 1 / 3 / 12
-rewarded states, deterministic and slippery: python scripts/exp_sr_small.py [n] [10x10,31x31,...]"""
+rewarded states, deterministic and slippery: python scripts/experiments/exp_sr_small.py [n] [10x10,31x31,...]"""
 import os
 import sys
 os.environ.setdefault('COBEL_DEBUG', '1')
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import numpy as np  # noqa: E402

@@ -1,12 +1,12 @@
 """C4 with the sparse-reward SR kernel: launch times for a sweep of resident wavefronts per CU
-(LDS padding limits them), against the row-streaming kernel.  `python scripts/exp_sr_wave.py`"""
+(LDS padding limits them), against the row-streaming kernel.  `python scripts/experiments/exp_sr_wave.py`"""
 import gc
 import json
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import numpy as np  # noqa: E402

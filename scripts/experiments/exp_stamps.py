@@ -1,6 +1,6 @@
 """Scratch: per-phase cycle shares of k_tab_wpi from the COBEL_STAMPS diagnostic build."""
 import sys, os, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'cobel-rl_amd'))
 import torch, numpy as np
 from cobel_amd import _lib

@@ -3,7 +3,7 @@ of `cobel_dqn_replay` (float64 / float32, DQN / DDQN targets) and random (inputs
 `cobel_mlp_forward` / `cobel_mlp_fit`, through the bodies of the GPU tests that pin them
 (tests/test_gpu_parity.py, tests/test_gpu_mlp.py).  float64 to round-off (1e-10 / 1e-9 relative);
 float32 within 1e-4 absolute: Adam divides by |g| + 1e-8, which turns the rounding of gradient
-entries near 1e-8 into ~1e-3 of a step (scripts/exp_f32_adam.py measures both paths against float64).
+entries near 1e-8 into ~1e-3 of a step (scripts/experiments/exp_f32_adam.py measures both paths against float64).
 
     python scripts/fuzz_networks.py [pairs]
 """

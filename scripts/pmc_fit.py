@@ -1,12 +1,12 @@
 """Add the Dyna-DSR training kernel's HBM traffic to profiles/rNN_pmc_traffic.json.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fit_fetch -o f --output-format csv \
-        -- python3 scripts/exp_mlp_fit.py
+        -- python3 scripts/experiments/exp_mlp_fit.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_fit_write -o w --output-format csv \
-        -- python3 scripts/exp_mlp_fit.py
+        -- python3 scripts/experiments/exp_mlp_fit.py
     python scripts/pmc_fit.py <fetch counter_collection.csv> <write counter_collection.csv> NN
 
-scripts/exp_mlp_fit.py launches cobel_mlp_fit on 32 768 float64 25-64-64-25 networks (the successor
+scripts/experiments/exp_mlp_fit.py launches cobel_mlp_fit on 32 768 float64 25-64-64-25 networks (the successor
 networks of 8 192 Dyna-DSR agents): its first six launches are the full step (the later ones leave
 parts out).  Same units as scripts/pmc_summary.py; FETCH_SIZE is reported both as counted and with
 the guide's doubling for wide coalesced reads (these are 8- and 16-byte-per-lane loads)."""
@@ -33,7 +33,7 @@ def main():
                            'hbm_bytes_per_launch': (2 * fk + wk) * 1024,
                            'hbm_bytes_per_launch_fetch_as_counted': (fk + wk) * 1024,
                            'algorithmic_bytes_per_launch': n * 8 * params * 8,
-                           'command': 'python3 scripts/exp_mlp_fit.py'}
+                           'command': 'python3 scripts/experiments/exp_mlp_fit.py'}
     json.dump(out, open(path, 'w'), indent=1)
     print(json.dumps(out['dyna_dsr_fit'], indent=1))
 

@@ -25,8 +25,8 @@ for dt in f64 f32; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_c5_write_$dt -o w --output-format csv -- python3 scripts/run_c5.py $dt 64 > $O/r${R}_pmc_c5_write_$dt.log 2>&1
 done
 echo "c5 pmc done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fit_fetch -o f --output-format csv -- python3 scripts/exp_mlp_fit.py > $O/r${R}_pmc_fit_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_fit_write -o w --output-format csv -- python3 scripts/exp_mlp_fit.py > $O/r${R}_pmc_fit_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fit_fetch -o f --output-format csv -- python3 scripts/experiments/exp_mlp_fit.py > $O/r${R}_pmc_fit_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_fit_write -o w --output-format csv -- python3 scripts/experiments/exp_mlp_fit.py > $O/r${R}_pmc_fit_write.log 2>&1
 echo "fit pmc done"
 # keep what the reductions read; the kernel traces of the counter passes are large
 find $O -name "*_agent_info.csv" -delete 2>/dev/null || true

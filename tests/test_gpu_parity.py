@@ -1625,7 +1625,7 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, 
     from cobel_amd.network import TorchNetwork
     dt = torch.float64 if dtype_name == 'f64' else torch.float32
     # (float32: Adam divides by |g| + 1e-8, so the rounding of gradient entries near 1e-8 shows
-    #  up at ~1e-3 of a step — scripts/exp_f32_adam.py; the shape sweep passes a wider f32_atol)
+    #  up at ~1e-3 of a step — scripts/experiments/exp_f32_adam.py; the shape sweep passes a wider f32_atol)
     tol = dict(rtol=1e-10, atol=1e-13) if dtype_name == 'f64' else dict(rtol=2e-4, atol=f32_atol)
     n, B, gamma, tau = 23, 32, 0.8, 0.01
     gen = torch.Generator(device='cuda').manual_seed(7)
