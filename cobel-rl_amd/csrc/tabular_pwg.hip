@@ -287,10 +287,34 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   };
   // ---- one batch, Q in LDS (called under lane < B) -------------------------------------------
   auto run_batch_lds = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
-    int first = 0;
+    // The first round, every lane of the batch, written out on its own: 91 % of the batches end
+    // here on trained agents (0 / 1 / 2 / 3 / 4 writers in 7 / 17 / 23 / 21 / 15 % of them,
+    // scripts/experiments/exp_pwg_hist.py), and as the first trip of one loop over the rounds it
+    // carried that loop's `act` masks and round state: 12.27 -> 12.06 ms per C3 launch.
+    // (With so few writers, finding the held-back lanes writer by writer — the writer's pair index
+    //  broadcast, two comparisons per lane, no hash tables — looked cheaper than the tables' ~35
+    //  vector and 9 LDS instructions.  Built as a loop over the writers and as four writers at
+    //  once: 13.3 and 13.1 ms.  Each writer is a scalar -> vector -> scalar hand-off, and the
+    //  compiler lowers a ballot of an OR of two comparisons to a select and a compare.)
+    int first = B;
     bool have_conf = false;
     unsigned long long conf = 0ull;
-    do {
+    {
+      const float4 row = Qs[ns];
+      const float q = Qf[idx];
+      const float qn = plan_td(q, max4(row), r, nt);
+      const bool ch = fbits(qn) != fbits(q);
+      const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
+      if (!changed) return;
+      conf = conflict_sets(idx, ns);
+      have_conf = true;
+      const unsigned long long blocked = __builtin_amdgcn_ballot_w64((conf & changed) != 0ull);
+      if (blocked) first = __ffsll((long long)blocked) - 1;
+      if (ch && lane < first) Qf[idx] = qn;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // Later rounds (a lane was held back): the lanes from `first` on, conflict sets from the tables.
+    while (first < B) {
       const bool act = lane >= first;
       float q = 0.0f, qn = 0.0f;
       if (act) {
@@ -312,14 +336,49 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
         __builtin_amdgcn_wave_barrier();
       }
       first = stop;
-    } while (first < B);
+    }
   };
   // ---- one batch, Q in global memory: inputs (row, q) already in registers -------------------
   auto run_batch_glb = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r, float4 row, float q) {
-    int first = 0;
+    int first = B;
     bool have_conf = false;
     unsigned long long conf = 0ull;
-    do {
+    // the lanes that go again take what the committed writers wrote, in lane order (a later writer
+    // of the same cell wins, as in the table): `pend` = the committed writers of a lane's conflict set
+    auto take_writes = [&](unsigned long long pend, float qn) {
+      while (__ballot(pend != 0ull)) {
+        const int e = pend ? (__ffsll((long long)pend) - 1) : 0;
+        const uint32_t ie = (uint32_t)__shfl((int)idx, e);
+        const float ve = __shfl(qn, e);
+        if (pend) {
+          if (ie == idx) q = ve;
+          if ((ie >> 2) == ns) {
+            const uint32_t c = ie & 3u;
+            row.x = c == 0u ? ve : row.x;
+            row.y = c == 1u ? ve : row.y;
+            row.z = c == 2u ? ve : row.z;
+            row.w = c == 3u ? ve : row.w;
+          }
+          pend &= pend - 1ull;
+        }
+      }
+    };
+    {
+      const float qn = plan_td(q, max4(row), r, nt);
+      const bool ch = fbits(qn) != fbits(q);
+      const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
+      if (!changed) return;
+      conf = conflict_sets(idx, ns);
+      have_conf = true;
+      const unsigned long long blocked = __builtin_amdgcn_ballot_w64((conf & changed) != 0ull);
+      if (blocked) first = __ffsll((long long)blocked) - 1;
+      if (ch && lane < first) Qgf[idx] = qn;
+      if (first < B) {
+        const unsigned long long committed = changed & ((1ull << first) - 1ull);
+        take_writes(lane >= first ? (conf & committed) : 0ull, qn);
+      }
+    }
+    while (first < B) {
       const bool act = lane >= first;
       float qn = q;
       if (act) qn = plan_td(q, max4(row), r, nt);
@@ -335,30 +394,12 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
         if (blocked) stop = __ffsll((long long)blocked) - 1;
         if (ch && lane < stop) Qgf[idx] = qn;
         if (stop < B) {
-          // the lanes that go again take what the committed lanes of their conflict sets wrote,
-          // in lane order (a later writer of the same cell wins, as in the table)
           const unsigned long long committed = changed & ((1ull << stop) - 1ull);
-          unsigned long long pend = lane >= stop ? (conf & committed) : 0ull;
-          while (__ballot(pend != 0ull)) {
-            const int e = pend ? (__ffsll((long long)pend) - 1) : 0;
-            const uint32_t ie = (uint32_t)__shfl((int)idx, e);
-            const float ve = __shfl(qn, e);
-            if (pend) {
-              if (ie == idx) q = ve;
-              if ((ie >> 2) == ns) {
-                const uint32_t c = ie & 3u;
-                row.x = c == 0u ? ve : row.x;
-                row.y = c == 1u ? ve : row.y;
-                row.z = c == 2u ? ve : row.z;
-                row.w = c == 3u ? ve : row.w;
-              }
-              pend &= pend - 1ull;
-            }
-          }
+          take_writes(lane >= stop ? (conf & committed) : 0ull, qn);
         }
       }
       first = stop;
-    } while (first < B);
+    }
   };
 
   // ---- prologue -------------------------------------------------------------------------------
