@@ -699,7 +699,7 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   if (r.n == 0) return COBEL_OK;
   // Worlds with at most eight rewarded states and up to 1 024 states (every builder of the reference):
   // the value rows collapse to a few elements each, see sr_wave.hip.
-  if (!world->succ_off && ((uintptr_t)r.rewards & 15u) == 0 && cobel_sr_wave_covers(world, r))
+  if (((uintptr_t)r.rewards & 15u) == 0 && cobel_sr_wave_covers(world, r))
     return cobel_sr_wave_launch(world, r, (hipStream_t)stream);
   sr_args A;
   A.rec = world->rec;

@@ -43,6 +43,10 @@ struct srw_args {
   uint32_t leaf[16];         // lo | len << 16
   uint8_t comb_dst[16], comb_src[16];
   int32_t n_leaves;
+  // transition rows that are distributions (cobel_world_set_transitions), STOCH kernels only
+  const uint32_t* succ_off;
+  const uint16_t* succ_state;
+  const double* succ_cdf;
 };
 
 __device__ __forceinline__ int t_of(uint64_t row, int k) { return (int)((row >> (16 * k)) & 0xffffu); }
@@ -190,7 +194,10 @@ __device__ __forceinline__ srw_kargs rare_args() {
 // 30 x 31 worlds with three rewarded states 3.22 -> 2.88 and 3.15 -> 2.81 ms per launch (16 384
 // instances x 128 steps).  The 32-slot form and the narrower rows measured 4-7 % SLOWER at five
 // waves (scripts/experiments/exp_sr_small.py) and keep six.
-template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
+// STOCH: the world's transition rows are distributions — the successor is drawn in the step
+// (one float64 of the env stream per step, as interface/gridworld.py:119-123 draws it) and its
+// world record fetched behind the draw; nothing else of the step knows the difference.
+template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD, bool STOCH = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) void k_sr_wave(
     const srw_args A) {
@@ -536,7 +543,7 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
     const uint4 c = W4[s];
     cw0 = rfl(c.x);
     cw1 = rfl(c.y);
-    if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+    if (!STOCH && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
     mask_cur = amask ? (uint32_t)amask[s] & 15u : 15u;
     tcur = load_trow(s);
     left_state = -1;
@@ -603,10 +610,26 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
       a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(q0, q1, q2, q3, mask_cur,
                                                            cobel_u01(w0, w1), ebb, lane));
     }
-    const int ns = (int)next_of(cw0, cw1, a);
-    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
-    const float r = __builtin_bit_cast(float, rl(cand.z, a));
-    const uint32_t end = rl(cand.w, a);
+    int ns;
+    uint32_t nw0, nw1, end;
+    float r;
+    if (STOCH) {
+      const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      ns = (int)rfl((uint32_t)cobel_draw_successor(
+          A.succ_off, A.succ_state, A.succ_cdf, ((size_t)world * S + (size_t)state) * 4 + a, ue));
+      const uint4 c = W4[ns];
+      nw0 = rfl(c.x);
+      nw1 = rfl(c.y);
+      r = __builtin_bit_cast(float, rfl(c.z));
+      end = rfl(c.w);
+    } else {
+      ns = (int)next_of(cw0, cw1, a);
+      nw0 = rl(cand.x, a);
+      nw1 = rl(cand.y, a);
+      r = __builtin_bit_cast(float, rl(cand.z, a));
+      end = rl(cand.w, a);
+    }
     const uint32_t nt = 1u - end;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
     // T[ns][.] as it stands before this step's write
@@ -758,7 +781,7 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
     cw0 = nw0;
     cw1 = nw1;
     if (!trial_over) {
-      if (lane < 4) cand = W4[next_of(cw0, cw1, lane)];
+      if (!STOCH && lane < 4) cand = W4[next_of(cw0, cw1, lane)];
       mask_cur = amask ? (uint32_t)amask[state] & 15u : 15u;
       step += 1;
       if (dense) dense_values(tq);
@@ -810,23 +833,28 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
 }
 
 #undef rr
-template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD>
+template <int NV, bool OCC, bool PSETS, bool ANY_S, int KX, bool ODD, bool STOCH = false>
 int launch(const srw_args& A, hipStream_t st) {
   size_t lds = OCC ? (size_t)A.S * 4 : 0;
   if (const size_t pad = cobel_debug_lds_pad(lds + 8 * 1024, 160 * 1024)) {   // (occupancy experiments)
     lds += pad;
     if (lds > 48 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD>),
+          reinterpret_cast<const void*>(&k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD, STOCH>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD>), dim3(A.r.n), dim3(64), lds, st, A);
+  hipLaunchKernelGGL((k_sr_wave<NV, OCC, PSETS, ANY_S, KX, ODD, STOCH>), dim3(A.r.n), dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
 template <int NV, bool ANY_S, bool ODD = false>
 int launch_nv(const srw_args& A, bool occ, bool psets, int kx, hipStream_t st) {
+  if (A.succ_off) {   // (drawn successors: without occupancy counters and parameter sets — covers())
+    if (kx == 32) return launch<NV, false, false, ANY_S, 32, ODD, true>(A, st);
+    if (kx) return launch<NV, false, false, ANY_S, 8, ODD, true>(A, st);
+    return launch<NV, false, false, ANY_S, 0, ODD, true>(A, st);
+  }
   if (kx == 32)   // (nine to 32 rewarded states; launch-wide hyper-parameters only)
     return occ ? launch<NV, true, false, ANY_S, 32, ODD>(A, st)
                : launch<NV, false, false, ANY_S, 32, ODD>(A, st);
@@ -853,7 +881,9 @@ bool cobel_sr_wave_covers(const cobel_world* world, const cobel_sr_run_t& r) {
   // with launch-wide hyper-parameters (the KX kernels)
   const bool rewards_ok = world->max_rewarded_states <= 2 ||
                           (world->max_rewarded_states <= 32 && world->rw && !r.param_index);
-  return S >= 2 && S <= 1024 && rewards_ok &&
+  // worlds whose transition rows are distributions: the plain instantiations only
+  const bool draws_ok = !world->succ_off || (!r.occupancy && !r.param_index);
+  return S >= 2 && S <= 1024 && rewards_ok && draws_ok &&
          !(r.flags & COBEL_F_SR_STREAM_ROWS);
 }
 
@@ -870,6 +900,9 @@ int cobel_sr_wave_launch(const cobel_world* world, const cobel_sr_run_t& r, hipS
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.rw = world->rw;
+  A.succ_off = world->succ_off;
+  A.succ_state = world->succ_state;
+  A.succ_cdf = world->succ_cdf;
   A.n_leaves = 0;
   for (int t = 0; t < 16; ++t) A.leaf[t] = 0u, A.comb_dst[t] = A.comb_src[t] = 0;
   leaf_plan plan{&A};
