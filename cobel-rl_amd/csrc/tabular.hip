@@ -42,6 +42,11 @@ struct tab_args {
   int32_t hash_buckets;
   int32_t hash_exact;  // S * 4 <= 4096: the two-table exact dependency lookup applies
   int32_t lpw;         // lane-per-instance kernel: instances per wave (64, 32 or 16)
+  // transition rows that are distributions (cobel_world_set_transitions): the generic
+  // (!FAST) instantiations of k_tab_wpi draw the successor in the step, else NULL
+  const uint32_t* succ_off;
+  const uint16_t* succ_state;
+  const double* succ_cdf;
 };
 
 __device__ __forceinline__ size_t mon_stripe_offset(const cobel_tab_run_t& r) {
@@ -610,15 +615,36 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     }
     STAMP(0);
     // ---- env.step (interface/gridworld.py:115-126) ----------------------------------------------
-    const int ns = (int)next_of(cw0, cw1, a);
-    const uint32_t nw0 = rl(cand.x, a), nw1 = rl(cand.y, a);
-    const uint32_t r_bits = rl(cand.z, a);
+    int ns;
+    uint32_t nw0, nw1, r_bits, end;
+    float ns_max;
+    if (!FAST && A.succ_off) {
+      // interface/gridworld.py:119-123: the successor is drawn from the row of sas — one double
+      // of the env stream per step (sub-stream 1 of the counter the trial starts share, as
+      // cobel_env_step_draw and k_tab_general draw it); any state may be entered, so its world
+      // record and Q row are fetched behind the draw instead of taken from the prefetched four
+      const double ue = cobel_draw_u01(ce, COBEL_SUB_DOUBLE, g, COBEL_STREAM_ENV, seed);
+      ce += 1u;
+      ns = (int)rfl((uint32_t)cobel_draw_successor(
+          A.succ_off, A.succ_state, A.succ_cdf, ((size_t)world * S + (size_t)state) * 4 + a, ue));
+      const uint4 c = WLDS ? L.Wl[ns] : W4[ns];
+      nw0 = rfl(c.x);
+      nw1 = rfl(c.y);
+      r_bits = rfl(c.z);
+      end = rfl(c.w);
+      ns_max = __builtin_bit_cast(float, rfl(__builtin_bit_cast(uint32_t, max4(Qs[ns]))));
+    } else {
+      ns = (int)next_of(cw0, cw1, a);
+      nw0 = rl(cand.x, a);
+      nw1 = rl(cand.y, a);
+      r_bits = rl(cand.z, a);
+      end = rl(cand.w, a);
+      ns_max = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, smax), a));
+    }
     const float r = __builtin_bit_cast(float, r_bits);
     // COBEL_IF_NONZERO: while Q and the model's reward estimates are all +0.0f the only thing
     // that can change that is a reward other than +0.0f (TD = r + gamma 0 - 0)
     if (AGENT == COBEL_AGENT_DYNAQ && learn && r_bits != 0u) iflags |= 2u;
-    const uint32_t end = rl(cand.w, a);
-    const float ns_max = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, smax), a));
     const uint32_t nt = 1u - end;
     const uint32_t sa = (uint32_t)state * 4u + (uint32_t)a;
     const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
@@ -1225,7 +1251,16 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   // (Dyna-Q plans batches above COBEL_MAX_BATCH in several passes of the generic wavefront
   //  kernel; QAgent's log replay gathers its records a step ahead, one lane each: general kernel)
   const int32_t pass = r.batch > COBEL_MAX_BATCH ? COBEL_MAX_BATCH : r.batch;
-  const bool general = world->n_actions != 4 || world->succ_off != nullptr ||
+  // (worlds whose transition rows are distributions: the generic wavefront kernels draw the
+  //  successor in the step — no fast / digest / lane-per-instance / persistent form for them)
+  const bool draws = world->succ_off != nullptr;
+  const bool replays = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
+                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
+  // (without replayed updates a lane per instance is the better shape — what k_tab_lpi is for
+  //  one-hot rows; measured on slippery 10 x 10 / 32 x 32 worlds, 65 536 instances x 512 steps:
+  //  Q-learning 6.0 / 6.3 ms on k_tab_general against 11.4 / 20.8 on the wavefront kernel, Dyna-Q
+  //  B 32 44 / 72 ms against 14.6 / 34.9: scripts/experiments/exp_tab_slippery.py)
+  const bool general = world->n_actions != 4 || (draws && !replays) ||
                        (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ) ||
                        (r.flags & COBEL_F_TAB_GENERAL) ||
                        cobel_tab_query(world->n_states, r.agent, pass, &lds_max, nullptr) != COBEL_OK;
@@ -1270,12 +1305,15 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   A.alpha_f = (float)r.alpha;
   A.gamma_f = (float)r.gamma;
   A.model_lr_f = (float)r.model_lr;
+  A.succ_off = world->succ_off;
+  A.succ_state = world->succ_state;
+  A.succ_cdf = world->succ_cdf;
   const bool occ = r.occupancy != nullptr;
   const bool wlds = world->n_states <= kWorldLdsStates;
   const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
   A.use_hash = replay ? 1 : 0;
-  const bool fast = r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
+  const bool fast = !draws && r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
                     r.batch <= COBEL_MAX_BATCH &&
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
@@ -1307,7 +1345,7 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   const size_t lds_lpi = (size_t)world->n_states * lpw * 16 + kThrBytes +
                          (size_t)world->n_states * 16 + (((size_t)world->n_states * 2 + 15) & ~(size_t)15);
   // (per-instance parameter sets: the lane-per-instance kernel keeps ONE threshold table per wave)
-  if (!replay && !occ && !r.param_index && (!learn || r.agent == COBEL_AGENT_Q) &&
+  if (!draws && !replay && !occ && !r.param_index && (!learn || r.agent == COBEL_AGENT_Q) &&
       lds_lpi + kMonBytes <= (size_t)kLdsLimit &&
       r.n >= 64 && !(r.flags & COBEL_F_FORCE_WAVE)) {
     const bool one = world->n_worlds == 1;

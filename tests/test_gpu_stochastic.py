@@ -105,7 +105,9 @@ def test_stochastic_world_runs_match_reference(Z, name):
         assert np.array_equal(np.array(tds, dtype=np.float64), g('td'))
     check_tables(ag, 0)
     assert int(env.env_ctr[0].item()) == int(g('env_draws'))
-    # vectorised: instance `inst` of one launch; the dispatcher names the general kernel
+    # vectorised: instance `inst` of one launch; the dispatcher names the generic wavefront kernel
+    # (no replayed updates, or QAgent's log replay beyond the wavefront kernels' batch limit: the
+    #  lane-per-instance general kernel)
     env = Gridworld(world, n_envs=inst + 70, seed=SEED)
     ag = cls(env.observation_space, env.action_space, EpsilonGreedy(0.1))
     ag.track_instances = True
@@ -115,7 +117,8 @@ def test_stochastic_world_runs_match_reference(Z, name):
     check_tables(ag, inst)
     assert int(env.env_ctr[inst].item()) == int(g('env_draws'))
     what = ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)
-    assert what['kernel'] == _lib.TAB_KERNEL_GENERAL
+    assert what['kernel'] == (_lib.TAB_KERNEL_GENERAL if (B == 0 or (not dyna and B > _lib.MAX_BATCH))
+                              else _lib.TAB_KERNEL_WPI)
 
 
 @pytest.mark.parametrize('name', ['slip4_sr', 'slip56_sr'])
