@@ -234,59 +234,76 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     const float r = __builtin_bit_cast(float, lo);
     const uint32_t p = s * 8u + a;
     const bool on = lane < B;
-    int first = 0;
-    bool have_conf = false;
+    int first = B;
     unsigned long long conf = 0ull;
-    do {
+    auto td_of = [&](float q) -> float {
+      const float m = max8(Qs[ns * 2u], Qs[ns * 2u + 1u]);
+      const float gnt = nt ? gamma_f : 0.0f;
+      float td = r + gnt * m;
+      td = td - q;
+      return q + alpha_f * td;
+    };
+    // (the first round on its own, in front of the loop over the rounds — most batches end with
+    //  it —, as in k_tab_pwg)
+    {
+      float q = 0.0f, qn = 0.0f;
+      if (on) {
+        q = Qf[p];
+        qn = td_of(q);
+      }
+      const bool ch = on && fbits(qn) != fbits(q);
+      const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
+      if (!changed) return;
+      {
+        // exact conflict sets: all EARLIER lanes that write a cell this lane reads — its own
+        // cell (both buckets of p) or a cell of row ns (the eight H1 buckets of ns % 8, the H2
+        // bucket of ns / 8)
+        const uint32_t h1 = p & 63u, h2 = p >> 6;
+        const unsigned long long bit = 1ull << lane;
+        if (on) {
+          atomicOr(&H1[h1], bit);
+          atomicOr(&H2[h2], bit);
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long cnd = 0ull;
+        if (on) {
+          const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 7u) * 8u]);
+          const ulonglong2 ra = r8[0], rb = r8[1], rc = r8[2], rd = r8[3];
+          const unsigned long long cell = H1[h1] & H2[h2];
+          const unsigned long long row =
+              (((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y))) & H2[ns >> 3];
+          cnd = (cell | row) & (bit - 1ull);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on) {
+          H1[h1] = 0ull;
+          H2[h2] = 0ull;
+        }
+        conf = cnd;
+      }
+      const unsigned long long blocked = __builtin_amdgcn_ballot_w64(on && (conf & changed) != 0ull);
+      if (blocked) first = __ffsll((long long)blocked) - 1;
+      if (ch && lane < first) Qf[p] = qn;
+      __builtin_amdgcn_wave_barrier();
+    }
+    while (first < B) {
       const bool act = on && lane >= first;
       float q = 0.0f, qn = 0.0f;
       if (act) {
-        const float m = max8(Qs[ns * 2u], Qs[ns * 2u + 1u]);
         q = Qf[p];
-        const float gnt = nt ? gamma_f : 0.0f;
-        float td = r + gnt * m;
-        td = td - q;
-        qn = q + alpha_f * td;
+        qn = td_of(q);
       }
       const bool ch = act && fbits(qn) != fbits(q);
       const unsigned long long changed = __ballot(ch);
       int stop = B;
       if (changed) {
-        if (!have_conf) {
-          // exact conflict sets: all EARLIER lanes that write a cell this lane reads — its own
-          // cell (both buckets of p) or a cell of row ns (the eight H1 buckets of ns % 8, the H2
-          // bucket of ns / 8)
-          const uint32_t h1 = p & 63u, h2 = p >> 6;
-          const unsigned long long bit = 1ull << lane;
-          if (on) {
-            atomicOr(&H1[h1], bit);
-            atomicOr(&H2[h2], bit);
-          }
-          __builtin_amdgcn_wave_barrier();
-          unsigned long long cnd = 0ull;
-          if (on) {
-            const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 7u) * 8u]);
-            const ulonglong2 ra = r8[0], rb = r8[1], rc = r8[2], rd = r8[3];
-            const unsigned long long cell = H1[h1] & H2[h2];
-            const unsigned long long row =
-                (((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y))) & H2[ns >> 3];
-            cnd = (cell | row) & (bit - 1ull);
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (on) {
-            H1[h1] = 0ull;
-            H2[h2] = 0ull;
-          }
-          conf = cnd;
-          have_conf = true;
-        }
         const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
         if (blocked) stop = __ffsll((long long)blocked) - 1;
         if (ch && lane < stop) Qf[p] = qn;
         __builtin_amdgcn_wave_barrier();
       }
       first = stop;
-    } while (first < B);
+    }
   };
 
   // what depends only on the state being entered: lane k < 8 evaluates successor k
