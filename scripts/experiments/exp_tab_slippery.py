@@ -1,5 +1,5 @@
 """Q-learning / Dyna-Q on deterministic and slippery gridworlds (the generic wavefront kernel draws
-the successor in the step): python scripts/experiments/exp_tab_slippery.py [n]"""
+the successor in the step): python scripts/experiments/exp_tab_slippery.py [n] [10x10,16x16,...]"""
 import os
 import sys
 os.environ.setdefault('COBEL_DEBUG', '1')
@@ -30,7 +30,8 @@ def slippery(world, p_slip=0.2):
 
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for (h, w) in ((10, 10), (32, 32)):
+sizes = [tuple(int(x) for x in a.split('x')) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else [(10, 10), (32, 32)]
+for (h, w) in sizes:
     for kind, batch in (('dynaq', 32), ('q', 0)):
         for slip in (False, True):
             world = make_gridworld(h, w, terminals=[0], goals=[0], rewards=np.array([[0, 1.0]]))
