@@ -119,11 +119,15 @@ COBEL_API int cobel_world_info(const cobel_world_t* world, int32_t* n_states, in
  * pair p = (world * S + s) * n_actions + a the possible successors succ_state[succ_off[p] ..
  * succ_off[p + 1]) in ascending state order and the normalised cumulative sum of their
  * probabilities (cumsum(p) / cumsum(p)[-1], as Generator.choice forms it; the last entry of a row
- * is 1).  Afterwards cobel_env_step_draw steps the world, and cobel_tab_run serves it through its
- * general kernel: every step draws one double of COBEL_STREAM_ENV (sub-stream 1) at the instance's
- * env counter, which trial starts share (they draw integers, sub-stream 0).  cobel_env_step,
- * cobel_sr_run, cobel_sfma_run and cobel_dqn_act refuse such a world (COBEL_E_UNSUPPORTED); the
- * table given to cobel_world_create (most likely successors) stays in place for them to see. */
+ * is 1).  Afterwards cobel_env_step_draw steps the world and cobel_tab_run, cobel_sr_run and
+ * cobel_sfma_run draw the successor inside their kernels (cobel_tab_run: the generic wavefront
+ * kernel for runs with replayed updates, the general kernel otherwise; cobel_sr_run: the wavefront
+ * kernel for plain runs, the row-streaming one with occupancy counters; per-instance parameter
+ * sets together with drawn successors are refused there): every step draws one double of
+ * COBEL_STREAM_ENV (sub-stream 1) at the instance's env counter, which trial starts share (they
+ * draw integers, sub-stream 0).  cobel_env_step and cobel_dqn_act refuse such a world
+ * (COBEL_E_UNSUPPORTED); the table given to cobel_world_create (most likely successors) stays in
+ * place for them to see. */
 COBEL_API int cobel_world_set_transitions(cobel_world_t* world,
                        const uint32_t* succ_off /* [host] [n_worlds * S * n_actions + 1] */,
                        const uint16_t* succ_state /* [host] [nnz] */,
