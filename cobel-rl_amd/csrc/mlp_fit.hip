@@ -1042,6 +1042,7 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
     if (int rc = raise_lds(&k_mlp_fit<double>, lds)) return rc;
     hipLaunchKernelGGL(k_mlp_fit<double>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   } else {
+    if (int rc = raise_lds(&k_mlp_fit<float>, lds)) return rc;   // (only a padded launch exceeds 64 KiB)
     hipLaunchKernelGGL(k_mlp_fit<float>, dim3(r.n), dim3(kFitThreads), lds, st, A);
   }
   COBEL_HIP_TRY(hipGetLastError());
@@ -1060,7 +1061,11 @@ static bool dqn_staged(int32_t n_inputs, int32_t is_float64) {
     if (!strcmp(v, "lds")) return true;
     if (!strcmp(v, "stream")) return false;
   }
-  return 2 * cobel_dqn_replay_lds_bytes(n_inputs, is_float64) <= 160 * 1024;
+  // (two workgroups of the staging kernel per CU: the LDS of the device the call runs on)
+  int dev = 0, n_cu = 0;
+  size_t lds_per_cu = 160 * 1024;
+  if (hipGetDevice(&dev) == hipSuccess) (void)cobel_device_limits(dev, &n_cu, &lds_per_cu);
+  return 2 * cobel_dqn_replay_lds_bytes(n_inputs, is_float64) <= lds_per_cu;
 }
 
 extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32_t n_hidden2,
