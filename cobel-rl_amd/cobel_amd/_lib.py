@@ -25,7 +25,7 @@ TAB_KERNEL_LPI, TAB_KERNEL_WPI, TAB_KERNEL_WPI_FAST, TAB_KERNEL_WPI_INDEX, TAB_K
 TAB_KERNEL_PWG = 5
 TAB_KERNEL_WQN = 6
 MAX_BATCH = 62       # largest batch of the wavefront kernels; larger ones run on the general kernel
-MAX_ACTIONS = 8
+MAX_ACTIONS = 32     # (action masks — one byte per state — exist up to eight)
 (I_STATE, I_STEP, I_TRIAL, I_CTR_ENV, I_CTR_POLICY, I_CTR_MEMORY, I_LOG_LEN, I_FLAGS,
  I_REWARD_LO, I_REWARD_HI, I_STEPS_LO, I_STEPS_HI, I_WORDS) = range(13)
 

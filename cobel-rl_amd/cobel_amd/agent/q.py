@@ -64,7 +64,12 @@ class QAgent(TabularAgent):
         raw = self._log[0, :n].cpu().numpy()
         lo = (raw & 0xFFFFFFFF).astype('uint32').view('float32')
         hi = (raw >> 32) & 0xFFFFFFFF
-        # (more than four actions: three action bits, the flag moves up — cobel_hip.h)
+        # (more than four actions: three action bits, the flag moves up; more than eight: five
+        #  action bits and 13-bit states — cobel_hip.h)
+        if self.n_actions > 8:
+            return [{'state': (int(h & 0x1FFF),), 'action': int((h >> 26) & 31), 'reward': float(r),
+                     'next_state': (int((h >> 13) & 0x1FFF),), 'terminal': int((h >> 31) & 1)}
+                    for r, h in zip(lo, hi)]
         a_mask, t_shift = (3, 30) if self.n_actions <= 4 else (7, 31)
         return [{'state': (int(h & 0x3FFF),), 'action': int((h >> 28) & a_mask), 'reward': float(r),
                  'next_state': (int((h >> 14) & 0x3FFF),), 'terminal': int((h >> t_shift) & 1)}

@@ -46,6 +46,8 @@ class EpsilonGreedy(Policy):
         single = vals.dim() == 1
         A = int(vals.shape[-1])
         assert 1 <= A <= _lib.MAX_ACTIONS, 'up to %d actions' % _lib.MAX_ACTIONS
+        if mask is not None and A > 8:
+            raise NotImplementedError('action masks are one byte per row: up to eight actions')
         vals = vals.reshape(-1, A).to(device=device, dtype=torch.float32).contiguous()
         n = vals.shape[0]
         bits = _mask_bits(mask, n, device, A)

@@ -40,35 +40,38 @@ struct gen_args {
 };
 
 // QAgent replay record: lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30 for
-// up to four actions (the layout of the fast kernels), nonterminal << 31 beyond.
+// up to four actions (the layout of the fast kernels), nonterminal << 31 up to eight, and beyond
+// eight actions (up to 32; worlds of at most 8 192 states) s | ns << 13 | action << 26 |
+// nonterminal << 31.
 __device__ __forceinline__ uint64_t log_pack_n(float r, uint32_t s, uint32_t a, uint32_t ns,
                                                uint32_t nt, int A) {
-  const uint32_t hi = s | (ns << 14) | (a << 28) | (nt << (A <= 4 ? 30 : 31));
+  const uint32_t hi = A <= 8 ? (s | (ns << 14) | (a << 28) | (nt << (A <= 4 ? 30 : 31)))
+                             : (s | (ns << 13) | (a << 26) | (nt << 31));
   return (uint64_t)__builtin_bit_cast(uint32_t, r) | ((uint64_t)hi << 32);
 }
 
 }  // namespace
 
-// policy/greedy.py:77-86 + Generator.choice for n <= 8 values: float64 probabilities, sequential
+// policy/greedy.py:77-86 + Generator.choice for n <= AMAX values: float64 probabilities, sequential
 // cumulative sum, normalisation by the last entry, searchsorted(side='right').
-template <typename V>
+template <typename V, int AMAX = 8>
 __device__ __forceinline__ int cobel_eps_greedy_select_n(const V* v, int A, uint32_t mask,
                                                          double u, double eps, double* probs) {
-  const uint32_t allowed = mask & ((1u << A) - 1u);
+  const uint32_t allowed = mask & (A >= 32 ? 0xffffffffu : ((1u << A) - 1u));
   const int n = __popc(allowed);
   V m = -(V)__builtin_huge_valf();
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < AMAX; ++a)
     if (a < A && ((allowed >> a) & 1u) && v[a] > m) m = v[a];
   int nt = 0;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) nt += (a < A && ((allowed >> a) & 1u) && v[a] == m) ? 1 : 0;
+  for (int a = 0; a < AMAX; ++a) nt += (a < A && ((allowed >> a) & 1u) && v[a] == m) ? 1 : 0;
   const double base = eps / (double)n;
   const double bonus = ((1.0 - eps) * 1.0) / (double)nt;
-  double cum[8];
+  double cum[AMAX];
   double run = 0.0;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < AMAX; ++a) {
     double p = 0.0;
     if (a < A && ((allowed >> a) & 1u)) p = base + ((v[a] == m) ? bonus : 0.0);
     if (probs && a < A) probs[a] = p;
@@ -77,16 +80,16 @@ __device__ __forceinline__ int cobel_eps_greedy_select_n(const V* v, int A, uint
   }
   double total = cum[0];
 #pragma unroll
-  for (int a = 1; a < 8; ++a) total = (a == A - 1) ? cum[a] : total;
+  for (int a = 1; a < AMAX; ++a) total = (a == A - 1) ? cum[a] : total;
   int pick = 0;
 #pragma unroll
-  for (int a = 0; a < 7; ++a) pick += (a < A - 1 && cum[a] / total <= u) ? 1 : 0;
+  for (int a = 0; a < AMAX - 1; ++a) pick += (a < A - 1 && cum[a] / total <= u) ? 1 : 0;
   return pick;
 }
 
 namespace {
 
-template <typename V>
+template <typename V, int AMAX>
 __global__ __launch_bounds__(256) void k_eps_greedy_n(const V* __restrict__ values,
                                                       const uint8_t* __restrict__ mask,
                                                       const double* __restrict__ u, double eps,
@@ -95,11 +98,12 @@ __global__ __launch_bounds__(256) void k_eps_greedy_n(const V* __restrict__ valu
                                                       int A) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  V v[8];
+  V v[AMAX];
 #pragma unroll
-  for (int a = 0; a < 8; ++a) v[a] = a < A ? values[(size_t)i * A + a] : (V)0;
-  double p[8];
-  const int act = cobel_eps_greedy_select_n<V>(v, A, mask ? mask[i] : 0xffu, u[i], eps, p);
+  for (int a = 0; a < AMAX; ++a) v[a] = a < A ? values[(size_t)i * A + a] : (V)0;
+  double p[AMAX];
+  const int act = cobel_eps_greedy_select_n<V, AMAX>(v, A, mask ? (uint32_t)mask[i] : 0xffffffffu,
+                                                     u[i], eps, p);
   action_out[i] = (uint8_t)act;
   if (probs_out)
     for (int a = 0; a < A; ++a) probs_out[(size_t)i * A + a] = p[a];
@@ -115,10 +119,21 @@ int eps_greedy_n(const V* values, const uint8_t* mask, const double* u, double e
   COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "%s: n = %d", who, n);
   COBEL_REQUIRE(n_actions >= 1 && n_actions <= COBEL_MAX_ACTIONS, COBEL_E_UNSUPPORTED,
                 "%s: %d actions (1..%d are served)", who, n_actions, COBEL_MAX_ACTIONS);
+  COBEL_REQUIRE(!mask || n_actions <= 8, COBEL_E_UNSUPPORTED,
+                "%s: action masks are one byte per row (up to eight actions), got %d actions", who,
+                n_actions);
   if (n == 0) return COBEL_OK;
-  hipLaunchKernelGGL((k_eps_greedy_n<V>), dim3((n + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, values, mask, u, epsilon, action_out, probs_out, n,
-                     n_actions);
+  const dim3 grid((n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_actions <= 8)
+    hipLaunchKernelGGL((k_eps_greedy_n<V, 8>), grid, dim3(256), 0, st, values, mask, u, epsilon,
+                       action_out, probs_out, n, n_actions);
+  else if (n_actions <= 16)
+    hipLaunchKernelGGL((k_eps_greedy_n<V, 16>), grid, dim3(256), 0, st, values, mask, u, epsilon,
+                       action_out, probs_out, n, n_actions);
+  else
+    hipLaunchKernelGGL((k_eps_greedy_n<V, 32>), grid, dim3(256), 0, st, values, mask, u, epsilon,
+                       action_out, probs_out, n, n_actions);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -270,7 +285,9 @@ int cobel_env_step_general(const cobel_world* world, int32_t* state, const uint8
 namespace {
 
 // One lane per instance; nothing is shared between lanes, so lanes return as they finish.
-template <int AGENT>
+// AMAX: the action counts an instantiation serves (8 / 16 / 32): rows of Q travel through AMAX
+// registers per lane.
+template <int AGENT, int AMAX>
 __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);   // (blocks of 8 .. 64 lanes, see the launch)
   if (i >= G.r.n) return;
@@ -363,18 +380,18 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     if (A & 1) return k < A ? k : A - 1;
     return k < A ? k : A - 2 + (k & 1);
   };
-  auto fetch_cells = [&](const upd_t& u, float (&row)[8], float& q) {
+  auto fetch_cells = [&](const upd_t& u, float (&row)[AMAX], float& q) {
     // (eight unconditional loads — the last valid action again beyond A — so that the count of
     //  loads in flight is a constant: with a load under a condition the compiler waits for ALL
     //  outstanding loads, the prefetch just issued included, before it uses the previous one)
     if (A & 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) row[k] = Q[(size_t)u.ns * A + (k < A ? k : A - 1)];
+      for (int k = 0; k < AMAX; ++k) row[k] = Q[(size_t)u.ns * A + (k < A ? k : A - 1)];
     } else {   // an even action count: rows are 8-byte aligned, four two-value loads (the lanes of a
                // wave are different instances: every load instruction is 64 separate lines)
       const float2* const r2 = reinterpret_cast<const float2*>(Q + (size_t)u.ns * A);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < AMAX / 2; ++k) {
         const float2 v = r2[2 * k < A ? k : A / 2 - 1];
         row[2 * k] = v.x;
         row[2 * k + 1] = v.y;
@@ -382,17 +399,17 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     }
     q = Q[(size_t)u.s * A + u.a];
   };
-  auto patch_cells = [&](const upd_t& u, float (&row)[8], float& q, int ws, int wa, float wv) {
+  auto patch_cells = [&](const upd_t& u, float (&row)[AMAX], float& q, int ws, int wa, float wv) {
     if (ws == u.ns) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) row[k] = slot_action(k) == wa ? wv : row[k];
+      for (int k = 0; k < AMAX; ++k) row[k] = slot_action(k) == wa ? wv : row[k];
     }
     if (ws == u.s && wa == u.a) q = wv;
   };
   auto run_batch = [&](auto load_rec, auto decode, bool f64) {
     if (B <= 0) return;
     upd_t cur = decode(load_rec(0));
-    float row[8], q;
+    float row[AMAX], q;
     fetch_cells(cur, row, q);
     rec_t rec_next = load_rec(B > 1 ? 1 : 0);
     int w1s = -1, w1a = 0, w2s = -1, w2a = 0;   // the cells of the last two updates and their values
@@ -400,14 +417,14 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     for (int j = 0; j < B; ++j) {
       // (unconditional: the last iterations request the last update's record and cells once more)
       const upd_t nxt = decode(rec_next);
-      float nrow[8], nq;
+      float nrow[AMAX], nq;
       fetch_cells(nxt, nrow, nq);
       rec_next = load_rec(j + 2 < B ? j + 2 : B - 1);
       patch_cells(cur, row, q, w2s, w2a, w2v);
       patch_cells(cur, row, q, w1s, w1a, w1v);
       float m = row[0];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) m = fmaxf(m, row[k]);   // (entries beyond A repeat the last action)
+      for (int k = 1; k < AMAX; ++k) m = fmaxf(m, row[k]);   // (entries beyond A repeat the last action)
       float qn;
       if (f64) {
         const double gnt = gamma * (double)cur.nt;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
       w1s = cur.s; w1a = cur.a; w1v = qn;
       cur = nxt;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) row[k] = nrow[k];
+      for (int k = 0; k < AMAX; ++k) row[k] = nrow[k];
       q = nq;
     }
   };
@@ -460,13 +477,13 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     budget -= 1;
 
     // ---- select + env.step --------------------------------------------------------------------
-    float qv[8];
+    float qv[AMAX];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) qv[a] = a < A ? Q[(size_t)state * A + a] : 0.0f;
+    for (int a = 0; a < AMAX; ++a) qv[a] = a < A ? Q[(size_t)state * A + a] : 0.0f;
     const double u = cobel_draw_u01(cp, 0u, g, pol_stream, seed);
     cp += 1u;
-    const int a = cobel_eps_greedy_select_n<float>(qv, A, amask ? (uint32_t)amask[state] : 0xffu,
-                                                   u, eps, nullptr);
+    const int a = cobel_eps_greedy_select_n<float, AMAX>(
+        qv, A, amask ? (uint32_t)amask[state] : 0xffffffffu, u, eps, nullptr);
     int ns;
     if (G.succ_off) {   // the successor is drawn from the row of sas (gridworld.py:119-123): one
                         // double of the env stream, at the counter the trial starts share
@@ -536,6 +553,9 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
               },
               [&](const rec_t& rc) -> upd_t {
                 const uint32_t hi = (uint32_t)(rc.bits >> 32);
+                if (AMAX > 8 && A > 8)   // (s | ns << 13 | action << 26 | nonterminal << 31)
+                  return upd_t{(int)(hi & 0x1fffu), (int)((hi >> 26) & 31u), (int)((hi >> 13) & 0x1fffu),
+                               __builtin_bit_cast(float, (uint32_t)rc.bits), (hi >> 31) & 1u};
                 const uint32_t ra = A <= 4 ? (hi >> 28) & 3u : (hi >> 28) & 7u;
                 const uint32_t rnt = A <= 4 ? (hi >> 30) & 1u : (hi >> 31) & 1u;
                 return upd_t{(int)(hi & 0x3fffu), (int)ra, (int)((hi >> 14) & 0x3fffu),
@@ -610,10 +630,21 @@ int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r,
   int lpb = 64;
   while (lpb > 8 && (long long)r.n < 8192ll * lpb) lpb >>= 1;
   const dim3 grid((unsigned)((r.n + lpb - 1) / lpb));
-  if (r.agent == COBEL_AGENT_DYNAQ)
-    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_DYNAQ>), grid, dim3(lpb), 0, st, G);
-  else
-    hipLaunchKernelGGL((k_tab_general<COBEL_AGENT_Q>), grid, dim3(lpb), 0, st, G);
+  COBEL_REQUIRE(G.A <= 8 || !(r.flags & COBEL_F_MASK_ACTIONS), COBEL_E_UNSUPPORTED,
+                "cobel_tab_run: action masks are one byte per state (up to eight actions), the world "
+                "has %d", G.A);
+  COBEL_REQUIRE(G.A <= 8 || !r.replay_log || G.S <= 8192, COBEL_E_UNSUPPORTED,
+                "cobel_tab_run: the replay log of a world with %d actions holds states below 8 192, "
+                "the world has %d", G.A, G.S);
+#define COBEL_GENERAL(AGENT)                                                                     \
+  do {                                                                                           \
+    if (G.A <= 8) hipLaunchKernelGGL((k_tab_general<AGENT, 8>), grid, dim3(lpb), 0, st, G);      \
+    else if (G.A <= 16) hipLaunchKernelGGL((k_tab_general<AGENT, 16>), grid, dim3(lpb), 0, st, G); \
+    else hipLaunchKernelGGL((k_tab_general<AGENT, 32>), grid, dim3(lpb), 0, st, G);              \
+  } while (0)
+  if (r.agent == COBEL_AGENT_DYNAQ) COBEL_GENERAL(COBEL_AGENT_DYNAQ);
+  else COBEL_GENERAL(COBEL_AGENT_Q);
+#undef COBEL_GENERAL
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }

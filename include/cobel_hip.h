@@ -39,7 +39,8 @@ extern "C" {
 #define COBEL_E_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. table exceeds LDS)   */
 
 #define COBEL_ACTIONS 4 /* gridworld / 4-neighbour topology action count (gridworld.py:86) */
-#define COBEL_MAX_ACTIONS 8 /* largest action count of cobel_world_create_n (hexagonal topology: 6) */
+#define COBEL_MAX_ACTIONS 32 /* largest action count of cobel_world_create_n (hexagonal topology: 6);
+                               action masks (one byte per row) exist up to eight actions */
 
 /* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (block, sub, instance, stream).
  * Each stream is consumed through a per-instance draw counter c:
@@ -195,7 +196,8 @@ COBEL_API int cobel_eps_greedy_f64(const double* values /* [dev] [N][4] */,
                                    void* stream);
 
 /* The same selection over rows of n_actions values (1..COBEL_MAX_ACTIONS; mask bit a = action a
- * allowed): action spaces other than four, e.g. the six neighbours of a hexagonal Topology. */
+ * allowed, NULL beyond eight actions): action spaces other than four, e.g. the six neighbours of a
+ * hexagonal Topology. */
 COBEL_API int cobel_eps_greedy_n(const float* values /* [dev] [N][n_actions] */,
                                  const uint8_t* mask /* [dev] [N] or NULL */,
                                  const double* u /* [dev] [N] */, double epsilon,
@@ -290,9 +292,13 @@ typedef struct {
                             batch > 0).  Every learning step appends one while there is room,
                             also at batch 0 (the reference's memory grows whether it replays or
                             not):
-                            lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30 */
+                            lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30
+                            (worlds of five to eight actions: nonterminal << 31; of nine to 32
+                            actions, at most 8 192 states: s | ns << 13 | action << 26 |
+                            nonterminal << 31)                                                */
   int32_t* inst;         /* [N][COBEL_I_WORDS]                                               */
-  const uint8_t* action_mask; /* [S] 4-bit masks shared by all instances, or NULL            */
+  const uint8_t* action_mask; /* [S] masks (bit a = action a) shared by all instances, or NULL;
+                                 worlds of up to eight actions                               */
   /* monitors (any may be NULL) */
   unsigned long long* lat_sum;  /* [trial_cap] sum over instances of logs['steps']           */
   unsigned long long* lat_cnt;  /* [trial_cap] instances that finished that trial            */

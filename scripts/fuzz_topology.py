@@ -1,4 +1,5 @@
-"""Randomised parity sweep for QAgent on Topology graphs with 1..8 actions — random directed graphs
+"""Randomised parity sweep for QAgent on Topology graphs with 1..8 actions (seeds from 10^6 on: 9..32)
+— random directed graphs
 (every node the same neighbour count, as `Topology` requires), random rewards / terminals / start
 nodes, replay batches 0..70 — against the NumPy restatement of the reference's loop
 (oracle/ref_loop.py, fed with the build's streams through TapeRNG).
@@ -26,6 +27,8 @@ def draw_case(seed: int) -> dict:
     r = np.random.default_rng(9_000_011 * seed + 3)
     S = int(r.integers(2, 61))
     A = int(r.choice([1, 2, 3, 4, 4, 5, 6, 6, 7, 8]))
+    if seed >= 1_000_000:   # (seeds from 10^6 on: nine to 32 neighbours — the wide general kernels)
+        A = int(r.choice([9, 10, 12, 13, 16, 17, 20, 24, 31, 32]))
     nbr = r.integers(0, S, (S, A))
     stay = r.random((S, A)) < 0.2             # missing neighbours are the node itself
     nbr = np.where(stay, np.arange(S)[:, None], nbr)

@@ -45,11 +45,12 @@ def test_random_sfma_cases_match_the_restatement(first):
 
 
 def test_random_topologies_match_the_restatement():
-    """scripts/fuzz_topology.py: QAgent on random graphs with 1..8 actions (four: wavefront
-    kernels, otherwise the general kernel), replay batches 0..70, against oracle/ref_loop.py."""
+    """scripts/fuzz_topology.py: QAgent on random graphs with 1..8 and 9..32 actions (four: wavefront
+    kernels, up to eight: k_tab_wqn / the general kernel, beyond: its wide instantiations), replay
+    batches 0..70, against oracle/ref_loop.py."""
     import fuzz_topology as fz
     failed = []
-    for seed in range(0, 120):
+    for seed in list(range(0, 120)) + list(range(1_000_000, 1_000_040)):   # (from 10^6: 9..32 actions)
         case = fz.draw_case(seed)
         bad = fz.run_case(case)
         if bad:

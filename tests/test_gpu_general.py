@@ -370,3 +370,76 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
     if batch:
         assert torch.equal(a._log, b._log)
     assert int(a.batches_done.item()) == int(b.batches_done.item())
+
+
+@pytest.mark.parametrize('A', [9, 12, 17, 32])
+def test_more_than_eight_actions(torch_cuda, A):
+    """Nine to 32 neighbours per node (interface/topology.py:110-112 takes any count): the wide
+    instantiations of the general kernel — QAgent with log replay against the restatement of the
+    reference's loop, the decoded replay memory, epsilon-greedy rows against NumPy, and the two
+    things that stay refused there (action masks, logged replay beyond 8 192 states)."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Topology
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import ref_loop
+    from oracle.philox import STREAM_ENV, STREAM_MEMORY, STREAM_POLICY, TapeRNG
+    r = np.random.default_rng(100 + A)
+    S = 40
+    nbr = r.integers(0, S, (S, A))
+    terminal = np.zeros(S, dtype=bool)
+    terminal[[7, 23]] = True
+    reward = np.zeros(S)
+    reward[7], reward[23], reward[11] = 1.0, -0.5, 0.25
+    nodes = {str(i): {'id': str(i), 'pose': np.array([float(i % 7), float(i // 7), 0., 0., 0., 0.]),
+                      'neighbors': [str(int(j)) for j in nbr[i]], 'reward': float(reward[i]),
+                      'terminal': bool(terminal[i])} for i in range(S)}
+    n, trials, steps, B = 70, 4, 30, 16
+    env = Topology(nodes, None, n_envs=n, seed=SEED)
+    assert int(env.action_space.n) == A
+    ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2), learning_rate=0.9, gamma=0.9)
+    ag.track_instances = True
+    ag.train(env, trials, steps, B)
+    torch.cuda.synchronize()
+    what = ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)
+    assert what['kernel'] == _lib.TAB_KERNEL_GENERAL
+    w = env.world
+    tab = dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'], starts=w['starting_states'])
+    Q = ag._q.cpu().numpy()
+    lat = ag.monitors.lat_trace.cpu().numpy()
+    for i in (0, 33, 69):
+        renv = ref_loop.RefGridworld(tab, TapeRNG(SEED, i, STREAM_ENV))
+        pol = ref_loop.RefEpsilonGreedy(0.2, TapeRNG(SEED, i, STREAM_POLICY))
+        ref = ref_loop.RefQAgent(S, A, pol, TapeRNG(SEED, i, STREAM_MEMORY), 0.9, 0.9, dtype=np.float32)
+        tr = ref_loop.new_trace()
+        ref.train(renv, trials, steps, B, trace=tr)
+        assert np.array_equal(lat[i, :trials], tr['steps'])
+        assert np.array_equal(Q[i].reshape(S, A), ref.Q)
+        if i == 0:   # the replay memory as the reference shows it (five action bits, 13-bit states)
+            M = ag.M
+            assert len(M) == len(ref.M)
+            for got, exp in zip(M, ref.M):
+                assert got['state'][0] == exp[0] and got['action'] == exp[1] and got['reward'] == exp[2]
+                assert got['next_state'][0] == exp[3] and got['terminal'] == exp[4]
+    # epsilon-greedy rows of A values against policy/greedy.py:77-86 in NumPy
+    v = r.integers(0, 3, (200, A)).astype(np.float32)
+    u = r.random(200)
+    dv = torch.as_tensor(v, device='cuda')
+    du = torch.as_tensor(u, device='cuda')
+    act = torch.empty(200, dtype=torch.uint8, device='cuda')
+    probs = torch.empty((200, A), dtype=torch.float64, device='cuda')
+    _lib.check(_lib.lib().cobel_eps_greedy_n(_lib.ptr(dv), None, _lib.ptr(du), 0.3, _lib.ptr(act),
+                                             _lib.ptr(probs), 200, A, None))
+    for k in range(200):
+        p = np.full(A, 0.3 / A)
+        ties = v[k] == v[k].max()
+        p[ties] += ((1.0 - 0.3) * 1.0) / ties.sum()
+        c = np.cumsum(p)
+        assert np.array_equal(probs[k].cpu().numpy(), p)
+        assert int(act[k].item()) == int(np.searchsorted(c / c[-1], u[k], side='right'))
+    # still refused beyond eight actions: action masks (one byte per row)
+    mask = torch.ones(200, dtype=torch.uint8, device='cuda')
+    rc = _lib.lib().cobel_eps_greedy_n(_lib.ptr(dv), _lib.ptr(mask), _lib.ptr(du), 0.3, _lib.ptr(act),
+                                       None, 200, A, None)
+    assert rc == _lib.E_UNSUPPORTED
