@@ -287,7 +287,17 @@ __device__ void forward(const mlp_lds<T>& L, T* out, int D, int t) {
     }
   }
   lds_barrier();
-  if (t < kB * kA) {
+  if (sizeof(T) == 4) {   // (float32: all 256 threads, two per output, half of the sum each — C5 -1 %;
+                          //  float64 measured 3 % SLOWER with the split forms here and below and keeps
+                          //  one thread per output)
+    const int s = t >> 3, a = (t >> 1) & 3, half = t & 1;
+    T acc = half ? (T)0 : L.b3[a];
+#pragma unroll 8
+    for (int k = 32 * half; k < 32 * half + 32; ++k)
+      acc = fma_t<T>(L.w3[a * kH + k], L.h2[s * kRow + k], acc);
+    acc = acc + __shfl_xor(acc, 1);
+    if (!half) out[s * kA + a] = acc;
+  } else if (t < kB * kA) {
     const int s = t >> 2, a = t & 3;
     T acc = L.b3[a];
 #pragma unroll 8
@@ -737,18 +747,50 @@ __device__ __forceinline__ void dqn_replay_body(const mlp_args& A) {
       L.h1[t] = acc > (T)0 ? acc : (T)0;
     }
     lds_barrier();
-    if (t < kH) {
-      T acc = L.b2[t];
+    if (sizeof(T) == 4) {
+      // (one row through the 64 x 64 layer and the output layer: as chains of 64 dependent
+      //  multiply-adds on one wave these two were 1.3 of the workgroup's 35 us; every wave takes a
+      //  quarter of the 64 x 64 sum, sixteen lanes a sixteenth of an output's.  float32 only.)
+      {
+        const int j = t & 63, part = t >> 6;
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 16 * part; k < 16 * part + 16; ++k) acc = fma_t<T>(L.wt2[k * kRow + j], L.h1[k], acc);
+        L.h2[(1 + part) * kRow + j] = acc;   // (rows 1 .. 4 of h2: free by now)
+      }
+      lds_barrier();
+      if (t < kH) {
+        T acc = L.b2[t];
+#pragma unroll
+        for (int part = 0; part < 4; ++part) acc = acc + L.h2[(1 + part) * kRow + t];
+        L.h2[t] = acc > (T)0 ? acc : (T)0;
+      }
+      lds_barrier();
+      if (t < 16 * kA) {
+        const int a = t >> 4, part = t & 15;
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 4 * part; k < 4 * part + 4; ++k) acc = fma_t<T>(L.w3[a * kH + k], L.h2[k], acc);
+        acc = acc + __shfl_xor(acc, 1);
+        acc = acc + __shfl_xor(acc, 2);
+        acc = acc + __shfl_xor(acc, 4);
+        acc = acc + __shfl_xor(acc, 8);
+        if (part == 0) ((T*)R.q_out)[(size_t)i * kA + a] = L.b3[a] + acc;
+      }
+    } else {
+      if (t < kH) {
+        T acc = L.b2[t];
 #pragma unroll 8
-      for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.wt2[k * kRow + t], L.h1[k], acc);
-      L.h2[t] = acc > (T)0 ? acc : (T)0;
-    }
-    lds_barrier();
-    if (t < kA) {
-      T acc = L.b3[t];
+        for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.wt2[k * kRow + t], L.h1[k], acc);
+        L.h2[t] = acc > (T)0 ? acc : (T)0;
+      }
+      lds_barrier();
+      if (t < kA) {
+        T acc = L.b3[t];
 #pragma unroll 8
-      for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[t * kH + k], L.h2[k], acc);
-      ((T*)R.q_out)[(size_t)i * kA + t] = acc;
+        for (int k = 0; k < kH; ++k) acc = fma_t<T>(L.w3[t * kH + k], L.h2[k], acc);
+        ((T*)R.q_out)[(size_t)i * kA + t] = acc;
+      }
     }
   }
   stamp(11);
