@@ -407,41 +407,59 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       // same cell), the rest goes again.  Same order of effects as the reference's loop; never
       // fewer lanes per round than the conflict-free prefix.  Who conflicts with whom is only
       // looked up — once per batch — when something changes.
-      bool have_conf = false;
-      do {
+      auto td_of = [&](float q, float m) -> float {
+        if (AGENT == COBEL_AGENT_DYNAQ) {
+          const double gnt = gamma * (double)nt;
+          double td = (double)r + gnt * (double)m;
+          td = td - (double)q;
+          return (float)((double)q + alpha * td);
+        }
+        const float gnt = nt ? gamma_f : 0.0f;
+        float td = r + gnt * m;
+        td = td - q;
+        return q + alpha_f * td;
+      };
+      // (the first round written out in front of the loop over the rounds — most batches end with
+      //  it —, as in k_tab_pwg §4.1d: trained agents on 16 x 16 / 24 x 24 mazes +1.3 / +0.7 %,
+      //  scripts/experiments/exp_occ_trained.py)
+      {
+        float q = 0.0f, qn = 0.0f;
+        if (on) {
+          const float4 row = Qs[ns];
+          q = Qf[idx];
+          qn = td_of(q, max4(row));
+        }
+        const bool ch = on && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
+        const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
+        if (!changed) {
+          STAMP(4);
+          return;
+        }
+        conflict_sets();
+        const unsigned long long blocked = __builtin_amdgcn_ballot_w64(on && (conf & changed) != 0ull);
+        first = blocked ? (__ffsll((long long)blocked) - 1) : BP;
+        if (ch && lane < first) Qf[idx] = qn;
+        __builtin_amdgcn_wave_barrier();
+      }
+      while (first < BP) {
         const bool act = on && lane >= first;
         float q = 0.0f, qn = 0.0f;
         if (act) {
           const float4 row = Qs[ns];
           q = Qf[idx];
-          const float m = max4(row);
-          if (AGENT == COBEL_AGENT_DYNAQ) {
-            const double gnt = gamma * (double)nt;
-            double td = (double)r + gnt * (double)m;
-            td = td - (double)q;
-            qn = (float)((double)q + alpha * td);
-          } else {
-            const float gnt = nt ? gamma_f : 0.0f;
-            float td = r + gnt * m;
-            td = td - q;
-            qn = q + alpha_f * td;
-          }
+          qn = td_of(q, max4(row));
         }
         const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
         const unsigned long long changed = __ballot(ch);
         int stop = BP;
         if (changed) {
-          if (!have_conf) {
-            conflict_sets();
-            have_conf = true;
-          }
           const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
           if (blocked) stop = __ffsll((long long)blocked) - 1;
           if (ch && lane < stop) Qf[idx] = qn;
           __builtin_amdgcn_wave_barrier();
         }
         first = stop;
-      } while (first < BP);
+      }
       STAMP(4);
       return;
     }
