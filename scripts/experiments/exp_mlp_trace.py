@@ -1,6 +1,6 @@
 """Per-phase wall-clock stamps of k_dqn_replay / k_mlp_fit (COBEL_DEBUG_MLP_TRACE): thread 0 of
 every workgroup stamps wall_clock64() (100 MHz) at the phase boundaries of its step.
-    python scripts/experiments/exp_mlp_trace.py c5|dsr [f64|f32] [stream|lds]"""
+    python scripts/experiments/exp_mlp_trace.py c5|dsr [f64|f32] [stream|lds] [reward|successor]"""
 import json
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
@@ -26,6 +26,10 @@ else:
     bench.run_dyna_dsr(torch.device('cuda', 0), n, iters=17)
 torch.cuda.synchronize()
 tr = trace.cpu().double()
+if what == 'dsr' and len(sys.argv) > 4:
+    # (the reward networks' launch — n workgroups, the later one — overwrites rows 0 .. n - 1 of the
+    #  successor networks' 4 n: `reward` / `successor` picks one launch's rows)
+    tr = tr[:n] if sys.argv[4] == 'reward' else tr[n:]
 names = ['start', 'target pass', 'inputs in LDS', 'forward + loss', 'output layer', 'second layer',
          'first layer', 'stores drained + extra rows in', 'extra rows out']
 if form == 'lds' and what == 'c5':
