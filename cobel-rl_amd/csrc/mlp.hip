@@ -26,12 +26,18 @@
 //     gradients never exist in memory; p, m, v are read once and written once, the target network's
 //     copy is read once (its forward pass; each thread keeps its tile of the 64 x 64 matrix for the
 //     blend; the small tensors, a sixth of the parameters, are read a second time) and written once.
+//   * requests go out in the order their answers are needed and nothing is waited for before
+//     everything that does not depend on it has been asked: slots, both networks' parameters, then
+//     both batches' rows / rewards / flags / actions; the optimizer state in the order the backward
+//     pass consumes it, a phase or two ahead; tensor pointers are formed where they are used
+//     (round 4: three dependent trips to memory per step where the first version made eleven).
 // HBM traffic per instance and step: 8 streams over the parameters (online read + write, two
 // moments read + write, target read + write) = 8 x 39 KB (float64).
 //
 // Arithmetic: the three 64 x 64 products are 16 x 16 x 4 MFMAs in the network's dtype (see
 // mfma_acc below), the thin layers fused multiply-adds with one accumulator per output in index
-// order — not torch's GEMM order, so results agree with the PyTorch path to rounding (1e-10
+// order (float32: the output layer's sums in two halves, the next observation's in four / sixteen
+// parts) — not torch's GEMM order, so results agree with the PyTorch path to rounding (1e-10
 // relative in float64 after ten steps; tests bound it), not bit for bit.  The optimizer update is
 // k_adam's (adam.hip), operation for operation.
 #include <stdlib.h>
