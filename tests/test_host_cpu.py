@@ -59,6 +59,15 @@ def test_struct_layouts_match_the_header():
     assert a == C.sizeof(_lib.DQNReplay) and b == _lib.DQNReplay.gamma.offset
     assert c == _lib.DQNReplay.q_out.offset and d == C.sizeof(_lib.DQNAct)
     assert e == _lib.DQNAct.epsilon.offset and f == _lib.DQNAct.seed.offset
+    # the limits the Python layer asserts against are the header's
+    src = ('#include "cobel_hip.h"\n#include <stdio.h>\n'
+           'int main(){printf("%d %d %lld\\n", COBEL_MAX_ACTIONS, COBEL_MAX_BATCH, '
+           '(long long)COBEL_TAB_SCRATCH_BYTES(1000));}')
+    subprocess.run(['gcc', '-x', 'c', '-', '-I', os.path.join(ROOT, 'include'), '-o', exe],
+                   input=src.encode(), check=True)
+    a, b, c = [int(x) for x in subprocess.check_output([exe]).split()]
+    os.remove(exe)
+    assert a == _lib.MAX_ACTIONS == 32 and b == _lib.MAX_BATCH and c == _lib.tab_scratch_bytes(1000)
 
 
 def test_sfma_metrics_match_reference(golden):
