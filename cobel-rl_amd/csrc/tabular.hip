@@ -132,7 +132,10 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
 // PSETS: hyper-parameters come from per-instance parameter sets (run.param_index).  A template
 // switch rather than a run-time one: the mere possibility of taking the loop constants from
 // memory changes the register allocation of the whole step loop.
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS>
+// STOCH (generic form only): the world's transition rows are distributions, the successor is
+// drawn in the step.  A template switch for the reason PSETS is one: as a run-time branch it cost
+// the one-hot runs of the generic kernel 3 % more vector instructions per step.
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     int ns;
     uint32_t nw0, nw1, r_bits, end;
     float ns_max;
-    if (!FAST && A.succ_off) {
+    if (STOCH) {
       // interface/gridworld.py:119-123: the successor is drawn from the row of sas — one double
       // of the env stream per step (sub-stream 1 of the counter the trial starts share, as
       // cobel_env_step_draw and k_tab_general draw it); any state may be entered, so its world
@@ -1149,21 +1152,27 @@ __global__ __launch_bounds__(256) void k_model_index(const uint64_t* __restrict_
   index[t] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
 }
 
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS>
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     COBEL_HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS>),
+        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS>), dim3(A.r.n), dim3(64), lds,
-                     st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH>), dim3(A.r.n), dim3(64),
+                     lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
 
 template <int AGENT, bool FAST, bool MIDX, bool PSETS>
 int dispatch_wpi2(const tab_args& A, bool occ, bool wlds, size_t lds, hipStream_t st) {
+  if (!FAST && A.succ_off) {   // (drawn successors: generic form only, see cobel_tab_run)
+    if (occ) return wlds ? launch_wpi<AGENT, true, true, false, false, PSETS, true>(A, lds, st)
+                         : launch_wpi<AGENT, true, false, false, false, PSETS, true>(A, lds, st);
+    return wlds ? launch_wpi<AGENT, false, true, false, false, PSETS, true>(A, lds, st)
+                : launch_wpi<AGENT, false, false, false, false, PSETS, true>(A, lds, st);
+  }
   if (occ) return wlds ? launch_wpi<AGENT, true, true, FAST, MIDX, PSETS>(A, lds, st)
                        : launch_wpi<AGENT, true, false, FAST, MIDX, PSETS>(A, lds, st);
   return wlds ? launch_wpi<AGENT, false, true, FAST, MIDX, PSETS>(A, lds, st)
