@@ -94,7 +94,11 @@ def main():
                     'WRITE_SIZE_KiB': wk, 'fetch_factor': factor,
                     'hbm_bytes_per_launch': (factor * fk + wk) * 1024,
                     'hbm_bytes_per_launch_fetch_as_counted': (fk + wk) * 1024}
-    with open(os.path.join(root, 'r%02d_pmc_traffic.json' % rnd), 'w') as fh:
+    path = os.path.join(root, 'r%02d_pmc_traffic.json' % rnd)
+    if os.path.exists(path):   # (entries other reductions added — pmc_c5.py, pmc_fit.py — stay)
+        for key, val in json.load(open(path)).items():
+            out.setdefault(key, val)
+    with open(path, 'w') as fh:
         json.dump(out, fh, indent=1)
     slim(fetch_csv, os.path.join(root, 'r%02d_pmc_fetch_size.csv' % rnd), 'FETCH_SIZE')
     slim(write_csv, os.path.join(root, 'r%02d_pmc_write_size.csv' % rnd), 'WRITE_SIZE')
