@@ -422,8 +422,11 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
     steps = n * env_steps * launches
     sec = sum(ms) * 1e-3
     what = runner.describe()
-    names = {_lib.TAB_KERNEL_GENERAL: 'k_tab_general', _lib.TAB_KERNEL_WPI: 'k_tab_wpi (generic, %d '
-             'passes)' % -(-batch // _lib.MAX_BATCH), _lib.TAB_KERNEL_WQN: 'k_tab_wqn'}
+    passes = -(-batch // _lib.MAX_BATCH)
+    names = {_lib.TAB_KERNEL_GENERAL: 'k_tab_general',
+             _lib.TAB_KERNEL_WPI: 'k_tab_wpi (generic, %d passes)' % passes,
+             _lib.TAB_KERNEL_WPI_INDEX: 'k_tab_wpi (digest in HBM, %d passes)' % passes,
+             _lib.TAB_KERNEL_WQN: 'k_tab_wqn'}
     kernel = names.get(what['kernel'], 'kernel %d' % what['kernel'])
     alg = b_step * steps + b_upd * batch * batches
     if which == 'hex_q':

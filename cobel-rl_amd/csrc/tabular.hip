@@ -135,7 +135,11 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
 // STOCH (generic form only): the world's transition rows are distributions, the successor is
 // drawn in the step.  A template switch for the reason PSETS is one: as a run-time branch it cost
 // the one-hot runs of the generic kernel 3 % more vector instructions per step.
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false>
+// MULTI (plain training with the digest in HBM only): more planning updates per step than one
+// wavefront takes in a pass — further passes of up to COBEL_MAX_BATCH updates behind the first,
+// their pairs drawn and gathered inside the step.
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false,
+          bool MULTI = false>
 __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   // sequential, so later updates see earlier ones as the reference's loop does, and inside a pass
   // the conflict analysis below applies unchanged.  BP = updates of the pass being planned.
   int Bp = B > kPassLanes ? kPassLanes : B;
-#define BP (FAST ? B : Bp)
+#define BP ((FAST && !MULTI) ? B : Bp)
   const uint32_t pol_stream = (!FAST && (flags & COBEL_F_TEST_STREAM)) ? COBEL_STREAM_POLICY_TEST
                                                                        : COBEL_STREAM_POLICY;
   const uint8_t* const amask =
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         // next step's batch: draw, start the gather; then run this step's batch
         uint32_t idx_next = 0u, mg_next = 0u;
         const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
-        if (lane < B) {   // one predicated region for everything the replay lanes do
+        if (lane < (MULTI ? Bp : B)) {   // one predicated region for everything the replay lanes do
           float r = 0.0f;
           idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SA);
           mg_next = (uint32_t)Mg[idx_next];
@@ -794,6 +798,29 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
             run_batch(idx_cur, m & 0x3fffu, (m >> 14) & 1u, r, true);
           }
           if (idx_next == fresh_idx) mg_next = fresh_m;   // the gather may have passed the store
+        }
+        if (MULTI && (iflags & 2u)) {
+          // updates kPassLanes .. B - 1 of this step's batch: element j of the vector draw comes
+          // from sub-stream j of the same counter (as the generic kernel's passes)
+          for (int j0 = kPassLanes; j0 < B; j0 += kPassLanes) {
+            Bp = B - j0 < kPassLanes ? B - j0 : kPassLanes;
+            const cobel_u4 b =
+                cobel_philox(cm >> 2, (uint32_t)(j0 + lane), g, COBEL_STREAM_MEMORY, seed);
+            uint32_t idx2 = 0u, m2 = 0u;
+            float r2 = 0.0f;
+            if (lane < Bp) {
+              idx2 = cobel_bounded(cobel_word(b, cm & 3u), SA);
+              m2 = (uint32_t)Mg[idx2];
+              if (idx2 == fresh_idx) m2 = fresh_m;   // (this step's own store may still be in flight)
+              if (__builtin_expect((m2 & 0x8000u) != 0u, 0)) {
+                r2 = __builtin_bit_cast(float, model32[2u * idx2]);
+                asm volatile("" : "+v"(r2));
+              }
+              if (idx2 == fresh_idx) r2 = fresh_r;
+            }
+            run_batch(idx2, m2 & 0x3fffu, (m2 >> 14) & 1u, r2);
+          }
+          Bp = kPassLanes;
         }
         idx_cur = idx_next;
         mg_cur = mg_next;
@@ -1152,15 +1179,16 @@ __global__ __launch_bounds__(256) void k_model_index(const uint64_t* __restrict_
   index[t] = (uint16_t)((hi & 0x3fffu) | (((hi >> 16) & 1u) << 14) | (lo ? 0x8000u : 0u));
 }
 
-template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false>
+template <int AGENT, bool OCC, bool WLDS, bool FAST, bool MIDX, bool PSETS, bool STOCH = false,
+          bool MULTI = false>
 int launch_wpi(const tab_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     COBEL_HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH>),
+        reinterpret_cast<const void*>(&k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH, MULTI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH>), dim3(A.r.n), dim3(64),
-                     lds, st, A);
+  hipLaunchKernelGGL((k_tab_wpi<AGENT, OCC, WLDS, FAST, MIDX, PSETS, STOCH, MULTI>), dim3(A.r.n),
+                     dim3(64), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -1172,6 +1200,12 @@ int dispatch_wpi2(const tab_args& A, bool occ, bool wlds, size_t lds, hipStream_
                          : launch_wpi<AGENT, true, false, false, false, PSETS, true>(A, lds, st);
     return wlds ? launch_wpi<AGENT, false, true, false, false, PSETS, true>(A, lds, st)
                 : launch_wpi<AGENT, false, false, false, false, PSETS, true>(A, lds, st);
+  }
+  if (FAST && MIDX && A.r.batch > kPassLanes) {   // (several passes per step: see MULTI)
+    if (occ) return wlds ? launch_wpi<AGENT, true, true, FAST, MIDX, PSETS, false, FAST && MIDX>(A, lds, st)
+                         : launch_wpi<AGENT, true, false, FAST, MIDX, PSETS, false, FAST && MIDX>(A, lds, st);
+    return wlds ? launch_wpi<AGENT, false, true, FAST, MIDX, PSETS, false, FAST && MIDX>(A, lds, st)
+                : launch_wpi<AGENT, false, false, FAST, MIDX, PSETS, false, FAST && MIDX>(A, lds, st);
   }
   if (occ) return wlds ? launch_wpi<AGENT, true, true, FAST, MIDX, PSETS>(A, lds, st)
                        : launch_wpi<AGENT, true, false, FAST, MIDX, PSETS>(A, lds, st);
@@ -1340,8 +1374,11 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
   A.use_hash = replay ? 1 : 0;
+  // (more than COBEL_MAX_BATCH updates per step: plain training takes them in passes only with the
+  //  digest in HBM — the MULTI instantiations)
+  const bool digest = r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   const bool fast = !draws && r.agent == COBEL_AGENT_DYNAQ && replay && !(r.flags & COBEL_F_EPISODIC) &&
-                    r.batch <= COBEL_MAX_BATCH &&
+                    (r.batch <= COBEL_MAX_BATCH || digest) &&
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
   A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;

@@ -184,9 +184,9 @@ def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
     if agent_name == 'dynaq':
         env, ag = _dynaq(torch, world, n, SEED, False)
         ag.train(env, trials, steps, B)
-        # Dyna-Q: two passes (62 + 38 updates) of the generic wavefront kernel ...
+        # Dyna-Q: two passes (62 + 38 updates) of the wavefront kernel with the digest in HBM ...
         assert ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)['kernel'] == \
-            _lib.TAB_KERNEL_WPI
+            _lib.TAB_KERNEL_WPI_INDEX
         # ... which leave what the lane-per-instance kernel leaves
         env2, ag2 = _dynaq(torch, world, n, SEED, True)
         ag2.train(env2, trials, steps, B)
