@@ -32,7 +32,7 @@ dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sizes = [tuple(int(x) for x in a.split('x')) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else [(10, 10), (32, 32)]
 for (h, w) in sizes:
-    for kind, batch in (('dynaq', 32), ('q', 0)):
+    for kind, batch in (('dynaq', 32), ('q', 0), ('q', 32)):
         for slip in (False, True):
             world = make_gridworld(h, w, terminals=[0], goals=[0], rewards=np.array([[0, 1.0]]))
             if slip:
