@@ -198,7 +198,7 @@ class DQN(Agent):
         from ..policy.greedy import EpsilonGreedy
         net = self._online
         if not self._fused_setting_ok(interface) or self.fused_loop is False \
-                or self.n_actions != 4 \
+                or not 1 <= self.n_actions <= 8 \
                 or self.use_graph is True \
                 or type(pol) is not EpsilonGreedy or not (self.target_update < 1.0) \
                 or getattr(self, '_no_replay', False) or not net.fused_mlp:

@@ -28,10 +28,17 @@ struct act_args {
   int32_t S, n_worlds;
   cobel_dqn_act_t r;
   cobel_eps_consts eps;
+  // action counts other than four (GEN instantiations; worlds of cobel_world_create_n)
+  int32_t n_actions;
+  const uint16_t* next_n;      // [n_worlds][S][n_actions]
+  const float* reward_s;       // [n_worlds][S]
+  const uint8_t* terminal_s;   // [n_worlds][S]
 };
 
 // DYNA: the memory is DynaDQN's tabular world model instead of a replay ring.
-template <typename T, bool DYNA>
+// GEN: 1 .. 8 actions but four (interface/topology.py:110-112, six on hexagonal graphs): the world
+// as neighbour / reward / terminal tables, the selection over n_actions values.
+template <typename T, bool DYNA, bool GEN = false>
 __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   const cobel_dqn_act_t& R = A.r;
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -46,18 +53,37 @@ __global__ __launch_bounds__(64) void k_dqn_act(const act_args A) {
   const int D = R.n_obs;
 
   // ---- select (policy/greedy.py:40-88) -----------------------------------------------------------
-  const T* const q = (const T*)R.q + (size_t)i * 4;
+  const int NA = GEN ? A.n_actions : 4;
+  const T* const q = (const T*)R.q + (size_t)i * NA;
   const uint32_t pc = R.policy_ctr[i];
   const double u = cobel_draw_u01(pc, 0u, g, R.policy_stream, R.seed);
   R.policy_ctr[i] = pc + 1u;
-  const int a = cobel_eps_greedy_select<T>(q[0], q[1], q[2], q[3], 15u, u, A.eps);
+  int a;
+  if (GEN) {
+    T qv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = k < NA ? q[k] : (T)0;
+    a = cobel_eps_greedy_select_n<T, 8>(qv, NA, 0xffu, u, R.epsilon, nullptr);
+  } else {
+    a = cobel_eps_greedy_select<T>(q[0], q[1], q[2], q[3], 15u, u, A.eps);
+  }
 
   // ---- env.step ------------------------------------------------------------------------------------
   const int s = R.state[i];
-  const int ns = W[s].next[a & 3];
-  const cobel_wrec entered = W[ns];
-  const float reward = entered.reward;
-  const bool done = entered.terminal != 0u;
+  int ns;
+  float reward;
+  bool done;
+  if (GEN) {
+    const size_t wb = (size_t)world * A.S;
+    ns = (int)A.next_n[(wb + s) * NA + a];
+    reward = A.reward_s[wb + ns];
+    done = A.terminal_s[wb + ns] != 0u;
+  } else {
+    ns = W[s].next[a & 3];
+    const cobel_wrec entered = W[ns];
+    reward = entered.reward;
+    done = entered.terminal != 0u;
+  }
 
   // ---- store ----------------------------------------------------------------------------------------
   const int slots = R.slots;
@@ -172,8 +198,18 @@ __global__ __launch_bounds__(256) void k_dqn_batch(const act_args A) {
 
 extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* run,
                              void* stream) {
-  if (int rc = cobel_world_check4(world, "cobel_dqn_act")) return rc;
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_dqn_act: NULL world/run");
+  const bool gen = world->n_actions != 4;
+  if (gen) {
+    if (int rc = cobel_world_check(world, "cobel_dqn_act")) return rc;
+    COBEL_REQUIRE(world->n_actions >= 1 && world->n_actions <= 8 && world->next_n &&
+                      !world->succ_off && !run->model_rewards,
+                  COBEL_E_UNSUPPORTED,
+                  "cobel_dqn_act: worlds of 1 .. 8 actions with one-hot rows and a replay ring are "
+                  "served (this one has %d actions)", world->n_actions);
+  } else if (int rc = cobel_world_check4(world, "cobel_dqn_act")) {
+    return rc;
+  }
   const cobel_dqn_act_t& r = *run;
   COBEL_REQUIRE(r.state && r.env_ctr && r.obs_table && r.q && r.policy_ctr, COBEL_E_ARG,
                 "cobel_dqn_act: NULL env / policy argument");
@@ -205,9 +241,16 @@ extern "C" int cobel_dqn_act(const cobel_world_t* world, const cobel_dqn_act_t* 
   A.n_worlds = world->n_worlds;
   A.r = r;
   A.eps = cobel_make_eps_consts(r.epsilon);
+  A.n_actions = world->n_actions;
+  A.next_n = world->next_n;
+  A.reward_s = world->reward_s;
+  A.terminal_s = world->terminal_s;
   const dim3 grid((unsigned)((r.n + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
-  if (r.is_float64 && dyna) hipLaunchKernelGGL((k_dqn_act<double, true>), grid, dim3(64), 0, st, A);
+  if (gen) {
+    if (r.is_float64) hipLaunchKernelGGL((k_dqn_act<double, false, true>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((k_dqn_act<float, false, true>), grid, dim3(64), 0, st, A);
+  } else if (r.is_float64 && dyna) hipLaunchKernelGGL((k_dqn_act<double, true>), grid, dim3(64), 0, st, A);
   else if (r.is_float64) hipLaunchKernelGGL((k_dqn_act<double, false>), grid, dim3(64), 0, st, A);
   else if (dyna) hipLaunchKernelGGL((k_dqn_act<float, true>), grid, dim3(64), 0, st, A);
   else hipLaunchKernelGGL((k_dqn_act<float, false>), grid, dim3(64), 0, st, A);

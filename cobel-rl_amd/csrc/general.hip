@@ -52,41 +52,6 @@ __device__ __forceinline__ uint64_t log_pack_n(float r, uint32_t s, uint32_t a, 
 
 }  // namespace
 
-// policy/greedy.py:77-86 + Generator.choice for n <= AMAX values: float64 probabilities, sequential
-// cumulative sum, normalisation by the last entry, searchsorted(side='right').
-template <typename V, int AMAX = 8>
-__device__ __forceinline__ int cobel_eps_greedy_select_n(const V* v, int A, uint32_t mask,
-                                                         double u, double eps, double* probs) {
-  const uint32_t allowed = mask & (A >= 32 ? 0xffffffffu : ((1u << A) - 1u));
-  const int n = __popc(allowed);
-  V m = -(V)__builtin_huge_valf();
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a)
-    if (a < A && ((allowed >> a) & 1u) && v[a] > m) m = v[a];
-  int nt = 0;
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a) nt += (a < A && ((allowed >> a) & 1u) && v[a] == m) ? 1 : 0;
-  const double base = eps / (double)n;
-  const double bonus = ((1.0 - eps) * 1.0) / (double)nt;
-  double cum[AMAX];
-  double run = 0.0;
-#pragma unroll
-  for (int a = 0; a < AMAX; ++a) {
-    double p = 0.0;
-    if (a < A && ((allowed >> a) & 1u)) p = base + ((v[a] == m) ? bonus : 0.0);
-    if (probs && a < A) probs[a] = p;
-    run = (a == 0) ? p : run + p;
-    cum[a] = run;
-  }
-  double total = cum[0];
-#pragma unroll
-  for (int a = 1; a < AMAX; ++a) total = (a == A - 1) ? cum[a] : total;
-  int pick = 0;
-#pragma unroll
-  for (int a = 0; a < AMAX - 1; ++a) pick += (a < A - 1 && cum[a] / total <= u) ? 1 : 0;
-  return pick;
-}
-
 namespace {
 
 template <typename V, int AMAX>

@@ -39,7 +39,8 @@ constexpr int kRow = 66;
 constexpr int kMaxD = 32;
 constexpr int kMaxO = 32;
 constexpr int kMaxEp = 4;
-constexpr int kA = 4;              // actions of the DQN step
+constexpr int kA = 4;              // actions of the DQN step's parameter-staging form (mlp.hip)
+constexpr int kAMax = 8;           // action counts the streaming form of the DQN step serves
 constexpr int kFitThreads = 512;   // threads of a training workgroup
 
 struct fit_args {
@@ -56,6 +57,7 @@ struct fit_args {
   const void* nonterminal;         // [n][rows]
   double gamma;
   unsigned long long* trace;       // experiments: [n][16] wall-clock stamps of thread 0 (or NULL)
+  int32_t n_actions;               // DQN: outputs = actions of the step (1 .. kAMax)
 };
 struct fwd_args {
   cobel_mlp_forward_t r;
@@ -165,13 +167,13 @@ struct act_lds {
   T* h1;    // [32][66]  -> delta1
   T* h2;    // [32][66]  -> delta2
   T* q;     // [32][33]  outputs -> delta3, columns >= O zero
-  T* qt;    // [32][4]   DQN: Q_target(s')
+  T* qt;    // [32][NA]  DQN: Q_target(s'), NA <= 8 actions
   int* aux; // [64]      DQN: row of each sample; DDQN: argmax_a Q_online(s')
   T* cst;   // [2]       Adam's bias corrections of this step (computed by one wave)
 };
 
 __host__ __device__ inline size_t fit_lds_elems() {
-  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kA + 64 + 2;
+  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kAMax + 64 + 2;
 }
 // forward only: the inputs sit where h2 will be written (read for the last time before that)
 __host__ __device__ inline size_t fwd_lds_elems() { return 2 * (size_t)kB * kRow; }
@@ -184,7 +186,7 @@ __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
   L.h2 = p; p += kB * kRow;
   L.x = p;  p += kB * kXRow;
   L.q = p;  p += kB * kXRow;
-  L.qt = p; p += kB * kA;
+  L.qt = p; p += kB * kAMax;
   L.aux = reinterpret_cast<int*>(p);
   L.cst = p + 64;
   return L;
@@ -484,7 +486,8 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   const bool is_active = !R.active || R.active[j / R.act_div] != 0;
   const bool is_training = DQN || !R.train || R.train[j] != 0;
   if (!is_active) return;
-  const int D = R.n_inputs, O = DQN ? kA : R.n_outputs;
+  const int NA = DQN ? A.n_actions : 0;   // (DQN: 1 .. kAMax actions)
+  const int D = R.n_inputs, O = DQN ? NA : R.n_outputs;
   const act_lds<T> L = carve_fit<T>(lds_raw);
   const int lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
   const int m0 = 16 * (wave >> 2), n0 = 16 * (wave & 3);
@@ -558,9 +561,9 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       xin.request(R.in_table, in_index, in_dense, slot, D, t);   // (for the pass after this one)
       {
         const acc_t acc = tp.run(L, lane);
-        if (has_out && li < kA) {
+        if (has_out && li < NA) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) L.qt[(r3 + mfma_acc<T>::row(lane, v)) * kA + li] = acc[v];
+          for (int v = 0; v < 4; ++v) L.qt[(r3 + mfma_acc<T>::row(lane, v)) * NA + li] = acc[v];
         }
       }
       stamp(1);
@@ -569,7 +572,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         forward_pass<T, false> op;
         op.request(w1, b1, w2, b2, w3, b3, D, O, wave, lane);
         const acc_t acc = op.run(L, lane);
-        if (has_out && li < kA) {
+        if (has_out && li < NA) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) L.q[(r3 + mfma_acc<T>::row(lane, v)) * kXRow + li] = acc[v];
         }
@@ -577,8 +580,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         if (t < kB) {
           int best = 0;
           T bv = L.q[t * kXRow];
-#pragma unroll
-          for (int a = 1; a < kA; ++a)
+          for (int a = 1; a < NA; ++a)
             if (L.q[t * kXRow + a] > bv) {   // first maximum, as torch.argmax
               bv = L.q[t * kXRow + a];
               best = a;
@@ -663,15 +665,14 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
             const int s = r3 + mfma_acc<T>::row(lane, v);
             T boot;
             if (A.ddqn) {
-              boot = L.qt[s * kA + L.aux[kB + s]];
+              boot = L.qt[s * NA + L.aux[kB + s]];
             } else {
-              boot = L.qt[s * kA];
-#pragma unroll
-              for (int a = 1; a < kA; ++a) boot = L.qt[s * kA + a] > boot ? L.qt[s * kA + a] : boot;
+              boot = L.qt[s * NA];
+              for (int a = 1; a < NA; ++a) boot = L.qt[s * NA + a] > boot ? L.qt[s * NA + a] : boot;
             }
             const T target = yv[v] + (boot * ntv[v]) * (T)A.gamma;
             const T d = acc[v] - target;
-            const T g = ((T)2 * d) * ((T)1 / (T)(kB * kA));
+            const T g = ((T)2 * d) * ((T)1 / (T)(kB * NA));
             L.q[s * kXRow + li] = li == actv[v] ? g : (T)0;
           }
         } else {
@@ -1056,7 +1057,8 @@ extern "C" int cobel_mlp_fit(const cobel_mlp_fit_t* run, void* stream) {
 // inputs, two workgroups of eight waves per CU) wins: Dyna-DQN's 25 one-hot inputs in float64,
 // 1.34 -> 1.0 ms per step of 8 192 instances.  COBEL_DEBUG_DQN_KERNEL = lds | stream pins one
 // (experiments, tests).
-static bool dqn_staged(int32_t n_inputs, int32_t is_float64) {
+static bool dqn_staged(int32_t n_inputs, int32_t is_float64, int32_t n_actions) {
+  if (n_actions != kA) return false;   // (the parameter-staging form is laid out for four actions)
   if (const char* v = cobel_debug_env("COBEL_DEBUG_DQN_KERNEL")) {   // exactly "lds" or "stream", else ignored
     if (!strcmp(v, "lds")) return true;
     if (!strcmp(v, "stream")) return false;
@@ -1072,13 +1074,13 @@ extern "C" int cobel_dqn_replay_query(int32_t n_inputs, int32_t n_hidden1, int32
                                       int32_t n_actions, int32_t batch, int32_t is_float64,
                                       int32_t* lds_bytes) {
   COBEL_REQUIRE(n_inputs >= 1 && n_inputs <= kMaxD && n_hidden1 == kH && n_hidden2 == kH &&
-                    n_actions == kA && batch == kB,
+                    n_actions >= 1 && n_actions <= kAMax && batch == kB,
                 COBEL_E_UNSUPPORTED,
                 "cobel_dqn_replay: the fused step covers Linear(D <= %d, 64)-ReLU-Linear(64, 64)-"
-                "ReLU-Linear(64, 4) on batches of 32 (got D %d, %d-%d, %d actions, batch %d)",
-                kMaxD, n_inputs, n_hidden1, n_hidden2, n_actions, batch);
+                "ReLU-Linear(64, A <= %d) on batches of 32 (got D %d, %d-%d, %d actions, batch %d)",
+                kMaxD, kAMax, n_inputs, n_hidden1, n_hidden2, n_actions, batch);
   if (lds_bytes)
-    *lds_bytes = dqn_staged(n_inputs, is_float64)
+    *lds_bytes = dqn_staged(n_inputs, is_float64, n_actions)
                      ? (int32_t)cobel_dqn_replay_lds_bytes(n_inputs, is_float64)
                      : (int32_t)(fit_lds_elems() * (is_float64 ? 8 : 4));
   return COBEL_OK;
@@ -1111,7 +1113,7 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
                 COBEL_E_ARG, "cobel_dqn_replay: the 64-wide weight matrices must be 16-byte aligned");
   if (r.n == 0) return COBEL_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (dqn_staged(r.n_inputs, r.is_float64))
+  if (dqn_staged(r.n_inputs, r.is_float64, r.n_actions))
     return cobel_dqn_replay_lds_launch(r, st, debug_trace_buffer());
   // the optimisation step of cobel_mlp_fit towards the Q-learning targets
   fit_args A;
@@ -1145,7 +1147,7 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   }
   f.n = r.n;
   f.n_inputs = r.n_inputs;
-  f.n_outputs = kA;
+  f.n_outputs = r.n_actions;
   f.is_float64 = r.is_float64;
   f.in_div = f.tgt_div = f.act_div = f.ep_div = 1;
   f.lr = r.lr;
@@ -1155,6 +1157,7 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   f.weight_decay = r.weight_decay;
   f.tau = r.tau;
   A.dqn = 1;
+  A.n_actions = r.n_actions;
   A.ddqn = r.ddqn;
   A.rows = r.batch_slots ? r.ring_slots : kB;
   A.steps_given = 1;

@@ -101,7 +101,7 @@ COBEL_API int cobel_world_create(const uint16_t* next /* [host] [n_worlds][S][4]
  * misc/topology_tools.py:175-272.  next is [n_worlds][S][n_actions]; n_actions = 4 is
  * cobel_world_create.  Such a world is served by cobel_env_step / cobel_env_reset, and by
  * cobel_tab_run through its general kernel (Q rows of n_actions entries); the entry points built
- * around four actions (cobel_sr_run, cobel_sfma_run, cobel_dqn_act) refuse it with
+ * around four actions (cobel_sr_run, cobel_sfma_run; cobel_dqn_act beyond eight) refuse it with
  * COBEL_E_UNSUPPORTED. */
 COBEL_API int cobel_world_create_n(const uint16_t* next /* [host] [n_worlds][S][n_actions] */,
                        const float* reward /* [host] [n_worlds][S] */,
@@ -761,7 +761,9 @@ typedef struct {
   uint32_t* env_ctr;        /* [N] next index on COBEL_STREAM_ENV                               */
   const double* obs_table;  /* [S][n_obs] float64                                               */
   /* policy */
-  const void* q;            /* [N][4] Q-values of the current observations, network dtype       */
+  const void* q;            /* [N][A] Q-values of the current observations, network dtype; A =
+                               the world's action count: four, or 1 .. 8 on a world of
+                               cobel_world_create_n (replay ring only, one-hot rows)            */
   uint32_t* policy_ctr;     /* [N] next index on the policy stream                              */
   uint32_t policy_stream;   /* COBEL_STREAM_POLICY or COBEL_STREAM_POLICY_TEST                  */
   int32_t is_float64;       /* dtype of q and of the ring's floating-point arrays               */

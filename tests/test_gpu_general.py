@@ -237,8 +237,9 @@ def test_state_count_beyond_lds_runs_on_the_general_kernel(torch_cuda):
 
 
 def test_dqn_on_hexagonal_topology(torch_cuda):
-    """DQN over six actions (PyTorch-ROCm loop; the fused step is a four-action kernel): runs,
-    selects all six actions, and instance i of a batch equals the same instance run alone."""
+    """DQN over six actions (the two-kernel loop since late round 4: the streaming form of the
+    replay step serves 1 .. 8 actions): runs, selects all six actions, and instance i of a batch
+    equals the same instance run alone."""
     torch = torch_cuda
     from collections import OrderedDict
     from cobel_amd.agent import DQN
@@ -261,7 +262,7 @@ def test_dqn_on_hexagonal_topology(torch_cuda):
         torch.cuda.synchronize()
         return ag
     vec, one = run(4, 0), run(1, 2)
-    assert vec.fused_steps == 0
+    assert vec.fused_steps > 0
     size = int(one.M.size[0].item())
     assert size == int(vec.M.size[2].item()) and size > 0
     assert torch.equal(vec.M.actions[2, :size], one.M.actions[0, :size])

@@ -1762,6 +1762,67 @@ def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, monkeypatch, 
     assert a.current_trial == b.current_trial == 8
 
 
+@pytest.mark.parametrize('dtype_name,ddqn', [('f64', False), ('f64', True), ('f32', False)])
+def test_dqn_two_kernel_loop_on_a_hexagonal_topology(torch_cuda, dtype_name, ddqn):
+    """demo/topology/demo_dqn.py --env hexagonal: six actions per node.  The two-kernel loop (the
+    streaming form of the replay step, selection over six Q-values, the world as neighbour tables)
+    against the PyTorch loop: transitions, rings, counters and monitors identical in float64,
+    weights to round-off."""
+    torch = torch_cuda
+    from collections import OrderedDict
+    from cobel_amd.agent import DQN
+    from cobel_amd.interface import Topology
+    from cobel_amd.memory import DQNMemory
+    from cobel_amd.misc.topology_tools import hexagonal
+    from cobel_amd.network import TorchNetwork
+    from cobel_amd.policy import EpsilonGreedy
+    nodes, starts = hexagonal(5, (0.0, 1.0))
+
+    def run(fused):
+        torch.manual_seed(11)
+        env = Topology(nodes, starts, n_envs=40, seed=777, instance_base=3)
+        assert int(env.action_space.n) == 6
+        net = torch.nn.Sequential(OrderedDict([
+            ('dense_1', torch.nn.Linear(6, 64)), ('relu_1', torch.nn.ReLU()),
+            ('dense_2', torch.nn.Linear(64, 64)), ('relu_2', torch.nn.ReLU()),
+            ('output', torch.nn.Linear(64, 6))]))
+        net = net.double() if dtype_name == 'f64' else net.float()
+        ag = DQN(env.observation_space, env.action_space, EpsilonGreedy(0.4), TorchNetwork(net),
+                 gamma=0.8, memory=DQNMemory(capacity=48))
+        ag.DDQN = ddqn
+        ag.fused_loop = None if fused else False
+        ag.use_graph = False if not fused else None
+        ag.train(env, 4, 12, 32)
+        ag.train(env, 2, 12, 32)
+        torch.cuda.synchronize()
+        return ag, env
+
+    (a, ea), (b, eb) = run(True), run(False)
+    assert a.fused_steps > 0 and b.fused_steps == 0
+    assert torch.equal(a.trial, b.trial) and int(a.trial.min()) == 6
+    if dtype_name == 'f32':
+        same = (a.M.actions == b.M.actions).all(dim=1) & (a.M.size == b.M.size)
+        assert float(same.float().mean()) >= 0.7, float(same.float().mean())
+        keep = same.nonzero().flatten()
+    else:
+        keep = torch.arange(40, device='cuda')
+        for k in ('lat_sum', 'lat_cnt', 'reward_sum'):
+            assert torch.equal(getattr(a.monitors, k), getattr(b.monitors, k)), k
+        assert torch.equal(ea.env_ctr, eb.env_ctr)
+    assert int(a.M.actions.max()) == 5
+    for x, y in ((a.M.size, b.M.size), (a.M.head, b.M.head), (a.M.actions, b.M.actions),
+                 (a.M.rewards, b.M.rewards), (a.M.states, b.M.states),
+                 (a.M.next_states, b.M.next_states), (a.M.terminals, b.M.terminals),
+                 (a.M.counter, b.M.counter), (a.policy.counter, b.policy.counter)):
+        assert torch.equal(x[keep], y[keep])
+    tol = dict(rtol=1e-9, atol=1e-12) if dtype_name == 'f64' else dict(rtol=5e-3, atol=1e-4)
+    for i in keep.cpu().numpy()[[0, len(keep) // 2, -1]]:
+        for x, y in zip(a._online.get_weights(int(i)), b._online.get_weights(int(i))):
+            assert np.allclose(x, y, **tol), float(np.abs(x - y).max())
+        for x, y in zip(a._target.get_weights(int(i)), b._target.get_weights(int(i))):
+            assert np.allclose(x, y, **tol)
+
+
 def test_full_size_c5_sample_and_conservation(torch_cuda, golden):
     """C5 at its full size — 8 192 linear_track(10, 2) instances, float64 6-64-64-4 networks, the
     two-kernel loop replayed from its HIP graph: eight instances spread over the range equal the
