@@ -593,7 +593,8 @@ COBEL_API int cobel_adam_step(void* param /* [dev] [N][per_instance] */,
 
 /* ------------------------------------------------------------------------------------------
  * One DQN replay step per instance in ONE kernel, for networks of the shape the reference's DQN
- * demos and tests use — Linear(D, 64) - ReLU - Linear(64, 64) - ReLU - Linear(64, 4), D <= 32,
+ * demos and tests use — Linear(D, 64) - ReLU - Linear(64, 64) - ReLU - Linear(64, A), D <= 32,
+ * A = 4 (1 .. 8 on the streaming form: the six neighbours of a hexagonal Topology),
  * batches of 32, float64 or float32, MSE loss, torch.optim.Adam without amsgrad:
  *   targets = Q_online(s); targets[a] = r + gamma * nt * max_a' Q_target(s')   (agent/dqn.py:346-364;
  *             ddqn != 0: a' = argmax Q_online(s'), :352-355)
