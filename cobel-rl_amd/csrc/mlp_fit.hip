@@ -470,7 +470,9 @@ struct forward_pass {
 
 // One optimisation step: eight waves per network.  Wave w owns the tile (rows 16 (w / 4) ..,
 // columns 16 (w % 4) ..) of every rows x 64 product and one or two tiles of every gradient.
-template <typename T, bool DQN>
+// NAC: the DQN step's action count when it is known at compile time (4: every gridworld / linear
+// track; as a run-time value the loops over the actions cost the four-action step 13 %), 0 = A.n_actions.
+template <typename T, bool DQN, int NAC = 0>
 __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   constexpr int NT = kFitThreads;
   typedef typename mfma_acc<T>::type acc_t;
@@ -486,7 +488,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   const bool is_active = !R.active || R.active[j / R.act_div] != 0;
   const bool is_training = DQN || !R.train || R.train[j] != 0;
   if (!is_active) return;
-  const int NA = DQN ? A.n_actions : 0;   // (DQN: 1 .. kAMax actions)
+  const int NA = DQN ? (NAC ? NAC : A.n_actions) : 0;   // (DQN: 1 .. kAMax actions)
   const int D = R.n_inputs, O = DQN ? NA : R.n_outputs;
   const act_lds<T> L = carve_fit<T>(lds_raw);
   const int lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
@@ -910,10 +912,10 @@ __global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 
 void k_mlp_fit(const fit_args A) {
   mlp_fit_body<T, false>(A);
 }
-template <typename T>
+template <typename T, int NAC = kA>
 __global__ __launch_bounds__(kFitThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_dqn_replay(const fit_args A) {
-  mlp_fit_body<T, true>(A);
+  mlp_fit_body<T, true, NAC>(A);
 }
 
 int shape_ok(int32_t D, int32_t O, const char* who) {
@@ -1169,13 +1171,19 @@ extern "C" int cobel_dqn_replay(const cobel_dqn_replay_t* run, void* stream) {
   f.debug_stage = debug_stage_env();
   A.trace = debug_trace_buffer();
   lds += cobel_debug_lds_pad(lds, 160 * 1024);                                    // (occupancy)
+  const bool four = r.n_actions == kA;
+  const void* const kernel =
+      r.is_float64 ? (four ? reinterpret_cast<const void*>(&k_dqn_replay<double, kA>)
+                           : reinterpret_cast<const void*>(&k_dqn_replay<double, 0>))
+                   : (four ? reinterpret_cast<const void*>(&k_dqn_replay<float, kA>)
+                           : reinterpret_cast<const void*>(&k_dqn_replay<float, 0>));
   if (lds > 64 * 1024) {
-    if (int rc = raise_lds(r.is_float64 ? reinterpret_cast<const void*>(&k_dqn_replay<double>)
-                                        : reinterpret_cast<const void*>(&k_dqn_replay<float>), lds))
-      return rc;
+    if (int rc = raise_lds(kernel, lds)) return rc;
   }
-  if (r.is_float64) hipLaunchKernelGGL(k_dqn_replay<double>, dim3(r.n), dim3(kFitThreads), lds, st, A);
-  else hipLaunchKernelGGL(k_dqn_replay<float>, dim3(r.n), dim3(kFitThreads), lds, st, A);
+  if (r.is_float64 && four) hipLaunchKernelGGL((k_dqn_replay<double, kA>), dim3(r.n), dim3(kFitThreads), lds, st, A);
+  else if (r.is_float64) hipLaunchKernelGGL((k_dqn_replay<double, 0>), dim3(r.n), dim3(kFitThreads), lds, st, A);
+  else if (four) hipLaunchKernelGGL((k_dqn_replay<float, kA>), dim3(r.n), dim3(kFitThreads), lds, st, A);
+  else hipLaunchKernelGGL((k_dqn_replay<float, 0>), dim3(r.n), dim3(kFitThreads), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
