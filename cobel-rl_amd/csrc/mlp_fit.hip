@@ -470,6 +470,21 @@ struct forward_pass {
 
 // One optimisation step: eight waves per network.  Wave w owns the tile (rows 16 (w / 4) ..,
 // columns 16 (w % 4) ..) of every rows x 64 product and one or two tiles of every gradient.
+// The kernel arguments as they lie in the kernarg segment, through a pointer the optimizer cannot
+// see through (constant address space: scalar loads): the step's tensor pointers are formed again
+// at the start of the phase that uses them instead of living — spilled — in scalar registers from
+// the top of the kernel (as in mlp.hip).
+typedef const __attribute__((address_space(4))) fit_args* fit_kargs;
+__device__ __forceinline__ fit_kargs fit_kr() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  fit_kargs p = (fit_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+#else
+  return nullptr;
+#endif
+}
+
 // NAC: the DQN step's action count when it is known at compile time (4: every gridworld / linear
 // track; as a run-time value the loops over the actions cost the four-action step 13 %), 0 = A.n_actions.
 template <typename T, bool DQN, int NAC = 0>
@@ -499,21 +514,36 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   stamp(0);
   const bool train = is_training;
   const size_t n1 = (size_t)kH * D, n2 = (size_t)kH * kH, n3 = (size_t)O * kH;
-  T* const w1 = (T*)R.w[0] + (size_t)j * n1;
-  T* const b1 = (T*)R.b[0] + (size_t)j * kH;
-  T* const w2 = (T*)R.w[1] + (size_t)j * n2;
-  T* const b2 = (T*)R.b[1] + (size_t)j * kH;
-  T* const w3 = (T*)R.w[2] + (size_t)j * n3;
-  T* const b3 = (T*)R.b[2] + (size_t)j * O;
   const bool has_target = R.w_target[0] != nullptr;
   const bool blend = R.tau != 0.0 && has_target;
-  // (without a target network the pointers alias the parameters: loads stay unconditional)
-  T* const tw1 = has_target ? (T*)R.w_target[0] + (size_t)j * n1 : w1;
-  T* const tb1 = has_target ? (T*)R.b_target[0] + (size_t)j * kH : b1;
-  T* const tw2 = has_target ? (T*)R.w_target[1] + (size_t)j * n2 : w2;
-  T* const tb2 = has_target ? (T*)R.b_target[1] + (size_t)j * kH : b2;
-  T* const tw3 = has_target ? (T*)R.w_target[2] + (size_t)j * n3 : w3;
-  T* const tb3 = has_target ? (T*)R.b_target[2] + (size_t)j * O : b3;
+  // (pointer makers: each call reads the kernarg segment again; without a target network the
+  //  target pointers alias the parameters, so that loads stay unconditional)
+  auto mk_w = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.w[l] + (size_t)j * n; };
+  auto mk_b = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.b[l] + (size_t)j * n; };
+  auto mk_tw = [&](int l, size_t n) -> T* {
+    return has_target ? (T*)fit_kr()->r.w_target[l] + (size_t)j * n : mk_w(l, n);
+  };
+  auto mk_tb = [&](int l, size_t n) -> T* {
+    return has_target ? (T*)fit_kr()->r.b_target[l] + (size_t)j * n : mk_b(l, n);
+  };
+  auto mk_mw = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.m_w[l] + (size_t)j * n; };
+  auto mk_vw = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.v_w[l] + (size_t)j * n; };
+  auto mk_mb = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.m_b[l] + (size_t)j * n; };
+  auto mk_vb = [&](int l, size_t n) -> T* { return (T*)fit_kr()->r.v_b[l] + (size_t)j * n; };
+  // (not const: re-formed at the start of every phase that uses them — REFRESH below — so that
+  //  none is live across the phases in between)
+  T* w1 = mk_w(0, n1);
+  T* b1 = mk_b(0, kH);
+  T* w2 = mk_w(1, n2);
+  T* b2 = mk_b(1, kH);
+  T* w3 = mk_w(2, n3);
+  T* b3 = mk_b(2, (size_t)O);
+  T* tw1 = mk_tw(0, n1);
+  T* tb1 = mk_tb(0, kH);
+  T* tw2 = mk_tw(1, n2);
+  T* tb2 = mk_tb(1, kH);
+  T* tw3 = mk_tw(2, n3);
+  T* tb3 = mk_tb(2, (size_t)O);
 
   // (the extra row's number: a scalar, fetched long before the row is)
   const int ep_row = R.ep_out && R.ep_rows > 0 && R.ep_table ? R.ep_index[j / R.ep_div] : 0;
@@ -534,12 +564,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       if (t < O) tb3[t] = tb3[t] + tau * (b3[t] - tb3[t]);
     }
   } else {
-    T* const m_w1 = (T*)R.m_w[0] + (size_t)j * n1; T* const v_w1 = (T*)R.v_w[0] + (size_t)j * n1;
-    T* const m_w2 = (T*)R.m_w[1] + (size_t)j * n2; T* const v_w2 = (T*)R.v_w[1] + (size_t)j * n2;
-    T* const m_w3 = (T*)R.m_w[2] + (size_t)j * n3; T* const v_w3 = (T*)R.v_w[2] + (size_t)j * n3;
-    T* const m_b1 = (T*)R.m_b[0] + (size_t)j * kH; T* const v_b1 = (T*)R.v_b[0] + (size_t)j * kH;
-    T* const m_b2 = (T*)R.m_b[1] + (size_t)j * kH; T* const v_b2 = (T*)R.v_b[1] + (size_t)j * kH;
-    T* const m_b3 = (T*)R.m_b[2] + (size_t)j * O;  T* const v_b3 = (T*)R.v_b[2] + (size_t)j * O;
+    T *m_w1, *v_w1, *m_w2, *v_w2, *m_w3, *v_w3, *m_b1, *v_b1, *m_b2, *v_b2, *m_b3, *v_b3;
     // waves 0 .. 3 also own an output tile: rows r3 .., outputs a3 ..
     const int r3 = 16 * ((wave >> 1) & 1), a3 = 16 * (wave & 1);
     const bool has_out = wave < 4 && a3 < O;
@@ -610,6 +635,8 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     // a = 8 lq ..) and the optimizer state of this wave's output-layer gradient tile dW3[a][k]
     // (outputs g0 = 16 (w / 4) .., neurons n0 ..).
     __builtin_amdgcn_sched_barrier(0);
+    // REFRESH: what the output layer's phase reads and writes
+    w3 = mk_w(2, n3); tw3 = mk_tw(2, n3); m_w3 = mk_mw(2, n3); v_w3 = mk_vw(2, n3);
     T yv[4], ntv[4];
     bool on[4];
     int actv[4];
@@ -745,6 +772,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       if (t < O)
         for (int s = 0; s < kB; ++s) gb = gb + L.q[s * kXRow + t];
       __builtin_amdgcn_sched_barrier(0);
+      w2 = mk_w(1, n2);   // REFRESH
 #pragma unroll
       for (int s = 0; s < 16; ++s) cw2[s] = w2[(uint32_t)((lq * 16 + s) * kH + n0 + li)];
       lds_barrier();
@@ -760,6 +788,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         }
       }
       if (t < O) {
+        b3 = mk_b(2, (size_t)O); tb3 = mk_tb(2, (size_t)O); m_b3 = mk_mb(2, (size_t)O); v_b3 = mk_vb(2, (size_t)O);   // REFRESH
         const adam_slot<T> sb = slot_load<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, blend, true);
         adam_apply<T>(b3, m_b3, v_b3, tb3, (uint32_t)t, gb, sb, c);
       }
@@ -774,6 +803,9 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     {
       const int k0 = 32 * (wave >> 2);
       adam_slot<T> s2a[4], s2b[4], s1[4];
+      // REFRESH: the second and the first layer's tensors
+      w2 = mk_w(1, n2); tw2 = mk_tw(1, n2); m_w2 = mk_mw(1, n2); v_w2 = mk_vw(1, n2);
+      w1 = mk_w(0, n1); tw1 = mk_tw(0, n1); m_w1 = mk_mw(0, n1); v_w1 = mk_vw(0, n1);
       lds_barrier();
       acc_t d1 = splat<T>((T)0);
       {
@@ -841,6 +873,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
               tw1 + (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * D + d));
       }
       if (t < kH) {
+        b2 = mk_b(1, kH); tb2 = mk_tb(1, kH); m_b2 = mk_mb(1, kH); v_b2 = mk_vb(1, kH);   // REFRESH
         const adam_slot<T> sb = slot_load<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, blend, true);
         adam_apply<T>(b2, m_b2, v_b2, tb2, (uint32_t)t, gb, sb, c);
       }
@@ -866,6 +899,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       if (t < kH) {
         T gb1 = (T)0;
         for (int s = 0; s < kB; ++s) gb1 = gb1 + L.h1[s * kRow + t];
+        b1 = mk_b(0, kH); tb1 = mk_tb(0, kH); m_b1 = mk_mb(0, kH); v_b1 = mk_vb(0, kH);   // REFRESH
         const adam_slot<T> sb = slot_load<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, blend, true);
         adam_apply<T>(b1, m_b1, v_b1, tb1, (uint32_t)t, gb1, sb, c);
       }
@@ -880,6 +914,8 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
   if (R.ep_out && R.ep_rows > 0) {
     __syncthreads();   // the new parameters are in memory; x / h1 / h2 are free
     forward_pass<T, true> ep;
+    w1 = mk_w(0, n1); b1 = mk_b(0, kH); w2 = mk_w(1, n2); b2 = mk_b(1, kH);   // REFRESH
+    w3 = mk_w(2, n3); b3 = mk_b(2, (size_t)O);
     ep.request(w1, b1, w2, b2, w3, b3, D, O, wave, lane);
     const int E = R.ep_rows;
     if (t < kMaxEp * 32) {
