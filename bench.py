@@ -324,7 +324,8 @@ def run_grid_search(device, runs=16):
     if iss is not None:
         roof['issue'] = iss
     roof = to_issue_bound(roof)
-    return {'value': combos * runs / dt, 'unit': 'simulations/s', 'env_steps': stats['env_steps'],
+    return {'value': combos * runs / dt, 'unit': 'simulations/s', 'dtype': 'f32',
+            'env_steps': stats['env_steps'],
             'env_steps_per_s': stats['env_steps'] / dt, 'seconds': dt,
             'env_steps_per_s_kernel': stats['env_steps'] / (stats['kernel_ms'] * 1e-3),
             'config': {'workload': 'GridSearchOptimizer.fit_vectorised: %d combinations x %d runs of '
@@ -638,12 +639,20 @@ def issue_roofline(key, env_steps_per_s, launch_ms, device, same_geometry):
          'valu_instr_per_s': achieved * 1e9, 'valu_peak_instr_per_s': peak * 1e9,
          'source': os.path.basename(files[-1]) + ' (' + entry['kernel'] + ')',
          'note': 'wave-level instructions per env step (a lane-per-instance kernel serves 64 env '
-                 'steps with one); valu_busy_frac = SQ_ACTIVE_INST_VALU / (SIMDs x launch cycles): '
-                 'float64 and transcendental instructions hold a SIMD longer than 4 cycles, so it '
-                 'exceeds valu_instr_per_s / valu_peak_instr_per_s where they matter'}
-    if same_geometry:   # busy fraction and floor hold for the launch geometry of the counter pass
-        r['valu_busy_frac'] = entry['valu_busy_frac']
-        r['floor_ms'] = launch_ms * entry['valu_busy_frac']
+                 'steps with one).  The counter pass fixes how long the vector ALUs are busy per env '
+                 'step (SQ_ACTIVE_INST_VALU x 4 cycles / clock / env steps: float64 and '
+                 'transcendental instructions hold a SIMD longer than 4 cycles, so it exceeds '
+                 'valu_per_step x 4 cycles where they matter); valu_busy_frac = that time x THIS '
+                 "run's env steps per second / 1024 SIMDs, floor_ms = that time x the env steps of "
+                 'a launch / 1024 SIMDs; profiled_valu_busy_frac is the fraction the counter pass '
+                 'itself saw'}
+    if same_geometry:   # the busy time per env step holds for the launch geometry of the counter pass
+        # SIMD-seconds of vector-ALU work per env step, a property of the code, not of this run
+        busy_s = entry['valu_busy_frac'] * VALU_PEAK_SIMDS * entry['seconds'] / entry['env_steps']
+        r['profiled_valu_busy_frac'] = entry['valu_busy_frac']
+        r['valu_busy_simd_ns_per_step'] = busy_s * 1e9
+        r['valu_busy_frac'] = busy_s * env_steps_per_s / VALU_PEAK_SIMDS
+        r['floor_ms'] = busy_s * env_steps_per_s * launch_ms / VALU_PEAK_SIMDS
     return r
 
 
@@ -945,6 +954,87 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
     return res, cfg
 
 
+def _sig(x, digits=6):
+    """floats to `digits` significant digits (the compact line is held under 6 000 bytes)"""
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _short(text, n=110):
+    return text if text is None or len(text) <= n else text[:n - 3] + '...'
+
+
+COMPACT_LIMIT = 6000      # bytes; the driver keeps an 8 KB tail of stdout and parses its last line
+
+
+def compact(res, full_path=None):
+    """The ONE line bench.py prints: every key of the contract, the headline's roofline and CPU
+    baseline with numbers only (no prose notes), the other legs reduced to {value, unit,
+    ms_per_step, dtype, bound, frac, frac_measured, cpu_baseline}.  The full objects — notes,
+    per-launch times, issue-counter provenance, every leg's configuration — go to `full_path`
+    (bench_full.json) and to stderr."""
+    out = _pick(res, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                      'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
+    cfg = res['config']
+    out['config'] = dict(_pick(cfg, ('instances_total', 'instances_per_gpu', 'env_steps_per_launch')),
+                         workload=_short(cfg['workload']), parallelism=_short(cfg['parallelism'], 64))
+    roof = res['roofline']
+    r = _pick(roof, ('bound', 'limiter', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_measured',
+                     'kernel', 'algorithmic_bytes_per_env_step', 'algorithmic_bytes_per_launch',
+                     'launch_ms_mean', 'evaluated_fraction', 'sec8d_bytes_per_env_step',
+                     'sec8d_achieved'))
+    if roof.get('issue'):
+        r['issue'] = _pick(roof['issue'], ('valu_per_step', 'salu_per_step', 'valu_busy_frac',
+                                           'profiled_valu_busy_frac', 'floor_ms'))
+    if roof.get('hbm_accounting'):
+        r['hbm_accounting'] = _pick(roof['hbm_accounting'], ('achieved', 'frac', 'traffic'))
+    out['roofline'] = r
+    if 'cpu_baseline' in res:
+        c = res['cpu_baseline']
+        out['cpu_baseline'] = dict(_pick(c, ('value', 'unit', 'cores', 'kind', 'port_over_reference')),
+                                   sample=_short(c.get('sample')))
+    if 'pretraining' in res:
+        out['pretraining'] = _pick(res['pretraining'], ('launches', 'untimed_launches_in_all',
+                                                        'env_steps_per_instance',
+                                                        'evaluated_fraction_at_start', 'train_until'))
+    if 'young_agents' in res:
+        out['young_agents'] = _pick(res['young_agents'], ('launches', 'launch_ms_mean', 'value_this_rank',
+                                                          'evaluated_fraction', 'frac'))
+    if 'monitors' in res:
+        out['monitors'] = res['monitors']
+    if 'repeat_windows' in res:
+        out['repeat_windows'] = _pick(res['repeat_windows'], ('count', 'seconds', 'ms_per_step_median',
+                                                              'ms_per_step_min', 'ms_per_step_max'))
+    legs = {}
+    for name, leg in res.get('other_configs', {}).items():
+        if 'error' in leg:
+            legs[name] = {'error': _short(leg['error'], 100)}
+            continue
+        lr = leg.get('roofline') or {}
+        e = dict(_pick(leg, ('value', 'unit', 'ms_per_step', 'dtype')),
+                 **_pick(lr, ('bound', 'frac', 'frac_measured')))
+        if 'cpu_baseline' in leg:
+            e['cpu_baseline'] = leg['cpu_baseline']['value']
+        legs[name] = e
+    if legs:
+        out['other_configs'] = legs
+    if full_path:
+        out['full'] = os.path.basename(full_path)
+    out = _sig(out)
+    line = json.dumps(out, separators=(',', ':'))
+    assert len(line) < COMPACT_LIMIT, 'compact bench line grew to %d bytes' % len(line)
+    return line
+
+
 def spawn_ranks(argv, n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH processes through
     torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.
@@ -999,6 +1089,11 @@ def main():
                          'barriers, the MIN all-reduce of the pre-training and the monitor all-gather '
                          'go through the backend (RCCL on a one-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--full', action='store_true',
+                    help='print the full result object as the one stdout line (profiling scripts) '
+                         'instead of the compact one')
+    ap.add_argument('--full-out', default='bench_full.json',
+                    help='where rank 0 writes the full result object ("" = nowhere)')
     ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
     ap.add_argument('--legs', default=None,
                     help='comma-separated subset of the legs behind --also (C5_f64, C5_f32, dyna_dqn, '
@@ -1051,7 +1146,7 @@ def main():
                 gc.collect()               # (the previous leg's tables: C4 alone holds 64 GiB)
                 torch.cuda.empty_cache()
                 r, _ = run_config(name, args, rank, world_size, device, dist)
-                others[name] = {'value': r['value'], 'unit': r['unit'],
+                others[name] = {'value': r['value'], 'unit': r['unit'], 'dtype': r['dtype'],
                                 'ms_per_step': r['ms_per_step'], 'config': r['config'],
                                 'warmup': r['warmup'], 'roofline': r['roofline']}
                 if 'transient' in r:
@@ -1093,7 +1188,18 @@ def main():
         if others:
             res['other_configs'] = others
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(res) + '\n').encode())
+        full = json.dumps(res)
+        if args.full_out:
+            try:
+                with open(args.full_out, 'w') as fh:
+                    fh.write(full + '\n')
+            except OSError as e:      # (a read-only cwd: the compact line is what counts)
+                print('bench.py: could not write %s: %s' % (args.full_out, e), file=sys.stderr)
+                args.full_out = ''
+        print('bench.py full result: ' + full, file=sys.stderr)
+        sys.stderr.flush()
+        line = full if args.full else compact(res, args.full_out or None)
+        os.write(json_fd, (line + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -39,7 +39,8 @@ class TabularAgent(FusedAgent):
         # work area of a launch (cobel_tab_run_t.scratch: ticket and slice counters of the
         # persistent-workgroup Dyna-Q kernel), one per agent: agents that share a world handle may
         # be in flight together
-        self._scratch = torch.empty(_lib.tab_scratch_bytes(self.n_envs) // 4, dtype=torch.int32,
+        # (zeroed once: its abort word is only ever raised by a launch, see check_launches)
+        self._scratch = torch.zeros(_lib.tab_scratch_bytes(self.n_envs) // 4, dtype=torch.int32,
                                     device=self.device)
         if self._q_host is not None:
             self._q.copy_(torch.as_tensor(self._q_host, device=self.device).expand_as(self._q))
@@ -124,6 +125,17 @@ class TabularAgent(FusedAgent):
             return
         _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
                                             _lib.current_stream(self.device)))
+
+    def check_launches(self) -> None:
+        """Waits for this agent's launches and raises ``CobelHipError`` if a sliced launch of the
+        persistent-workgroup kernel gave up waiting for a ring entry (``cobel_tab_scratch_check``:
+        a lost producer wavefront ends in an error, not in a hung GPU)."""
+        _lib.check(_lib.lib().cobel_tab_scratch_check(
+            _lib.ptr(self._scratch), self._scratch.numel() * 4, _lib.current_stream(self.device)))
+
+    def env_steps(self) -> int:
+        self.check_launches()
+        return super().env_steps()
 
     def describe_launch(self, interface, pol, flags, trials_target, steps, budget, batch) -> dict:
         """Which kernel ``_launch`` would take with these arguments (``cobel_tab_describe``)."""

@@ -1481,6 +1481,19 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   return tab_run_impl(world, run, stream, nullptr);
 }
 
+extern "C" int cobel_tab_scratch_check(const void* scratch, int64_t scratch_bytes, void* stream) {
+  if (!scratch || scratch_bytes < (int64_t)COBEL_TAB_SCRATCH_BYTES(1)) return COBEL_OK;
+  uint32_t word = 0;
+  hipStream_t st = (hipStream_t)stream;
+  COBEL_HIP_TRY(hipMemcpyAsync(&word, static_cast<const uint32_t*>(scratch) + COBEL_TAB_SCRATCH_ABORT_WORD,
+                               sizeof(word), hipMemcpyDeviceToHost, st));
+  COBEL_HIP_TRY(hipStreamSynchronize(st));
+  if (word != 0u)
+    return cobel_fail(COBEL_E_HIP, "cobel_tab_run: a sliced launch gave up waiting for a ring entry "
+                                   "(a producer wavefront was lost); the tables are incomplete");
+  return COBEL_OK;
+}
+
 extern "C" int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run_t* run,
                                   int32_t* out) {
   COBEL_REQUIRE(out, COBEL_E_ARG, "cobel_tab_describe: NULL out");

@@ -39,6 +39,10 @@ namespace {
 constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
 constexpr int kMaxGlobalWaves = 4;
 constexpr int kMaxSlices = 8;
+// word of the scratch header a sliced launch raises when a wave gives up waiting for a ring entry
+// (COBEL_TAB_SCRATCH_ABORT_WORD in cobel_hip.h), and the polls (~1-2 us each) before it does
+constexpr uint32_t kAbortWord = COBEL_TAB_SCRATCH_ABORT_WORD;
+constexpr uint32_t kRingSpinLimit = 1u << 22;
 struct pwg_args {
   const cobel_wrec* rec;
   const uint16_t* starts;
@@ -766,9 +770,26 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
             i = (int)(t * 8u + q);
           } else {
             const uint32_t* const slot = A.ring + (size_t)q * A.ring_stride + (t - nq);
-            uint32_t e;
-            while ((e = rfl(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == 0u)
+            // The entry is written by the wave that runs the predecessor slice — a few
+            // milliseconds at most.  Should it never come (a producer that faulted or was
+            // killed), the wait gives up after kRingSpinLimit polls (seconds), raises the
+            // launch's abort word and leaves; the other waiting waves see the word and follow,
+            // so the grid drains and cobel_tab_scratch_check reports COBEL_E_HIP instead of the
+            // whole GPU hanging.
+            uint32_t e, spins = 0u;
+            while ((e = rfl(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == 0u) {
               __builtin_amdgcn_s_sleep(32);
+              ++spins;
+              if (spins >= kRingSpinLimit ||
+                  ((spins & 1023u) == 0u &&
+                   rfl(__hip_atomic_load(A.queue + kAbortWord, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT)) != 0u)) {
+                if (lane == 0)
+                  __hip_atomic_store(A.queue + kAbortWord, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                return;
+              }
+            }
             // (this CU's L1 is dropped; the wave's own loads behind the fence need no wait for it)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             sl = e >> 24;
@@ -815,6 +836,12 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
         if (more) pos = atomicAdd(A.tail + q * 8u, 1u);
         if (!qg) t = atomicAdd(A.queue + q * 8u, 1u);
       }
+      // Release: the instance's tables are complete in this XCD's L2 before the entry that
+      // publishes them.  Workgroup scope on purpose — its code is the wait for this wave's stores
+      // (vmcnt(0)) without the L2 write-back an agent-scope release adds: the consumer is a wave
+      // of the SAME XCD (a queue has one owner), so the tables reach it through this L2, and
+      // writing every dirty model line back to HBM per hand-off is what slicing must not cost.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       stores_done();
       if (lane == 0 && more)
         __hip_atomic_store(A.ring + (size_t)q * A.ring_stride + pos,

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "cobel_common.h"
@@ -43,24 +44,34 @@ size_t cobel_debug_lds_pad(size_t base, size_t limit) {
 // CUs and LDS bytes per CU of a device, asked once per device (the persistent-workgroup kernel
 // sizes its grid and its workgroup by them).
 int cobel_device_limits(int device, int* n_cu, size_t* lds_per_cu) {
-  static int cu[64];
-  static size_t lds[64];
+  struct limits {
+    std::once_flag once;
+    int cu = 0;
+    size_t lds = 0;
+    hipError_t err = hipSuccess;
+  };
+  static limits table[64];
   COBEL_REQUIRE(device >= 0 && device < 64, COBEL_E_ARG, "cobel_device_limits: device %d", device);
-  if (!cu[device]) {
+  limits& l = table[device];
+  // (agents of several host threads may ask at once: filled exactly once per device, and a reader
+  //  sees both values or waits)
+  std::call_once(l.once, [&l, device] {
     hipDeviceProp_t prop;
-    COBEL_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    l.err = hipGetDeviceProperties(&prop, device);
+    if (l.err != hipSuccess) return;
     size_t b = prop.maxSharedMemoryPerMultiProcessor;
     if (b == 0 || b > 160 * 1024) b = 160 * 1024;   // (gfx950: 160 KiB; the kernels are laid out for it)
-    lds[device] = b;
-    cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  *n_cu = cu[device];
-  *lds_per_cu = lds[device];
+    l.lds = b;
+    l.cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  });
+  COBEL_HIP_TRY(l.err);
+  *n_cu = l.cu;
+  *lds_per_cu = l.lds;
   return COBEL_OK;
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1015; }
+extern "C" int cobel_abi_version(void) { return 1016; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {

@@ -340,8 +340,9 @@ typedef struct {
                             batch is 0 + alpha (0 + gamma nt 0 - 0) = 0).  steps_done minus this is
                             the number of batches skipped that way (episodic replay: per trial).  */
   void* scratch;         /* optional [dev] work area of the call, caller-owned (the library allocates
-                            nothing in a run): COBEL_TAB_SCRATCH_BYTES(n) bytes, contents undefined
-                            between calls, never shared by two calls in flight.  The
+                            nothing in a run): COBEL_TAB_SCRATCH_BYTES(n) bytes, zeroed once by the
+                            caller after allocating it, contents otherwise undefined between
+                            calls, never shared by two calls in flight.  The
                             persistent-workgroup Dyna-Q kernel keeps its ticket counters and the
                             rings of its ready slices there; with it a launch of few instances
                             per GPU (a shard of a split batch) is handed out in slices of an
@@ -352,6 +353,19 @@ typedef struct {
   int64_t scratch_bytes;
 } cobel_tab_run_t;
 #define COBEL_TAB_SCRATCH_BYTES(n) ((256 + 7 * ((int64_t)(n) + 8)) * 4)
+/* Word (uint32) of the scratch area a sliced launch raises when one of its wavefronts gave up
+ * waiting for a ring entry that never came (a producer wavefront that faulted or was killed: the
+ * wait is bounded — seconds — so that the grid drains instead of hanging the GPU).  Valid from the
+ * end of a call to the start of the next one on the same area; read by cobel_tab_scratch_check.
+ * What slicing relies on, for a maintainer: (1) the hand-off of an instance from the wavefront that
+ * ran slice k to the one that runs slice k + 1 goes through ONE XCD's L2 — a queue of tickets is
+ * served by the workgroups of a single XCD (HW_REG_XCC_ID, claimed through the `owner` words), the
+ * producer waits for its stores (vmcnt(0), a workgroup-scope release) before it publishes the
+ * entry, the consumer drops its CU's L1 (agent-scope acquire) before it reads; the per-XCD L2s are
+ * not written back per hand-off; (2) every ticket that exists is held by a resident wavefront that
+ * finishes (one persistent workgroup per CU, grid <= CU count), so a waiting wavefront waits for
+ * work in progress, never for work not yet scheduled. */
+#define COBEL_TAB_SCRATCH_ABORT_WORD 255
 
 /* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —
  * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — are planned by
@@ -387,6 +401,14 @@ enum {
 };
 COBEL_API int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run_t* run,
                                  int32_t* out /* [host] [4] */);
+
+/* After a cobel_tab_run call that was given a scratch area: waits for `stream`, reads the area's
+ * abort word and returns COBEL_OK, or COBEL_E_HIP when a sliced launch gave up (the tables of the
+ * call are then incomplete and must be discarded).  scratch NULL or smaller than
+ * COBEL_TAB_SCRATCH_BYTES(1): COBEL_OK (nothing was sliced).  The reference has no counterpart:
+ * its loop cannot lose a producer (agent/dyna_q.py:140-215 is one thread). */
+COBEL_API int cobel_tab_scratch_check(const void* scratch /* [dev] */, int64_t scratch_bytes,
+                                      void* stream);
 
 /* The additions NumPy's pairwise summation (np.sum over a contiguous float32 vector, agent/sr.py:
  * 302-306 `np.sum(SR[j] * rewards)`) performs on a vector of n elements of which only the k <= 32 at

@@ -8,6 +8,7 @@ of a 1 GiB table exactly ONCE with loads of each of those widths (lanes of a loa
 more), streams the table with 16-byte loads, and — one workgroup — reads byte 0 and then byte 64 of
 4 096 lines to tell whether a miss fills a whole line.
 
+    python scripts/pmc_calibrate_gather.py build                    # hipcc, OUTSIDE any profiler
     python scripts/pmc_calibrate_gather.py run                      # the launches (under rocprofv3)
     python scripts/pmc_calibrate_gather.py reduce OUT.json DIR...   # counter CSVs -> per-pattern table
 
@@ -39,15 +40,24 @@ PATTERNS = [  # (id, kernel name fragment, label, loads, bytes per load, distinc
 ]
 
 
+def stale():
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC)
+
+
 def build():
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+    """Compile the calibration kernels.  Never called from `run`: under `rocprofv3 --pmc` the
+    profiler's preloaded library has initialised the GPU before this script starts, and a compiler
+    spawned from there is an exec from a GPU-initialised process (forbidden on this pool)."""
+    if stale():
         subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950',
                                '-fPIC', '-shared', '-o', LIB, SRC])
 
 
 def run():
+    if stale():
+        sys.exit('scripts/calib/libpmc_calib.so is missing or older than gather_patterns.hip: run '
+                 '`python3 scripts/pmc_calibrate_gather.py build` first, outside the profiler')
     import torch
-    build()
     lib = C.CDLL(LIB)
     lib.calib_run.argtypes = [C.c_int, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p]
     dev = torch.device('cuda', 0)
@@ -122,7 +132,9 @@ def reduce_(out, dirs):
 
 
 if __name__ == '__main__':
-    if sys.argv[1] == 'run':
+    if sys.argv[1] == 'build':
+        build()
+    elif sys.argv[1] == 'run':
         run()
     else:
         reduce_(sys.argv[2], sys.argv[3:])

@@ -14,9 +14,9 @@ R=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 mkdir -p $O
-python3 bench.py > $O/r${R}_bench.json 2> $O/r${R}_bench.err
+python3 bench.py --full-out $O/r${R}_bench_full.json > $O/r${R}_bench.json 2> $O/r${R}_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d $O/r${R}_stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --min-seconds 0 > $O/r${R}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/r${R}_stats -o s --output-format csv -- python3 bench.py --full --no-cpu-baseline --min-seconds 0 > $O/r${R}_stats.log 2>&1
 python3 scripts/kernel_stats_timed.py $O/r${R}_stats/s_kernel_trace.csv $O/r${R}_kernel_stats_timed.csv > /dev/null
 echo "stats done"
 bash scripts/profile_pmc.sh $R calib sq traffic

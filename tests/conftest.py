@@ -1,7 +1,6 @@
 """Shared fixtures.  ``-m gpu`` tests need an MI355X and run the HIP library through its C ABI;
 everything else runs on CPU (oracle vs golden vectors, host logic, symbol checks)."""
 import os
-os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
 import sys
 
 import numpy as np
@@ -18,6 +17,18 @@ SEED = 0xC0BE1
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # the library honours its COBEL_DEBUG_* experiment variables only under the master switch
+    # COBEL_DEBUG=1; the suite runs WITHOUT it (the production configuration) and strips stray
+    # variables of a developer's shell — the tests that pin a kernel set both (debug_env below)
+    for k in [k for k in os.environ if k == 'COBEL_DEBUG' or k.startswith('COBEL_DEBUG_')]:
+        del os.environ[k]
+
+
+def debug_env(monkeypatch, **variables):
+    """Set COBEL_DEBUG_<NAME> experiment variables for one test, with the master switch."""
+    monkeypatch.setenv('COBEL_DEBUG', '1')
+    for k, v in variables.items():
+        monkeypatch.setenv('COBEL_DEBUG_' + k, str(v))
 
 
 @pytest.fixture(scope='session')

@@ -128,15 +128,40 @@ def test_two_gpus_over_rccl_report_the_same_monitors():
     assert a['monitors'] == dict(b['monitors'], collectives_in_timed_region=0)
 
 
-def test_every_default_leg_runs_and_carries_a_roofline():
+def test_every_default_leg_runs_and_carries_a_roofline(tmp_path):
     """The default command at 1/50 of the instance counts: no leg may end in an "error" key (round
-    2's C6 leg did, unnoticed) and every leg states its roofline."""
+    2's C6 leg did, unnoticed) and every leg states its roofline.  The stdout line is the COMPACT
+    object (round 4's full line of 22 KB was not taken by the driver's parser): under 6 000 bytes,
+    every key of the contract, a dtype on every leg; the full objects are in --full-out."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    full_path = str(tmp_path / 'bench_full.json')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--scale', '0.02',
                           '--steps', '2', '--warmup', '1', '--min-seconds', '0', '--max-pretrain',
-                          '24'], capture_output=True, text=True, timeout=1500, env=env)
+                          '24', '--full-out', full_path], capture_output=True, text=True, timeout=1500,
+                         env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    r = _line(out.stdout)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(line) == 1 and out.stdout.strip() == line[0], out.stdout[-2000:]
+    assert len(line[0]) < 6000, len(line[0])
+    c = json.loads(line[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline',
+                'pretraining', 'young_agents', 'other_configs'):
+        assert key in c, key
+    for key in ('bound', 'limiter', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel',
+                'algorithmic_bytes_per_env_step', 'issue'):
+        assert key in c['roofline'], key
+    assert c['roofline']['issue']['valu_per_step'] > 0
+    assert c['cpu_baseline']['value'] > 0 and c['cpu_baseline']['cores'] == 1
+    assert c['cpu_baseline']['kind'] == 'port' and c['cpu_baseline']['unit'] == 'env-steps/s'
+    assert 'workload' in c['config'] and 'model' not in c['config']
+    for name, leg in c['other_configs'].items():
+        assert set(leg) >= {'value', 'unit', 'dtype', 'bound', 'frac'}, (name, leg)
+        assert leg['dtype'] in ('f32', 'f64'), (name, leg)
+    r = json.load(open(full_path))
+    assert c['value'] == pytest.approx(r['value'], rel=1e-5)
+    assert c['roofline']['frac'] == pytest.approx(r['roofline']['frac'], rel=1e-5)
+    assert set(c['other_configs']) == set(r['other_configs'])
     assert r['metric'].startswith('gridworld env-steps/sec') and r['n_gpus'] == 1
     assert r['cpu_baseline']['value'] > 0 and r['cpu_baseline']['cores'] == 1
     roof = r['roofline']

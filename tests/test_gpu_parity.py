@@ -1502,6 +1502,70 @@ def test_full_size_c3_sample_and_conservation(torch_cuda):
     assert finished + running == n * launches * budget
 
 
+def test_full_size_c3_trained_agents_vs_oracle(torch_cuda):
+    """C3 in the state the headline is TIMED in: bench.py's own launches (65 536 instances, 512 env
+    steps each, 50 planning updates per step) until the kernel reports that >= 95 % of the planning
+    batches it draws are evaluated (~29 000 steps per instance; young agents skip most batches and
+    that is all the two-launch test above sees), then two more launches — 32 instances spread over
+    the range against the C oracle run for the same steps: Q, the model's three tables, the
+    digest, state / step / trial and the three stream counters, bit for bit
+    (agent/dyna_q.py:140-215, :275-330, memory/dyna_q.py:122-157)."""
+    torch = torch_cuda
+    import bench
+    from oracle import c_oracle
+    n = 65536
+    cfg = dict(bench.CONFIGS['C3'])
+    env, agent = bench.build_agent('C3', cfg, n, 0, torch.device('cuda', 0))
+    runner = bench.Runner(cfg, env, agent)
+    assert runner.describe()['kernel'] == runner._lib.TAB_KERNEL_PWG
+    per_launch = n * cfg['env_steps_per_launch']
+    launches, frac = 0, 0.0
+    while frac < cfg['train_until'] and launches < 96:
+        for _ in range(7):
+            runner.launch()
+        b0 = int(agent.batches_done.item())
+        runner.launch()               # (the fraction of ONE launch, as bench.py measures it)
+        launches += 8
+        frac = (int(agent.batches_done.item()) - b0) / per_launch
+    assert frac >= cfg['train_until'], 'pre-training did not reach the full-work state: %.3f' % frac
+    for _ in range(2):
+        runner.launch()
+    launches += 2
+    steps = launches * cfg['env_steps_per_launch']
+    assert agent.env_steps() == n * steps
+    ids = np.unique(np.concatenate([np.arange(0, n, 2179), [1, 63, 64, n - 1]]))[:32]
+    assert len(ids) == 32
+    w = _oracle_world(env.worlds)
+    sel = torch.as_tensor(ids, device='cuda')
+    q = agent._q[sel].cpu().numpy().astype(np.float64)
+    inst = agent.inst[sel].cpu().numpy()
+    raw = agent.M.table[sel].cpu().numpy()
+    m_r = (raw & 0xFFFFFFFF).astype(np.uint32).view(np.float32).astype(np.float64)
+    m_s = ((raw >> 32) & 0xFFFF).astype(np.int64)
+    m_t = ((raw >> 48) & 1).astype(np.int64)
+    trained = 0
+    for k, g in enumerate(ids):
+        o = c_oracle.TabOracle(w, 1, c_oracle.AG_DYNAQ, env.seed, True, instance_base=int(g))
+        for _ in range(launches):
+            o.run(0x7fffffff, cfg['steps_per_trial'], cfg['batch'],
+                  step_budget=cfg['env_steps_per_launch'])
+        assert np.array_equal(q[k], o.Q[0]), g
+        assert np.array_equal(m_r[k], o.MR[0]) and np.array_equal(m_s[k], o.MS[0]), g
+        assert np.array_equal(m_t[k], o.MT[0]), g
+        for col, key in ((0, 'state'), (1, 'step'), (2, 'trial'), (3, 'ctr_env'), (4, 'ctr_policy'),
+                         (5, 'ctr_memory')):
+            assert int(inst[k, col]) == int(o.inst[key][0]), (g, key)
+        trained += int(np.count_nonzero(o.Q[0]) > 512)
+    assert trained >= 24, 'the sampled instances are not trained agents'
+    # the digest the planning lanes read agrees with the table after 30 000 steps of updates
+    fresh = torch.empty_like(agent.M.index[sel])
+    from cobel_amd import _lib
+    _lib.check(_lib.lib().cobel_model_index_build(_lib.ptr(agent.M.table[sel].contiguous()),
+                                                  _lib.ptr(fresh), len(ids), 1024, None))
+    torch.cuda.synchronize()
+    assert torch.equal(fresh, agent.M.index[sel])
+
+
 def test_full_size_c2_sample_and_conservation(torch_cuda):
     """C2 at 65 536 x 5x5 (lane-per-instance kernel): 1 024 instances bit-exact against the oracle,
     conservation of steps and trials over all of them."""
@@ -1614,12 +1678,12 @@ def test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, 
     kernel: the form of the step cobel_dqn_replay picks by itself (None), or one of the two pinned
     (COBEL_DEBUG_DQN_KERNEL: parameters staged in LDS / weight operands streamed from memory)."""
     if kernel:
-        os.environ['COBEL_DEBUG_DQN_KERNEL'] = kernel
+        os.environ['COBEL_DEBUG'], os.environ['COBEL_DEBUG_DQN_KERNEL'] = '1', kernel
         try:
             return test_fused_dqn_replay_equals_torch_path(torch_cuda, dtype_name, n_in, ddqn, None,
                                                            f32_atol)
         finally:
-            del os.environ['COBEL_DEBUG_DQN_KERNEL']
+            del os.environ['COBEL_DEBUG_DQN_KERNEL'], os.environ['COBEL_DEBUG']
     torch = torch_cuda
     import bench
     from cobel_amd.network import TorchNetwork
@@ -1708,6 +1772,7 @@ def test_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, golden, monkeypatch, 
     pinned — the batch is read through the ring slots in both."""
     torch = torch_cuda
     if kernel:
+        monkeypatch.setenv('COBEL_DEBUG', '1')
         monkeypatch.setenv('COBEL_DEBUG_DQN_KERNEL', kernel)
     from cobel_amd.agent import DQN
     from cobel_amd.interface import Topology
@@ -1881,6 +1946,7 @@ def test_dyna_dqn_two_kernel_loop_equals_torch_loop(torch_cuda, monkeypatch, ker
     library picks for 20 one-hot inputs in float64 (streaming) or the parameter-staging one pinned."""
     torch = torch_cuda
     if kernel:
+        monkeypatch.setenv('COBEL_DEBUG', '1')
         monkeypatch.setenv('COBEL_DEBUG_DQN_KERNEL', kernel)
     import bench
     from cobel_amd.agent import DynaDQN

@@ -91,6 +91,7 @@ def test_global_q_waves_against_the_oracle():
 
 
 def _sliced(monkeypatch, slices, limit=None, **args):
+    monkeypatch.setenv('COBEL_DEBUG', '1')
     if slices is not None:
         monkeypatch.setenv('COBEL_DEBUG_PWG_SLICES', slices)
     if limit is not None:
@@ -100,6 +101,7 @@ def _sliced(monkeypatch, slices, limit=None, **args):
     finally:
         monkeypatch.delenv('COBEL_DEBUG_PWG_SLICES', raising=False)
         monkeypatch.delenv('COBEL_DEBUG_PWG_XCCLIMIT', raising=False)
+        monkeypatch.delenv('COBEL_DEBUG', raising=False)
 
 
 def test_slices_of_an_instances_steps_equal_whole_instances(monkeypatch):
@@ -131,3 +133,35 @@ def test_queues_without_an_xcd_of_their_own_are_claimed(monkeypatch):
     single = _sliced(monkeypatch, '128,64,64', limit=0, **args)
     _same(plain, masked)
     _same(plain, single)
+
+
+def test_experiment_variables_need_the_master_switch(monkeypatch):
+    """A stray COBEL_DEBUG_* variable in a production environment changes nothing: the library
+    reads them only under COBEL_DEBUG=1 (the suite itself runs without it, tests/conftest.py)."""
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld([make_obstacle_maze(32, 32, 1234)], n_envs=700, seed=SEED,
+                    device=torch.device('cuda', 0))
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    agent._bind(env)
+    agent._env_in(env)
+    flags = _lib.F_LEARN | agent._policy_in(agent.policy, env, False)
+    agent.monitors.reserve(64, 700, False)
+
+    def describe():
+        return agent.describe_launch(env, agent.policy, flags, 0x7fffffff, 60, 64, 50)
+
+    assert 'COBEL_DEBUG' not in __import__('os').environ
+    plain = describe()
+    assert plain['kernel'] == _lib.TAB_KERNEL_PWG
+    monkeypatch.setenv('COBEL_DEBUG_LDS_PAD', '1024')
+    monkeypatch.setenv('COBEL_DEBUG_PWG_SLICES', '1,63')
+    assert describe() == plain                       # ignored without the master switch
+    monkeypatch.setenv('COBEL_DEBUG', '1')
+    padded = describe()                              # (an occupancy experiment: the padded kernel)
+    assert padded['kernel'] == _lib.TAB_KERNEL_WPI_INDEX and padded != plain
+    monkeypatch.setenv('COBEL_DEBUG', 'yes')         # only exactly "1" switches them on
+    assert describe() == plain
