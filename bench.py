@@ -292,10 +292,17 @@ def run_grid_search(device, runs=16):
         ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(arrays['epsilon']),
                    learning_rate=arrays['learning_rate'], gamma=arrays['gamma'])
         ag.track_instances = True
+        # HIP events around the launch itself (train() also uploads the parameter arrays and
+        # reserves the monitors: host work and copies that are not the kernel's)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        launch = ag._launch
+
+        def timed_launch(*a, **k):
+            e0.record()
+            launch(*a, **k)
+            e1.record()
+        ag._launch = timed_launch
         ag.train(env, trials, steps, batch)
-        e1.record()
         lat = ag.monitors.lat_trace[:, :trials].double().mean(dim=1).cpu().numpy()
         stats['env_steps'] += ag.env_steps()
         stats['batches'] += int(ag.batches_done.item())

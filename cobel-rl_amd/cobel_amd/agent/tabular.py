@@ -130,8 +130,10 @@ class TabularAgent(FusedAgent):
         """Waits for this agent's launches and raises ``CobelHipError`` if a sliced launch of the
         persistent-workgroup kernel gave up waiting for a ring entry (``cobel_tab_scratch_check``:
         a lost producer wavefront ends in an error, not in a hung GPU)."""
-        _lib.check(_lib.lib().cobel_tab_scratch_check(
-            _lib.ptr(self._scratch), self._scratch.numel() * 4, _lib.current_stream(self.device)))
+        scratch = getattr(self, '_scratch', None)     # (SR / SFMA keep their own tables: no slices)
+        if scratch is not None:
+            _lib.check(_lib.lib().cobel_tab_scratch_check(
+                _lib.ptr(scratch), scratch.numel() * 4, _lib.current_stream(self.device)))
 
     def env_steps(self) -> int:
         self.check_launches()
