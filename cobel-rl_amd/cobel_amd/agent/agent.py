@@ -344,7 +344,12 @@ class FusedAgent(Agent):
         self._seed, self._instance_base = interface.seed, interface.instance_base
         if self.n_states is None:
             self.n_states = interface.handle.n_states
-            self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
+            # (a mask assigned before the first training run is kept: the reference's agents take
+            #  theirs as an attribute set after construction, dyna_q.py:134-136)
+            if self.action_mask is None:
+                self.action_mask = np.ones((self.n_states, self.n_actions), dtype=bool)
+            assert np.shape(self.action_mask) == (self.n_states, self.n_actions), \
+                'action_mask must be (%d, %d)' % (self.n_states, self.n_actions)
             # the key an agent's table is indexed by: the pose, or (pre-rendered observations) the
             # flattened observation components in order
             keys = interface.observation_key_table() if hasattr(interface, 'observation_key_table') \
@@ -381,7 +386,11 @@ class FusedAgent(Agent):
     def _mask_bits(self):
         m = np.asarray(self.action_mask, dtype=bool).reshape(self.n_states, self.n_actions)
         assert m.any(axis=1).all(), 'The action mask masks all actions!'
-        bits = (m * (1 << np.arange(self.n_actions))).sum(axis=1).astype(np.uint8)
+        # (one byte per state up to eight actions, one 32-bit word beyond: cobel_hip.h)
+        bits = (m * (1 << np.arange(self.n_actions, dtype=np.int64))).sum(axis=1)
+        bits = bits.astype(np.uint8 if self.n_actions <= 8 else np.uint32)
+        if self.n_actions > 8:
+            bits = bits.view(np.int32)
         return torch.as_tensor(bits, device=self.device)
 
     def _policy_in(self, pol, interface, test: bool) -> int:

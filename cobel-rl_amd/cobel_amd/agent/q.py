@@ -46,13 +46,20 @@ class QAgent(TabularAgent):
         self.log_budget_bytes = 4 << 30
         self._log_now = True
 
+    def _log_words(self) -> int:
+        """``COBEL_LOG_WORDS``: 64-bit words per logged experience (two where states and action
+        do not fit beside the reward in one)."""
+        return 2 if ((self.n_actions > 8 and self.n_states > 8192) or self.n_states > 16384) else 1
+
     def reserve_replay(self, entries: int) -> None:
-        """Make room for ``entries`` logged experiences per instance (8 B each)."""
+        """Make room for ``entries`` logged experiences per instance (8 B each; 16 B in worlds
+        beyond 16 384 states, or beyond 8 192 with more than eight actions)."""
         if entries <= self._log_cap:
             return
-        new = torch.zeros((self.n_envs, entries), dtype=torch.int64, device=self.device)
+        w = self._log_words()
+        new = torch.zeros((self.n_envs, entries * w), dtype=torch.int64, device=self.device)
         if self._log is not None:
-            new[:, : self._log_cap] = self._log
+            new[:, : self._log_cap * w] = self._log
         self._log, self._log_cap = new, entries
 
     @property
@@ -61,6 +68,13 @@ class QAgent(TabularAgent):
         if self._log is None:
             return []
         n = int(self.inst[0, _lib.I_LOG_LEN].item())
+        if self._log_words() == 2:   # {reward, action | nonterminal << 8}, {state, next state}
+            raw = self._log[0, :2 * n].cpu().numpy().reshape(n, 2)
+            rew = (raw[:, 0] & 0xFFFFFFFF).astype('uint32').view('float32')
+            meta = (raw[:, 0] >> 32) & 0xFFFFFFFF
+            return [{'state': (int(w & 0xFFFFFFFF),), 'action': int(m & 0xFF), 'reward': float(r),
+                     'next_state': (int((w >> 32) & 0xFFFFFFFF),), 'terminal': int((m >> 8) & 1)}
+                    for r, m, w in zip(rew, meta, raw[:, 1])]
         raw = self._log[0, :n].cpu().numpy()
         lo = (raw & 0xFFFFFFFF).astype('uint32').view('float32')
         hi = (raw >> 32) & 0xFFFFFFFF
@@ -92,7 +106,7 @@ class QAgent(TabularAgent):
         assert batch_size >= 0     # (above _lib.MAX_BATCH: the general kernel, any size)
         self._bind(interface)
         used = int(self.inst[:, _lib.I_LOG_LEN].max().item())
-        need = (used + trials * steps) * 8 * self.n_envs
+        need = (used + trials * steps) * 8 * self._log_words() * self.n_envs
         self._log_now = bool(self.log_experiences) or (
             self.log_experiences is None and (need <= self.log_budget_bytes
                                               or (used + trials * steps) <= self._log_cap))

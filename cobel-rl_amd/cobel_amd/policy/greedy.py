@@ -18,10 +18,15 @@ from .policy import Policy
 def _mask_bits(mask, n: int, device, actions: int = 4):
     if mask is None:
         return None
-    m = torch.as_tensor(np.asarray(mask), device=device).reshape(n, actions).to(torch.int32)
+    m = torch.as_tensor(np.asarray(mask), device=device).reshape(n, actions).to(torch.int64)
     assert bool((m.sum(dim=1) > 0).all()), 'The action mask masks all actions!'
-    w = (1 << torch.arange(actions, dtype=torch.int32, device=device))
-    return (m * w).sum(dim=1).to(torch.uint8).contiguous()
+    w = (1 << torch.arange(actions, dtype=torch.int64, device=device))
+    bits = (m * w).sum(dim=1)
+    # (one byte per row up to eight actions, one 32-bit word beyond: cobel_hip.h)
+    if actions <= 8:
+        return bits.to(torch.uint8).contiguous()
+    # (the low words of the little-endian int64 sums)
+    return bits.contiguous().view(torch.int32)[::2].contiguous()
 
 
 class EpsilonGreedy(Policy):
@@ -46,8 +51,6 @@ class EpsilonGreedy(Policy):
         single = vals.dim() == 1
         A = int(vals.shape[-1])
         assert 1 <= A <= _lib.MAX_ACTIONS, 'up to %d actions' % _lib.MAX_ACTIONS
-        if mask is not None and A > 8:
-            raise NotImplementedError('action masks are one byte per row: up to eight actions')
         vals = vals.reshape(-1, A).to(device=device, dtype=torch.float32).contiguous()
         n = vals.shape[0]
         bits = _mask_bits(mask, n, device, A)

@@ -43,6 +43,8 @@ struct gen_args {
 // up to four actions (the layout of the fast kernels), nonterminal << 31 up to eight, and beyond
 // eight actions (up to 32; worlds of at most 8 192 states) s | ns << 13 | action << 26 |
 // nonterminal << 31.
+// (worlds whose states or actions do not fit the packed word — cobel_hip.h COBEL_LOG_WORDS — keep
+//  TWO words per entry: {f32 reward, action | nonterminal << 8}, {state, next state})
 __device__ __forceinline__ uint64_t log_pack_n(float r, uint32_t s, uint32_t a, uint32_t ns,
                                                uint32_t nt, int A) {
   const uint32_t hi = A <= 8 ? (s | (ns << 14) | (a << 28) | (nt << (A <= 4 ? 30 : 31)))
@@ -53,6 +55,15 @@ __device__ __forceinline__ uint64_t log_pack_n(float r, uint32_t s, uint32_t a, 
 }  // namespace
 
 namespace {
+
+// The action mask of row i (bit a = action a allowed; policy/greedy.py:79-81): one byte per row in
+// worlds of up to eight actions, one 32-bit word per row beyond (the AMAX = 16 / 32 instantiations).
+template <int AMAX>
+__device__ __forceinline__ uint32_t mask_word(const uint8_t* mask, int i) {
+  if (!mask) return 0xffffffffu;
+  if (AMAX > 8) return reinterpret_cast<const uint32_t*>(mask)[i];
+  return (uint32_t)mask[i];
+}
 
 template <typename V, int AMAX>
 __global__ __launch_bounds__(256) void k_eps_greedy_n(const V* __restrict__ values,
@@ -67,8 +78,7 @@ __global__ __launch_bounds__(256) void k_eps_greedy_n(const V* __restrict__ valu
 #pragma unroll
   for (int a = 0; a < AMAX; ++a) v[a] = a < A ? values[(size_t)i * A + a] : (V)0;
   double p[AMAX];
-  const int act = cobel_eps_greedy_select_n<V, AMAX>(v, A, mask ? (uint32_t)mask[i] : 0xffffffffu,
-                                                     u[i], eps, p);
+  const int act = cobel_eps_greedy_select_n<V, AMAX>(v, A, mask_word<AMAX>(mask, i), u[i], eps, p);
   action_out[i] = (uint8_t)act;
   if (probs_out)
     for (int a = 0; a < A; ++a) probs_out[(size_t)i * A + a] = p[a];
@@ -84,9 +94,8 @@ int eps_greedy_n(const V* values, const uint8_t* mask, const double* u, double e
   COBEL_REQUIRE(n >= 0, COBEL_E_RANGE, "%s: n = %d", who, n);
   COBEL_REQUIRE(n_actions >= 1 && n_actions <= COBEL_MAX_ACTIONS, COBEL_E_UNSUPPORTED,
                 "%s: %d actions (1..%d are served)", who, n_actions, COBEL_MAX_ACTIONS);
-  COBEL_REQUIRE(!mask || n_actions <= 8, COBEL_E_UNSUPPORTED,
-                "%s: action masks are one byte per row (up to eight actions), got %d actions", who,
-                n_actions);
+  COBEL_REQUIRE(!mask || n_actions <= 8 || ((uintptr_t)mask & 3u) == 0, COBEL_E_ARG,
+                "%s: the masks of a %d-action row are 32-bit words, 4-byte aligned", who, n_actions);
   if (n == 0) return COBEL_OK;
   const dim3 grid((n + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
@@ -264,8 +273,10 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
   uint64_t* const model = AGENT == COBEL_AGENT_DYNAQ ? G.r.model + (size_t)i * S * A : nullptr;
   uint16_t* const mindex =
       (AGENT == COBEL_AGENT_DYNAQ && G.r.model_index) ? G.r.model_index + (size_t)i * S * A : nullptr;
-  uint64_t* const rlog =
-      (AGENT == COBEL_AGENT_Q && G.r.replay_log) ? G.r.replay_log + (size_t)i * G.r.log_cap : nullptr;
+  const bool wide = COBEL_LOG_WORDS(A, S) == 2;
+  uint64_t* const rlog = (AGENT == COBEL_AGENT_Q && G.r.replay_log)
+                             ? G.r.replay_log + (size_t)i * G.r.log_cap * (wide ? 2 : 1)
+                             : nullptr;
 
   auto next_of = [&](int s, int a) -> int {
     return G.rec ? (int)G.rec[wbase + s].next[a] : (int)G.next_n[(wbase + s) * A + a];
@@ -335,9 +346,9 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     float r;
     uint32_t nt;
   };
-  struct rec_t {       // a drawn index and the 64-bit record found there
+  struct rec_t {       // a drawn index and the 64-bit record found there (wide logs: two)
     uint32_t idx;
-    uint64_t bits;
+    uint64_t bits, bits2;
   };
   // (slot k of a prefetched row holds action k; beyond A the last action — or, when rows are loaded
   //  two values at a time, the last PAIR — once more)
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
         [&](int j) -> rec_t {
           const uint32_t idx =
               cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, SA);
-          return rec_t{idx, model[idx]};
+          return rec_t{idx, model[idx], 0ull};
         },
         [&](const rec_t& rc) -> upd_t {
           const uint32_t hi = (uint32_t)(rc.bits >> 32);
@@ -447,8 +458,8 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
     for (int a = 0; a < AMAX; ++a) qv[a] = a < A ? Q[(size_t)state * A + a] : 0.0f;
     const double u = cobel_draw_u01(cp, 0u, g, pol_stream, seed);
     cp += 1u;
-    const int a = cobel_eps_greedy_select_n<float, AMAX>(
-        qv, A, amask ? (uint32_t)amask[state] : 0xffffffffu, u, eps, nullptr);
+    const int a = cobel_eps_greedy_select_n<float, AMAX>(qv, A, mask_word<AMAX>(amask, state), u,
+                                                         eps, nullptr);
     int ns;
     if (G.succ_off) {   // the successor is drawn from the row of sas (gridworld.py:119-123): one
                         // double of the env stream, at the counter the trial starts share
@@ -483,7 +494,13 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
         td_online = td;
       }
       if (rlog && loglen < (uint32_t)G.r.log_cap) {   // q.py:213
-        rlog[loglen] = log_pack_n(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt, A);
+        if (wide) {
+          rlog[2u * loglen] = (uint64_t)__builtin_bit_cast(uint32_t, r) |
+                              ((uint64_t)((uint32_t)a | (nt << 8)) << 32);
+          rlog[2u * loglen + 1u] = (uint64_t)(uint32_t)state | ((uint64_t)(uint32_t)ns << 32);
+        } else {
+          rlog[loglen] = log_pack_n(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt, A);
+        }
         loglen += 1u;
       }
     }
@@ -514,10 +531,14 @@ __global__ __launch_bounds__(64) void k_tab_general(const gen_args G) {
               [&](int j) -> rec_t {
                 const uint32_t idx =
                     cobel_draw_bounded(cm, (uint32_t)j, g, COBEL_STREAM_MEMORY, seed, loglen);
-                return rec_t{idx, rlog[idx]};
+                if (wide) return rec_t{idx, rlog[2u * idx], rlog[2u * idx + 1u]};
+                return rec_t{idx, rlog[idx], 0ull};
               },
               [&](const rec_t& rc) -> upd_t {
                 const uint32_t hi = (uint32_t)(rc.bits >> 32);
+                if (wide)
+                  return upd_t{(int)(uint32_t)rc.bits2, (int)(hi & 0xffu), (int)(rc.bits2 >> 32),
+                               __builtin_bit_cast(float, (uint32_t)rc.bits), (hi >> 8) & 1u};
                 if (AMAX > 8 && A > 8)   // (s | ns << 13 | action << 26 | nonterminal << 31)
                   return upd_t{(int)(hi & 0x1fffu), (int)((hi >> 26) & 31u), (int)((hi >> 13) & 0x1fffu),
                                __builtin_bit_cast(float, (uint32_t)rc.bits), (hi >> 31) & 1u};
@@ -595,12 +616,9 @@ int cobel_tab_general_launch(const cobel_world* world, const cobel_tab_run_t& r,
   int lpb = 64;
   while (lpb > 8 && (long long)r.n < 8192ll * lpb) lpb >>= 1;
   const dim3 grid((unsigned)((r.n + lpb - 1) / lpb));
-  COBEL_REQUIRE(G.A <= 8 || !(r.flags & COBEL_F_MASK_ACTIONS), COBEL_E_UNSUPPORTED,
-                "cobel_tab_run: action masks are one byte per state (up to eight actions), the world "
-                "has %d", G.A);
-  COBEL_REQUIRE(G.A <= 8 || !r.replay_log || G.S <= 8192, COBEL_E_UNSUPPORTED,
-                "cobel_tab_run: the replay log of a world with %d actions holds states below 8 192, "
-                "the world has %d", G.A, G.S);
+  COBEL_REQUIRE(G.A <= 8 || !(r.flags & COBEL_F_MASK_ACTIONS) || ((uintptr_t)r.action_mask & 3u) == 0,
+                COBEL_E_ARG, "cobel_tab_run: the action masks of a %d-action world are 32-bit words, "
+                "4-byte aligned", G.A);
 #define COBEL_GENERAL(AGENT)                                                                     \
   do {                                                                                           \
     if (G.A <= 8) hipLaunchKernelGGL((k_tab_general<AGENT, 8>), grid, dim3(lpb), 0, st, G);      \

@@ -656,7 +656,7 @@ static const size_t kLdsLimit = 160 * 1024;
 extern "C" int cobel_sr_init(float* sr, uint16_t* trans, float* rewards, int32_t n,
                              int32_t n_states, void* stream) {
   COBEL_REQUIRE(sr && trans && rewards, COBEL_E_ARG, "cobel_sr_init: NULL table");
-  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 4096, COBEL_E_RANGE,
+  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 65535, COBEL_E_RANGE,
                 "cobel_sr_init: bad sizes n=%d S=%d", n, n_states);
   if (n == 0) return COBEL_OK;
   hipLaunchKernelGGL(k_sr_init, dim3(8192), dim3(256), 0, (hipStream_t)stream, sr, trans, rewards,
@@ -672,9 +672,6 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
                 world->n_actions);
   COBEL_REQUIRE(world && run, COBEL_E_ARG, "cobel_sr_run: NULL world/run");
   const cobel_sr_run_t& r = *run;
-  COBEL_REQUIRE(!world->succ_off || !r.param_index, COBEL_E_UNSUPPORTED,
-                "cobel_sr_run: per-instance parameter sets on a world whose transition rows are "
-                "distributions");
   COBEL_REQUIRE(r.sr && r.trans && r.rewards && r.inst, COBEL_E_ARG,
                 "cobel_sr_run: sr, trans, rewards and inst are required");
   COBEL_REQUIRE(((uintptr_t)r.sr & 15u) == 0 && ((uintptr_t)r.inst & 7u) == 0, COBEL_E_ARG,
@@ -693,9 +690,12 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   const int leaves = count_leaves(S);
   size_t lds = sr_lds_bytes(S, leaves, occ);
   lds += cobel_debug_lds_pad(lds, kLdsLimit);   // (occupancy experiments only)
-  COBEL_REQUIRE(S <= 4096 && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
-                "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu)", S, lds,
-                kLdsLimit);
+  // (what bounds the state count is the LDS of ONE workgroup: six rows of S values and the leaf
+  //  sums — 6 336 states, e.g. 79 x 79; the reference's own tensors, agent/sr.py:130-135, are 2.6 GB
+  //  per agent there)
+  COBEL_REQUIRE(leaves <= kMaxLeaves && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
+                "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu) and %d leaf "
+                "sums (limit %d)", S, lds, kLdsLimit, leaves, kMaxLeaves);
   if (r.n == 0) return COBEL_OK;
   // Worlds with at most eight rewarded states and up to 1 024 states (every builder of the reference):
   // the value rows collapse to a few elements each, see sr_wave.hip.
@@ -718,6 +718,12 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (S % 4) == 0;
   if (world->succ_off) {   // the successor is drawn: the row-streaming kernel without its prefetch
+    if (r.param_index) {
+      if (vec) return occ ? launch_sr<true, true, false, true, true>(A, lds, st)
+                          : launch_sr<true, false, false, true, true>(A, lds, st);
+      return occ ? launch_sr<false, true, false, true, true>(A, lds, st)
+                 : launch_sr<false, false, false, true, true>(A, lds, st);
+    }
     if (vec) return occ ? launch_sr<true, true, false, false, true>(A, lds, st)
                         : launch_sr<true, false, false, false, true>(A, lds, st);
     return occ ? launch_sr<false, true, false, false, true>(A, lds, st)
@@ -743,12 +749,14 @@ extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const
                                    int32_t n_states, void* stream) {
   COBEL_REQUIRE(sr && trans && rewards && states && q_out, COBEL_E_ARG,
                 "cobel_sr_retrieve_q: NULL argument");
-  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 4096, COBEL_E_RANGE,
+  COBEL_REQUIRE(n >= 0 && n_states > 0 && n_states <= 65535, COBEL_E_RANGE,
                 "cobel_sr_retrieve_q: bad sizes");
   if (n == 0) return COBEL_OK;
   const int leaves = count_leaves(n_states);
   const size_t lds = sr_lds_bytes(n_states, leaves, false);
-  COBEL_REQUIRE(lds <= kLdsLimit, COBEL_E_UNSUPPORTED, "cobel_sr_retrieve_q: LDS %zu", lds);
+  COBEL_REQUIRE(leaves <= kMaxLeaves && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
+                "cobel_sr_retrieve_q: %d states need %zu B of LDS and %d leaf sums", n_states, lds,
+                leaves);
   hipStream_t st = (hipStream_t)stream;
   if ((n_states % 4) == 0 && ((uintptr_t)sr & 15u) == 0) {
     if (lds > 64 * 1024)

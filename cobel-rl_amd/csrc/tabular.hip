@@ -1302,8 +1302,6 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   COBEL_REQUIRE(r.trial_cap >= 0 && r.log_cap >= 0, COBEL_E_RANGE, "cobel_tab_run: negative cap");
   COBEL_REQUIRE(!r.param_index || (r.param_sets && r.n_param_sets > 0), COBEL_E_ARG,
                 "cobel_tab_run: param_index given without parameter sets");
-  COBEL_REQUIRE(r.agent != COBEL_AGENT_Q || world->n_states <= 16384, COBEL_E_UNSUPPORTED,
-                "cobel_tab_run: replay records address at most 16384 states");
   // Runs outside what the wavefront kernels are built for — an action count other than four
   // (hexagonal topologies), transition rows that are distributions (the successor is drawn),
   // more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take

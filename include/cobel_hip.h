@@ -39,8 +39,14 @@ extern "C" {
 #define COBEL_E_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. table exceeds LDS)   */
 
 #define COBEL_ACTIONS 4 /* gridworld / 4-neighbour topology action count (gridworld.py:86) */
-#define COBEL_MAX_ACTIONS 32 /* largest action count of cobel_world_create_n (hexagonal topology: 6);
-                               action masks (one byte per row) exist up to eight actions */
+#define COBEL_MAX_ACTIONS 32 /* largest action count of cobel_world_create_n (hexagonal topology: 6).
+                               Action masks (bit a = action a allowed, policy/greedy.py:79-81) are
+                               one byte per row in worlds of up to eight actions and one 32-bit
+                               word per row (4-byte aligned) in worlds of nine to 32 */
+/* 64-bit words per entry of a QAgent's replay log (cobel_tab_run_t.replay_log) in a world of A
+ * actions and S states: ONE packed word while states and action fit beside the reward, TWO where
+ * they do not — the reference's memory (agent/q.py:213) is a list of tuples of any size. */
+#define COBEL_LOG_WORDS(A, S) ((((A) > 8 && (S) > 8192) || (S) > 16384) ? 2 : 1)
 
 /* Random streams: Philox-4x32-10, key = (seed lo, seed hi), ctr = (block, sub, instance, stream).
  * Each stream is consumed through a per-instance draw counter c:
@@ -196,10 +202,11 @@ COBEL_API int cobel_eps_greedy_f64(const double* values /* [dev] [N][4] */,
                                    void* stream);
 
 /* The same selection over rows of n_actions values (1..COBEL_MAX_ACTIONS; mask bit a = action a
- * allowed, NULL beyond eight actions): action spaces other than four, e.g. the six neighbours of a
- * hexagonal Topology. */
+ * allowed: bytes up to eight actions, 32-bit words beyond): action spaces other than four, e.g. the
+ * six neighbours of a hexagonal Topology. */
 COBEL_API int cobel_eps_greedy_n(const float* values /* [dev] [N][n_actions] */,
-                                 const uint8_t* mask /* [dev] [N] or NULL */,
+                                 const uint8_t* mask /* [dev] [N] bytes (n_actions <= 8) or
+                                                        32-bit words, or NULL */,
                                  const double* u /* [dev] [N] */, double epsilon,
                                  uint8_t* action_out /* [dev] [N] */,
                                  double* probs_out /* [dev] [N][n_actions] or NULL */, int32_t n,
@@ -288,17 +295,19 @@ typedef struct {
                             kept in sync by the kernel.  When present the planning kernel reads
                             it from HBM/L2 instead of holding a copy in LDS: nine instances per
                             CU instead of six.                                                 */
-  uint64_t* replay_log;  /* Q: [N][log_cap] packed experiences (q.py:213), or NULL (needed for
-                            batch > 0).  Every learning step appends one while there is room,
-                            also at batch 0 (the reference's memory grows whether it replays or
-                            not):
+  uint64_t* replay_log;  /* Q: [N][log_cap][COBEL_LOG_WORDS(actions, states)] experiences
+                            (q.py:213), or NULL (needed for batch > 0).  Every learning step
+                            appends one while there is room, also at batch 0 (the reference's
+                            memory grows whether it replays or not).  One word per entry:
                             lo = f32 reward, hi = s | ns << 14 | action << 28 | nonterminal << 30
                             (worlds of five to eight actions: nonterminal << 31; of nine to 32
                             actions, at most 8 192 states: s | ns << 13 | action << 26 |
-                            nonterminal << 31)                                                */
+                            nonterminal << 31).  Two words per entry (more than 16 384 states, or
+                            more than eight actions and more than 8 192 states): word 0 lo = f32
+                            reward, hi = action | nonterminal << 8; word 1 lo = s, hi = ns      */
   int32_t* inst;         /* [N][COBEL_I_WORDS]                                               */
-  const uint8_t* action_mask; /* [S] masks (bit a = action a) shared by all instances, or NULL;
-                                 worlds of up to eight actions                               */
+  const uint8_t* action_mask; /* [S] masks (bit a = action a) shared by all instances, or NULL:
+                                 bytes in worlds of up to eight actions, 32-bit words beyond */
   /* monitors (any may be NULL) */
   unsigned long long* lat_sum;  /* [trial_cap] sum over instances of logs['steps']           */
   unsigned long long* lat_cnt;  /* [trial_cap] instances that finished that trial            */

@@ -377,8 +377,7 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
 def test_more_than_eight_actions(torch_cuda, A):
     """Nine to 32 neighbours per node (interface/topology.py:110-112 takes any count): the wide
     instantiations of the general kernel — QAgent with log replay against the restatement of the
-    reference's loop, the decoded replay memory, epsilon-greedy rows against NumPy, and the two
-    things that stay refused there (action masks, logged replay beyond 8 192 states)."""
+    reference's loop, the decoded replay memory, epsilon-greedy rows against NumPy."""
     torch = torch_cuda
     from cobel_amd import _lib
     from cobel_amd.agent import QAgent
@@ -439,8 +438,13 @@ def test_more_than_eight_actions(torch_cuda, A):
         c = np.cumsum(p)
         assert np.array_equal(probs[k].cpu().numpy(), p)
         assert int(act[k].item()) == int(np.searchsorted(c / c[-1], u[k], side='right'))
-    # still refused beyond eight actions: action masks (one byte per row)
-    mask = torch.ones(200, dtype=torch.uint8, device='cuda')
-    rc = _lib.lib().cobel_eps_greedy_n(_lib.ptr(dv), _lib.ptr(mask), _lib.ptr(du), 0.3, _lib.ptr(act),
-                                       None, 200, A, None)
-    assert rc == _lib.E_UNSUPPORTED
+    # beyond eight actions the masks are 32-bit words (round 5; tests/test_gpu_lifted.py): all ones
+    # changes nothing, a misaligned pointer is refused
+    mask = torch.full((201,), -1, dtype=torch.int32, device='cuda')
+    act2 = torch.empty(200, dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().cobel_eps_greedy_n(_lib.ptr(dv), _lib.ptr(mask), _lib.ptr(du), 0.3,
+                                             _lib.ptr(act2), None, 200, A, None))
+    assert torch.equal(act, act2)
+    rc = _lib.lib().cobel_eps_greedy_n(_lib.ptr(dv), mask.data_ptr() + 1, _lib.ptr(du), 0.3,
+                                       _lib.ptr(act2), None, 200, A, None)
+    assert rc == _lib.E_ARG
