@@ -51,17 +51,26 @@ __host__ __device__ __forceinline__ int padded(int S) {
   return (S + (((S + 127) >> 7) << 3) + 3) & ~3;
 }
 
-struct sr_plan {
-  uint16_t leaf_start[kMaxLeaves];
-  uint8_t leaf_len[kMaxLeaves];
-  uint8_t op_dst[kMaxLeaves], op_src[kMaxLeaves];
+template <int MAXL, typename IDX>
+struct sr_plan_t {
+  uint16_t leaf_start[MAXL];
+  uint8_t leaf_len[MAXL];
+  IDX op_dst[MAXL], op_src[MAXL];
+  typedef IDX idx_t;
   int n_leaves, n_ops;
   int balanced;  // 1: n_leaves in {1, 2, 4, 8}, all leaves 128 long -> butterfly combine
 };
+typedef sr_plan_t<kMaxLeaves, uint8_t> sr_plan;
+// Worlds whose six rows do not fit one workgroup's LDS (more than 6 336 states; BIG kernels): the
+// rows are read where they lie, the plan and the leaf sums are all the LDS holds — up to 65 535
+// states (the 16-bit state ids of a world handle).
+constexpr int kMaxLeavesBig = 1024;
+typedef sr_plan_t<kMaxLeavesBig, uint16_t> sr_plan_big;
 
 // NumPy pairwise_sum recursion (n <= 128: leaf; else split at n/2 rounded down to a multiple
 // of 8), flattened: leaves in address order plus the post-order list of "dst += src" combines.
-__device__ void build_plan(sr_plan* p, int S, int* stack /* 64 ints of LDS scratch */) {
+template <typename PLAN>
+__device__ void build_plan(PLAN* p, int S, int* stack /* 64 ints of LDS scratch */) {
   int* const st_start = stack;
   int* const st_n = stack + 16;
   int* const st_phase = stack + 32;
@@ -96,8 +105,8 @@ __device__ void build_plan(sr_plan* p, int S, int* stack /* 64 ints of LDS scrat
       st_n[top] = n - n2;
       st_phase[top] = 0;
     } else {
-      p->op_dst[no] = (uint8_t)st_left[top];
-      p->op_src[no] = (uint8_t)ret;
+      p->op_dst[no] = (typename PLAN::idx_t)st_left[top];
+      p->op_src[no] = (typename PLAN::idx_t)ret;
       ++no;
       ret = st_left[top];
       --top;
@@ -110,9 +119,11 @@ __device__ void build_plan(sr_plan* p, int S, int* stack /* 64 ints of LDS scrat
 
 // V = pairwise_sum_k(row[k] * rw[k]) by one wave; row and rw are in padded LDS layout.
 // Returns the value in every lane.
+// (PADDED: row and rw in the padded LDS layout; else plain arrays, e.g. in global memory)
+template <bool PADDED = true, typename PLAN = sr_plan>
 __device__ __forceinline__ float wave_pairwise_dot(const float* row, const float* rw,
-                                                   const sr_plan* plan, float* leafsum,
-                                                   int lane) {
+                                                   const PLAN* plan, float* leafsum, int lane) {
+  auto phys = [](int e) -> int { return PADDED ? e + ((e >> 7) << 3) : e; };
   const int k = lane & 7;
   const int nl = plan->n_leaves;
   for (int l0 = 0; l0 < nl; l0 += 8) {
@@ -187,6 +198,7 @@ struct sr_lds {
   float* rw;
   float* rows;
   sr_plan* plan;
+  sr_plan_big* plan_big;   // BIG kernels (no rows, no reward vector in LDS)
   float* leafsum;  // [4][LS], LS = leaf_stride(leaves)
   float* V;        // [4]
   uint64_t* thr;   // [48] epsilon-greedy thresholds, entry t * 3 + k (cobel_policy.h)
@@ -222,6 +234,29 @@ __device__ __forceinline__ sr_lds carve(unsigned char* base, int S, int leaves) 
   off += 384;
   L.occ = reinterpret_cast<uint32_t*>(base + off);
   return L;
+}
+
+// BIG kernels: leaf sums, values, thresholds, the plan and 64 ints for building it.
+__device__ __forceinline__ sr_lds carve_big(unsigned char* base, int S, int leaves) {
+  sr_lds L;
+  L.PS = S;
+  L.LS = leaf_stride(leaves);
+  L.rows = nullptr;
+  L.rw = nullptr;
+  L.plan = nullptr;
+  L.occ = nullptr;
+  size_t off = 0;
+  L.leafsum = reinterpret_cast<float*>(base + off);
+  off += (size_t)4 * L.LS * 4;
+  L.V = reinterpret_cast<float*>(base + off);
+  off += 32;
+  L.thr = reinterpret_cast<uint64_t*>(base + off);
+  off += 384;
+  L.plan_big = reinterpret_cast<sr_plan_big*>(base + off);
+  return L;
+}
+size_t sr_lds_bytes_big(int leaves) {
+  return (size_t)4 * leaf_stride(leaves) * 4 + 32 + 384 + ((sizeof(sr_plan_big) + 15) & ~(size_t)15) + 256;
 }
 
 size_t sr_lds_bytes(int S, int leaves, bool occ) {
@@ -261,12 +296,16 @@ __device__ __forceinline__ uint32_t next_of(uint32_t w0, uint32_t w1, int a) {
 // trial starts share, as cobel_env_step_draw and the general tabular kernel), first successor whose
 // cumulative probability exceeds it; the record of the state entered is then fetched, not taken
 // from the prefetched four.
-template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false>
+// BIG: more states than six rows of them fit the LDS (VEC and PRE off): every row is read where
+// it lies — the value rows by the dot products, SR[s] and SR[ns] by the update, the reward
+// estimate too —, same arithmetic, same order of the pairwise sums.
+template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false, bool BIG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_sr(
     const sr_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  static_assert(!BIG || (!VEC && !PRE), "BIG kernels stream rows element by element");
   const int S = A.S;
-  const sr_lds L = carve(lds_raw, S, A.leaves);
+  const sr_lds L = BIG ? carve_big(lds_raw, S, A.leaves) : carve(lds_raw, S, A.leaves);
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
   const uint32_t g = A.r.instance_base + (uint32_t)i;
@@ -278,11 +317,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   float* const Rg = A.r.rewards + (size_t)i * S;
   uint32_t* const occ = L.occ;  // only if OCC
 
-  for (int e = t; e < S; e += 256) {
-    L.rw[phys(e)] = Rg[e];
-    if (OCC) occ[e] = 0u;
+  if (BIG) {
+    if (t == 0)
+      build_plan(L.plan_big, S, reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(L.plan_big) +
+                                                       ((sizeof(sr_plan_big) + 15) & ~(size_t)15)));
+  } else {
+    for (int e = t; e < S; e += 256) {
+      L.rw[phys(e)] = Rg[e];
+      if (OCC) occ[e] = 0u;
+    }
+    if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.rows));   // rows: free scratch here
   }
-  if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.rows));   // rows: free scratch here
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -351,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   // registers on purpose: an array carried around the loop is demoted to scratch memory)
   float4 pre0 = {0, 0, 0, 0}, pre1 = pre0, pre2 = pre0, pre3 = pre0;
   int pre_mode = 0;     // 0 load at the top of the step, 1 in `pre`, 2 in the LDS spare row 4
-  float* const spare = L.rows + (size_t)4 * L.PS;
+  float* const spare = BIG ? nullptr : L.rows + (size_t)4 * L.PS;
 
   while (true) {
     if (!(iflags & 1u)) {
@@ -370,9 +415,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
     // ---- retrieve_q (sr.py:302-306): wave a evaluates V[T[s][a]] ----------------------------
     const int my_row = t_of(tcur, wave);
-    float* const my_buf = L.rows + (size_t)wave * L.PS;
+    float* const my_buf = BIG ? SRg + (size_t)my_row * S : L.rows + (size_t)wave * L.PS;
     const int e0 = lane * 4;
-    if (PRE && pre_mode == 1) {
+    if (BIG) {
+      // (read in place by the dot product below)
+    } else if (PRE && pre_mode == 1) {
       if (e0 < S) *reinterpret_cast<float4*>(my_buf + phys(e0)) = pre0;
       if (e0 + 256 < S) *reinterpret_cast<float4*>(my_buf + phys(e0 + 256)) = pre1;
       if (e0 + 512 < S) *reinterpret_cast<float4*>(my_buf + phys(e0 + 512)) = pre2;
@@ -404,7 +451,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         dw[1] = (cp & 1u) ? pblk.w : pblk.y;
       }
     }
-    const float v = wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * L.LS, lane);
+    const float v = BIG ? wave_pairwise_dot<false>(my_buf, Rg, L.plan_big, L.leafsum + wave * L.LS, lane)
+                        : wave_pairwise_dot(my_buf, L.rw, L.plan, L.leafsum + wave * L.LS, lane);
     if (lane == 0) L.V[wave] = v;
     lds_barrier();
     const float4 q = *reinterpret_cast<const float4*>(L.V);
@@ -467,40 +515,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if (learn) {
       // rows already in LDS? (T[s][.] as it was when the value rows were loaded)
       int src_s = -1, src_ns = -1;
-#pragma unroll
-      for (int k2 = 3; k2 >= 0; --k2) {
-        const int rowk = t_of(tcur, k2);
-        if (rowk == state) src_s = k2;
-        if (rowk == ns) src_ns = k2;
-      }
-      if (ns == state && src_ns < 0) src_ns = 4;  // shares the spare row with SR[s]
       const bool need_ns = nt != 0u;
-      // (every wave is past its dot product — the barrier behind L.V — so the value rows that are
-      //  not a source of this update are free, and the spare row is no longer being copied from)
-      if (src_s < 0) {
-        load_row<VEC>(L.rows + (size_t)4 * L.PS, SRg + (size_t)state * S, S, t, 256);
-        src_s = 4;
-      }
-      if (need_ns && src_ns < 0) {
-        // first visit of (s, a): SR[ns] is not among the value rows yet; it goes into one of them
-        // that this update does not read
-        src_ns = src_s == 0 ? 1 : 0;
-        load_row<VEC>(L.rows + (size_t)src_ns * L.PS, SRg + (size_t)ns * S, S, t, 256);
+      if (!BIG) {
+#pragma unroll
+        for (int k2 = 3; k2 >= 0; --k2) {
+          const int rowk = t_of(tcur, k2);
+          if (rowk == state) src_s = k2;
+          if (rowk == ns) src_ns = k2;
+        }
+        if (ns == state && src_ns < 0) src_ns = 4;  // shares the spare row with SR[s]
+        // (every wave is past its dot product — the barrier behind L.V — so the value rows that are
+        //  not a source of this update are free, and the spare row is no longer being copied from)
+        if (src_s < 0) {
+          load_row<VEC>(L.rows + (size_t)4 * L.PS, SRg + (size_t)state * S, S, t, 256);
+          src_s = 4;
+        }
+        if (need_ns && src_ns < 0) {
+          // first visit of (s, a): SR[ns] is not among the value rows yet; it goes into one of them
+          // that this update does not read
+          src_ns = src_s == 0 ? 1 : 0;
+          load_row<VEC>(L.rows + (size_t)src_ns * L.PS, SRg + (size_t)ns * S, S, t, 256);
+        }
       }
       if (t == 0) {
         // sr.py:272-274 (float32): rewards[ns] += (r - rewards[ns]) * lr; transitions[s][a] = ns
-        const float old = L.rw[phys(ns)];
+        const float old = BIG ? Rg[ns] : L.rw[phys(ns)];
         const float d = r - old;
         const float upd = old + d * alpha_f;
-        L.rw[phys(ns)] = upd;
+        if (!BIG) L.rw[phys(ns)] = upd;
         Rg[ns] = upd;
         Tg[state * 4 + a] = (uint16_t)ns;
       }
       tcur = t_set(tcur, a, (uint32_t)ns);
       lds_barrier();
       // sr.py:276-284: td = e_s + gamma * (SR[ns] | e_ns) - SR[s];  SR[s] += lr * td
-      const float* const row_s = L.rows + (size_t)src_s * L.PS;
-      const float* const row_n = L.rows + (size_t)(need_ns ? src_ns : src_s) * L.PS;
+      // (BIG: both rows where they lie; an element of SR[s] is read and written by the same thread)
+      const float* const row_s = BIG ? SRg + (size_t)state * S : L.rows + (size_t)src_s * L.PS;
+      const float* const row_n = BIG ? SRg + (size_t)(need_ns ? ns : state) * S
+                                     : L.rows + (size_t)(need_ns ? src_ns : src_s) * L.PS;
       float* const out = SRg + (size_t)state * S;
       auto upd1 = [&](int e, float cs, float cn) -> float {
         double td = (e == state) ? 1.0 : 0.0;
@@ -528,7 +580,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
           if (PRE) *reinterpret_cast<float4*>(spare + phys(e)) = o;
         }
       } else {
-        for (int e = t; e < S; e += 256) out[e] = upd1(e, row_s[phys(e)], row_n[phys(e)]);
+        for (int e = t; e < S; e += 256) {
+          const int pe = BIG ? e : phys(e);
+          out[e] = upd1(e, row_s[pe], row_n[pe]);
+        }
       }
     }
 
@@ -544,7 +599,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     trew += (double)r;
     nsteps += 1ull;
     executed += 1ull;
-    if (OCC && t == 0) occ[ns] += 1u;
+    if (OCC && t == 0) {
+      if (BIG) atomicAdd(A.r.occupancy + (size_t)world * S + ns, 1ull);
+      else occ[ns] += 1u;
+    }
     if (ns != state) {   // (a bumping move stays in the row just updated)
       tleft = tcur;
       left_state = state;
@@ -576,7 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     else __syncthreads();
   }
 
-  if (OCC) {
+  if (OCC && !BIG) {
     __syncthreads();
     for (int e = t; e < S; e += 256) {
       const uint32_t c = occ[e];
@@ -597,17 +655,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 // q[i][a] = V[T[s_i][a]] for given states — predict_on_batch (sr.py:310-324).
-template <bool VEC>
+template <bool VEC, bool BIG = false>
 __global__ __launch_bounds__(256) void k_sr_q(const float* __restrict__ sr,
                                               const uint16_t* __restrict__ trans,
                                               const float* __restrict__ rewards,
                                               const int32_t* __restrict__ states,
                                               float* __restrict__ q_out, int S, int leaves) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const sr_lds L = carve(lds_raw, S, leaves);
+  const sr_lds L = BIG ? carve_big(lds_raw, S, leaves) : carve(lds_raw, S, leaves);
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = (int)blockIdx.x;
   const float* const SRg = sr + (size_t)i * S * S;
+  if (BIG) {
+    if (t == 0)
+      build_plan(L.plan_big, S, reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(L.plan_big) +
+                                                       ((sizeof(sr_plan_big) + 15) & ~(size_t)15)));
+    __syncthreads();
+    const int s = states[i];
+    const int row = (int)trans[((size_t)i * S + s) * 4 + wave];
+    const float v = wave_pairwise_dot<false>(SRg + (size_t)row * S, rewards + (size_t)i * S,
+                                             L.plan_big, L.leafsum + wave * L.LS, lane);
+    if (lane == 0) q_out[(size_t)i * 4 + wave] = v;
+    return;
+  }
   for (int e = t; e < S; e += 256) L.rw[phys(e)] = rewards[(size_t)i * S + e];
   if (t == 0) build_plan(L.plan, S, reinterpret_cast<int*>(L.rows + (size_t)4 * L.PS));
   __syncthreads();
@@ -637,14 +707,14 @@ __global__ __launch_bounds__(256) void k_sr_init(float* __restrict__ sr,
   }
 }
 
-template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false>
+template <bool VEC, bool OCC, bool PRE, bool PSETS, bool STOCH = false, bool BIG = false>
 int launch_sr(const sr_args& A, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     COBEL_HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE, PSETS, STOCH>),
+        reinterpret_cast<const void*>(&k_sr<VEC, OCC, PRE, PSETS, STOCH, BIG>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE, PSETS, STOCH>), dim3(A.r.n), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((k_sr<VEC, OCC, PRE, PSETS, STOCH, BIG>), dim3(A.r.n), dim3(256), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
@@ -690,12 +760,14 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   const int leaves = count_leaves(S);
   size_t lds = sr_lds_bytes(S, leaves, occ);
   lds += cobel_debug_lds_pad(lds, kLdsLimit);   // (occupancy experiments only)
-  // (what bounds the state count is the LDS of ONE workgroup: six rows of S values and the leaf
-  //  sums — 6 336 states, e.g. 79 x 79; the reference's own tensors, agent/sr.py:130-135, are 2.6 GB
-  //  per agent there)
-  COBEL_REQUIRE(leaves <= kMaxLeaves && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
-                "cobel_sr_run: %d states need %zu B of LDS per instance (limit %zu) and %d leaf "
-                "sums (limit %d)", S, lds, kLdsLimit, leaves, kMaxLeaves);
+  // More states than six rows of them fit one workgroup's LDS (6 336, e.g. 79 x 79): the BIG
+  // kernels, rows read where they lie — the reference's loop has no size limit (agent/sr.py:
+  // 109-140; its own tensors are 2.6 GB per agent there).
+  const bool big = leaves > kMaxLeaves || lds > kLdsLimit;
+  if (big) {
+    COBEL_REQUIRE(leaves <= kMaxLeavesBig, COBEL_E_RANGE, "cobel_sr_run: %d states", S);
+    lds = sr_lds_bytes_big(leaves);
+  }
   if (r.n == 0) return COBEL_OK;
   // Worlds with at most eight rewarded states and up to 1 024 states (every builder of the reference):
   // the value rows collapse to a few elements each, see sr_wave.hip.
@@ -716,6 +788,16 @@ extern "C" int cobel_sr_run(const cobel_world_t* world, const cobel_sr_run_t* ru
   A.succ_state = world->succ_state;
   A.succ_cdf = world->succ_cdf;
   hipStream_t st = (hipStream_t)stream;
+  if (big) {
+#define COBEL_SR_BIG(OC, PS)                                                        \
+  return world->succ_off ? launch_sr<false, OC, false, PS, true, true>(A, lds, st)  \
+                         : launch_sr<false, OC, false, PS, false, true>(A, lds, st)
+    if (occ && r.param_index) COBEL_SR_BIG(true, true);
+    if (occ) COBEL_SR_BIG(true, false);
+    if (r.param_index) COBEL_SR_BIG(false, true);
+    COBEL_SR_BIG(false, false);
+#undef COBEL_SR_BIG
+  }
   const bool vec = (S % 4) == 0;
   if (world->succ_off) {   // the successor is drawn: the row-streaming kernel without its prefetch
     if (r.param_index) {
@@ -754,10 +836,14 @@ extern "C" int cobel_sr_retrieve_q(const float* sr, const uint16_t* trans, const
   if (n == 0) return COBEL_OK;
   const int leaves = count_leaves(n_states);
   const size_t lds = sr_lds_bytes(n_states, leaves, false);
-  COBEL_REQUIRE(leaves <= kMaxLeaves && lds <= kLdsLimit, COBEL_E_UNSUPPORTED,
-                "cobel_sr_retrieve_q: %d states need %zu B of LDS and %d leaf sums", n_states, lds,
-                leaves);
   hipStream_t st = (hipStream_t)stream;
+  if (leaves > kMaxLeaves || lds > kLdsLimit) {   // (rows read where they lie, see cobel_sr_run)
+    COBEL_REQUIRE(leaves <= kMaxLeavesBig, COBEL_E_RANGE, "cobel_sr_retrieve_q: %d states", n_states);
+    hipLaunchKernelGGL((k_sr_q<false, true>), dim3(n), dim3(256), sr_lds_bytes_big(leaves), st, sr,
+                       trans, rewards, states, q_out, n_states, leaves);
+    COBEL_HIP_TRY(hipGetLastError());
+    return COBEL_OK;
+  }
   if ((n_states % 4) == 0 && ((uintptr_t)sr & 15u) == 0) {
     if (lds > 64 * 1024)
       COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sr_q<true>),

@@ -45,6 +45,51 @@ def test_sr_on_a_72x72_world_vs_oracle():
     assert q.shape[-1] == 4
 
 
+def test_sr_beyond_the_lds_rows_vs_oracle():
+    """81 x 81 = 6 561 states: six rows of them no longer fit one workgroup's LDS, the BIG kernels
+    read every row where it lies (same pairwise sums, same float64 row update).  Two instances
+    with visit counters against the C oracle, bit for bit; retrieve_q through its entry point
+    against the values the oracle's own walk selected by."""
+    import torch
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import c_oracle
+    side = 81
+    world = make_open_field(side, side, 0, 1)
+    world['starting_states'] = np.array([1, side, side + 1, side + 2, 2 * side + 2, side * side - 1])
+    n, trials, steps = 2, 5, 40
+    env = Gridworld(world, n_envs=n, seed=SEED)
+    ag = SR(env.observation_space, env.action_space, EpsilonGreedy(0.3), learning_rate=0.25, gamma=0.9)
+    ag.track_instances = True
+    ag.track_occupancy = True
+    ag.train(env, trials, steps)
+    torch.cuda.synchronize()
+    w = c_oracle.OracleWorld([dict(next=world['next'], reward=world['rewards'],
+                                   terminal=world['terminals'], starts=world['starting_states'])])
+    o = c_oracle.SROracle(w, n, SEED, True, alpha=0.25, gamma=0.9, epsilon=0.3, trial_cap=trials,
+                          occupancy=True)
+    o.run(trials, steps)
+    assert np.array_equal(ag._T.cpu().numpy().astype(np.int64), o.T)
+    assert np.array_equal(ag._rw.cpu().numpy().astype(np.float64), o.RW)
+    for i in range(n):
+        assert np.array_equal(ag._sr[i].cpu().numpy().astype(np.float64), o.SR[i]), i
+    inst = ag.inst.cpu().numpy()
+    assert np.array_equal(inst[:, 0], o.inst['state']) and np.array_equal(inst[:, 2], o.inst['trial'])
+    assert np.array_equal(inst[:, 3], o.inst['ctr_env'].astype(np.int32))
+    assert np.array_equal(ag.monitors.lat_trace.cpu().numpy()[:, :trials], o.lat_trace[:, :trials])
+    assert np.array_equal(ag.monitors.occupancy.cpu().numpy().astype(np.uint64), o.occupancy)
+    assert o.RW.any() and int((o.lat_trace[:, :trials] < steps - 1).sum()) > 0   # (a goal was met)
+    # retrieve_q: V[T[s][a]] = pairwise sum of SR[T[s][a]] * R in float32, NumPy's order
+    states = np.array([side + 1, 1])
+    q = ag.retrieve_q(states).cpu().numpy()
+    for i, s_ in enumerate(states):
+        for a in range(4):
+            row = o.SR[i][o.T[i][s_, a]].astype(np.float32)
+            assert q[i, a] == np.sum(row * o.RW[i].astype(np.float32)), (i, a)
+
+
 def test_sr_parameter_sets_on_a_world_of_distributions(golden):
     """Per-instance learning rate / gamma / epsilon together with drawn successors (refused until
     round 5): the instances of a parameter set equal a run with that set launch-wide."""
