@@ -179,7 +179,10 @@ class RefDynaQ(_Tabular):
 
 
 class RefQAgent(_Tabular):
-    """agent/q.py:115-354 for Discrete observations (dense zero table == lazy rows)."""
+    """agent/q.py:115-354 for Discrete observations (dense zero table == lazy rows).
+    `action_mask` / `mask_actions`: NOT in the reference's QAgent — the drop-in class offers the
+    mask its Dyna-Q has (dyna_q.py:134-136, :180 `select_action(Q[state], action_mask[state])`),
+    and this is that line restated so that the masked QAgent runs have a checker."""
 
     def __init__(self, n_states, n_actions, policy, replay_rng, learning_rate=0.9, gamma=0.8,
                  dtype=np.float64):
@@ -188,6 +191,8 @@ class RefQAgent(_Tabular):
         self.Q = np.zeros((n_states, n_actions), dtype=dtype)
         self.M: list = []
         self.current_trial = 0
+        self.action_mask = np.ones((n_states, n_actions), dtype=bool)
+        self.mask_actions = False
 
     def train(self, env, trials, steps=32, batch_size=32, trace=None):
         for _ in range(trials):
@@ -195,7 +200,8 @@ class RefQAgent(_Tabular):
             trial_reward = 0.0
             step = -1
             for step in range(steps):
-                action = self.policy.select_action(self.Q[state])
+                action = self.policy.select_action(
+                    self.Q[state], self.action_mask[state] if self.mask_actions else None)
                 ns, reward, end, _, _ = env.step(action)
                 exp = (state, action, float(reward), ns, 1 - end)
                 self.M.append(exp)

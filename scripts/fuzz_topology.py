@@ -1,5 +1,6 @@
-"""Randomised parity sweep for QAgent on Topology graphs with 1..8 actions (seeds from 10^6 on: 9..32)
-— random directed graphs
+"""Randomised parity sweep for QAgent on Topology graphs with 1..8 actions (seeds from 10^6 on: 9..32;
+from 2 * 10^6 on: 1..32 with a random action mask in half of the cases — bytes up to eight actions,
+32-bit words beyond) — random directed graphs
 (every node the same neighbour count, as `Topology` requires), random rewards / terminals / start
 nodes, replay batches 0..70 — against the NumPy restatement of the reference's loop
 (oracle/ref_loop.py, fed with the build's streams through TapeRNG).
@@ -29,6 +30,8 @@ def draw_case(seed: int) -> dict:
     A = int(r.choice([1, 2, 3, 4, 4, 5, 6, 6, 7, 8]))
     if seed >= 1_000_000:   # (seeds from 10^6 on: nine to 32 neighbours — the wide general kernels)
         A = int(r.choice([9, 10, 12, 13, 16, 17, 20, 24, 31, 32]))
+    if seed >= 2_000_000:   # (round 5: any count, masks)
+        A = int(r.choice([1, 2, 4, 6, 8, 9, 12, 16, 17, 31, 32]))
     nbr = r.integers(0, S, (S, A))
     stay = r.random((S, A)) < 0.2             # missing neighbours are the node itself
     nbr = np.where(stay, np.arange(S)[:, None], nbr)
@@ -41,7 +44,11 @@ def draw_case(seed: int) -> dict:
     starts = None
     if r.random() < 0.5:
         starts = sorted(set(int(x) for x in r.choice(free, int(r.integers(1, 5)))))
-    return dict(seed=seed, S=S, A=A, nbr=nbr, terminal=terminal, reward=reward, starts=starts,
+    mask = None
+    if seed >= 2_000_000 and r.random() < 0.5:
+        mask = r.random((S, A)) < 0.6
+        mask[np.arange(S), r.integers(0, A, S)] = True     # (never all actions masked)
+    return dict(seed=seed, S=S, A=A, nbr=nbr, terminal=terminal, reward=reward, starts=starts, mask=mask,
                 n=int(r.choice([1, 2, 64, 130])), base=int(r.choice([0, 3, 1 << 16])),
                 trials=int(r.integers(1, 6)), steps=int(r.integers(1, 41)),
                 batch=int(r.choice([0, 0, 1, 8, 24, 62, 63, 70])),
@@ -51,7 +58,8 @@ def draw_case(seed: int) -> dict:
 
 def describe(c: dict) -> str:
     return ('seed %(seed)d S=%(S)d A=%(A)d n=%(n)d base=%(base)d trials=%(trials)d steps=%(steps)d '
-            'B=%(batch)d a=%(alpha)g g=%(gamma)g e=%(eps)g second=%(second)d' % c)
+            'B=%(batch)d a=%(alpha)g g=%(gamma)g e=%(eps)g second=%(second)d' % c
+            + (' masked' if c.get('mask') is not None else ''))
 
 
 def run_case(c: dict):
@@ -73,6 +81,9 @@ def run_case(c: dict):
     ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(c['eps']),
                 learning_rate=c['alpha'], gamma=c['gamma'])
     ag.track_instances = True
+    if c.get('mask') is not None:
+        ag.mask_actions = True
+        ag.action_mask = c['mask'].copy()
     ag.train(env, c['trials'], c['steps'], c['batch'])
     if c['second']:
         ag.train(env, c['trials'], c['steps'], c['batch'])
@@ -90,6 +101,8 @@ def run_case(c: dict):
         pol = ref_loop.RefEpsilonGreedy(c['eps'], TapeRNG(SEED, g, STREAM_POLICY))
         ref = ref_loop.RefQAgent(S, A, pol, TapeRNG(SEED, g, STREAM_MEMORY), c['alpha'], c['gamma'],
                                  dtype=np.float32)
+        if c.get('mask') is not None:
+            ref.mask_actions, ref.action_mask = True, c['mask']
         tr = ref_loop.new_trace()
         ref.train(renv, c['trials'], c['steps'], c['batch'], trace=tr)
         if c['second']:

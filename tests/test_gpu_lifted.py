@@ -135,36 +135,6 @@ def _graph(S, A, seed):
     return nodes, nbr
 
 
-class _MaskedRefQ:
-    """oracle.ref_loop.RefQAgent with the action mask of the tabular agents (dyna_q.py:134-136,
-    :180: `policy.select_action(Q[state], action_mask[state])`) — the reference's own QAgent takes
-    none, the drop-in class offers the one its Dyna-Q has."""
-
-    def __new__(cls, *args, mask=None, **kw):
-        from oracle import ref_loop
-
-        class Masked(ref_loop.RefQAgent):
-            def train(self, env, trials, steps=32, batch_size=32, trace=None):
-                for _ in range(trials):
-                    state, _ = env.reset()
-                    step = -1
-                    for step in range(steps):
-                        action = self.policy.select_action(self.Q[state], mask[state])
-                        ns, reward, end, _, _ = env.step(action)
-                        exp = (state, action, float(reward), ns, 1 - end)
-                        self.M.append(exp)
-                        self._td(*exp)
-                        state = ns
-                        for i in self.rng.integers(0, len(self.M), batch_size):
-                            self._td(*self.M[i])
-                        if end:
-                            break
-                    self.current_trial += 1
-                    if trace is not None:
-                        trace['steps'].append(step)
-        return Masked(*args, **kw)
-
-
 @pytest.mark.parametrize('A,S', [(12, 40), (32, 64), (12, 9000), (9, 16384)])
 def test_masked_wide_action_rows_and_wide_replay_logs(A, S):
     """QAgent with log replay on random graphs: a 12- and a 32-action graph with an action mask
@@ -203,8 +173,8 @@ def test_masked_wide_action_rows_and_wide_replay_logs(A, S):
     for i in sorted({0, n // 2, n - 1}):
         renv = ref_loop.RefGridworld(tab, TapeRNG(SEED, i, STREAM_ENV))
         pol = ref_loop.RefEpsilonGreedy(0.2, TapeRNG(SEED, i, STREAM_POLICY))
-        ref = _MaskedRefQ(S, A, pol, TapeRNG(SEED, i, STREAM_MEMORY), 0.9, 0.9, dtype=np.float32,
-                          mask=mask)
+        ref = ref_loop.RefQAgent(S, A, pol, TapeRNG(SEED, i, STREAM_MEMORY), 0.9, 0.9, dtype=np.float32)
+        ref.mask_actions, ref.action_mask = True, mask
         tr = ref_loop.new_trace()
         ref.train(renv, trials, steps, B, trace=tr)
         assert np.array_equal(lat[i, :trials], tr['steps'])
