@@ -156,7 +156,8 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   // successor l % 4 of a packed record pair as bfe(bfi(sel, w1, w0), sh, 16).
   uint32_t succ_sel = (lane & 2) ? 0xffffffffu : 0u, succ_sh = (uint32_t)(lane & 1) * 16u;
   uint32_t SAv = SA;
-  asm volatile("" : "+v"(succ_sel), "+v"(succ_sh), "+v"(SAv));
+  uint32_t qlane = (uint32_t)(lane & 3);
+  asm volatile("" : "+v"(succ_sel), "+v"(succ_sh), "+v"(SAv), "+v"(qlane));
   auto succ_of = [&](uint32_t w0, uint32_t w1) -> uint32_t {
     return (((w1 & succ_sel) | (w0 & ~succ_sel)) >> succ_sh) & 0xffffu;
   };
@@ -479,19 +480,21 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
 
     // ---- everything this step reads from Q ----------------------------------------------------------
     const uint32_t succ = succ_of(cw0, cw1);
-    float4 qrow, srow;
+    float4 srow;
+    float qc;   // component lane % 4 of Q[state]: ONE compare gives the tie pattern, the maximum is two
+                // quad permutes away, and the chosen action's value a readlane
     float4 prow = {0.0f, 0.0f, 0.0f, 0.0f};   // QG, lane j < B: Q[ns_j] ...
     float pq = 0.0f;                           // ... and Q[s_j][a_j] of the pair it replays
     if (QG) {
       stores_done();   // (the previous step's planning stores, by other lanes of this wave)
-      qrow = Qg[state];
+      qc = Qgf[(uint32_t)state * 4u + qlane];
       srow = Qg[succ];
       if (lane < B && (iflags & 2u)) {
         prow = Qg[mg_cur & 0x3fffu];
         pq = Qgf[idx_cur];
       }
     } else {
-      qrow = Qs[state];
+      qc = Qf[(uint32_t)state * 4u + qlane];
       srow = Qs[succ];
     }
     const float smax = max4(srow);
@@ -499,9 +502,11 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     // ---- select (policy/greedy.py:40-88): integer thresholds of the tie pattern's CDF ---------------
     int a;
     {
-      const float m = max4(qrow);
-      const int t = (int)(((uint32_t)__ballot(qrow.x == m) & 1u) | ((uint32_t)__ballot(qrow.y == m) & 2u) |
-                          ((uint32_t)__ballot(qrow.z == m) & 4u) | ((uint32_t)__ballot(qrow.w == m) & 8u));
+      // (lanes 4k .. 4k + 3 hold the four values: maximum over the quad, tie pattern = the low four
+      //  bits of one ballot)
+      float m = fmaxf(qc, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp((int)fbits(qc), 0xB1, 0xf, 0xf, true)));
+      m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp((int)fbits(m), 0x4E, 0xf, 0xf, true)));
+      const int t = (int)((uint32_t)__ballot(qc == m) & 15u);
       const uint64_t K = cobel_u53(w0, w1);
       const unsigned long long passed = __ballot(thr_mine <= K);
       a = __popcll((passed >> (t * 3)) & 7ull);
@@ -544,7 +549,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     const uint32_t fresh_m = (uint32_t)ns | (nt << 14) | (fbits(Rn) ? 0x8000u : 0u);
     fix_sa = sa;
     fix_r = Rn;
-    const float q_sa = (a & 2) ? ((a & 1) ? qrow.w : qrow.z) : ((a & 1) ? qrow.y : qrow.x);
+    const float q_sa = __builtin_bit_cast(float, rl(fbits(qc), a));
     const float gnt = nt ? gamma_f : 0.0f;
     float td = r + gnt * ns_max;
     td = td - q_sa;
