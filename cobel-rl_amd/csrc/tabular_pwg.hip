@@ -504,8 +504,16 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     {
       // (lanes 4k .. 4k + 3 hold the four values: maximum over the quad, tie pattern = the low four
       //  bits of one ballot)
-      float m = fmaxf(qc, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp((int)fbits(qc), 0xB1, 0xf, 0xf, true)));
-      m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp((int)fbits(m), 0x4E, 0xf, 0xf, true)));
+      // (the permute fused into the maximum: the compiler keeps v_mov_b32_dpp and v_max_f32 apart)
+      float m;
+      // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
+      //  not look for hazards inside an asm block)
+      asm("s_nop 1\n\t"
+          "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+          : "=&v"(m)
+          : "v"(qc));
       const int t = (int)((uint32_t)__ballot(qc == m) & 15u);
       const uint64_t K = cobel_u53(w0, w1);
       const unsigned long long passed = __ballot(thr_mine <= K);
