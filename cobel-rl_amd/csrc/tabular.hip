@@ -609,7 +609,11 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     // Only four successors are possible, so lane k < 4 reads the Q row (and, for small worlds, the
     // world record) of next[state][k] now; once the action is known the chosen one is a readlane
     // away and the select -> step -> TD chain pays a single LDS round trip.
-    const float4 qrow = Qs[state];
+    // (lane l holds component l % 4 of Q[state]: ONE compare then gives the tie pattern — the low
+    //  four bits of its ballot —, the row's maximum is two fused quad permutes away, and Q[s][a] a
+    //  readlane: eight vector compares / selects and six scalar instructions less on the chain from
+    //  the LDS answer to the action; k_tab_pwg 12.10 -> 11.52 ms per C3 launch with the same change)
+    const float qc = reinterpret_cast<const float*>(Qs)[(uint32_t)state * 4u + (uint32_t)(lane & 3)];
     const uint32_t succ = next_of(cw0, cw1, lane & 3);
     const float4 srow = Qs[succ];
     const float smax = max4(srow);
@@ -624,18 +628,27 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     int a;
     if (mask_cur == 15u) {
       // integer thresholds of the tie pattern's CDF, held one per lane in thr_lo / thr_hi
-      const float m = max4(qrow);
-      // (the row is wave-uniform: each compare yields an all-or-nothing lane mask, and the tie
-      //  pattern is assembled from bit k of mask k on the scalar unit)
-      const int t = (int)(((uint32_t)__ballot(qrow.x == m) & 1u) | ((uint32_t)__ballot(qrow.y == m) & 2u) |
-                          ((uint32_t)__ballot(qrow.z == m) & 4u) | ((uint32_t)__ballot(qrow.w == m) & 8u));
+      // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
+      //  not look for hazards inside an asm block)
+      float m;
+      asm("s_nop 1\n\t"
+          "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+          : "=&v"(m)
+          : "v"(qc));
+      const int t = (int)((uint32_t)__ballot(qc == m) & 15u);
       // every lane e < 48 compares its own threshold (entry e = t * 3 + k) with the draw; the
       // three bits of this tie pattern in the ballot count the thresholds passed
       const uint64_t K = cobel_u53(w0, w1);
       const unsigned long long passed = __ballot(thr_mine <= K);
       a = __popcll((passed >> (t * 3)) & 7ull);
     } else {
-      a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qrow.x, qrow.y, qrow.z, qrow.w, mask_cur,
+      const float qx = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, qc), 0));
+      const float qy = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, qc), 1));
+      const float qz = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, qc), 2));
+      const float qw = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, qc), 3));
+      a = (int)rfl((uint32_t)cobel_eps_greedy_select_wave(qx, qy, qz, qw, mask_cur,
                                                           cobel_u01(w0, w1), ebb, lane));
     }
     STAMP(0);
@@ -738,7 +751,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         }
       }
       // online TD (agent/dyna_q.py:290-299), float32; Q[ns] and Q[s][a] were read above
-      const float q = (a & 2) ? ((a & 1) ? qrow.w : qrow.z) : ((a & 1) ? qrow.y : qrow.x);
+      const float q = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, qc), a));
       const float gnt = nt ? gamma_f : 0.0f;
       float td = r + gnt * ns_max;
       td = td - q;

@@ -350,7 +350,11 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     refresh();
     // ---- successors of the current state, and its own row -------------------------------------------
     enter_state(state);
-    const float4 qa = Qs[(uint32_t)state * 2u], qb = Qs[(uint32_t)state * 2u + 1u];
+    // (lane l holds value l % 8 of the padded row Q[state]: the row's maximum is three fused DPP
+    //  steps — two quad permutes and a half-row mirror —, the tie pattern the low eight bits of ONE
+    //  ballot and Q[s][a] a readlane, where eight compares, fifteen scalar instructions and seven
+    //  selects stood; as in k_tab_pwg / k_tab_wpi)
+    const float qc = Qf[(uint32_t)state * 8u + (uint32_t)(lane & 7)];
     smax = max8(Qs[sn * 2u], Qs[sn * 2u + 1u]);
     // ---- select --------------------------------------------------------------------------------------
     const int src_lane = 62 + (int)((cp >> 1) & 1u);
@@ -359,11 +363,18 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     cp += 1u;
     int a = 0;
     if (A > 1) {
-      const float m = max8(qa, qb);
-      const uint32_t t = ((uint32_t)__ballot(qa.x == m) & 1u) | ((uint32_t)__ballot(qa.y == m) & 2u) |
-                         ((uint32_t)__ballot(qa.z == m) & 4u) | ((uint32_t)__ballot(qa.w == m) & 8u) |
-                         ((uint32_t)__ballot(qb.x == m) & 16u) | ((uint32_t)__ballot(qb.y == m) & 32u) |
-                         ((uint32_t)__ballot(qb.z == m) & 64u) | ((uint32_t)__ballot(qb.w == m) & 128u);
+      float m;
+      // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
+      //  not look for hazards inside an asm block)
+      asm("s_nop 1\n\t"
+          "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+          : "=&v"(m)
+          : "v"(qc));
+      const uint32_t t = (uint32_t)__ballot(qc == m) & 255u;
       const uint64_t K = cobel_u53(w0, w1);
       const unsigned long long T = lane < A - 1 ? thr[(size_t)t * (A - 1) + lane] : ~0ull;
       a = __popcll(__ballot(lane < A - 1 && T <= K));
@@ -381,10 +392,7 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     uint64_t fresh_cur = 0;
     bool appended = false;
     if (learn) {
-      const float qrow[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-      float q_sa = qrow[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) q_sa = a == k ? qrow[k] : q_sa;
+      const float q_sa = __builtin_bit_cast(float, rl(fbits(qc), a));
       const float gnt = nt ? gamma_f : 0.0f;
       float td = r + gnt * ns_max;
       td = td - q_sa;
