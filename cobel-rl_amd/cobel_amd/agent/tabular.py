@@ -123,8 +123,15 @@ class TabularAgent(FusedAgent):
         if describe is not None:
             _lib.check(_lib.lib().cobel_tab_describe(interface.handle.ptr, C.byref(run), describe))
             return
+        # (`launch_events`: a pair of torch.cuda.Event recorded right around the library call —
+        #  bench.py times the kernel without the host's preparation of its arguments)
+        ev = getattr(self, 'launch_events', None)
+        if ev is not None:
+            ev[0].record()
         _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
                                             _lib.current_stream(self.device)))
+        if ev is not None:
+            ev[1].record()
 
     def check_launches(self) -> None:
         """Waits for this agent's launches and raises ``CobelHipError`` if a sliced launch of the
