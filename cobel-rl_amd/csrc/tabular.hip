@@ -1040,8 +1040,8 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
     cw0 = c.x;
     cw1 = c.y;
   }
-  int budget = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
-  unsigned long long executed = 0;
+  const int budget0 = A.r.step_budget > 0 ? A.r.step_budget : 0x7fffffff;
+  int budget = budget0;   // steps executed by this lane = budget0 - budget (two 64-bit counters less per step)
   bool done = !active;
 
   for (;;) {
@@ -1116,8 +1116,6 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
         e[5] = __builtin_bit_cast(int32_t, td_online);
       }
       trew += (double)r;
-      nsteps += 1ull;
-      executed += 1ull;
       const bool trial_over = end || (step + 1 >= A.r.steps_per_trial);
       state = ns;
       cw0 = nrec.x;
@@ -1165,10 +1163,11 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
     inst[COBEL_I_FLAGS] = (int32_t)iflags;
     if (LOG) inst[COBEL_I_LOG_LEN] = (int32_t)loglen;
     *reinterpret_cast<double*>(inst + COBEL_I_REWARD_LO) = trew;
-    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) = nsteps;
+    *reinterpret_cast<unsigned long long*>(inst + COBEL_I_STEPS_LO) =
+        nsteps + (unsigned long long)(budget0 - budget);
   }
   if (A.r.steps_done) {   // one atomic per wave
-    unsigned long long tot = executed;
+    unsigned long long tot = active ? (unsigned long long)(budget0 - budget) : 0ull;
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0 && tot) atomicAdd(A.r.steps_done, tot);
   }
