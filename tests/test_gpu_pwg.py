@@ -165,3 +165,37 @@ def test_experiment_variables_need_the_master_switch(monkeypatch):
     assert padded['kernel'] == _lib.TAB_KERNEL_WPI_INDEX and padded != plain
     monkeypatch.setenv('COBEL_DEBUG', 'yes')         # only exactly "1" switches them on
     assert describe() == plain
+
+
+def test_scratch_check_reports_a_raised_abort_word():
+    """cobel_tab_scratch_check: COBEL_OK on the area of a finished run, COBEL_E_HIP (CobelHipError)
+    once the abort word — what a sliced launch raises when a wave gives up waiting for a ring entry
+    — is set; a NULL / short area is never an error."""
+    from cobel_amd import _lib
+    out_agent = {}
+
+    def run():
+        from cobel_amd.agent import DynaQ
+        from cobel_amd.interface import Gridworld
+        from cobel_amd.misc.gridworld_tools import make_obstacle_maze
+        from cobel_amd.policy import EpsilonGreedy
+        env = Gridworld([make_obstacle_maze(32, 32, 1234)], n_envs=3400, seed=SEED,
+                        device=torch.device('cuda', 0))
+        agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+        agent.train(env, 1, 40, 50)       # (3 400 instances: a sliced launch of the PWG kernel)
+        out_agent['a'] = agent
+        return agent
+
+    agent = run()
+    assert 0 < agent.env_steps() <= 3400 * 40      # (env_steps() checks the area on the way)
+    agent.check_launches()
+    lib = _lib.lib()
+    st = _lib.current_stream(agent.device)
+    assert lib.cobel_tab_scratch_check(None, 0, st) == _lib.OK
+    assert lib.cobel_tab_scratch_check(_lib.ptr(agent._scratch), 16, st) == _lib.OK
+    agent._scratch[255] = 1                        # COBEL_TAB_SCRATCH_ABORT_WORD
+    with pytest.raises(Exception) as err:
+        agent.check_launches()
+    assert 'sliced launch' in str(err.value)
+    agent._scratch[255] = 0
+    agent.check_launches()
