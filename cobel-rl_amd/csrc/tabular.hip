@@ -629,7 +629,8 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     if (mask_cur == 15u) {
       // integer thresholds of the tie pattern's CDF, held one per lane in thr_lo / thr_hi
       // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
-      //  not look for hazards inside an asm block)
+      //  not look for hazards inside an asm block.  Every lane of the wave is active here — a
+      //  permute that reads a disabled lane leaves its destination unwritten)
       float m;
       asm("s_nop 1\n\t"
           "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"

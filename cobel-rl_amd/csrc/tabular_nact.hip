@@ -365,7 +365,8 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     if (A > 1) {
       float m;
       // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
-      //  not look for hazards inside an asm block)
+      //  not look for hazards inside an asm block.  Every lane of the wave is active here — a
+      //  permute that reads a disabled lane leaves its destination unwritten)
       asm("s_nop 1\n\t"
           "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
           "s_nop 1\n\t"
