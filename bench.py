@@ -384,21 +384,39 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
     (misc/topology_tools.py:175-272) — k_tab_wqn since round 4, one wavefront per instance with the
     tables in LDS (k_tab_general, one lane per instance, before); `dynaq_b100` = Dyna-Q
     on C3's mazes with 100 planning updates per step (agent/dyna_q.py:319-330 has no limit) — the
-    generic k_tab_wpi in two passes of <= 62 lanes."""
+    generic k_tab_wpi in two passes of <= 62 lanes; `wide_q` = QAgent with a replay batch of 32 and
+    an action mask on a random graph of 256 nodes with twelve neighbours each (interface/topology.py:
+    110-112 takes any count) — k_tab_general, one lane per instance with every table in L2: the
+    functional path, timed so that its price is on record."""
     from cobel_amd import _lib
     from cobel_amd.agent import DynaQ, QAgent
     from cobel_amd.interface import Gridworld, Topology
     from cobel_amd.misc.topology_tools import hexagonal
     from cobel_amd.policy import EpsilonGreedy
-    if which == 'hex_q':
-        nodes, starts = hexagonal(16)
+    if which in ('hex_q', 'wide_q'):
+        if which == 'hex_q':
+            nodes, starts = hexagonal(16)
+        else:
+            rg = np.random.default_rng(12)
+            nbr = rg.integers(0, 256, (256, 12))
+            nodes = {str(i): {'id': str(i), 'pose': np.array([float(i % 16), float(i // 16), 0., 0., 0., 0.]),
+                              'neighbors': [str(int(j)) for j in nbr[i]],
+                              'reward': 1.0 if i == 255 else 0.0, 'terminal': i == 255}
+                     for i in range(256)}
+            starts = None
         env = Topology(nodes, starts, n_envs=n, seed=SEED, device=device)
         agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
         batch, spt, A = 32, 100, int(env.action_space.n)
+        if which == 'wide_q':
+            agent.mask_actions = True
+            agent.action_mask = np.ones((256, 12), dtype=bool)
+            agent.action_mask[:, 11] = False            # (one neighbour of every node closed)
         agent._bind(env)
         agent.reserve_replay(env_steps * (launches + 2))
-        desc = ('QAgent (alpha .9, gamma .8, eps .1, replay batch 32 from the experience log) on a '
-                'hexagonal Topology of %d nodes, %d actions' % (len(nodes), A))
+        desc = ('QAgent (alpha .9, gamma .8, eps .1, replay batch 32 from the experience log%s) on a '
+                '%s of %d nodes, %d actions' % (', action mask' if which == 'wide_q' else '',
+                                                'hexagonal Topology' if which == 'hex_q' else 'random graph',
+                                                len(nodes), A))
         # online step: state r/w 8 + Q[s,:] 4A + next 2 + reward 4 + terminal 1 + Q[ns,:] 4A +
         # Q[s,a] write 4 + counters 16, log append 8; one replayed update: record 8 + Q[ns,:] 4A +
         # Q[s,a] RMW 8
@@ -439,13 +457,14 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
              _lib.TAB_KERNEL_WQN: 'k_tab_wqn'}
     kernel = names.get(what['kernel'], 'kernel %d' % what['kernel'])
     alg = b_step * steps + b_upd * batch * batches
-    if which == 'hex_q':
-        traffic = pmc_traffic_leg('general_hex_q', kernel) if n == 65536 else None
+    traffic = None
+    if which in ('hex_q', 'wide_q'):
+        traffic = pmc_traffic_leg('general_' + which, kernel) if n == 65536 else None
     roof = _hbm_roofline(alg / steps, steps / sec, kernel,
                          'latency' if what['kernel'] == _lib.TAB_KERNEL_GENERAL else 'issue',
                          '%d B per env step + %d B per replayed / planned update of the batches the '
                          'kernel evaluated (%d of %d drawn)' % (b_step, b_upd, batches, steps))
-    if which == 'hex_q' and traffic is not None:
+    if traffic is not None:
         roof['traffic'] = traffic
         roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC, profiles/)'
         roof['frac_measured'] = traffic / (sec / launches) / 1e9 / HBM_PEAK_GBS
@@ -525,6 +544,8 @@ class Runner:
         agent._bind(env)
         agent._env_in(env)
         self.flags = _lib.F_LEARN | agent._policy_in(agent.policy, env, False)
+        if getattr(agent, 'mask_actions', False):
+            self.flags |= _lib.F_MASK_ACTIONS
         agent.monitors.reserve(4096, agent.n_envs, False)
 
     def launch(self):
@@ -1112,7 +1133,7 @@ def main():
     ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
     ap.add_argument('--legs', default=None,
                     help='comma-separated subset of the legs behind --also (C5_f64, C5_f32, dyna_dqn, '
-                         'dyna_dsr, C1, grid_search, general_hex_q, general_dynaq_b100); default: all')
+                         'dyna_dsr, C1, grid_search, general_hex_q, general_wide_q, general_dynaq_b100); default: all')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -1184,6 +1205,7 @@ def main():
             ('C1', lambda: run_c1(device, not args.no_cpu_baseline)),
             ('grid_search', lambda: run_grid_search(device, 16 if args.scale == 1.0 else 4)),
             ('general_hex_q', lambda: run_general(device, 'hex_q', scaled(65536))),
+            ('general_wide_q', lambda: run_general(device, 'wide_q', scaled(65536))),
             ('general_dynaq_b100', lambda: run_general(device, 'dynaq_b100', scaled(65536))),
         ]
         if args.legs is not None:

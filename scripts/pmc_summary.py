@@ -25,7 +25,7 @@ import os
 import sys
 
 KERNELS = {'C3': 'k_tab_pwg', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma',
-           'general_hex_q': 'k_tab_wqn'}
+           'general_hex_q': 'k_tab_wqn', 'general_wide_q': 'k_tab_general<'}
 # bench.py times the LAST `--steps` (4) launches of each kernel; everything before them is untimed
 # warm-up (C3: the pre-training that takes the agents to the full-work state, C6: 40 launches)
 TIMED = 4
@@ -83,7 +83,7 @@ def main():
            'fetch_factor': factor, 'calibration': cal}
     for cfg, tag in KERNELS.items():
         names = [k for k in fetch if tag in k]
-        if cfg == 'general_hex_q' and not names:
+        if cfg.startswith('general_') and not names:
             continue          # (passes made without that leg)
         assert len(names) == 1 and names[0] in write, (cfg, names)
         f, w = fetch[names[0]][-TIMED:], write[names[0]][-TIMED:]   # the timed launches

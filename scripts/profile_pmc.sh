@@ -24,7 +24,7 @@ for w in $WHAT; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $O/r${R}_sq_b -o b --output-format csv -- $CMD > $O/r${R}_sq_b.json 2> $O/r${R}_sq_b.err
   echo "sq done";;
  traffic)
-  CMD="python3 bench.py --full --no-cpu-baseline --no-c5 --legs general_hex_q --min-seconds 0"
+  CMD="python3 bench.py --full --no-cpu-baseline --no-c5 --legs general_hex_q,general_wide_q --min-seconds 0"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/r${R}_pmc_fetch -o f --output-format csv -- $CMD > $O/r${R}_pmc_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/r${R}_pmc_write -o w --output-format csv -- $CMD > $O/r${R}_pmc_write.log 2>&1
   rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d $O/r${R}_pmc_req -o q --output-format csv -- $CMD > $O/r${R}_pmc_req.log 2>&1
