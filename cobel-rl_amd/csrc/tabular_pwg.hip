@@ -39,6 +39,8 @@ namespace {
 constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
 constexpr int kMaxGlobalWaves = 4;
 constexpr int kMaxSlices = 8;
+constexpr uint32_t kWholeTicket = 0x40000000u;
+constexpr uint32_t kWholeSlice = 0xffu;   // slice number of an instance that runs all its steps as one ticket
 // word of the scratch header a sliced launch raises when a wave gives up waiting for a ring entry
 // (COBEL_TAB_SCRATCH_ABORT_WORD in cobel_hip.h), and the polls (~1-2 us each) before it does
 constexpr uint32_t kAbortWord = COBEL_TAB_SCRATCH_ABORT_WORD;
@@ -58,6 +60,8 @@ struct pwg_args {
   // slices (n_slices > 1): an instance's steps of this call are cut into n_slices tickets
   int32_t n_slices;
   int32_t slice_steps[kMaxSlices];
+  uint32_t whole;        // sliced launches: instances per queue — its first ones — that run unsliced,
+                         // ONE ticket each (second counter of the queue), on the global-memory waves
   uint32_t* owner;       // [8] XCD (id + 1) that serves each queue, 0 = nobody yet
   uint32_t* tail;        // eight counters, 32 B apart: entries pushed onto each queue's ring
   uint32_t* ring;        // eight rings of ring_stride words: the tickets after a queue's first nq
@@ -755,12 +759,17 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
       while (k0 < 8u) {
         const uint32_t q = (x + k0) & 7u;
         const uint32_t nq = ((uint32_t)A.r.n + 7u - q) / 8u;
-        const uint32_t total = nq * (uint32_t)A.n_slices;
+        // (sliced launches: the queue's first nw instances run whole — tickets of counter 1 —, the
+        //  other ns in slices — counter 0: first slices, then the ring)
+        const uint32_t nw = sliced ? min(nq, A.whole) : 0u;
+        const uint32_t ns = nq - nw;
+        const uint32_t total = ns * (uint32_t)A.n_slices;
         uint32_t t = t_next;
         t_next = 0xffffffffu;
+        if (t >= total) t = 0xffffffffu;   // (drawn ahead, beyond the sliced tickets: the whole ones are left)
         if (t == 0xffffffffu) {
           t = 0x10000000u;
-          if (lane == 0 && total) {
+          if (lane == 0 && nq) {
             bool serve = true;
             if (sliced) {
               uint32_t o = __hip_atomic_load(A.owner + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -770,20 +779,39 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
               }
               serve = o == x + 1u;
             }
-            // a wave with Q in global memory needs about three times as long for a ticket: it
-            // leaves the last `reserve` tickets of a queue to the LDS waves, which finish them
-            // sooner than it would finish one
-            if (serve && !(qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT) + A.reserve >= total))
-              t = atomicAdd(A.queue + q * 8u, 1u);
+            if (serve) {
+              // A wave with Q in global memory needs two to three times as long for a ticket.  With
+              // whole instances set aside (nw > 0) those are all it draws; otherwise it leaves the
+              // last `reserve` tickets of a queue to the LDS waves, which finish them sooner than
+              // it would finish one.  The LDS waves draw slices first, left-over whole instances last.
+              if (qg && nw) {
+                const uint32_t b = atomicAdd(A.queue + q * 8u + 1u, 1u);
+                if (b < nw) t = kWholeTicket | b;
+              } else if (!(qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT) + A.reserve >= total)) {
+                t = atomicAdd(A.queue + q * 8u, 1u);
+                if (t >= total) {
+                  t = 0x10000000u;
+                  if (nw) {
+                    const uint32_t b = atomicAdd(A.queue + q * 8u + 1u, 1u);
+                    if (b < nw) t = kWholeTicket | b;
+                  }
+                }
+              }
+            }
           }
           t = rfl(t);
         }
+        if (t & kWholeTicket) {
+          i = (int)((t & 0xffffffu) * 8u + q);
+          sl = kWholeSlice;
+          break;
+        }
         if (t < total) {
-          if (t < nq) {
-            i = (int)(t * 8u + q);
+          if (t < ns) {
+            i = (int)((nw + t) * 8u + q);
           } else {
-            const uint32_t* const slot = A.ring + (size_t)q * A.ring_stride + (t - nq);
+            const uint32_t* const slot = A.ring + (size_t)q * A.ring_stride + (t - ns);
             // The entry is written by the wave that runs the predecessor slice — a few
             // milliseconds at most.  Should it never come (a producer that faulted or was
             // killed), the wait gives up after kRingSpinLimit polls (seconds), raises the
@@ -824,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
     if (i < 0) break;
     int budget = A.r.step_budget;
     if (A.n_slices > 1) {
-      const int slice = (int)(tstate >> 16);
+      const int slice = (int)(tstate >> 16);   // (kWholeSlice: all steps of the call)
 #pragma unroll
       for (int j = 0; j < kMaxSlices; ++j)
         if (j == slice) budget = A.slice_steps[j];
@@ -844,7 +872,7 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
       // trip to memory (an LDS wave: the global-memory waves look at the queue's length first)
       const uint32_t q = (uint32_t)i & 7u;
       const uint32_t sl1 = (tstate >> 16) + 1u;
-      const bool more = sl1 < (uint32_t)A.n_slices;
+      const bool more = sl1 < (uint32_t)A.n_slices;   // (kWholeSlice + 1 is not)
       uint32_t pos = 0u, t = 0xffffffffu;
       if (lane == 0) {
         if (more) pos = atomicAdd(A.tail + q * 8u, 1u);
@@ -912,15 +940,24 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
 
 // The slices of a launch (see k_tab_pwg).  A slice boundary costs an instance ~19 us on C3 (9.6 us
 // of ticket, prologue and write-back, the rest in steps that run slower while more tables are on
-// the move; scripts/experiments/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch:
-// measured on one MI355X (ms per launch of 512 steps; unsliced / best): 8 192 instances 1.96 / 1.76
-// with 320 + 128 + 64 (256 + 128 + 64 + 64: 1.80, 384 + 64 + 32 + 32: 1.88), 16 384: 3.30 / 3.26 with
-// 384 + 128, 32 768: 6.40 / 6.33 with 448 + 64; 65 536 is not sliced.
-static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, bool scratch,
-                       int32_t* steps /* [kMaxSlices] */) {
+// the move; scripts/experiments/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch.
+// Measured on one MI355X, C3, 13 waves on each of 256 CUs (ms per launch of 512 steps; unsliced /
+// planned): 32 768 instances 6.40 / 6.07 with 448 + 64, 16 384: 3.30 / 3.12 with 384 + 128; 65 536
+// is not sliced.
+// Between 1.75 and 3.5 instances per wave slot (5 900 .. 11 600 instances: what an eight-way split
+// of C3 leaves each GPU) the global-memory waves are kept out of the slices: a wave that keeps Q
+// in memory needs 1.0 of such a launch's 1.6 ms for ONE instance, so each of them runs exactly one,
+// whole, and the LDS waves share the others in slices of 384 + 128 (profiles/r05_sweeps.txt: 6 000 /
+// 7 000 / 8 192 / 10 000 / 11 000 instances 1.42 / 1.56 / 1.70 / 2.07 / 2.28 ms with everything in
+// slices of 320 + 128 + 64 -> 1.27 / 1.40 / 1.61 / 2.00 / 2.22; 5 400 and 12 000 gain nothing).
+// Measured and dropped there: giving the global-memory waves later slices on top (they share the
+// CU's issue slots with the LDS waves: 1.63), whole instances first for the LDS waves too (1.63-1.67).
+static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int nl, int ng, bool scratch,
+                       int32_t* steps /* [kMaxSlices] */, uint32_t* whole) {
   const char* const forced = cobel_debug_env("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
   for (int j = 0; j < kMaxSlices; ++j) steps[j] = 0;
   steps[0] = r.step_budget;
+  *whole = 0u;
   if (!scratch || grid < n_cu || r.step_budget < 64) return 1;
   if (forced) {
     int v[kMaxSlices] = {0}, k = 0, sum = 0;
@@ -938,7 +975,7 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, 
     }
     return 1;
   }
-  const double rounds = (double)r.n / ((double)grid * waves);
+  const double rounds = (double)r.n / ((double)grid * (nl + ng));
   const int b = r.step_budget;
   if (rounds >= 14.0 || rounds < 1.0) return 1;
   if (rounds >= 7.0) {
@@ -947,6 +984,13 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int waves, 
     return 2;
   }
   if (rounds >= 3.5) {
+    steps[1] = b / 4;
+    steps[0] = b - steps[1];
+    return 2;
+  }
+  if (rounds >= 1.75 && nl > 0 && ng > 0) {
+    // one whole instance per global-memory wave (a queue's share of them, rounded up)
+    *whole = (uint32_t)((ng * grid + 7) / 8);
     steps[1] = b / 4;
     steps[0] = b - steps[1];
     return 2;
@@ -990,8 +1034,13 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   A.owner = scratch ? base + 64 : base;
   A.tail = scratch ? base + 128 : base;
   A.ring = scratch ? base + 256 : base;
-  A.n_slices = plan_slices(r, grid, n_cu, waves, scratch, A.slice_steps);
+  A.n_slices = plan_slices(r, grid, n_cu, nl, ng, scratch, A.slice_steps, &A.whole);
   A.ring_stride = (uint32_t)((r.n + 7) / 8) * (uint32_t)(A.n_slices - 1);
+  {
+    const char* const w_env = cobel_debug_env("COBEL_DEBUG_PWG_WHOLE");   // (experiments, tests)
+    if (w_env) A.whole = (uint32_t)strtoul(w_env, nullptr, 0);
+    if (nl == 0 || A.n_slices < 2) A.whole = 0u;   // (nobody else would draw the slices)
+  }
   {
     const char* const m_env = cobel_debug_env("COBEL_DEBUG_PWG_XCCLIMIT");   // (tests)
     A.xcc_limit = m_env ? (uint32_t)atoi(m_env) & 7u : 7u;

@@ -67,6 +67,10 @@ def main():
     for kind, sl in (('LDS', slice(0, nl)), ('global', slice(nl, waves))):
         if sl.start >= waves:
             continue
+        e = end[:, sl].ravel()
+        print(kind, 'waves finish (us): percentiles 1 / 10 / 50 / 90 / 99 / max  %s;  idle before the last '
+              'wave ends: %.1f %% of the slot time' % ('  '.join('%.0f' % v for v in np.percentile(
+                  e, [1, 10, 50, 90, 99, 100])), 100 * (1 - e.mean() / end.max())))
         print(kind, 'waves finish (us) by XCD: ' + '  '.join(
             '%d: %.0f-%.0f (median %.0f)' % (x, end[:, sl][xcc[:, sl] == x].min(),
                                            end[:, sl][xcc[:, sl] == x].max(),

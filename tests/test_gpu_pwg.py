@@ -90,8 +90,10 @@ def test_global_q_waves_against_the_oracle():
         assert np.array_equal(out['q'][i], ref.Q), i
 
 
-def _sliced(monkeypatch, slices, limit=None, **args):
+def _sliced(monkeypatch, slices, limit=None, whole=None, **args):
     monkeypatch.setenv('COBEL_DEBUG', '1')
+    if whole is not None:
+        monkeypatch.setenv('COBEL_DEBUG_PWG_WHOLE', str(whole))
     if slices is not None:
         monkeypatch.setenv('COBEL_DEBUG_PWG_SLICES', slices)
     if limit is not None:
@@ -101,6 +103,7 @@ def _sliced(monkeypatch, slices, limit=None, **args):
     finally:
         monkeypatch.delenv('COBEL_DEBUG_PWG_SLICES', raising=False)
         monkeypatch.delenv('COBEL_DEBUG_PWG_XCCLIMIT', raising=False)
+        monkeypatch.delenv('COBEL_DEBUG_PWG_WHOLE', raising=False)
         monkeypatch.delenv('COBEL_DEBUG', raising=False)
 
 
@@ -115,11 +118,28 @@ def test_slices_of_an_instances_steps_equal_whole_instances(monkeypatch):
     auto = _run(0, **args)                                     # 320 + 128 + 64 by the plan
     odd = _sliced(monkeypatch, '300,7,100,64,41', **args)      # uneven slices
     one = _sliced(monkeypatch, '512', **args)                  # whole instances
+    # (a queue's first instances whole, on the global-memory waves — 425 = all of them, more than those
+    #  waves get through: the LDS waves take what is left —, the rest in slices)
+    mixed = [_sliced(monkeypatch, '300,7,100,64,41', whole=w, **args) for w in (1, 60, 150, 424, 425)]
     assert auto['kinds'] == {_lib.TAB_KERNEL_PWG} and plain['kinds'] == {_lib.TAB_KERNEL_WPI_INDEX}
     assert plain['q'].any() and plain['batches'] > 0 and plain['lat_cnt'].sum() > 0
     _same(plain, auto)
     _same(plain, odd)
     _same(plain, one)
+    for m in mixed:
+        _same(plain, m)
+
+
+def test_whole_instances_for_the_global_memory_waves_by_the_plan():
+    """1.5 .. 3.5 instances per wave slot (the shard an eight-way split of C3 leaves a GPU): by the
+    plan each global-memory wave runs one whole instance and the LDS waves share the rest in slices
+    (plan_slices, csrc/tabular_pwg.hip).  Same results as one wave per instance."""
+    from cobel_amd import _lib
+    args = dict(n=7001, side=32, seeds=[1234, 1235, 1236], launches=2, steps=256, spt=60)
+    plain = _run(_lib.F_NO_PWG, **args)
+    auto = _run(0, **args)
+    assert auto['kinds'] == {_lib.TAB_KERNEL_PWG} and plain['batches'] > 0
+    _same(plain, auto)
 
 
 def test_queues_without_an_xcd_of_their_own_are_claimed(monkeypatch):
