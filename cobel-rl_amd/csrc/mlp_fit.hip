@@ -94,6 +94,15 @@ __device__ __forceinline__ v4d mfma(double a, double b, v4d c) {
 __device__ __forceinline__ v4f mfma(float a, float b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ float uniform(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double uniform(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <typename T>
 struct adam_consts {
   T bc2_sqrt, step_size, one_m_b1, b2, one_m_b2, eps, wd, tau;
@@ -168,12 +177,13 @@ struct act_lds {
   T* h2;    // [32][66]  -> delta2
   T* q;     // [32][33]  outputs -> delta3, columns >= O zero
   T* qt;    // [32][NA]  DQN: Q_target(s'), NA <= 8 actions
-  int* aux; // [64]      DQN: row of each sample; DDQN: argmax_a Q_online(s')
+  int* aux; // [64]      DQN: row of each sample; the action taken in it
   T* cst;   // [2]       Adam's bias corrections of this step (computed by one wave)
+  T* tg;    // [32]      DQN: the Q-learning target of each sample
 };
 
 __host__ __device__ inline size_t fit_lds_elems() {
-  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kAMax + 64 + 2;
+  return 2 * (size_t)kB * kXRow + 2 * (size_t)kB * kRow + kB * kAMax + 64 + 2 + kB;
 }
 // forward only: the inputs sit where h2 will be written (read for the last time before that)
 __host__ __device__ inline size_t fwd_lds_elems() { return 2 * (size_t)kB * kRow; }
@@ -189,6 +199,7 @@ __device__ __forceinline__ act_lds<T> carve_fit(unsigned char* raw) {
   L.qt = p; p += kB * kAMax;
   L.aux = reinterpret_cast<int*>(p);
   L.cst = p + 64;
+  L.tg = p + 64 + 2;
   return L;
 }
 
@@ -575,12 +586,23 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     const T* const in_dense =
         R.in_table ? nullptr : (const T*)R.in_dense + (size_t)j * rows * D;
     for (int e = t; e < kB * kXRow; e += NT) L.q[e] = (T)0;
+    int my_action = 0, my_best = 0;
+    T my_reward = (T)0, my_nt = (T)0;
 
     if (DQN) {
       // ---- Q_target(s') [and the online network's choice among the next actions] ---------------
       forward_pass<T, false> tp;
       tp.request(tw1, tb1, tw2, tb2, tw3, tb3, D, O, wave, lane);
-      if (t < kB) L.aux[t] = A.slots ? A.slots[(size_t)j * kB + t] : t;
+      if (t < kB) {
+        const int sl = A.slots ? A.slots[(size_t)j * kB + t] : t;
+        L.aux[t] = sl;
+        // (the sample's action, reward and terminal flag, requested by the thread that will form
+        //  its target: three trips to memory that now start with the kernel's first ones)
+        const size_t row = (size_t)j * rows + sl;
+        my_action = (int)A.actions[row];
+        my_reward = ((const T*)A.rewards)[row];
+        my_nt = ((const T*)A.nonterminal)[row];
+      }
       lds_barrier();
       load_inputs<T, NT, true>(L.x, R.in_table, R.in_table ? A.next_index + (size_t)j * kB : nullptr,
                          R.in_table ? nullptr : (const T*)A.next_dense + (size_t)j * rows * D, slot,
@@ -612,7 +634,7 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
               bv = L.q[t * kXRow + a];
               best = a;
             }
-          L.aux[kB + t] = best;
+          my_best = best;
         }
       }
     }
@@ -624,6 +646,19 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     xin.store(L.x, t);
     lds_barrier();
     stamp(2);
+    if (DQN && t < kB) {
+      // new = r + (boot * nt) * gamma (the reference's operation order, agent/dqn.py:356-360); read by
+      // the output tiles two barriers further down
+      T boot;
+      if (A.ddqn) {
+        boot = L.qt[t * NA + my_best];
+      } else {
+        boot = L.qt[t * NA];
+        for (int a = 1; a < NA; ++a) boot = L.qt[t * NA + a] > boot ? L.qt[t * NA + a] : boot;
+      }
+      L.tg[t] = my_reward + (boot * my_nt) * (T)A.gamma;
+      L.aux[kB + t] = my_action;
+    }
 
     // ---- forward --------------------------------------------------------------------------------
     dense_relu<T, 8, 1>(o1, L.x, kXRow, L.h1, m0, n0, lane);
@@ -637,20 +672,11 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     __builtin_amdgcn_sched_barrier(0);
     // REFRESH: what the output layer's phase reads and writes
     w3 = mk_w(2, n3); tw3 = mk_tw(2, n3); m_w3 = mk_mw(2, n3); v_w3 = mk_vw(2, n3);
-    T yv[4], ntv[4];
+    T yv[4];
     bool on[4];
-    int actv[4];
     int count = kB;
     if (has_out) {
-      if (DQN) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const size_t row = (size_t)j * rows + L.aux[r3 + mfma_acc<T>::row(lane, v)];
-          actv[v] = (int)A.actions[row];
-          yv[v] = ((const T*)A.rewards)[row];
-          ntv[v] = ((const T*)A.nonterminal)[row];
-        }
-      } else {
+      if (!DQN) {
         const uint8_t* const mask = R.sample_mask ? R.sample_mask + (size_t)j * kB : nullptr;
         const T* const y = (const T*)R.targets + (size_t)(j / R.tgt_div) * kB * O;
 #pragma unroll
@@ -686,23 +712,15 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       const acc_t acc = output_tile<T>(o3, L.h2, r3, lane);
       if (a3 + li < O) {
         if (DQN) {
-          // new = r + (boot * nt) * gamma (the reference's operation order); loss = mean over the
-          // 32 x 4 outputs of (Q - targets)^2 with targets == Q except at the action taken, so the
-          // gradient is 2 (Q[s][a] - new[s]) / 128 there and zero elsewhere
+          // loss = mean over the 32 x NA outputs of (Q - targets)^2 with targets == Q except at the
+          // action taken (there: the sample's Q-learning target, L.tg), so the gradient is
+          // 2 (Q[s][a] - new[s]) / (32 NA) there and zero elsewhere
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int s = r3 + mfma_acc<T>::row(lane, v);
-            T boot;
-            if (A.ddqn) {
-              boot = L.qt[s * NA + L.aux[kB + s]];
-            } else {
-              boot = L.qt[s * NA];
-              for (int a = 1; a < NA; ++a) boot = L.qt[s * NA + a] > boot ? L.qt[s * NA + a] : boot;
-            }
-            const T target = yv[v] + (boot * ntv[v]) * (T)A.gamma;
-            const T d = acc[v] - target;
+            const T d = acc[v] - L.tg[s];
             const T g = ((T)2 * d) * ((T)1 / (T)(kB * NA));
-            L.q[s * kXRow + li] = li == actv[v] ? g : (T)0;
+            L.q[s * kXRow + li] = li == L.aux[kB + s] ? g : (T)0;
           }
         } else {
           // mean over the marked samples and the O outputs of (out - target)^2
@@ -732,9 +750,10 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
     lds_barrier();
     adam_consts<T> c;
     {
+      // (the same two numbers in every lane: kept in scalar registers through the three Adam phases)
       const T bc1 = L.cst[0];
-      c.bc2_sqrt = L.cst[1];
-      c.step_size = (T)R.lr / bc1;
+      c.bc2_sqrt = uniform(L.cst[1]);
+      c.step_size = uniform((T)R.lr / bc1);
       c.one_m_b1 = (T)(1.0 - R.beta1);
       c.b2 = (T)R.beta2;
       c.one_m_b2 = (T)(1.0 - R.beta2);
@@ -757,9 +776,6 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) d2 = mfma(ar[s], cw3[s], d2);
       }
-      T hv[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) hv[v] = L.h2[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li];
       acc_t g3 = splat<T>((T)0);
       if (has_g) {
 #pragma unroll
@@ -776,9 +792,13 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) cw2[s] = w2[(uint32_t)((lq * 16 + s) * kH + n0 + li)];
       lds_barrier();
+      // (h2 at this thread's own four places, read only now — everybody's reads of the tile for the
+      //  gradient are behind the barrier — and replaced by delta2: four values fewer across the products)
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        L.h2[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] = hv[v] > (T)0 ? d2[v] : (T)0;
+      for (int v = 0; v < 4; ++v) {
+        T* const h = L.h2 + (m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li;
+        *h = *h > (T)0 ? d2[v] : (T)0;
+      }
       if (has_g) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -818,9 +838,6 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
       for (int v = 0; v < 4; ++v)   // (the registers of cw2 are free now)
         s2a[v] = slot_load<T>(w2, m_w2, v_w2, tw2,
                               (uint32_t)((n0 + mfma_acc<T>::row(lane, v)) * kH + k0 + li), blend, true);
-      T hv[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) hv[v] = L.h1[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li];
       acc_t g2[2] = {splat<T>((T)0), splat<T>((T)0)};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -834,8 +851,10 @@ __device__ __forceinline__ void mlp_fit_body(const fit_args& A) {
         for (int s = 0; s < kB; ++s) gb = gb + L.h2[s * kRow + t];
       lds_barrier();
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        L.h1[(m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li] = hv[v] > (T)0 ? d1[v] : (T)0;
+      for (int v = 0; v < 4; ++v) {
+        T* const h = L.h1 + (m0 + mfma_acc<T>::row(lane, v)) * kRow + n0 + li;
+        *h = *h > (T)0 ? d1[v] : (T)0;
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < 4; ++v)
