@@ -136,7 +136,16 @@ __device__ __forceinline__ int cobel_eps_greedy_select_thr(float v0, float v1, f
   const float m = fmaxf(fmaxf(fmaxf(v0, v1), v2), v3);
   const int t = (int)(v0 == m) | ((int)(v1 == m) << 1) | ((int)(v2 == m) << 2) |
                 ((int)(v3 == m) << 3);
-  const uint64_t T = lane < 3 ? thr_lds[t * 3 + lane] : ~0ull;
+  // (an LDS-typed pointer and the row's address by a 24-bit multiply-add written out: the compiler's choice for
+  //  t * 24 + lane * 8 + table is v_mad_u64_u32, whose addend — the table's address plus the lane's
+  //  offset, hoisted out of the caller's step loop — is a register PAIR that gets spilled and is
+  //  reloaded in every step)
+  typedef const __attribute__((address_space(3))) unsigned char* lds_bytes;
+  typedef const __attribute__((address_space(3))) uint64_t* lds_u64;
+  const uint32_t lane_addr = (uint32_t)(uintptr_t)((lds_bytes)thr_lds + ((uint32_t)lane << 3));
+  uint32_t addr;
+  asm("v_mad_u32_u24 %0, %1, 24, %2" : "=v"(addr) : "v"(t), "v"(lane_addr));
+  const uint64_t T = lane < 3 ? *(lds_u64)(uintptr_t)addr : ~0ull;
   return __popcll(__ballot(lane < 3 && T <= K));
 }
 // policy/greedy.py:77-86 + Generator.choice for n <= AMAX values: float64 probabilities, sequential

@@ -110,10 +110,12 @@ __device__ __forceinline__ void load_row(row_regs<NV>& d, const float* __restric
     }
     return;
   }
-  const float4* const p = reinterpret_cast<const float4*>(src) + lane;
+  // (a wave-uniform base and a 32-bit lane offset, as above: `+ lane` on the pointer is a 64-bit
+  //  per-lane value that gets hoisted out of the step loop, spilled, and reloaded in every step)
+  const float4* const p = reinterpret_cast<const float4*>(src);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    if (!ANY_S || j * 64 + lane < quads) d.c[j] = p[j * 64];
+    if (!ANY_S || j * 64 + lane < quads) d.c[j] = p[(uint32_t)(j * 64 + lane)];
     else d.c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
@@ -708,7 +710,7 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
       // Everything issued before this point has landed: the gathers, the row of ns, and the row
       // store of the previous step.
       wait_vm0();
-      float4* const out = reinterpret_cast<float4*>(SRg + (size_t)state * S) + lane;
+      float4* const out = reinterpret_cast<float4*>(SRg + (size_t)state * S);   // (wave-uniform)
       const bool want_fresh =
           !trial_over && !dense && (t_of(tq, 0) == state || t_of(tq, 1) == state ||
                                     t_of(tq, 2) == state || t_of(tq, 3) == state);
@@ -743,7 +745,7 @@ __attribute__((amdgpu_waves_per_eu((NV == 4 && ANY_S && KX == 8) ? 5 : 6, 8))) v
           if (ue + 128u < n) o1[ue + 128u] = o4.z;
           if (ue + 192u < n) o1[ue + 192u] = o4.w;
         } else if (!ANY_S || j * 64 + lane < quads) {
-          out[j * 64] = o4;
+          out[(uint32_t)(j * 64 + lane)] = o4;
         }
         reinterpret_cast<float4*>(frow)[j * 64 + lane] = o4;
         // the row the next step starts from: SR[ns], or the row just written after a bump
