@@ -1033,8 +1033,9 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
   const float alpha_f = A.alpha_f, gamma_f = A.gamma_f;
 
-  cobel_u4 pblk = {0, 0, 0, 0}, eblk = {0, 0, 0, 0};
+  cobel_u4 pblk = {0, 0, 0, 0}, eblk = {0, 0, 0, 0}, eblk2 = {0, 0, 0, 0};
   uint32_t pb_idx = ~0u, eb_idx = ~0u;
+  bool eb2_ok = false;
   uint32_t cw0 = 0, cw1 = 0;
   if (iflags & 1u) {
     const uint4 c = wrec(state);
@@ -1046,15 +1047,42 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   bool done = !active;
 
   for (;;) {
+    // The block of the env stream a trial start draws from (four starts per block).  The lanes of a
+    // wave start trials at different steps — with trained agents some lane does in almost every
+    // step —, and a Philox block costs the WAVE its 18 multiplications whoever needs it.  So when
+    // one lane has to have a block, every lane works one out: the one its next start needs, or,
+    // having that, the one after it (eblk2).  A wave then pays for the rounds every ~20 steps
+    // instead of every step; same blocks, same words (the stream is counter based).
+    {
+      const bool starts = !done && !(iflags & 1u) && trial < A.r.trials_target;
+      const bool have = (ce >> 2) == eb_idx || (eb2_ok && (ce >> 2) == eb_idx + 1u);
+      if (__any(starts && !have)) {
+        if (eb2_ok && (ce >> 2) == eb_idx + 1u) {   // the block after has become the current one
+          eblk = eblk2;
+          eb_idx += 1u;
+          eb2_ok = false;
+        }
+        const bool cur = (ce >> 2) != eb_idx;
+        if (!done && (cur || !eb2_ok)) {
+          const cobel_u4 b = cobel_philox((ce >> 2) + (cur ? 0u : 1u), 0u, g, COBEL_STREAM_ENV, seed);
+          if (cur) {
+            eblk = b;
+            eb_idx = ce >> 2;
+            eb2_ok = false;
+          } else {
+            eblk2 = b;
+            eb2_ok = true;
+          }
+        }
+      }
+    }
     if (!done && !(iflags & 1u)) {
       if (trial >= A.r.trials_target) {
         done = true;
       } else {
-        if ((ce >> 2) != eb_idx) {
-          eb_idx = ce >> 2;
-          eblk = cobel_philox(eb_idx, 0u, g, COBEL_STREAM_ENV, seed);
-        }
-        const int pick = (int)cobel_bounded(cobel_word(eblk, ce & 3u), start_cnt);
+        const bool second = (ce >> 2) != eb_idx;   // (then: eb_idx + 1, in eblk2)
+        const int pick = (int)cobel_bounded(
+            second ? cobel_word(eblk2, ce & 3u) : cobel_word(eblk, ce & 3u), start_cnt);
         state = ONE_WORLD ? (int)Sl[pick] : (int)A.starts[start_lo + pick];
         ce += 1u;
         step = 0;
