@@ -950,7 +950,12 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
 constexpr int kMonSlots = 512;
 constexpr int kMonBytes = kMonSlots * 16;
 
-template <bool ONE_WORLD, bool MON, bool LOG>
+// EXTRA: action masks, the last experience, per-trial latency traces or a run that does not learn
+// — each a wave-uniform branch, TAKEN in every step of a plain training run.  One wave per SIMD has
+// nobody to run while its instruction buffer refills behind a taken branch (the counters of
+// exp_c2_parts.py / r05: 17 branches and 48 instruction fetches per wave-step, no LDS wait to speak
+// of), so plain training is its own instantiation without them.
+template <bool ONE_WORLD, bool MON, bool LOG, bool EXTRA>
 __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = A.S;
@@ -1024,10 +1029,12 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
   uint32_t loglen = LOG ? (uint32_t)inst[COBEL_I_LOG_LEN] : 0u;
 
   const uint32_t flags = A.r.flags;
-  const bool learn = flags & COBEL_F_LEARN;
+  const bool learn = EXTRA ? (flags & COBEL_F_LEARN) != 0u : true;
   const uint32_t pol_stream =
       (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
-  const uint8_t* const amask = (flags & COBEL_F_MASK_ACTIONS) ? A.r.action_mask : nullptr;
+  const uint8_t* const amask = (EXTRA && (flags & COBEL_F_MASK_ACTIONS)) ? A.r.action_mask : nullptr;
+  int32_t* const last_exp = EXTRA ? A.r.last_exp : nullptr;
+  const bool traces = EXTRA && A.r.lat_trace != nullptr;
   const uint64_t seed = A.r.seed;
   const int start_lo = A.start_off[world];
   const uint32_t start_cnt = (uint32_t)(A.start_off[world + 1] - start_lo);
@@ -1135,8 +1142,8 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
           loglen += 1u;
         }
       }
-      if (A.r.last_exp) {
-        int32_t* const e = A.r.last_exp + (size_t)ii * 6;
+      if (last_exp) {
+        int32_t* const e = last_exp + (size_t)ii * 6;
         e[0] = state;
         e[1] = a;
         e[2] = ns;
@@ -1167,7 +1174,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
         }
       }
       if (ended) {
-        if (A.r.lat_trace && trial >= 0 && trial < A.r.trial_cap)
+        if (traces && trial >= 0 && trial < A.r.trial_cap)
           A.r.lat_trace[(size_t)ii * A.r.trial_cap + trial] = step;
         trial += 1;
         iflags &= ~1u;
@@ -1462,13 +1469,18 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
       describe[3] = lpw;
       return COBEL_OK;
     }
-#define COBEL_LPI(ONE, MON, LOG)                                                               \
+#define COBEL_LPI_X(ONE, MON, LOG, EXTRA)                                                      \
   do {                                                                                         \
     if (bytes > 64 * 1024)                                                                     \
       COBEL_HIP_TRY(hipFuncSetAttribute(                                                       \
-          reinterpret_cast<const void*>(&k_tab_lpi<ONE, MON, LOG>),                            \
+          reinterpret_cast<const void*>(&k_tab_lpi<ONE, MON, LOG, EXTRA>),                     \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));                            \
-    hipLaunchKernelGGL((k_tab_lpi<ONE, MON, LOG>), grid, dim3(64), bytes, st, A);              \
+    hipLaunchKernelGGL((k_tab_lpi<ONE, MON, LOG, EXTRA>), grid, dim3(64), bytes, st, A);       \
+  } while (0)
+#define COBEL_LPI(ONE, MON, LOG)                                                               \
+  do {                                                                                         \
+    if (extra) COBEL_LPI_X(ONE, MON, LOG, true);                                               \
+    else COBEL_LPI_X(ONE, MON, LOG, false);                                                    \
   } while (0)
 #define COBEL_LPI2(ONE, MON)                                                                   \
   do {                                                                                         \
@@ -1477,12 +1489,16 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   } while (0)
     // (QAgent with a log but no replay in this call still appends its experiences)
     const bool logs = r.agent == COBEL_AGENT_Q && learn && r.replay_log != nullptr && r.log_cap > 0;
+    // (k_tab_lpi's EXTRA: anything but plain training without masks, traces and last experience)
+    const bool extra = !learn || ((r.flags & COBEL_F_MASK_ACTIONS) && r.action_mask) || r.last_exp ||
+                       r.lat_trace;
     if (one && mon) COBEL_LPI2(true, true);
     else if (one) COBEL_LPI2(true, false);
     else if (mon) COBEL_LPI2(false, true);
     else COBEL_LPI2(false, false);
 #undef COBEL_LPI2
 #undef COBEL_LPI
+#undef COBEL_LPI_X
     COBEL_HIP_TRY(hipGetLastError());
     return COBEL_OK;
   }
