@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
     {
       const bool starts = !done && !(iflags & 1u) && trial < A.r.trials_target;
       const bool have = (ce >> 2) == eb_idx || (eb2_ok && (ce >> 2) == eb_idx + 1u);
-      if (__any(starts && !have)) {
+      if (__builtin_expect(__any(starts && !have), 0)) {
         if (eb2_ok && (ce >> 2) == eb_idx + 1u) {   // the block after has become the current one
           eblk = eblk2;
           eb_idx += 1u;
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(64) void k_tab_lpi(const tab_args A) {
     if (__any(ended)) {
       if (MON && ended) {
         const int slot = trial - mon_base;
-        if (slot < kMonSlots) {
+        if (__builtin_expect(slot < kMonSlots, 1)) {
           // (low half of wcnt: instances that finished the trial; high half: those with a positive
           //  reward — one wave, so neither exceeds 64)
           atomicAdd(&wsum[slot], (uint32_t)step);
