@@ -78,9 +78,13 @@ __host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool sha
   return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * 32 + kHashWords * 8);
 }
 
+// PLAIN: training with a replay batch on a world of more than one action — what the step's
+// wave-uniform tests (learn, B > 0, A > 1) are compiled away for (as k_tab_lpi's EXTRA: a taken
+// branch is an instruction-buffer refill the wave waits for).
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int S = G.S, A = G.A;
+  const int S = G.S, A = PLAIN ? max(G.A, 2) : G.A;
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int i = (int)blockIdx.x * G.wpg + wave;
@@ -186,10 +190,11 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
   asm volatile("" : "+v"(trew));
 
   const uint32_t flags = G.r.flags;
-  const bool learn = (flags & COBEL_F_LEARN) != 0;
+  const bool learn = PLAIN || (flags & COBEL_F_LEARN) != 0;
   uint64_t* const rlog = G.r.replay_log ? G.r.replay_log + (size_t)i * G.r.log_cap : nullptr;
   const uint32_t cap = rlog ? (uint32_t)G.r.log_cap : 0u;
-  const int B = (learn && !(flags & COBEL_F_NO_REPLAY) && rlog) ? G.r.batch : 0;
+  const int B = PLAIN ? max(G.r.batch, 1)
+                      : ((learn && !(flags & COBEL_F_NO_REPLAY) && rlog) ? G.r.batch : 0);
   const uint32_t pol_stream =
       (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
   uint64_t seed = G.r.seed;
@@ -532,10 +537,15 @@ int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hi
   G.r = r;
   G.alpha_f = (float)r.alpha;
   G.gamma_f = (float)r.gamma;
+  const bool plain = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.replay_log &&
+                     r.batch > 0 && G.A > 1;
+  const void* const kernel = plain ? reinterpret_cast<const void*>(&k_tab_wqn<true>)
+                                   : reinterpret_cast<const void*>(&k_tab_wqn<false>);
   if (lds > 64 * 1024)
-    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wqn),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_tab_wqn, dim3((unsigned)((r.n + wpg - 1) / wpg)), dim3(64 * wpg), lds, st, G);
+    COBEL_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)((r.n + wpg - 1) / wpg)), block(64 * wpg);
+  if (plain) hipLaunchKernelGGL(k_tab_wqn<true>, grid, block, lds, st, G);
+  else hipLaunchKernelGGL(k_tab_wqn<false>, grid, block, lds, st, G);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
