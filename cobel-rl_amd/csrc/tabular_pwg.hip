@@ -55,7 +55,8 @@ struct pwg_args {
   float alpha_f, gamma_f, model_lr_f;
   int32_t nl, ng;        // waves per workgroup with Q in LDS / with Q in global memory
   // tickets (all counters zeroed before the launch)
-  uint32_t* queue;       // eight heads, 32 B apart: next ticket of each queue
+  uint32_t* queue;       // eight heads, 32 B apart: word 0 = next (sliced) ticket of each queue, word 1 =
+                         // next of its whole-instance tickets (sliced launches with `whole` > 0)
   uint32_t reserve;      // tickets per queue the global-memory waves leave to the others
   // slices (n_slices > 1): an instance's steps of this call are cut into n_slices tickets
   int32_t n_slices;
