@@ -386,14 +386,15 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
     on C3's mazes with 100 planning updates per step (agent/dyna_q.py:319-330 has no limit) — the
     generic k_tab_wpi in two passes of <= 62 lanes; `wide_q` = QAgent with a replay batch of 32 and
     an action mask on a random graph of 256 nodes with twelve neighbours each (interface/topology.py:
-    110-112 takes any count) — k_tab_general, one lane per instance with every table in L2: the
-    functional path, timed so that its price is on record."""
+    110-112 takes any count) — k_tab_wqn on rows of 16 since round 5 (the selection's float64 CDF
+    worked out by the wave); `wide_q_lane` = the same run forced onto k_tab_general, one lane per
+    instance with every table in L2: the functional path, timed so that its price is on record."""
     from cobel_amd import _lib
     from cobel_amd.agent import DynaQ, QAgent
     from cobel_amd.interface import Gridworld, Topology
     from cobel_amd.misc.topology_tools import hexagonal
     from cobel_amd.policy import EpsilonGreedy
-    if which in ('hex_q', 'wide_q'):
+    if which in ('hex_q', 'wide_q', 'wide_q_lane'):
         if which == 'hex_q':
             nodes, starts = hexagonal(16)
         else:
@@ -407,14 +408,15 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
         env = Topology(nodes, starts, n_envs=n, seed=SEED, device=device)
         agent = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
         batch, spt, A = 32, 100, int(env.action_space.n)
-        if which == 'wide_q':
+        if which != 'hex_q':
+            agent.force_general = which == 'wide_q_lane'
             agent.mask_actions = True
             agent.action_mask = np.ones((256, 12), dtype=bool)
             agent.action_mask[:, 11] = False            # (one neighbour of every node closed)
         agent._bind(env)
         agent.reserve_replay(env_steps * (launches + 2))
         desc = ('QAgent (alpha .9, gamma .8, eps .1, replay batch 32 from the experience log%s) on a '
-                '%s of %d nodes, %d actions' % (', action mask' if which == 'wide_q' else '',
+                '%s of %d nodes, %d actions' % (', action mask' if which != 'hex_q' else '',
                                                 'hexagonal Topology' if which == 'hex_q' else 'random graph',
                                                 len(nodes), A))
         # online step: state r/w 8 + Q[s,:] 4A + next 2 + reward 4 + terminal 1 + Q[ns,:] 4A +
@@ -458,7 +460,7 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
     kernel = names.get(what['kernel'], 'kernel %d' % what['kernel'])
     alg = b_step * steps + b_upd * batch * batches
     traffic = None
-    if which in ('hex_q', 'wide_q'):
+    if which in ('hex_q', 'wide_q', 'wide_q_lane'):
         traffic = pmc_traffic_leg('general_' + which, kernel) if n == 65536 else None
     roof = _hbm_roofline(alg / steps, steps / sec, kernel,
                          'latency' if what['kernel'] == _lib.TAB_KERNEL_GENERAL else 'issue',
@@ -469,9 +471,9 @@ def run_general(device, which, n=65536, env_steps=64, launches=4):
         roof['traffic_unit'] = 'HBM bytes per launch (rocprofv3 PMC, profiles/)'
         roof['frac_measured'] = traffic / (sec / launches) / 1e9 / HBM_PEAK_GBS
         roof['measured_over_algorithmic'] = traffic / (alg / launches)
-    if which == 'hex_q' and what['kernel'] == _lib.TAB_KERNEL_WQN:
+    if which in ('hex_q', 'wide_q') and what['kernel'] == _lib.TAB_KERNEL_WQN:
         # (tables in LDS for the whole launch: held against instruction issue, as C2 / C6)
-        iss = issue_roofline('general_hex_q', steps / sec, float(np.mean(ms)), device, n == 65536)
+        iss = issue_roofline('general_' + which, steps / sec, float(np.mean(ms)), device, n == 65536)
         if iss is not None:
             roof['issue'] = iss
             roof = to_issue_bound(roof)
@@ -1133,7 +1135,8 @@ def main():
     ap.add_argument('--no-c5', action='store_true', help='skip the network legs (profiling runs)')
     ap.add_argument('--legs', default=None,
                     help='comma-separated subset of the legs behind --also (C5_f64, C5_f32, dyna_dqn, '
-                         'dyna_dsr, C1, grid_search, general_hex_q, general_wide_q, general_dynaq_b100); default: all')
+                         'dyna_dsr, C1, grid_search, general_hex_q, general_wide_q, general_wide_q_lane, '
+                         'general_dynaq_b100); default: all')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -1206,6 +1209,7 @@ def main():
             ('grid_search', lambda: run_grid_search(device, 16 if args.scale == 1.0 else 4)),
             ('general_hex_q', lambda: run_general(device, 'hex_q', scaled(65536))),
             ('general_wide_q', lambda: run_general(device, 'wide_q', scaled(65536))),
+            ('general_wide_q_lane', lambda: run_general(device, 'wide_q_lane', scaled(65536))),
             ('general_dynaq_b100', lambda: run_general(device, 'dynaq_b100', scaled(65536))),
         ]
         if args.legs is not None:

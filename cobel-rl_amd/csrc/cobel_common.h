@@ -76,7 +76,7 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
                         size_t* lds_bytes);
 int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);
 
-// tabular_nact.hip: Q-learning on worlds of 1..8 (not four) actions, one wavefront per instance
+// tabular_nact.hip: Q-learning on worlds of 1..32 (not four) actions, one wavefront per instance
 bool cobel_tab_nact_covers(const cobel_world* world, const cobel_tab_run_t& r, size_t* lds_bytes,
                            int* instances_per_workgroup);
 int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hipStream_t st);

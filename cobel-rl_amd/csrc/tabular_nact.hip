@@ -25,6 +25,16 @@
 // Same streams, counters, arithmetic and order of effects as k_tab_general: identical Q tables,
 // logs, counters and monitors (tests/test_gpu_general.py, scripts/fuzz_topology.py).
 //
+// Round 5: nine to 32 actions on the same kernel with rows of 16 / 32 values (template W) while a
+// cell's key s W + a fits the conflict tables' 13 bits (512 / 256 states).  No threshold table
+// there (2^A tie patterns): the wave works the selection's float64 CDF out itself, in the order
+// cobel_eps_greedy_select_n (cobel_policy.h) states it — lane k holds value k, the cumulative sum is
+// ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
+// compares with the draw — and action masks (32-bit words, an LDS copy) take part in it; the
+// replayed updates read a row's maximum with W / 4 LDS reads, the conflict sets OR W buckets.
+// Masked twelve-action QAgent on a 256-node graph, B 32: 6.8e8 env-steps/s against the 1.9e8 of
+// k_tab_general (bench.py general_wide_q / general_wide_q_lane).
+//
 // Reference behaviour restated: agent/q.py:160-228 (train), :289-315 (update_q), :344-354 (replay);
 // interface/topology.py:126-157 (step); policy/greedy.py:40-88.
 #include <math.h>
@@ -71,18 +81,30 @@ __device__ __forceinline__ uint64_t log_pack8(float r, uint32_t s, uint32_t a, u
 __host__ __device__ inline size_t nact_thr_words(int A) {
   return A > 1 ? ((size_t)1 << A) * (size_t)(A - 1) : 1;
 }
-// LDS of a workgroup of `wpg` instances (bytes): thresholds | worlds | per instance Q + hash
+// the row width an action count is served with: rows of 8, 16 or 32 values (pad cells: -inf)
+__host__ __device__ inline int nact_width(int A) { return A <= 8 ? 8 : (A <= 16 ? 16 : 32); }
+// LDS of a workgroup of `wpg` instances (bytes): thresholds (rows of 8) or the action masks (wider
+// rows) | worlds | per instance Q + hash
 __host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool shared) {
-  const size_t thr = (nact_thr_words(A) * 8 + 15) & ~(size_t)15;
-  const size_t world = (size_t)S * 24;
-  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * 32 + kHashWords * 8);
+  const int W = nact_width(A);
+  const size_t thr = W == 8 ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15 : (((size_t)S * 4 + 15) & ~(size_t)15);
+  const size_t world = (size_t)S * (2 * W + 8);
+  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4 + kHashWords * 8);
+}
+// QAgent replay record of nine to 32 actions (general.hip): hi = s | ns << 13 | action << 26 | nt << 31
+__device__ __forceinline__ uint64_t log_pack32(float r, uint32_t s, uint32_t a, uint32_t ns, uint32_t nt) {
+  return (uint64_t)fbits(r) | ((uint64_t)(s | (ns << 13) | (a << 26) | (nt << 31)) << 32);
 }
 
 // PLAIN: training with a replay batch on a world of more than one action — what the step's
 // wave-uniform tests (learn, B > 0, A > 1) are compiled away for (as k_tab_lpi's EXTRA: a taken
 // branch is an instruction-buffer refill the wave waits for).
-template <bool PLAIN>
+// W: the row width (8: one to eight actions, thresholds from the table; 16 / 32: nine to 32 actions —
+// round 5 —, the selection's float64 CDF worked out by the wave in the reference's order, action
+// masks from an LDS copy).
+template <bool PLAIN, int W>
 __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
+  constexpr uint32_t WU = (uint32_t)W;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = G.S, A = PLAIN ? max(G.A, 2) : G.A;
   const int lane = (int)(threadIdx.x & 63u);
@@ -95,23 +117,30 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
 
   // ---- LDS carve-up ---------------------------------------------------------------------------
   unsigned long long* const thr = reinterpret_cast<unsigned long long*>(lds_raw);
-  size_t off = (nact_thr_words(A) * 8 + 15) & ~(size_t)15;
-  const size_t wbytes = (size_t)S * 24;
+  uint32_t* const maskL = reinterpret_cast<uint32_t*>(lds_raw);          // W > 8: [S] allowed actions
+  size_t off = W == 8 ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15 : (((size_t)S * 4 + 15) & ~(size_t)15);
+  const size_t wbytes = (size_t)S * (2 * W + 8);
   unsigned char* const wl = lds_raw + off + (G.shared_world ? 0 : (size_t)wave * wbytes);
   off += G.shared_world ? wbytes : wbytes * (size_t)G.wpg;
-  uint16_t* const nextL = reinterpret_cast<uint16_t*>(wl);               // [S][8]
-  uint2* const RT = reinterpret_cast<uint2*>(wl + (size_t)S * 16);       // [S] {reward bits, terminal}
-  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * 32 + kHashWords * 8);
-  float4* const Qs = reinterpret_cast<float4*>(mine);                    // [S][2]
+  uint16_t* const nextL = reinterpret_cast<uint16_t*>(wl);               // [S][W]
+  uint2* const RT = reinterpret_cast<uint2*>(wl + (size_t)S * 2 * W);    // [S] {reward bits, terminal}
+  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * W * 4 + kHashWords * 8);
+  float4* const Qs = reinterpret_cast<float4*>(mine);                    // [S][W / 4]
   float* const Qf = reinterpret_cast<float*>(mine);
-  unsigned long long* const H1 = reinterpret_cast<unsigned long long*>(mine + (size_t)S * 32);
+  unsigned long long* const H1 = reinterpret_cast<unsigned long long*>(mine + (size_t)S * W * 4);
   unsigned long long* const H2 = H1 + 64;
 
   // ---- the threshold table (whole workgroup) ----------------------------------------------------
   // thr[t * (A - 1) + k] = ceil(cdf_k * 2^53) of the tie pattern t (bit a set: action a attains
   // the maximum): probs = eps / A + ((1 - eps) * tie) / n_ties, sequential cumulative sum, divided
   // by its last entry (greedy.py:83-86, Generator.choice) — cobel_make_eps_consts for A values.
-  if (A > 1) {
+  const uint32_t* const amask_g =
+      (W > 8 && (G.r.flags & COBEL_F_MASK_ACTIONS)) ? reinterpret_cast<const uint32_t*>(G.r.action_mask) : nullptr;
+  if (W > 8) {
+    const uint32_t all = A >= 32 ? 0xffffffffu : ((1u << A) - 1u);
+    for (int s = (int)threadIdx.x; s < S; s += (int)blockDim.x) maskL[s] = amask_g ? amask_g[s] & all : all;
+  }
+  if (W == 8 && A > 1) {
     const double eps = G.r.epsilon;
     for (int t = (int)threadIdx.x; t < (1 << A); t += (int)blockDim.x) {
       const int nt = __popc((unsigned)t);
@@ -144,8 +173,8 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     const int nthr = G.shared_world ? (int)blockDim.x : 64;
     const int tid = G.shared_world ? (int)threadIdx.x : lane;
     if (G.shared_world || present) {
-      for (int e = tid; e < S * 8; e += nthr) {
-        const int s = e >> 3, a = e & 7;
+      for (int e = tid; e < S * W; e += nthr) {
+        const int s = e / W, a = e % W;
         nextL[e] = a < A ? G.next_n[(wbase + s) * A + a] : (uint16_t)s;
       }
       for (int s = tid; s < S; s += nthr)
@@ -155,20 +184,20 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
   // ---- this instance's Q table (pad cells: -inf) and conflict tables ----------------------------
   float* const Qg = G.r.q + (size_t)(present ? i : 0) * S * A;
   if (present) {
-    for (int e0 = 0; e0 < S * 8; e0 += 512) {
+    for (int e0 = 0; e0 < S * W; e0 += 512) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int e = e0 + j * 64 + lane;
-        const int s = e >> 3, a = e & 7;
-        const bool ok = e < S * 8 && a < A;
+        const int s = e / W, a = e % W;
+        const bool ok = e < S * W && a < A;
         v[j] = Qg[ok ? (size_t)s * A + a : 0];
         if (!ok) v[j] = -__builtin_huge_valf();
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int e = e0 + j * 64 + lane;
-        if (e < S * 8) Qf[e] = v[j];
+        if (e < S * W) Qf[e] = v[j];
       }
     }
     for (int b = lane; b < kHashWords; b += 64) H1[b] = 0ull;
@@ -204,6 +233,17 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
   float alpha_f = G.alpha_f, gamma_f = G.gamma_f;
   asm volatile("" : "+v"(alpha_f), "+v"(gamma_f));
   const uint32_t nt_shift = A <= 4 ? 30u : 31u, a_mask = A <= 4 ? 3u : 7u;
+  // the maximum of a row of W values (pad cells hold -inf)
+  auto row_max = [&](uint32_t row) -> float {
+    float4 v = Qs[row * (WU / 4u)];
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+    for (uint32_t j = 1; j < WU / 4u; ++j) {
+      v = Qs[row * (WU / 4u) + j];
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    return m;
+  };
 
   // Cached Philox output: lanes < B hold memory block mb_idx (four consecutive batches), lanes 62
   // and 63 the policy blocks 2 pb_idx and 2 pb_idx + 1 (action draws 4 pb_idx .. 4 pb_idx + 3).
@@ -234,15 +274,17 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
   // ---- B sequential float32 TD updates (q.py:305-313), speculative rounds ------------------------
   auto run_batch = [&](uint64_t rec) {
     const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
-    const uint32_t s = hi & 0x3fffu, ns = (hi >> 14) & 0x3fffu, a = (hi >> 28) & a_mask,
-                   nt = (hi >> nt_shift) & 1u;
+    const uint32_t s = W == 8 ? hi & 0x3fffu : hi & 0x1fffu;
+    const uint32_t ns = W == 8 ? (hi >> 14) & 0x3fffu : (hi >> 13) & 0x1fffu;
+    const uint32_t a = W == 8 ? (hi >> 28) & a_mask : (hi >> 26) & 31u;
+    const uint32_t nt = W == 8 ? (hi >> nt_shift) & 1u : hi >> 31;
     const float r = __builtin_bit_cast(float, lo);
-    const uint32_t p = s * 8u + a;
+    const uint32_t p = s * WU + a;
     const bool on = lane < B;
     int first = B;
     unsigned long long conf = 0ull;
     auto td_of = [&](float q) -> float {
-      const float m = max8(Qs[ns * 2u], Qs[ns * 2u + 1u]);
+      const float m = W == 8 ? max8(Qs[ns * 2u], Qs[ns * 2u + 1u]) : row_max(ns);
       const float gnt = nt ? gamma_f : 0.0f;
       float td = r + gnt * m;
       td = td - q;
@@ -261,8 +303,8 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
       if (!changed) return;
       {
         // exact conflict sets: all EARLIER lanes that write a cell this lane reads — its own
-        // cell (both buckets of p) or a cell of row ns (the eight H1 buckets of ns % 8, the H2
-        // bucket of ns / 8)
+        // cell (both buckets of p) or a cell of row ns (the W H1 buckets from (ns W) % 64, the H2
+        // bucket (ns W) / 64; W = 8: the eight buckets of ns % 8, bucket ns / 8)
         const uint32_t h1 = p & 63u, h2 = p >> 6;
         const unsigned long long bit = 1ull << lane;
         if (on) {
@@ -272,11 +314,13 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long cnd = 0ull;
         if (on) {
-          const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 7u) * 8u]);
+          const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns * WU) & 63u]);
           const ulonglong2 ra = r8[0], rb = r8[1], rc = r8[2], rd = r8[3];
           const unsigned long long cell = H1[h1] & H2[h2];
-          const unsigned long long row =
-              (((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y))) & H2[ns >> 3];
+          unsigned long long any = ((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y));
+#pragma unroll
+          for (uint32_t j = 4; j < WU / 2u; ++j) any |= r8[j].x | r8[j].y;
+          const unsigned long long row = any & H2[(ns * WU) >> 6];
           cnd = (cell | row) & (bit - 1ull);
         }
         __builtin_amdgcn_wave_barrier();
@@ -311,11 +355,11 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     }
   };
 
-  // what depends only on the state being entered: lane k < 8 evaluates successor k
+  // what depends only on the state being entered: lane k < W evaluates successor k
   uint32_t sn = 0, srw = 0, ste = 0;
   float smax = 0.0f;
   auto enter_state = [&](int s) {
-    sn = nextL[(uint32_t)s * 8u + (uint32_t)(lane & 7)];
+    sn = nextL[(uint32_t)s * WU + (uint32_t)(lane & (W - 1))];
     const uint2 rt = RT[sn];
     srw = rt.x;
     ste = rt.y;
@@ -359,15 +403,57 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     //  steps — two quad permutes and a half-row mirror —, the tie pattern the low eight bits of ONE
     //  ballot and Q[s][a] a readlane, where eight compares, fifteen scalar instructions and seven
     //  selects stood; as in k_tab_pwg / k_tab_wpi)
-    const float qc = Qf[(uint32_t)state * 8u + (uint32_t)(lane & 7)];
-    smax = max8(Qs[sn * 2u], Qs[sn * 2u + 1u]);
+    const float qc = Qf[(uint32_t)state * WU + (uint32_t)(lane & (W - 1))];
+    smax = W == 8 ? max8(Qs[sn * 2u], Qs[sn * 2u + 1u]) : row_max(sn);
     // ---- select --------------------------------------------------------------------------------------
     const int src_lane = 62 + (int)((cp >> 1) & 1u);
     const uint32_t w0 = rl((cp & 1u) ? blk.z : blk.x, src_lane);
     const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
     cp += 1u;
     int a = 0;
-    if (A > 1) {
+    if (W > 8) {
+      // policy/greedy.py:77-86 + Generator.choice as cobel_eps_greedy_select_n states them, by the
+      // wave: lane k holds value k of the row; float64 probabilities eps / n + (tie ? (1 - eps) / n_ties
+      // : 0) of the allowed actions, their cumulative sum IN ORDER (one add per action, every lane
+      // the same chain, lane k keeps entry k), normalised by the last entry, searchsorted(side='right')
+      const uint32_t k = (uint32_t)(lane & (W - 1));
+      const uint32_t allowed = rfl(maskL[state]);
+      const bool ok = ((allowed >> k) & 1u) != 0u;
+      const float q_ok = ok ? qc : -__builtin_huge_valf();
+      float m;
+      // (the maximum over a row of 16 lanes: two quad permutes, a half-row and a row mirror, each
+      //  fused into the maximum; every lane of the wave is active here)
+      asm("s_nop 1\n\t"
+          "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+          : "=&v"(m)
+          : "v"(q_ok));
+      if (W > 16) m = fmaxf(m, __shfl_xor(m, 16));
+      const uint32_t ties = (uint32_t)__ballot(ok && qc == m) & (W >= 32 ? 0xffffffffu : ((1u << W) - 1u));
+      const int n = __popc(allowed), n_ties = __popc(ties);
+      const double eps = G.r.epsilon;
+      const double base = eps / (double)n;
+      const double bonus = ((1.0 - eps) * 1.0) / (double)n_ties;
+      const double both = base + bonus;
+      double run = 0.0, ck = 0.0;
+#pragma unroll
+      for (uint32_t j = 0; j < WU; ++j) {
+        const double pj = ((allowed >> j) & 1u) ? (((ties >> j) & 1u) ? both : base) : 0.0;
+        run = j == 0u ? pj : run + pj;
+        ck = k == j ? run : ck;
+      }
+      const unsigned long long cb = __builtin_bit_cast(unsigned long long, ck);
+      const double total = __builtin_bit_cast(
+          double, ((unsigned long long)rl((uint32_t)(cb >> 32), A - 1) << 32) | rl((uint32_t)cb, A - 1));
+      const double u = cobel_u01(w0, w1);
+      const bool pass = (int)k < A - 1 && ck / total <= u;
+      a = __popc((uint32_t)__ballot(pass) & (W >= 32 ? 0xffffffffu : ((1u << W) - 1u)));
+    } else if (A > 1) {
       float m;
       // (two wait states between a VALU write of a register and a DPP read of it: the compiler does
       //  not look for hazards inside an asm block.  Every lane of the wave is active here — a
@@ -392,7 +478,7 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
     const uint32_t end = rl(ste, a);
     const uint32_t nt = 1u - end;
     const float ns_max = __builtin_bit_cast(float, rl(fbits(smax), a));
-    const uint32_t p_sa = (uint32_t)state * 8u + (uint32_t)a;
+    const uint32_t p_sa = (uint32_t)state * WU + (uint32_t)a;
     const bool trial_over = end || (step + 1 >= G.r.steps_per_trial);
     // ---- online TD (q.py:305-313, float32) and the log (q.py:213) ----------------------------------------
     uint64_t fresh_cur = 0;
@@ -403,7 +489,8 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
       float td = r + gnt * ns_max;
       td = td - q_sa;
       const float qn = q_sa + alpha_f * td;
-      fresh_cur = log_pack8(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt, nt_shift);
+      fresh_cur = W == 8 ? log_pack8(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt, nt_shift)
+                         : log_pack32(r, (uint32_t)state, (uint32_t)a, (uint32_t)ns, nt);
       appended = loglen < cap;      // (a full log takes no record)
       if (lane == 0) {
         Qf[p_sa] = qn;
@@ -463,8 +550,8 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
 
   // ---- write back ---------------------------------------------------------------------------------
   __builtin_amdgcn_wave_barrier();
-  for (int e = lane; e < S * 8; e += 64) {
-    const int s = e >> 3, a = e & 7;
+  for (int e = lane; e < S * W; e += 64) {
+    const int s = e / W, a = e % W;
     if (a < A) Qg[(size_t)s * A + a] = Qf[e];
   }
   if (lane == 0) {
@@ -486,10 +573,15 @@ __global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
 // waves per workgroup and the LDS they take; false: the run is not covered
 bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out, size_t* lds_out) {
   const int S = world->n_states, A = world->n_actions;
-  if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 8 || !world->next_n || world->succ_off ||
-      r.param_index || r.occupancy || r.last_exp || (r.flags & COBEL_F_MASK_ACTIONS) ||
+  const int W = nact_width(A);
+  const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
+  // (rows of 8: no masks — the threshold table knows tie patterns only; wider rows: the conflict
+  //  tables key a cell by s W + a in 13 bits, the packed log record holds 13-bit states)
+  if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
+      r.param_index || r.occupancy || r.last_exp || (masked && W == 8) ||
+      (masked && (!r.action_mask || ((uintptr_t)r.action_mask & 3u))) ||
       (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
-      S > 1024 || r.n < 1)
+      S > 1024 || (size_t)S * W > 8192 || r.n < 1)
     return false;
   const bool shared = world->n_worlds == 1;
   int n_cu = 0;
@@ -539,13 +631,26 @@ int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hi
   G.gamma_f = (float)r.gamma;
   const bool plain = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.replay_log &&
                      r.batch > 0 && G.A > 1;
-  const void* const kernel = plain ? reinterpret_cast<const void*>(&k_tab_wqn<true>)
-                                   : reinterpret_cast<const void*>(&k_tab_wqn<false>);
-  if (lds > 64 * 1024)
-    COBEL_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int W = nact_width(G.A);
   const dim3 grid((unsigned)((r.n + wpg - 1) / wpg)), block(64 * wpg);
-  if (plain) hipLaunchKernelGGL(k_tab_wqn<true>, grid, block, lds, st, G);
-  else hipLaunchKernelGGL(k_tab_wqn<false>, grid, block, lds, st, G);
+#define COBEL_WQN(PLAIN, W)                                                                       \
+  do {                                                                                            \
+    if (lds > 64 * 1024)                                                                          \
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wqn<PLAIN, W>),      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+    hipLaunchKernelGGL((k_tab_wqn<PLAIN, W>), grid, block, lds, st, G);                           \
+  } while (0)
+  if (W == 8) {
+    if (plain) COBEL_WQN(true, 8);
+    else COBEL_WQN(false, 8);
+  } else if (W == 16) {
+    if (plain) COBEL_WQN(true, 16);
+    else COBEL_WQN(false, 16);
+  } else {
+    if (plain) COBEL_WQN(true, 32);
+    else COBEL_WQN(false, 32);
+  }
+#undef COBEL_WQN
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }

@@ -4,7 +4,7 @@ vector ALUs were — what bench.py's `roofline.issue` objects are made of.
 
     A="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
     B="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
-    CMD="python3 bench.py --full --no-cpu-baseline --min-seconds 0 --also C2,C6 --legs grid_search,general_dynaq_b100,general_hex_q"
+    CMD="python3 bench.py --full --no-cpu-baseline --min-seconds 0 --also C2,C6 --legs grid_search,general_dynaq_b100,general_hex_q,general_wide_q"
     rocprofv3 --kernel-trace --pmc $A -d gpurun_out/sq_a -o a --output-format csv -- $CMD > gpurun_out/sq_a.json
     rocprofv3 --kernel-trace --pmc $B -d gpurun_out/sq_b -o b --output-format csv -- $CMD > gpurun_out/sq_b.json
     python scripts/pmc_sq.py gpurun_out/sq_a.json <a_counter_collection.csv> <b_counter_collection.csv> <a_kernel_trace.csv> NN
@@ -26,7 +26,8 @@ LEGS = {   # leg -> (kernel name fragment, what must not be in the name, timed d
     'C6': ('k_sfma', None, 4),
     'grid_search': ('k_tab_wpi<', None, None),
     'general_dynaq_b100': ('k_tab_wpi<', None, 4),
-    'general_hex_q': ('k_tab_wqn', None, 4),
+    'general_hex_q': ('k_tab_wqn<true, 8>', None, 4),
+    'general_wide_q': ('k_tab_wqn<true, 16>', None, 4),
 }
 
 
@@ -56,7 +57,7 @@ def main():
     for k in ('C2', 'C6'):
         if k in legs and 'config' in legs[k]:
             steps[k] = legs[k]['config']['instances_per_gpu'] * legs[k]['config']['env_steps_per_launch']
-    for k in ('general_dynaq_b100', 'general_hex_q'):
+    for k in ('general_dynaq_b100', 'general_hex_q', 'general_wide_q'):
         if k in legs and 'config' in legs[k]:
             c = legs[k]['config']
             steps[k] = c['instances_per_gpu'] * c['env_steps_per_launch']

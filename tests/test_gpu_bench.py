@@ -175,7 +175,7 @@ def test_every_default_leg_runs_and_carries_a_roofline(tmp_path):
     assert r['pretraining']['untimed_launches_in_all'] == r['pretraining']['launches'] + 1
     legs = r['other_configs']
     assert set(legs) >= {'C1', 'C2', 'C4', 'C6', 'C5_f64', 'C5_f32', 'dyna_dqn', 'dyna_dsr', 'grid_search',
-                         'general_hex_q', 'general_wide_q', 'general_dynaq_b100'}
+                         'general_hex_q', 'general_wide_q', 'general_wide_q_lane', 'general_dynaq_b100'}
     for name, leg in legs.items():
         assert 'error' not in leg, (name, leg)
         assert leg['roofline'] is not None, name

@@ -373,11 +373,13 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
     assert int(a.batches_done.item()) == int(b.batches_done.item())
 
 
+@pytest.mark.parametrize('general', [False, True])
 @pytest.mark.parametrize('A', [9, 12, 17, 32])
-def test_more_than_eight_actions(torch_cuda, A):
+def test_more_than_eight_actions(torch_cuda, A, general):
     """Nine to 32 neighbours per node (interface/topology.py:110-112 takes any count): the wide
-    instantiations of the general kernel — QAgent with log replay against the restatement of the
-    reference's loop, the decoded replay memory, epsilon-greedy rows against NumPy."""
+    rows of the wavefront kernel (k_tab_wqn<., 16 / 32>) and, forced, of the general kernel — QAgent
+    with log replay against the restatement of the reference's loop, the decoded replay memory,
+    epsilon-greedy rows against NumPy."""
     torch = torch_cuda
     from cobel_amd import _lib
     from cobel_amd.agent import QAgent
@@ -400,10 +402,11 @@ def test_more_than_eight_actions(torch_cuda, A):
     assert int(env.action_space.n) == A
     ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2), learning_rate=0.9, gamma=0.9)
     ag.track_instances = True
+    ag.force_general = general
     ag.train(env, trials, steps, B)
     torch.cuda.synchronize()
     what = ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)
-    assert what['kernel'] == _lib.TAB_KERNEL_GENERAL
+    assert what['kernel'] == (_lib.TAB_KERNEL_GENERAL if general else _lib.TAB_KERNEL_WQN)
     w = env.world
     tab = dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'], starts=w['starting_states'])
     Q = ag._q.cpu().numpy()
