@@ -103,7 +103,7 @@ __device__ __forceinline__ uint64_t log_pack32(float r, uint32_t s, uint32_t a, 
 // round 5 —, the selection's float64 CDF worked out by the wave in the reference's order, action
 // masks from an LDS copy).
 template <bool PLAIN, int W>
-__global__ __launch_bounds__(256) void k_tab_wqn(const nact_args G) {
+__global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   constexpr uint32_t WU = (uint32_t)W;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = G.S, A = PLAIN ? max(G.A, 2) : G.A;
@@ -587,10 +587,24 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   int n_cu = 0;
   size_t lds_cu = 0;
   if (cobel_device_limits(world->device, &n_cu, &lds_cu) != COBEL_OK) return false;
-  // four instances per workgroup where they share the world's copy; as many workgroups per CU as
-  // LDS allows (the limit: 64 KiB of dynamic LDS need no opt-in, the rest of the 160 KiB does)
-  int wpg = shared ? 4 : 1;
-  while (wpg > 1 && nact_lds_bytes(S, A, wpg, shared) > lds_cu / 2) wpg >>= 1;
+  // Instances per workgroup where they share the world's copy: the count (1, 2, 4 or 8) that puts the
+  // most wavefronts on a CU — up to four unless eight win (rows of 16 on 256 states: 17.5 KB per
+  // instance + 11 KB of world and masks, eight in ONE workgroup where two workgroups of four miss
+  // the 160 KiB by 2 KB and three of two make six)
+  int wpg = 1;
+  if (shared) {
+    size_t best = 0;
+    for (int w = 1; w <= 8; w <<= 1) {
+      const size_t need = nact_lds_bytes(S, A, w, shared);
+      if (need > lds_cu) break;
+      size_t waves = (lds_cu / need) * (size_t)w;
+      if (waves > 16) waves = 16;
+      if (waves > best || (waves == best && w <= 4)) {
+        best = waves;
+        wpg = w;
+      }
+    }
+  }
   const size_t lds = nact_lds_bytes(S, A, wpg, shared);
   if (lds > lds_cu) return false;
   *wpg_out = wpg;
