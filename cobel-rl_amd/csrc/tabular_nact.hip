@@ -32,7 +32,7 @@
 // ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
 // compares with the draw — and action masks (32-bit words, an LDS copy) take part in it; the
 // replayed updates read a row's maximum with W / 4 LDS reads, the conflict sets OR W buckets.
-// Masked twelve-action QAgent on a 256-node graph, B 32: 6.8e8 env-steps/s against the 1.9e8 of
+// Masked twelve-action QAgent on a 256-node graph, B 32: 8.1e8 env-steps/s against the 1.9e8 of
 // k_tab_general (bench.py general_wide_q / general_wide_q_lane).
 //
 // Reference behaviour restated: agent/q.py:160-228 (train), :289-315 (update_q), :344-354 (replay);
