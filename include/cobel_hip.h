@@ -106,7 +106,8 @@ COBEL_API int cobel_world_create(const uint16_t* next /* [host] [n_worlds][S][4]
  * start node (interface/topology.py:110-112), six on the hexagonal graphs of
  * misc/topology_tools.py:175-272.  next is [n_worlds][S][n_actions]; n_actions = 4 is
  * cobel_world_create.  Such a world is served by cobel_env_step / cobel_env_reset, and by
- * cobel_tab_run through its general kernel (Q rows of n_actions entries); the entry points built
+ * cobel_tab_run (Q rows of n_actions entries: QAgent on the wavefront kernel of
+ * csrc/tabular_nact.hip while the tables fit, else the general kernel); the entry points built
  * around four actions (cobel_sr_run, cobel_sfma_run; cobel_dqn_act beyond eight) refuse it with
  * COBEL_E_UNSUPPORTED. */
 COBEL_API int cobel_world_create_n(const uint16_t* next /* [host] [n_worlds][S][n_actions] */,
@@ -381,9 +382,11 @@ typedef struct {
  * Dyna-Q in ceil(batch / 62) passes per step (the passes run one after the other, so the
  * sequential order of the reference's loop is kept); QAgent's log replay beyond 62 runs on the
  * general kernel: one lane per instance, every update in the reference's sequential order, tables
- * in HBM / L2; that kernel is also taken for worlds with an action count other than four (Q is then
- * [N][S][n_actions], replay records carry the action in bits 28-30 and the nonterminal flag in bit
- * 31 of the high word) and for state counts whose tables exceed the LDS. */
+ * in HBM / L2; that kernel is also taken where no wavefront kernel covers a world with an action
+ * count other than four (Q is then [N][S][n_actions], replay records carry the action in bits 28-30
+ * and the nonterminal flag in bit 31 of the high word; QAgent without parameter sets / visit
+ * counters runs one wavefront per instance on 1 .. 32 actions) and for state counts whose tables
+ * exceed the LDS. */
 #define COBEL_MAX_BATCH 62
 
 /* 0 = this (S, agent, batch) combination is supported; fills *lds_bytes with the LDS per instance. */
