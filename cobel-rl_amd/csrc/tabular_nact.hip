@@ -30,7 +30,8 @@
 // there (2^A tie patterns): the wave works the selection's float64 CDF out itself, in the order
 // cobel_eps_greedy_select_n (cobel_policy.h) states it — lane k holds value k, the cumulative sum is
 // ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
-// compares with the draw — and action masks (32-bit words, an LDS copy) take part in it; the
+// compares with the draw — and action masks (an LDS copy; masked runs on rows of 8 take this path
+// too) take part in it; the
 // replayed updates read a row's maximum with W / 4 LDS reads, the conflict sets OR W buckets.
 // Masked twelve-action QAgent on a 256-node graph, B 32: 8.1e8 env-steps/s against the 1.9e8 of
 // k_tab_general (bench.py general_wide_q / general_wide_q_lane).
@@ -85,9 +86,10 @@ __host__ __device__ inline size_t nact_thr_words(int A) {
 __host__ __device__ inline int nact_width(int A) { return A <= 8 ? 8 : (A <= 16 ? 16 : 32); }
 // LDS of a workgroup of `wpg` instances (bytes): thresholds (rows of 8) or the action masks (wider
 // rows) | worlds | per instance Q + hash
-__host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool shared) {
+__host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool shared, bool masked) {
   const int W = nact_width(A);
-  const size_t thr = W == 8 ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15 : (((size_t)S * 4 + 15) & ~(size_t)15);
+  const size_t thr = (W == 8 && !masked) ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15
+                                         : (((size_t)S * 4 + 15) & ~(size_t)15);
   const size_t world = (size_t)S * (2 * W + 8);
   return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4 + kHashWords * 8);
 }
@@ -102,8 +104,11 @@ __device__ __forceinline__ uint64_t log_pack32(float r, uint32_t s, uint32_t a, 
 // W: the row width (8: one to eight actions, thresholds from the table; 16 / 32: nine to 32 actions —
 // round 5 —, the selection's float64 CDF worked out by the wave in the reference's order, action
 // masks from an LDS copy).
-template <bool PLAIN, int W>
+// CDF: the selection worked out by the wave (always on the wider rows; on rows of 8 for runs with
+// an action mask — the threshold table knows tie patterns only).
+template <bool PLAIN, int W, bool CDF = (W > 8)>
 __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
+  static_assert(CDF || W == 8, "the threshold table serves rows of eight");
   constexpr uint32_t WU = (uint32_t)W;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int S = G.S, A = PLAIN ? max(G.A, 2) : G.A;
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
 
   // ---- LDS carve-up ---------------------------------------------------------------------------
   unsigned long long* const thr = reinterpret_cast<unsigned long long*>(lds_raw);
-  uint32_t* const maskL = reinterpret_cast<uint32_t*>(lds_raw);          // W > 8: [S] allowed actions
-  size_t off = W == 8 ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15 : (((size_t)S * 4 + 15) & ~(size_t)15);
+  uint32_t* const maskL = reinterpret_cast<uint32_t*>(lds_raw);          // CDF: [S] allowed actions
+  size_t off = !CDF ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15 : (((size_t)S * 4 + 15) & ~(size_t)15);
   const size_t wbytes = (size_t)S * (2 * W + 8);
   unsigned char* const wl = lds_raw + off + (G.shared_world ? 0 : (size_t)wave * wbytes);
   off += G.shared_world ? wbytes : wbytes * (size_t)G.wpg;
@@ -134,13 +139,17 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   // thr[t * (A - 1) + k] = ceil(cdf_k * 2^53) of the tie pattern t (bit a set: action a attains
   // the maximum): probs = eps / A + ((1 - eps) * tie) / n_ties, sequential cumulative sum, divided
   // by its last entry (greedy.py:83-86, Generator.choice) — cobel_make_eps_consts for A values.
-  const uint32_t* const amask_g =
-      (W > 8 && (G.r.flags & COBEL_F_MASK_ACTIONS)) ? reinterpret_cast<const uint32_t*>(G.r.action_mask) : nullptr;
-  if (W > 8) {
+  // (action masks: one byte per state up to eight actions, one 32-bit word beyond)
+  const uint8_t* const amask_g = (CDF && (G.r.flags & COBEL_F_MASK_ACTIONS)) ? G.r.action_mask : nullptr;
+  if (CDF) {
     const uint32_t all = A >= 32 ? 0xffffffffu : ((1u << A) - 1u);
-    for (int s = (int)threadIdx.x; s < S; s += (int)blockDim.x) maskL[s] = amask_g ? amask_g[s] & all : all;
+    for (int s = (int)threadIdx.x; s < S; s += (int)blockDim.x) {
+      uint32_t m = all;
+      if (amask_g) m &= W == 8 ? (uint32_t)amask_g[s] : reinterpret_cast<const uint32_t*>(amask_g)[s];
+      maskL[s] = m;
+    }
   }
-  if (W == 8 && A > 1) {
+  if (!CDF && A > 1) {
     const double eps = G.r.epsilon;
     for (int t = (int)threadIdx.x; t < (1 << A); t += (int)blockDim.x) {
       const int nt = __popc((unsigned)t);
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
     const uint32_t w1 = rl((cp & 1u) ? blk.w : blk.y, src_lane);
     cp += 1u;
     int a = 0;
-    if (W > 8) {
+    if (CDF) {
       // policy/greedy.py:77-86 + Generator.choice as cobel_eps_greedy_select_n states them, by the
       // wave: lane k holds value k of the row; float64 probabilities eps / n + (tie ? (1 - eps) / n_ties
       // : 0) of the allowed actions, their cumulative sum IN ORDER (one add per action, every lane
@@ -428,11 +437,14 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
           "s_nop 1\n\t"
           "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
           "s_nop 1\n\t"
-          "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-          "s_nop 1\n\t"
-          "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+          "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
           : "=&v"(m)
           : "v"(q_ok));
+      if (W > 8) {
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+            : "+v"(m));
+      }
       if (W > 16) m = fmaxf(m, __shfl_xor(m, 16));
       const uint32_t ties = (uint32_t)__ballot(ok && qc == m) & (W >= 32 ? 0xffffffffu : ((1u << W) - 1u));
       const int n = __popc(allowed), n_ties = __popc(ties);
@@ -575,11 +587,11 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   const int S = world->n_states, A = world->n_actions;
   const int W = nact_width(A);
   const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
-  // (rows of 8: no masks — the threshold table knows tie patterns only; wider rows: the conflict
-  //  tables key a cell by s W + a in 13 bits, the packed log record holds 13-bit states)
+  // (the conflict tables key a cell by s W + a in 13 bits, the wide rows' packed log record holds
+  //  13-bit states)
   if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
-      r.param_index || r.occupancy || r.last_exp || (masked && W == 8) ||
-      (masked && (!r.action_mask || ((uintptr_t)r.action_mask & 3u))) ||
+      r.param_index || r.occupancy || r.last_exp ||
+      (masked && (!r.action_mask || (W > 8 && ((uintptr_t)r.action_mask & 3u)))) ||
       (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
       S > 1024 || (size_t)S * W > 8192 || r.n < 1)
     return false;
@@ -595,7 +607,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   if (shared) {
     size_t best = 0;
     for (int w = 1; w <= 8; w <<= 1) {
-      const size_t need = nact_lds_bytes(S, A, w, shared);
+      const size_t need = nact_lds_bytes(S, A, w, shared, masked);
       if (need > lds_cu) break;
       size_t waves = (lds_cu / need) * (size_t)w;
       if (waves > 16) waves = 16;
@@ -605,7 +617,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
       }
     }
   }
-  const size_t lds = nact_lds_bytes(S, A, wpg, shared);
+  const size_t lds = nact_lds_bytes(S, A, wpg, shared, masked);
   if (lds > lds_cu) return false;
   *wpg_out = wpg;
   *lds_out = lds;
@@ -647,22 +659,26 @@ int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hi
                      r.batch > 0 && G.A > 1;
   const int W = nact_width(G.A);
   const dim3 grid((unsigned)((r.n + wpg - 1) / wpg)), block(64 * wpg);
-#define COBEL_WQN(PLAIN, W)                                                                       \
+#define COBEL_WQN(PLAIN, W, CDF)                                                                  \
   do {                                                                                            \
     if (lds > 64 * 1024)                                                                          \
-      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wqn<PLAIN, W>),      \
+      COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tab_wqn<PLAIN, W, CDF>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-    hipLaunchKernelGGL((k_tab_wqn<PLAIN, W>), grid, block, lds, st, G);                           \
+    hipLaunchKernelGGL((k_tab_wqn<PLAIN, W, CDF>), grid, block, lds, st, G);                      \
   } while (0)
-  if (W == 8) {
-    if (plain) COBEL_WQN(true, 8);
-    else COBEL_WQN(false, 8);
+  const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
+  if (W == 8 && masked) {
+    if (plain) COBEL_WQN(true, 8, true);
+    else COBEL_WQN(false, 8, true);
+  } else if (W == 8) {
+    if (plain) COBEL_WQN(true, 8, false);
+    else COBEL_WQN(false, 8, false);
   } else if (W == 16) {
-    if (plain) COBEL_WQN(true, 16);
-    else COBEL_WQN(false, 16);
+    if (plain) COBEL_WQN(true, 16, true);
+    else COBEL_WQN(false, 16, true);
   } else {
-    if (plain) COBEL_WQN(true, 32);
-    else COBEL_WQN(false, 32);
+    if (plain) COBEL_WQN(true, 32, true);
+    else COBEL_WQN(false, 32, true);
   }
 #undef COBEL_WQN
   COBEL_HIP_TRY(hipGetLastError());

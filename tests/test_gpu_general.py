@@ -312,11 +312,16 @@ def test_batches_done_counts_what_planning_evaluates(torch_cuda):
     assert int(qa.batches_done.item()) == int(qa.monitors.steps_done.item())
 
 
-@pytest.mark.parametrize('A,n_worlds,batch', [(6, 1, 32), (6, 1, 0), (6, 3, 62), (5, 1, 8), (7, 2, 24),
-                                              (8, 1, 32), (3, 1, 16), (2, 2, 5), (1, 1, 4)])
-def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch):
-    """Q-learning on worlds of 1..8 (not four) actions runs one wavefront per instance with its
-    tables in LDS (csrc/tabular_nact.hip); the lane-per-instance general kernel executes the
+@pytest.mark.parametrize('A,n_worlds,batch,masked',
+                         [(6, 1, 32, False), (6, 1, 0, False), (6, 3, 62, False), (5, 1, 8, False),
+                          (7, 2, 24, False), (8, 1, 32, False), (3, 1, 16, False), (2, 2, 5, False),
+                          (1, 1, 4, False), (6, 1, 32, True), (8, 1, 20, True), (3, 1, 0, True),
+                          (12, 1, 32, True), (20, 1, 16, False)])
+def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch,
+                                                                            masked):
+    """Q-learning on worlds of 1..32 (not four) actions, with an action mask or without, runs one
+    wavefront per instance with its tables in LDS (csrc/tabular_nact.hip: rows of 8 / 16 / 32
+    values); the lane-per-instance general kernel executes the
     reference's loop literally: same Q, logs, counters, monitors — training in two sessions with a
     test phase in between, launches cut at odd step counts."""
     torch = torch_cuda
@@ -350,9 +355,13 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
         ag.force_general = general
         ag.track_instances = True
         ag.track_responses = True
+        if masked:   # (masked rows: the wave works the selection's CDF out itself — no threshold table)
+            m = np.random.default_rng(7 * A).random((S, A)) < 0.6
+            m[np.arange(S), np.random.default_rng(A).integers(0, A, S)] = True
+            ag.mask_actions, ag.action_mask = True, m
         ag._bind(env)
         ag._env_in(env)
-        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False)
+        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False) | (_lib.F_MASK_ACTIONS if masked else 0)
         ag.monitors.reserve(64, 150, True)
         if batch:
             ag.reserve_replay(400)
