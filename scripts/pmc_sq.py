@@ -26,8 +26,8 @@ LEGS = {   # leg -> (kernel name fragment, what must not be in the name, timed d
     'C6': ('k_sfma', None, 4),
     'grid_search': ('k_tab_wpi<', None, None),
     'general_dynaq_b100': ('k_tab_wpi<', None, 4),
-    'general_hex_q': ('k_tab_wqn<true, 8>', None, 4),
-    'general_wide_q': ('k_tab_wqn<true, 16>', None, 4),
+    'general_hex_q': ('k_tab_wqn<true, 8,', None, 4),
+    'general_wide_q': ('k_tab_wqn<true, 16,', None, 4),
 }
 
 

@@ -25,7 +25,7 @@ import os
 import sys
 
 KERNELS = {'C3': 'k_tab_pwg', 'C2': 'k_tab_lpi<', 'C4': 'k_sr_wave<', 'C6': 'k_sfma',
-           'general_hex_q': 'k_tab_wqn<true, 8>', 'general_wide_q': 'k_tab_wqn<true, 16>',
+           'general_hex_q': 'k_tab_wqn<true, 8,', 'general_wide_q': 'k_tab_wqn<true, 16,',
            'general_wide_q_lane': 'k_tab_general<'}
 # bench.py times the LAST `--steps` (4) launches of each kernel; everything before them is untimed
 # warm-up (C3: the pre-training that takes the agents to the full-work state, C6: 40 launches)
