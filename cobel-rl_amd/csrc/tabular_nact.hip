@@ -26,7 +26,7 @@
 // logs, counters and monitors (tests/test_gpu_general.py, scripts/fuzz_topology.py).
 //
 // Round 5: nine to 32 actions on the same kernel with rows of 16 / 32 values (template W) while a
-// cell's key s W + a fits the conflict tables' 13 bits (512 / 256 states).  No threshold table
+// cell's key s W + a fits the conflict tables' 14 bits (1 024 / 512 states).  No threshold table
 // there (2^A tie patterns): the wave works the selection's float64 CDF out itself, in the order
 // cobel_eps_greedy_select_n (cobel_policy.h) states it — lane k holds value k, the cumulative sum is
 // ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
@@ -59,7 +59,9 @@ struct nact_args {
   float alpha_f, gamma_f;
 };
 
-constexpr int kHashWords = 64 + 128;   // H1: bits 0-5 of s * 8 + a; H2: bits 6-12
+// H1: bits 0-5 of a cell's key s W + a; H2: the bits above — 6-12 on rows of 8 (1 024 states), 6-13 on
+// the wider rows (1 024 / 512 states)
+__host__ __device__ constexpr int nact_hash_words(int W) { return 64 + (W == 8 ? 128 : 256); }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -91,7 +93,7 @@ __host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool sha
   const size_t thr = (W == 8 && !masked) ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15
                                          : (((size_t)S * 4 + 15) & ~(size_t)15);
   const size_t world = (size_t)S * (2 * W + 8);
-  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4 + kHashWords * 8);
+  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4 + nact_hash_words(W) * 8);
 }
 // QAgent replay record of nine to 32 actions (general.hip): hi = s | ns << 13 | action << 26 | nt << 31
 __device__ __forceinline__ uint64_t log_pack32(float r, uint32_t s, uint32_t a, uint32_t ns, uint32_t nt) {
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   off += G.shared_world ? wbytes : wbytes * (size_t)G.wpg;
   uint16_t* const nextL = reinterpret_cast<uint16_t*>(wl);               // [S][W]
   uint2* const RT = reinterpret_cast<uint2*>(wl + (size_t)S * 2 * W);    // [S] {reward bits, terminal}
-  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * W * 4 + kHashWords * 8);
+  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * W * 4 + nact_hash_words(W) * 8);
   float4* const Qs = reinterpret_cast<float4*>(mine);                    // [S][W / 4]
   float* const Qf = reinterpret_cast<float*>(mine);
   unsigned long long* const H1 = reinterpret_cast<unsigned long long*>(mine + (size_t)S * W * 4);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         if (e < S * W) Qf[e] = v[j];
       }
     }
-    for (int b = lane; b < kHashWords; b += 64) H1[b] = 0ull;
+    for (int b = lane; b < nact_hash_words(W); b += 64) H1[b] = 0ull;
   }
   __syncthreads();
   if (!present) return;
@@ -587,13 +589,13 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   const int S = world->n_states, A = world->n_actions;
   const int W = nact_width(A);
   const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
-  // (the conflict tables key a cell by s W + a in 13 bits, the wide rows' packed log record holds
-  //  13-bit states)
+  // (the conflict tables key a cell by s W + a in 13 bits, 14 on the wide rows; their packed log
+  //  record holds 13-bit states)
   if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
       r.param_index || r.occupancy || r.last_exp ||
       (masked && (!r.action_mask || (W > 8 && ((uintptr_t)r.action_mask & 3u)))) ||
       (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
-      S > 1024 || (size_t)S * W > 8192 || r.n < 1)
+      S > 1024 || (size_t)S * W > (W == 8 ? 8192u : 16384u) || r.n < 1)
     return false;
   const bool shared = world->n_worlds == 1;
   int n_cu = 0;

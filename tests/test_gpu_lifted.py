@@ -136,7 +136,8 @@ def _graph(S, A, seed):
 
 
 @pytest.mark.parametrize('A,S,general', [(12, 40, False), (12, 40, True), (32, 64, False), (32, 64, True),
-                                         (17, 256, False), (12, 9000, False), (9, 16384, False)])
+                                         (17, 256, False), (17, 512, False), (12, 1000, False),
+                                         (12, 9000, False), (9, 16384, False)])
 def test_masked_wide_action_rows_and_wide_replay_logs(A, S, general):
     """QAgent with log replay on random graphs: a 12- and a 32-action graph with an action mask
     (32-bit mask words beyond eight actions), a 12-action graph of 9 000 nodes and a nine-action one of
@@ -166,8 +167,8 @@ def test_masked_wide_action_rows_and_wide_replay_logs(A, S, general):
     ag.train(env, trials, steps, B)
     torch.cuda.synchronize()
     what = ag.describe_launch(env, ag.policy, _lib.F_LEARN | _lib.F_MASK_ACTIONS, trials, steps, 0, B)
-    # (the wavefront kernel keys a cell by s W + a in 13 bits: up to 512 / 256 states on rows of 16 / 32)
-    wave = not general and S * (16 if A <= 16 else 32) <= 8192
+    # (the wavefront kernel keys a cell by s W + a in 14 bits: up to 1 024 / 512 states on rows of 16 / 32)
+    wave = not general and S * (16 if A <= 16 else 32) <= 16384
     assert what['kernel'] == (_lib.TAB_KERNEL_WQN if wave else _lib.TAB_KERNEL_GENERAL)
     assert ag._log_words() == (2 if S > 8192 else 1)
     w = env.world
