@@ -40,6 +40,7 @@ constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
 constexpr int kMaxGlobalWaves = 4;
 constexpr int kMaxSlices = 8;
 constexpr uint32_t kWholeTicket = 0x40000000u;
+constexpr uint32_t kWholeThenSlices = 0x80000000u;   // pwg_args::whole: see the ticket draw
 constexpr uint32_t kWholeSlice = 0xffu;   // slice number of an instance that runs all its steps as one ticket
 // word of the scratch header a sliced launch raises when a wave gives up waiting for a ring entry
 // (COBEL_TAB_SCRATCH_ABORT_WORD in cobel_hip.h), and the polls (~1-2 us each) before it does
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
         const uint32_t nq = ((uint32_t)A.r.n + 7u - q) / 8u;
         // (sliced launches: the queue's first nw instances run whole — tickets of counter 1 —, the
         //  other ns in slices — counter 0: first slices, then the ring)
-        const uint32_t nw = sliced ? min(nq, A.whole) : 0u;
+        const uint32_t nw = sliced ? min(nq, A.whole & 0xffffffu) : 0u;
         const uint32_t ns = nq - nw;
         const uint32_t total = SLICED ? ns * (uint32_t)A.n_slices : ns;
         uint32_t t = t_next;
@@ -792,8 +793,11 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
               if (qg && nw) {
                 const uint32_t b = atomicAdd(A.queue + q * 8u + 1u, 1u);
                 if (b < nw) t = kWholeTicket | b;
-              } else if (!(qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT) + A.reserve >= total)) {
+              }
+              // (kWholeThenSlices: a global-memory wave whose whole instances are gone goes on with slices)
+              if (t == 0x10000000u && !(qg && nw && !(A.whole & kWholeThenSlices)) &&
+                  !(qg && __hip_atomic_load(A.queue + q * 8u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT) + A.reserve >= total)) {
                 t = atomicAdd(A.queue + q * 8u, 1u);
                 if (t >= total) {
                   t = 0x10000000u;
@@ -989,6 +993,10 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int nl, int
     return 2;
   }
   if (rounds >= 3.5) {
+    // (from 4.5 per slot: two whole instances per global-memory wave first, then slices — 16 384 /
+    //  20 000 instances 3.12 -> 3.09 / 3.78 -> 3.75 ms; at 12 000, 3.6 per slot, it costs 3 %)
+    if (rounds >= 4.5 && nl > 0 && ng > 0)
+      *whole = (uint32_t)(2 * ((ng * grid + 7) / 8)) | kWholeThenSlices;
     steps[1] = b / 4;
     steps[0] = b - steps[1];
     return 2;

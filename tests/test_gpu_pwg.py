@@ -120,7 +120,8 @@ def test_slices_of_an_instances_steps_equal_whole_instances(monkeypatch):
     one = _sliced(monkeypatch, '512', **args)                  # whole instances
     # (a queue's first instances whole, on the global-memory waves — 425 = all of them, more than those
     #  waves get through: the LDS waves take what is left —, the rest in slices)
-    mixed = [_sliced(monkeypatch, '300,7,100,64,41', whole=w, **args) for w in (1, 60, 150, 424, 425)]
+    mixed = [_sliced(monkeypatch, '300,7,100,64,41', whole=w, **args)
+             for w in (1, 60, 150, 424, 425, 0x80000000 + 30, 0x80000000 + 200)]   # (flag: ... then slices)
     assert auto['kinds'] == {_lib.TAB_KERNEL_PWG} and plain['kinds'] == {_lib.TAB_KERNEL_WPI_INDEX}
     assert plain['q'].any() and plain['batches'] > 0 and plain['lat_cnt'].sum() > 0
     _same(plain, auto)
