@@ -316,7 +316,7 @@ def test_batches_done_counts_what_planning_evaluates(torch_cuda):
                          [(6, 1, 32, False), (6, 1, 0, False), (6, 3, 62, False), (5, 1, 8, False),
                           (7, 2, 24, False), (8, 1, 32, False), (3, 1, 16, False), (2, 2, 5, False),
                           (1, 1, 4, False), (6, 1, 32, True), (8, 1, 20, True), (3, 1, 0, True),
-                          (12, 1, 32, True), (20, 1, 16, False)])
+                          (12, 1, 32, True), (20, 1, 16, False), (12, 2, 16, True), (30, 3, 9, False)])
 def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch,
                                                                             masked):
     """Q-learning on worlds of 1..32 (not four) actions, with an action mask or without, runs one
