@@ -30,8 +30,8 @@
 // there (2^A tie patterns): the wave works the selection's float64 CDF out itself, in the order
 // cobel_eps_greedy_select_n (cobel_policy.h) states it — lane k holds value k, the cumulative sum is
 // ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
-// compares with the draw — and action masks (an LDS copy; masked runs on rows of 8 take this path
-// too) take part in it; the
+// compares with the draw — and action masks (an LDS copy) and per-instance parameter sets take part
+// in it (such runs on rows of 8 take this path too); the
 // replayed updates read a row's maximum with W / 4 LDS reads, the conflict sets OR W buckets.
 // Masked twelve-action QAgent on a 256-node graph, B 32: 8.1e8 env-steps/s against the 1.9e8 of
 // k_tab_general (bench.py general_wide_q / general_wide_q_lane).
@@ -241,7 +241,18 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   asm volatile("" : "+v"(seed));
   const int start_lo = G.start_off[world];
   const uint32_t start_cnt = (uint32_t)(G.start_off[world + 1] - start_lo);
+  // hyper-parameters: launch-wide, or this instance's parameter set (grid-search fan-out; the
+  // selection is then the wave's own CDF — the threshold table is one epsilon's)
   float alpha_f = G.alpha_f, gamma_f = G.gamma_f;
+  double eps_sel = G.r.epsilon;
+  if (CDF && G.r.param_index) {
+    const int kset = (int)G.r.param_index[i];
+    const cobel_param_set_t* const P =
+        G.r.param_sets + (kset < G.r.n_param_sets ? kset : G.r.n_param_sets - 1);
+    alpha_f = P->alpha_f;
+    gamma_f = P->gamma_f;
+    eps_sel = P->epsilon;
+  }
   asm volatile("" : "+v"(alpha_f), "+v"(gamma_f));
   const uint32_t nt_shift = A <= 4 ? 30u : 31u, a_mask = A <= 4 ? 3u : 7u;
   // the maximum of a row of W values (pad cells hold -inf)
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
       if (W > 16) m = fmaxf(m, __shfl_xor(m, 16));
       const uint32_t ties = (uint32_t)__ballot(ok && qc == m) & (W >= 32 ? 0xffffffffu : ((1u << W) - 1u));
       const int n = __popc(allowed), n_ties = __popc(ties);
-      const double eps = G.r.epsilon;
+      const double eps = eps_sel;
       const double base = eps / (double)n;
       const double bonus = ((1.0 - eps) * 1.0) / (double)n_ties;
       const double both = base + bonus;
@@ -515,6 +526,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
     }
     trew += (double)r;
     executed += 1ull;
+    if (!PLAIN && G.r.occupancy && lane == 0) atomicAdd(G.r.occupancy + wbase + ns, 1ull);
     state = ns;
     // ---- replay: this step's batch (gathered a step ago), the next one's gather ----------------------------
     if (B > 0) {
@@ -592,7 +604,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   // (the conflict tables key a cell by s W + a in 13 bits, 14 on the wide rows; their packed log
   //  record holds 13-bit states)
   if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
-      r.param_index || r.occupancy || r.last_exp ||
+      r.last_exp || (r.param_index && !r.param_sets) ||
       (masked && (!r.action_mask || (W > 8 && ((uintptr_t)r.action_mask & 3u)))) ||
       (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
       S > 1024 || (size_t)S * W > (W == 8 ? 8192u : 16384u) || r.n < 1)
@@ -609,7 +621,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   if (shared) {
     size_t best = 0;
     for (int w = 1; w <= 8; w <<= 1) {
-      const size_t need = nact_lds_bytes(S, A, w, shared, masked);
+      const size_t need = nact_lds_bytes(S, A, w, shared, masked || r.param_index != nullptr);
       if (need > lds_cu) break;
       size_t waves = (lds_cu / need) * (size_t)w;
       if (waves > 16) waves = 16;
@@ -619,7 +631,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
       }
     }
   }
-  const size_t lds = nact_lds_bytes(S, A, wpg, shared, masked);
+  const size_t lds = nact_lds_bytes(S, A, wpg, shared, masked || r.param_index != nullptr);
   if (lds > lds_cu) return false;
   *wpg_out = wpg;
   *lds_out = lds;
@@ -658,7 +670,7 @@ int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hi
   G.alpha_f = (float)r.alpha;
   G.gamma_f = (float)r.gamma;
   const bool plain = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.replay_log &&
-                     r.batch > 0 && G.A > 1;
+                     r.batch > 0 && G.A > 1 && !r.occupancy;
   const int W = nact_width(G.A);
   const dim3 grid((unsigned)((r.n + wpg - 1) / wpg)), block(64 * wpg);
 #define COBEL_WQN(PLAIN, W, CDF)                                                                  \
@@ -669,7 +681,7 @@ int cobel_tab_nact_launch(const cobel_world* world, const cobel_tab_run_t& r, hi
     hipLaunchKernelGGL((k_tab_wqn<PLAIN, W, CDF>), grid, block, lds, st, G);                      \
   } while (0)
   const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
-  if (W == 8 && masked) {
+  if (W == 8 && (masked || r.param_index)) {
     if (plain) COBEL_WQN(true, 8, true);
     else COBEL_WQN(false, 8, true);
   } else if (W == 8) {

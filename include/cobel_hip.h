@@ -384,8 +384,8 @@ typedef struct {
  * general kernel: one lane per instance, every update in the reference's sequential order, tables
  * in HBM / L2; that kernel is also taken where no wavefront kernel covers a world with an action
  * count other than four (Q is then [N][S][n_actions], replay records carry the action in bits 28-30
- * and the nonterminal flag in bit 31 of the high word; QAgent without parameter sets / visit
- * counters runs one wavefront per instance on 1 .. 32 actions) and for state counts whose tables
+ * and the nonterminal flag in bit 31 of the high word; QAgent runs one wavefront per instance on
+ * 1 .. 32 actions) and for state counts whose tables
  * exceed the LDS. */
 #define COBEL_MAX_BATCH 62
 

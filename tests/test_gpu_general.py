@@ -316,7 +316,9 @@ def test_batches_done_counts_what_planning_evaluates(torch_cuda):
                          [(6, 1, 32, False), (6, 1, 0, False), (6, 3, 62, False), (5, 1, 8, False),
                           (7, 2, 24, False), (8, 1, 32, False), (3, 1, 16, False), (2, 2, 5, False),
                           (1, 1, 4, False), (6, 1, 32, True), (8, 1, 20, True), (3, 1, 0, True),
-                          (12, 1, 32, True), (20, 1, 16, False), (12, 2, 16, True), (30, 3, 9, False)])
+                          (12, 1, 32, True), (20, 1, 16, False), (12, 2, 16, True), (30, 3, 9, False),
+                          (6, 1, 32, 'psets'), (12, 1, 16, 'psets'), (6, 2, 8, 'occupancy'),
+                          (12, 1, 32, 'occupancy')])
 def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch,
                                                                             masked):
     """Q-learning on worlds of 1..32 (not four) actions, with an action mask or without, runs one
@@ -350,18 +352,25 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
         if n_worlds > 1:    # (several graphs in one handle: instance g walks graph g % n_worlds)
             from cobel_amd.interface.gridworld import WorldHandle
             env.handle = WorldHandle([Topology(w, None, seed=1).world for w in worlds], env.device)
-        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2), learning_rate=0.7,
-                    gamma=0.9)
+        if masked == 'psets':   # (per-instance hyper-parameters: the grid search's fan-out; the CDF path)
+            pr = np.random.default_rng(5)
+            ag = QAgent(env.observation_space, env.action_space,
+                        EpsilonGreedy(pr.choice([0.05, 0.2, 0.5], 150)),
+                        learning_rate=pr.choice([0.3, 0.7, 0.9], 150), gamma=pr.choice([0.8, 0.95], 150))
+        else:
+            ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.2), learning_rate=0.7,
+                        gamma=0.9)
         ag.force_general = general
         ag.track_instances = True
         ag.track_responses = True
-        if masked:   # (masked rows: the wave works the selection's CDF out itself — no threshold table)
+        ag.track_occupancy = masked == 'occupancy'
+        if masked is True:   # (masked rows: the wave works the selection's CDF out itself — no threshold table)
             m = np.random.default_rng(7 * A).random((S, A)) < 0.6
             m[np.arange(S), np.random.default_rng(A).integers(0, A, S)] = True
             ag.mask_actions, ag.action_mask = True, m
         ag._bind(env)
         ag._env_in(env)
-        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False) | (_lib.F_MASK_ACTIONS if masked else 0)
+        flags = _lib.F_LEARN | ag._policy_in(ag.policy, env, False) | (_lib.F_MASK_ACTIONS if masked is True else 0)
         ag.monitors.reserve(64, 150, True)
         if batch:
             ag.reserve_replay(400)
