@@ -36,8 +36,7 @@
 
 namespace {
 
-constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks
-constexpr int kMaxGlobalWaves = 4;
+constexpr int kHashBytes = 128 * 8;   // two 64-bucket tables of lane masks per global-memory wave
 constexpr int kMaxSlices = 8;
 constexpr uint32_t kWholeTicket = 0x40000000u;
 constexpr uint32_t kWholeThenSlices = 0x80000000u;   // pwg_args::whole: see the ticket draw
@@ -146,8 +145,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   const int S = A.S;
   float4* const Qs = reinterpret_cast<float4*>(lds);
   float* const Qf = reinterpret_cast<float*>(lds);
-  unsigned long long* const H =
-      reinterpret_cast<unsigned long long*>(lds + (QG ? (size_t)0 : (size_t)S * 16));
+  unsigned long long* const H = reinterpret_cast<unsigned long long*>(lds);   // (QG only)
   const uint32_t g = A.r.instance_base + (uint32_t)i;
   const int world = (int)(g % (uint32_t)A.n_worlds);
   const uint4* const W4 = reinterpret_cast<const uint4*>(A.rec + (size_t)world * S);
@@ -277,6 +275,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     td = td - (double)q;
     return (float)((double)q + alpha * td);
   };
+  // (global-memory waves)
   // exact conflict sets (see k_tab_wpi): all EARLIER lanes that write a cell this lane reads
   auto conflict_sets = [&](uint32_t idx, uint32_t ns) -> unsigned long long {
     unsigned long long* const H1 = H;
@@ -297,34 +296,48 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
     return cnd;
   };
   // ---- one batch, Q in LDS (called under lane < B) -------------------------------------------
+  // Which lanes must wait is found IN the table (round 6; until then two tables of lane masks per
+  // wave, 1 KiB next to every Q table — the tenth table did not fit the CU's 160 KiB beside them):
+  // a lane that changes its cell raises the cell to the TAG ~lane with ds_max_u32 — tags are the
+  // bit patterns 0xffffffc0 .. 0xffffffff, above every float that is not a NaN of exactly that
+  // payload, so the cell then holds the tag of the EARLIEST lane that writes it; every lane reads
+  // its five inputs again and is held back iff one of them is a tag above its own — an earlier
+  // writer of a cell it reads, the very set the lane masks gave.  The earliest writer of a cell
+  // then stores the new value (committed) or puts the old one back (held back): one store per
+  // cell.  1 + 2 + 1 LDS instructions and a v_max3 pair for 9 and ~35 vector instructions.
+  uint32_t* const Qu = reinterpret_cast<uint32_t*>(lds);
+  const uint4* const Qs4u = reinterpret_cast<const uint4*>(lds);
+  uint32_t tag_mine = ~(uint32_t)lane;
+  auto tag_round = [&](uint32_t idx, uint32_t ns, bool act, bool ch, float q, float qn) -> int {
+    if (ch) atomicMax(&Qu[idx], tag_mine);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t t = 0u, c2 = 0u;
+    if (act) {
+      const uint4 r2 = Qs4u[ns];
+      c2 = Qu[idx];
+      t = max(max(max(r2.x, r2.y), r2.z), max(r2.w, c2));
+    }
+    const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
+    const int stop = blocked ? __ffsll((long long)blocked) - 1 : B;
+    if (ch && c2 == tag_mine) Qf[idx] = lane < stop ? qn : q;
+    __builtin_amdgcn_wave_barrier();
+    return stop;
+  };
   auto run_batch_lds = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r) {
     // The first round, every lane of the batch, written out on its own: 91 % of the batches end
     // here on trained agents (0 / 1 / 2 / 3 / 4 writers in 7 / 17 / 23 / 21 / 15 % of them,
     // scripts/experiments/exp_pwg_hist.py), and as the first trip of one loop over the rounds it
     // carried that loop's `act` masks and round state: 12.27 -> 12.06 ms per C3 launch.
-    // (With so few writers, finding the held-back lanes writer by writer — the writer's pair index
-    //  broadcast, two comparisons per lane, no hash tables — looked cheaper than the tables' ~35
-    //  vector and 9 LDS instructions.  Built as a loop over the writers and as four writers at
-    //  once: 13.3 and 13.1 ms.  Each writer is a scalar -> vector -> scalar hand-off, and the
-    //  compiler lowers a ballot of an OR of two comparisons to a select and a compare.)
-    int first = B;
-    bool have_conf = false;
-    unsigned long long conf = 0ull;
+    int first;
     {
       const float4 row = Qs[ns];
       const float q = Qf[idx];
       const float qn = plan_td(q, max4(row), r, nt);
       const bool ch = fbits(qn) != fbits(q);
-      const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
-      if (!changed) return;
-      conf = conflict_sets(idx, ns);
-      have_conf = true;
-      const unsigned long long blocked = __builtin_amdgcn_ballot_w64((conf & changed) != 0ull);
-      if (blocked) first = __ffsll((long long)blocked) - 1;
-      if (ch && lane < first) Qf[idx] = qn;
-      __builtin_amdgcn_wave_barrier();
+      if (!__builtin_amdgcn_ballot_w64(ch)) return;
+      first = tag_round(idx, ns, true, ch, q, qn);
     }
-    // Later rounds (a lane was held back): the lanes from `first` on, conflict sets from the tables.
+    // Later rounds (a lane was held back): the lanes from `first` on.
     while (first < B) {
       const bool act = lane >= first;
       float q = 0.0f, qn = 0.0f;
@@ -334,19 +347,8 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
         qn = plan_td(q, max4(row), r, nt);
       }
       const bool ch = act && fbits(qn) != fbits(q);
-      const unsigned long long changed = __ballot(ch);
-      int stop = B;
-      if (changed) {
-        if (!have_conf) {
-          conf = conflict_sets(idx, ns);
-          have_conf = true;
-        }
-        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
-        if (blocked) stop = __ffsll((long long)blocked) - 1;
-        if (ch && lane < stop) Qf[idx] = qn;
-        __builtin_amdgcn_wave_barrier();
-      }
-      first = stop;
+      if (!__ballot(ch)) return;
+      first = tag_round(idx, ns, act, ch, q, qn);
     }
   };
   // ---- one batch, Q in global memory: inputs (row, q) already in registers -------------------
@@ -443,8 +445,10 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       nonzero |= fbits(qv.x) | fbits(qv.y) | fbits(qv.z) | fbits(qv.w);
     }
   }
-  for (int b = lane; b < 128; b += 64) H[b] = 0ull;
-  __builtin_amdgcn_wave_barrier();
+  if (QG) {
+    for (int b = lane; b < 128; b += 64) H[b] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+  }
   // COBEL_IF_NONZERO (bit 1, launch-local): see k_tab_wpi
   if (!__ballot(nonzero != 0u)) {
     // (the digest, a state's four entries per request, eight requests in flight)
@@ -549,11 +553,12 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       R = __builtin_bit_cast(float, rfl(model32[2u * sa]));
     }
     __builtin_amdgcn_sched_barrier(0);
-    uint2 mdig_next = {0u, 0u};
-    if (!trial_over) {
-      cand = W4[succ_of(nw0, nw1)];
-      mdig_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
-    }
+    // (unconditional: at a trial's end the two requests are wasted — begin_trial asks again — but a
+    //  request under a condition merges with the old value, and the merge is a copy behind a wait
+    //  for the answer, a memory round trip per step of the global-memory waves: 25.7 -> 32 ms per
+    //  launch of those alone in one build of round 6)
+    cand = W4[succ_of(nw0, nw1)];
+    const uint2 mdig_next = *reinterpret_cast<const uint2*>(&Mg[(uint32_t)ns * 4u]);
 
     // ---- model store (memory/dyna_q.py:92-96) and online TD (agent/dyna_q.py:290-299), float32 ------
     if (sa == fix_sa) R = fix_r;
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = (int)rfl(threadIdx.x >> 6);
   const int waves = A.nl + A.ng;
-  const size_t slice_l = (size_t)A.S * 16 + kHashBytes;
+  const size_t slice_l = (size_t)A.S * 16;
   const bool qg = wave >= A.nl;
   unsigned char* const lds =
       lds_raw + (qg ? (size_t)A.nl * slice_l + (size_t)(wave - A.nl) * kHashBytes
@@ -919,15 +924,16 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   int n_cu = 0;
   size_t total = 0;
   if (cobel_device_limits(world->device, &n_cu, &total) != COBEL_OK) return false;
-  const size_t slice_l = (size_t)S * 16 + kHashBytes;
+  const size_t slice_l = (size_t)S * 16;
   int nl = (int)(total / slice_l);
   if (nl > 16) nl = 16;
-  int ng = (int)((total - (size_t)nl * slice_l) / kHashBytes);
-  if (ng > 16 - nl) ng = 16 - nl;
-  // Measured on C3 (32 x 32, trained agents, scripts/experiments/exp_pwg.py): 9 + 0 / 3 / 4 / 5 / 6 / 7 waves take
-  // 14.1 / 12.9 / 12.75 / 12.8 / 14.7 / 17.2 ms per launch — the Q tables of the global-memory waves
-  // compete for the XCD's 4 MiB of L2 with the digests and model records of all of them.
-  if (ng > kMaxGlobalWaves) ng = kMaxGlobalWaves;
+  // LDS waves only (round 6).  While every Q table had 1 KiB of lane masks beside it nine fitted a
+  // CU at 32 x 32 and four global-memory waves on top paid (9 + 0 / 9 + 4: 12.7 / 11.5 ms per C3
+  // launch); with the dependencies found in the table itself ten fit, and a global-memory wave next
+  // to ten costs the others more in L2 misses on their digests than it adds (10 + 0 / 1 / 2 / 3:
+  // 10.9 / 11.2 / 11.1 / 11.3 ms; scripts/experiments/pwg_r06/).  Global-memory waves remain for
+  // COBEL_F_PWG_GLOBAL and forced mixes (tests, experiments).
+  int ng = 0;
   if (force) {
     int a = 0, b = 0;
     if (sscanf(force, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b >= 1 && a + b <= 16 &&
@@ -938,7 +944,7 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   } else if (r.flags & COBEL_F_PWG_GLOBAL) {
     nl = 0;
     ng = 16;
-  } else if (ng == 0) {
+  } else if (total / (slice_l + 1024) >= 16) {
     return false;   // LDS is not what limits the resident instances: k_tab_wpi as it is
   }
   *nl_out = nl;

@@ -15,6 +15,8 @@ if os.environ.get('COBEL_LIB'):      # A/B builds of the library
 dev = torch.device('cuda', 0)
 pre = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cfg = dict(bench.CONFIGS['C3'])
+if os.environ.get('PWG_N'):          # a shard of the batch (what each GPU of a split runs)
+    cfg['instances'] = int(os.environ['PWG_N'])
 env, agent = bench.build_agent('C3', cfg, cfg['instances'], 0, dev)
 if 'nopwg' in sys.argv:
     agent.extra_flags = _lib.F_NO_PWG
@@ -27,7 +29,7 @@ ev[pre + 4].record()
 torch.cuda.synchronize()
 ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(pre + 4)]
 what = r.describe()
-print('lib=%s PWG=%s %s kernel %d: launches 2-5 %s | last 4 %s ms  -> %.3e steps/s' % (
-    os.environ.get('COBEL_LIB', '-'), os.environ.get('COBEL_DEBUG_PWG', '-'), 'nopwg' if 'nopwg' in sys.argv else '', what['kernel'],
+print('n=%d lib=%s PWG=%s %s kernel %d: launches 2-5 %s | last 4 %s ms  -> %.3e steps/s' % (
+    cfg['instances'], os.environ.get('COBEL_LIB', '-'), os.environ.get('COBEL_DEBUG_PWG', '-'), 'nopwg' if 'nopwg' in sys.argv else '', what['kernel'],
     ' '.join('%.2f' % m for m in ms[1:5]), ' '.join('%.2f' % m for m in ms[-4:]),
     cfg['instances'] * cfg['env_steps_per_launch'] / (min(ms[-4:]) * 1e-3)), flush=True)

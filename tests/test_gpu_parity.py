@@ -1631,8 +1631,8 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
     import bench
     from cobel_amd import _lib
     dev = torch.device('cuda', 0)
-    # (C3: one persistent workgroup per CU — nine wavefronts with Q in LDS, 17 408 B each, and a few
-    #  with Q in global memory, 1 024 B of hash tables each; F_NO_PWG: one workgroup per instance)
+    # (C3: one persistent workgroup per CU — ten wavefronts, each with its instance's Q table in LDS,
+    #  16 384 B, which is all of it; F_NO_PWG: one workgroup per instance, tables of lane masks beside Q)
     for name, n, kernel, lds, per_cu, per_wg, extra in [
             ('C3', 256, _lib.TAB_KERNEL_PWG, None, 1, None, 0),
             ('C3', 256, _lib.TAB_KERNEL_WPI_INDEX, 1024 * 16 + 1024, 9, 1, _lib.F_NO_PWG),
@@ -1649,8 +1649,8 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
             assert got['instances_per_workgroup'] == per_wg, (name, got)
         else:
             waves = got['instances_per_workgroup']
-            assert 9 < waves <= 16 and got['workgroups_per_cu'] == 1
-            assert got['lds_bytes'] == 9 * (1024 * 16 + 1024) + (waves - 9) * 1024 <= 160 * 1024
+            assert waves == 10 and got['workgroups_per_cu'] == 1
+            assert got['lds_bytes'] == 10 * 1024 * 16 == 160 * 1024
         if lds is not None:
             assert (got['lds_bytes'], got['workgroups_per_cu']) == (lds, per_cu), (name, got)
         assert ag.env_steps() == 0 and int(ag.inst[:, _lib.I_STEPS_LO].sum().item()) == 0
