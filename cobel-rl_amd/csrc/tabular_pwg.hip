@@ -925,6 +925,9 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   size_t total = 0;
   if (cobel_device_limits(world->device, &n_cu, &total) != COBEL_OK) return false;
   const size_t slice_l = (size_t)S * 16;
+#if defined(COBEL_PWG_STAMPS)
+  total -= 1024;   // (the timing build keeps a word per wave in LDS)
+#endif
   int nl = (int)(total / slice_l);
   if (nl > 16) nl = 16;
   // LDS waves only (round 6).  While every Q table had 1 KiB of lane masks beside it nine fitted a
@@ -956,17 +959,21 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
 // The slices of a launch (see k_tab_pwg).  A slice boundary costs an instance ~19 us on C3 (9.6 us
 // of ticket, prologue and write-back, the rest in steps that run slower while more tables are on
 // the move; scripts/experiments/exp_pwg_stamps.py), a short last slice saves waiting at the end of the launch.
-// Measured on one MI355X, C3, 13 waves on each of 256 CUs (ms per launch of 512 steps; unsliced /
-// planned): 32 768 instances 6.40 / 6.07 with 448 + 64, 16 384: 3.30 / 3.12 with 384 + 128; 65 536
-// is not sliced.
-// Between 1.75 and 3.5 instances per wave slot (5 900 .. 11 600 instances: what an eight-way split
-// of C3 leaves each GPU) the global-memory waves are kept out of the slices: a wave that keeps Q
-// in memory needs 1.0 of such a launch's 1.6 ms for ONE instance, so each of them runs exactly one,
-// whole, and the LDS waves share the others in slices of 384 + 128 (profiles/r05_sweeps.txt: 6 000 /
-// 7 000 / 8 192 / 10 000 / 11 000 instances 1.42 / 1.56 / 1.70 / 2.07 / 2.28 ms with everything in
-// slices of 320 + 128 + 64 -> 1.27 / 1.40 / 1.61 / 2.00 / 2.22; 5 400 and 12 000 gain nothing).
-// Measured and dropped there: giving the global-memory waves later slices on top (they share the
-// CU's issue slots with the LDS waves: 1.63), whole instances first for the LDS waves too (1.63-1.67).
+// Measured on one MI355X, C3, TEN LDS waves on each of 256 CUs (round 6; ms per launch of 512
+// steps, profiles/r06_sweeps.txt): 8 192 instances 1.61 whole / 1.48 with 384 + 128 (1.51 with 320 +
+// 128 + 64, more slices: slower); 16 384: 3.00 / 2.85 with 448 + 64 (2.88 with 384 + 128, three
+// slices 2.94); 32 768: 5.64 whichever way; 65 536: slices cost 1.5 %.  With waves that keep Q in
+// global memory (forced mixes only since round 6: cobel_tab_pwg_plan) between 1.75 and 3.5 instances
+// per wave slot those waves are kept out of the slices: each runs exactly ONE whole instance, and the
+// LDS waves share the others in slices (round 5: such a wave needs 1.0 of a 1.6 ms launch for one).
+// A staggered split — every wave slot starts with the HEAD of a split instance, of a length spread
+// over (0, budget), the tails are handed out last, longest first: one boundary per wave slot instead
+// of two per instance — was built and measured in round 6 (scripts/experiments/pwg_r06/
+// staggered_split.patch): 65 536 instances 11.01 -> 10.89 ms, but 16 384 / 8 192 only 2.96 / 1.62.
+// The waves of a SIMD do not run at one speed — the arbiter serves the oldest first: 358 / 431 /
+// 559 us per ticket for the first / second / third wave of a SIMD (s_setprio turns the order
+// round, the sum stays) — so a long tail drawn late by a third wave ends the launch; even slices
+// keep all instances at the same pace whatever the wave.
 static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int nl, int ng, bool scratch,
                        int32_t* steps /* [kMaxSlices] */, uint32_t* whole) {
   const char* const forced = cobel_debug_env("COBEL_DEBUG_PWG_SLICES");   // "320,128,64" (tests, experiments)
@@ -992,7 +999,15 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int nl, int
   }
   const double rounds = (double)r.n / ((double)grid * (nl + ng));
   const int b = r.step_budget;
-  if (rounds >= 14.0 || rounds < 1.0) return 1;
+  if (rounds < 1.0) return 1;
+  if (ng == 0) {
+    if (rounds >= 10.0) return 1;
+    steps[1] = rounds >= 5.0 ? b / 8 : b / 4;
+    steps[0] = b - steps[1];
+    return 2;
+  }
+  // (mixes with global-memory waves: round 5's plan)
+  if (rounds >= 14.0) return 1;
   if (rounds >= 7.0) {
     steps[1] = b / 8;
     steps[0] = b - steps[1];
@@ -1001,13 +1016,13 @@ static int plan_slices(const cobel_tab_run_t& r, int grid, int n_cu, int nl, int
   if (rounds >= 3.5) {
     // (from 4.5 per slot: two whole instances per global-memory wave first, then slices — 16 384 /
     //  20 000 instances 3.12 -> 3.09 / 3.78 -> 3.75 ms; at 12 000, 3.6 per slot, it costs 3 %)
-    if (rounds >= 4.5 && nl > 0 && ng > 0)
+    if (rounds >= 4.5 && nl > 0)
       *whole = (uint32_t)(2 * ((ng * grid + 7) / 8)) | kWholeThenSlices;
     steps[1] = b / 4;
     steps[0] = b - steps[1];
     return 2;
   }
-  if (rounds >= 1.75 && nl > 0 && ng > 0) {
+  if (rounds >= 1.75 && nl > 0) {
     // one whole instance per global-memory wave (a queue's share of them, rounded up)
     *whole = (uint32_t)((ng * grid + 7) / 8);
     steps[1] = b / 4;

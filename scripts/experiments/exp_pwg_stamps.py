@@ -2,7 +2,7 @@
 cycles per phase — ticket draw, prologue, steps, write-back — summed per wave by the kernel into the
 scratch area, read back here and split by the two kinds of wave.
 
-    COBEL_LIB=$PWD/gpurun_ab/libcobel_stamps.so python scripts/experiments/exp_pwg_stamps.py [instances] [pretrain launches]
+    COBEL_LIB=$PWD/cobel-rl_amd/lib/libcobel_S.so python scripts/experiments/exp_pwg_stamps.py [instances] [pretrain launches]
 """
 import os
 os.environ.setdefault('COBEL_DEBUG', '1')   # (master switch of the library's COBEL_DEBUG_* experiment variables)
@@ -39,7 +39,7 @@ def main():
     slices = len(os.environ.get('COBEL_DEBUG_PWG_SLICES', '512').split(','))
     off = 256 + 8 * ((n + 7) // 8) * (slices - 1)
     st = sc[off:off + grid * waves * 8].reshape(grid, waves, 8).astype(np.float64)
-    nl = 9 if waves == 13 else waves
+    nl = waves
     print('launch %.3f ms, %d waves per workgroup' % (ms, waves))
     for name, sel in (('LDS waves', st[:, :nl]), ('global-memory waves', st[:, nl:])):
         if sel.size == 0:
@@ -53,6 +53,10 @@ def main():
                  100 * (1 - sel[..., 2].sum() / tot), tot / sel[..., 4].size))
 
 
+    # by wave slot of the workgroup: the SIMD's arbiter serves its oldest wave first (wave w runs on SIMD w % 4)
+    with np.errstate(all='ignore'):
+        per = st[..., 2].sum(axis=0) / st[..., 4].sum(axis=0)
+    print('cycles in the steps per ticket, by wave slot: ' + '  '.join('%d: %.0f' % (w, per[w]) for w in range(waves)))
     ss = sc[off + 26624:off + 26624 + 3].astype(np.float64)
     if ss.any():
         tickets = st[..., 4].sum()
