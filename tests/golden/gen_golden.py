@@ -167,6 +167,8 @@ def gen_worlds():
         'windy_5x6_down': gt.make_windy_gridworld(
             5, 6, np.array([0, 1, 2, 1, 0, 3]), 3, 1.0, 'down'),
         'open_32x32': gt.make_open_field(32, 32, 0, 1),
+        'open_32x32_near': dict(gt.make_open_field(32, 32, 0, 1),
+                                starting_states=np.array([1, 2, 32, 33, 34, 64, 65, 66])),
         't_maze_3_2_right': gt.make_t_maze(3, 2, 'right', 1.0),
         't_maze_2_4_left': gt.make_t_maze(2, 4, 'left', 2.0),
         'double_t_maze_3_2_lr': gt.make_double_t_maze(3, 2, 'left-right', 1.5),
@@ -690,6 +692,65 @@ def gen_sr(worlds):
     np.savez_compressed(_out('sr_traces.npz'), **out)
 
 
+def gen_sr32(worlds=None):
+    """SR at config C4's own size (32 x 32 = 1 024 states: `retrieve_q`'s row sums change their
+    association at 128-element leaves there, agent/sr.py:288-308).  Three float32-coerced runs of
+    the reference's `SR.train`: trials that start next to the goal (the reward estimate gets its
+    one non-zero entry the way C4 does), and two runs whose reward estimates are pre-loaded — all
+    1 024 entries non-zero / twenty of them — so that the sums have many terms.  Stored: the rows
+    of SR that differ from the identity and their indices, `rewards`, argmax(`transitions`),
+    `retrieve_q` of every step."""
+    if worlds is None:
+        worlds = {'open_32x32': gt.make_open_field(32, 32, 0, 1),
+                  'open_32x32_near': dict(gt.make_open_field(32, 32, 0, 1),
+                                          starting_states=np.array([1, 2, 32, 33, 34, 64, 65, 66]))}
+    gen = np.random.default_rng(20261005)
+    dense = gen.random(1024).astype(np.float32)
+    sparse = np.zeros(1024, dtype=np.float32)
+    sparse[gen.choice(1024, size=20, replace=False)] = (gen.random(20) * 2 - 0.5).astype(np.float32)
+    cases = {
+        'open32_near_f32': ('open_32x32_near', 0, 8, 60, None),
+        'open32_dense_f32': ('open_32x32', 1, 2, 90, dense),
+        'open32_r20_f32': ('open_32x32', 2, 2, 90, sparse),
+    }
+    out = {}
+    for name, (wname, inst, trials, steps, rw0) in cases.items():
+        world = worlds[wname]
+        env = _env(world, inst)
+        pol = EpsilonGreedy(0.1, rng=TapeRNG(SEED, inst, STREAM_POLICY))
+        ag = SR(env.observation_space, env.action_space, pol)
+        ag.SR = ag.SR.astype(np.float32)
+        ag.rewards = ag.rewards.astype(np.float32) if rw0 is None else rw0.copy()
+        tr = Tracer(None)
+        qs = []
+        orig = ag.retrieve_q
+
+        def spy(state, orig=orig, qs=qs):
+            q = orig(state)
+            qs.append(np.asarray(q, dtype=np.float64))
+            return q
+
+        ag.retrieve_q = spy
+        ag.callbacks.custom_callbacks = {k: list(v) for k, v in tr.callbacks().items()}
+        for k in ('on_trial_begin', 'on_step_begin'):
+            ag.callbacks.custom_callbacks.setdefault(k, [])
+        ag.train(env, trials, steps)
+        assert ag.SR.dtype == np.float32 and ag.rewards.dtype == np.float32
+        d = tr.pack()
+        del d['td']
+        rows = np.flatnonzero((ag.SR != np.eye(1024, dtype=np.float32)).any(axis=1))
+        d.update(SR_rows=rows.astype(np.int16), SR_values=ag.SR[rows], rewards=np.array(ag.rewards),
+                 T=np.argmax(ag.transitions, axis=-1).astype(np.int16), q=np.array(qs),
+                 cfg=np.array([inst, 1, trials, steps, 0], dtype=np.int64),
+                 alpha=np.float64(ag.learning_rate), gamma=np.float64(ag.gamma), eps=np.float64(0.1))
+        if rw0 is not None:
+            d['rewards0'] = rw0
+        for k, v in d.items():
+            out['%s/%s' % (name, k)] = v
+        out['%s/world' % name] = np.array(wname)
+    np.savez_compressed(_out('sr32_traces.npz'), **out)
+
+
 MODES = ['default', 'reverse', 'forward', 'blend_forward', 'blend_reverse', 'interpolate',
          'sweeping']
 
@@ -1169,6 +1230,7 @@ def main():
     gen_dynaq_memory()
     gen_qagent(worlds)
     gen_sr(worlds)
+    gen_sr32(worlds)
     gen_monitor(worlds)
     gen_sfma()
     gen_qagent_topology()

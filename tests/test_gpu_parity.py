@@ -306,6 +306,40 @@ def test_sr_golden(torch_cuda, golden, golden_worlds, name):
     assert np.array_equal(agent.SR[inst].cpu().numpy().astype(np.float64), D[name + '/SR'])
 
 
+@pytest.mark.parametrize('stream_rows', [False, True])
+@pytest.mark.parametrize('name', ['open32_near_f32', 'open32_dense_f32', 'open32_r20_f32'])
+def test_sr_golden_at_32x32(torch_cuda, golden, golden_worlds, name, stream_rows):
+    """Config C4's own size against the REAL reference (tests/golden/gen_golden.py gen_sr32): one,
+    twenty and 1 024 non-zero reward estimates — 1 024-term row sums in NumPy's pairwise order
+    (agent/sr.py:288-308) — on the sparse-reward kernel where it serves (k_sr_wave: up to 32
+    rewarded states) and on the row-streaming kernel (k_sr), bit for bit."""
+    torch = torch_cuda
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    D = golden('sr32_traces')
+    inst, f32, trials, steps, _ = [int(x) for x in D[name + '/cfg']]
+    env = Gridworld(as_world(golden_worlds(str(D[name + '/world']))), n_envs=3, seed=SEED,
+                    instance_base=0)
+    agent = SR(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    agent.track_instances = True
+    agent.stream_rows = stream_rows
+    if name + '/rewards0' in D.files:
+        agent._bind(env)
+        agent._rw.copy_(torch.as_tensor(D[name + '/rewards0'], device='cuda')[None].expand(3, -1))
+    agent.train(env, trials, steps)
+    sr = np.eye(1024, dtype=np.float32)
+    sr[D[name + '/SR_rows'].astype(int)] = D[name + '/SR_values']
+    assert np.array_equal(agent.monitors.lat_trace[inst].cpu().numpy(), D[name + '/steps'])
+    assert np.array_equal(agent.T[inst].cpu().numpy(), D[name + '/T'])
+    assert np.array_equal(agent.rewards[inst].cpu().numpy(), D[name + '/rewards'])
+    assert np.array_equal(agent.SR[inst].cpu().numpy(), sr)
+    # (only the sparse-reward kernel counts its traffic.  It serves this world — one rewarded state —
+    #  whatever the estimates hold: pre-loaded non-zero entries elsewhere send the instance to its
+    #  full sums from memory, csrc/sr_wave.hip `dense`)
+    assert (int(agent.traffic[1].item()) > 0) == (not stream_rows)
+
+
 # ---------------------------------------------------------------------------------------------
 # Parity against the C oracle on the benchmark workloads themselves (same seeded inputs, sizes the
 # oracle finishes in seconds), launched exactly like bench.py launches them.

@@ -208,6 +208,46 @@ def test_sr_golden(golden, golden_worlds, name):
     assert np.array_equal(ag.T, D[name + '/T'])
 
 
+def _sr32_full(D, name):
+    sr = np.eye(1024, dtype=np.float32)
+    sr[D[name + '/SR_rows'].astype(int)] = D[name + '/SR_values']
+    return sr
+
+
+@pytest.mark.parametrize('name', ['open32_near_f32', 'open32_dense_f32', 'open32_r20_f32'])
+def test_sr_golden_at_32x32(golden, golden_worlds, name):
+    """Config C4's own size: 1 024-term row sums (`retrieve_q`, agent/sr.py:288-308) of the REAL
+    reference — one, twenty and 1 024 non-zero reward estimates — against the C restatement's
+    pairwise order and the NumPy restatement, bit for bit."""
+    D = golden('sr32_traces')
+    inst, f32, trials, steps, _ = [int(x) for x in D[name + '/cfg']]
+    tab = _world(golden_worlds, str(D[name + '/world']))
+    rw0 = D[name + '/rewards0'] if name + '/rewards0' in D.files else None
+    w = c_oracle.OracleWorld([tab])
+    o = c_oracle.SROracle(w, 1, SEED, True, instance_base=inst, trial_cap=trials)
+    if rw0 is not None:
+        o.RW[0] = rw0
+    tr, q = o.run(trials, steps, trace_inst=0, trace_cap=100000)
+    assert np.array_equal(tr[:, 0], D[name + '/state'])
+    assert np.array_equal(tr[:, 1], D[name + '/action'])
+    assert np.array_equal(tr[:, 3], D[name + '/next_state'])
+    assert np.array_equal(q, D[name + '/q'])
+    assert np.array_equal(o.lat_trace[0], D[name + '/steps'])
+    assert np.array_equal(o.SR[0].astype(np.float32), _sr32_full(D, name))
+    assert np.array_equal(o.RW[0].astype(np.float32), D[name + '/rewards'])
+    assert np.array_equal(o.T[0], D[name + '/T'])
+    env = ref_loop.RefGridworld(tab, TapeRNG(SEED, inst, STREAM_ENV))
+    pol = ref_loop.RefEpsilonGreedy(0.1, TapeRNG(SEED, inst, STREAM_POLICY))
+    ag = ref_loop.RefSR(1024, 4, pol, dtype=np.float32)
+    if rw0 is not None:
+        ag.rewards = rw0.copy()
+    trace = {'sarsn': [], 'q': [], 'steps': [], 'trial_reward': []}
+    ag.train(env, trials, steps, trace)
+    assert np.array_equal(np.array(trace['q']), D[name + '/q'])
+    assert np.array_equal(ag.SR, _sr32_full(D, name)) and np.array_equal(ag.T, D[name + '/T'])
+    assert np.array_equal(ag.rewards, D[name + '/rewards'])
+
+
 def test_float32_tables_track_float64_reference(golden):
     """North-star tolerance, on the reference's own two runs: with identical draws the float32 run
     stays within 1e-6 of the float64 run on the 5x5 config for as long as the trajectories
