@@ -392,6 +392,67 @@ def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torc
 
 
 @pytest.mark.parametrize('general', [False, True])
+@pytest.mark.parametrize('A', [6, 12])
+def test_parameter_sets_and_visit_counts_against_the_oracle(torch_cuda, A, general):
+    """Per-instance hyper-parameters (the grid search's fan-out) and the visit counters on worlds of
+    six / twelve actions, on the wavefront kernel (k_tab_wqn) and the lane-per-instance kernel
+    (k_tab_general), EACH against the restatement of the reference's loop (agent/q.py:305-354,
+    policy/greedy.py:60-88) run instance by instance with that instance's parameters — not kernel
+    against kernel."""
+    torch = torch_cuda
+    from cobel_amd import _lib
+    from cobel_amd.agent import QAgent
+    from cobel_amd.interface import Topology
+    from cobel_amd.policy import EpsilonGreedy
+    from oracle import ref_loop
+    from oracle.philox import STREAM_ENV, STREAM_MEMORY, STREAM_POLICY, TapeRNG
+    r = np.random.default_rng(900 + A)
+    S = 31
+    nbr = r.integers(0, S, (S, A))
+    nbr = np.where(r.random((S, A)) < 0.15, np.arange(S)[:, None], nbr)
+    terminal = np.zeros(S, dtype=bool)
+    terminal[[5, 19]] = True
+    reward = np.zeros(S)
+    reward[5], reward[19], reward[12] = 1.0, -0.5, 0.25
+    nodes = {str(i): {'id': str(i), 'pose': np.array([float(i % 6), float(i // 6), 0., 0., 0., 0.]),
+                      'neighbors': [str(int(j)) for j in nbr[i]], 'reward': float(reward[i]),
+                      'terminal': bool(terminal[i])} for i in range(S)}
+    n, trials, steps, B = 36, 4, 25, 12
+    pr = np.random.default_rng(5)
+    eps = pr.choice([0.05, 0.2, 0.5], n)
+    alpha = pr.choice([0.3, 0.7, 0.9], n)
+    gamma = pr.choice([0.8, 0.95], n)
+    env = Topology(nodes, None, n_envs=n, seed=SEED, instance_base=11)
+    ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha,
+                gamma=gamma)
+    ag.track_instances = True
+    ag.track_occupancy = True
+    ag.force_general = general
+    ag.train(env, trials, steps, B)
+    torch.cuda.synchronize()
+    what = ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)
+    assert what['kernel'] == (_lib.TAB_KERNEL_GENERAL if general else _lib.TAB_KERNEL_WQN)
+    w = env.world
+    tab = dict(next=w['next'], reward=w['rewards'], terminal=w['terminals'], starts=w['starting_states'])
+    Q = ag._q.cpu().numpy()
+    lat = ag.monitors.lat_trace.cpu().numpy()
+    visits = np.zeros(S, dtype=np.int64)
+    for i in range(n):
+        g = 11 + i
+        renv = ref_loop.RefGridworld(tab, TapeRNG(SEED, g, STREAM_ENV))
+        pol = ref_loop.RefEpsilonGreedy(float(eps[i]), TapeRNG(SEED, g, STREAM_POLICY))
+        ref = ref_loop.RefQAgent(S, A, pol, TapeRNG(SEED, g, STREAM_MEMORY), float(alpha[i]),
+                                 float(gamma[i]), dtype=np.float32)
+        tr = ref_loop.new_trace()
+        ref.train(renv, trials, steps, B, trace=tr)
+        assert np.array_equal(lat[i, :trials], tr['steps']), i
+        assert np.array_equal(Q[i].reshape(S, A), ref.Q), i
+        visits += np.bincount(np.array(tr['sarsn'])[:, 3].astype(int), minlength=S)
+    assert np.array_equal(ag.monitors.occupancy.cpu().numpy().reshape(-1)[:S].astype(np.int64), visits)
+    assert visits.sum() == ag.env_steps() and len(set(zip(eps, alpha, gamma))) > 4
+
+
+@pytest.mark.parametrize('general', [False, True])
 @pytest.mark.parametrize('A', [9, 12, 17, 32])
 def test_more_than_eight_actions(torch_cuda, A, general):
     """Nine to 32 neighbours per node (interface/topology.py:110-112 takes any count): the wide

@@ -638,6 +638,74 @@ def test_param_sets_sr_equal_uniform_runs(torch_cuda, golden_worlds):
         assert torch.equal(mixed.inst[sel], uni.inst[sel]), k
 
 
+@pytest.mark.parametrize('agent_name', ['dynaq', 'q'])
+def test_param_sets_tabular_against_the_oracle_instance_by_instance(torch_cuda, golden_worlds, agent_name):
+    """A mixed launch of Dyna-Q / QAgent, instance by instance against the C restatement
+    (agent/dyna_q.py:275-330, agent/q.py:305-354) run with THAT instance's parameters."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    from cobel_amd.agent import DynaQ, QAgent
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.memory import DynaQMemory
+    from cobel_amd.policy import EpsilonGreedy
+    tab = golden_worlds('walls_8x8')
+    n, trials, steps, B = 24, 6, 30, 24
+    _, alpha, gamma, eps, mlr = _pset_arrays(n)
+    env = Gridworld(as_world(tab), n_envs=n, seed=777, instance_base=40)
+    if agent_name == 'dynaq':
+        ag = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha,
+                   gamma=gamma, memory=DynaQMemory(64, 4, mlr))
+    else:
+        ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha,
+                    gamma=gamma)
+    ag.track_instances = True
+    ag.train(env, trials, steps, B)
+    torch.cuda.synchronize()
+    w = c_oracle.OracleWorld([tab])
+    for i in range(n):
+        o = c_oracle.TabOracle(w, 1, c_oracle.AG_DYNAQ if agent_name == 'dynaq' else c_oracle.AG_Q, 777,
+                               True, instance_base=40 + i, alpha=float(alpha[i]), gamma=float(gamma[i]),
+                               epsilon=float(eps[i]), model_lr=float(mlr[i]), trial_cap=trials,
+                               log_cap=0 if agent_name == 'dynaq' else trials * steps)
+        o.run(trials, steps, B)
+        assert np.array_equal(ag._q[i].cpu().numpy().astype(np.float64), o.Q[0]), i
+        assert np.array_equal(ag.monitors.lat_trace[i, :trials].cpu().numpy(), o.lat_trace[0]), i
+        if agent_name == 'dynaq':
+            assert np.array_equal(ag.M.rewards[i].astype(np.float64), o.MR[0]), i
+            assert np.array_equal(ag.M.states[i], o.MS[0]) and np.array_equal(ag.M.terminals[i], o.MT[0])
+
+
+def test_param_sets_sr_against_the_oracle_instance_by_instance(torch_cuda, golden_worlds):
+    """The same mixed launch, instance by instance against the C restatement of agent/sr.py:255-308
+    run with THAT instance's learning rate, discount and epsilon (not launch against launch)."""
+    torch = torch_cuda
+    from oracle import c_oracle
+    from cobel_amd.agent import SR
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.policy import EpsilonGreedy
+    tab = golden_worlds('walls_8x8')
+    n, trials, steps = 24, 5, 30
+    _, alpha, gamma, eps, _ = _pset_arrays(n)
+    for stream_rows in (False, True):
+        env = Gridworld(as_world(tab), n_envs=n, seed=4711, instance_base=3)
+        ag = SR(env.observation_space, env.action_space, EpsilonGreedy(eps), learning_rate=alpha,
+                gamma=gamma)
+        ag.track_instances = True
+        ag.stream_rows = stream_rows
+        ag.train(env, trials, steps)
+        torch.cuda.synchronize()
+        w = c_oracle.OracleWorld([tab])
+        for i in range(n):
+            o = c_oracle.SROracle(w, 1, 4711, True, instance_base=3 + i, alpha=float(alpha[i]),
+                                  gamma=float(gamma[i]), epsilon=float(eps[i]), trial_cap=trials)
+            o.run(trials, steps)
+            assert np.array_equal(ag._sr[i].cpu().numpy().astype(np.float64), o.SR[0]), (stream_rows, i)
+            assert np.array_equal(ag._T[i].cpu().numpy(), o.T[0]), (stream_rows, i)
+            assert np.array_equal(ag._rw[i].cpu().numpy().astype(np.float64), o.RW[0]), (stream_rows, i)
+            assert np.array_equal(ag.monitors.lat_trace[i, :trials].cpu().numpy(), o.lat_trace[0])
+    assert len({(float(a), float(g), float(e)) for a, g, e in zip(alpha, gamma, eps)}) > 2
+
+
 def test_grid_search_vectorised_equals_sequential(torch_cuda, golden_worlds, tmp_path):
     """GridSearchOptimizer.fit_vectorised: every (combination, run) is one instance of a single
     Dyna-Q launch with per-instance learning rate / epsilon; the fit equals the reference-style
