@@ -260,6 +260,8 @@ _SIGNATURES = {
     'cobel_tab_query': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),
     'cobel_tab_run': (C.c_int, [_P, C.POINTER(TabRun), _P]),
+    'cobel_dynaq_run': (C.c_int, [_P, C.POINTER(TabRun), _P]),
+    'cobel_q_run': (C.c_int, [_P, C.POINTER(TabRun), _P]),
     'cobel_tab_describe': (C.c_int, [_P, C.POINTER(TabRun), C.POINTER(C.c_int32)]),
     'cobel_tab_scratch_check': (C.c_int, [_P, C.c_int64, _P]),
     'cobel_pack_model': (C.c_uint64, [C.c_float, C.c_uint16, C.c_uint8]),

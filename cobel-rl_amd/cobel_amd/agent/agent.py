@@ -501,3 +501,8 @@ class FusedAgent(Agent):
                     break
         self._policy_out(pol)
         self._env_out(interface)
+        # (a sliced launch that gave up waiting for a ring entry leaves incomplete tables: raise here,
+        #  not when somebody happens to ask for the step count — the abort word is sticky)
+        check = getattr(self, 'check_launches', None)
+        if check is not None:
+            check()

@@ -125,13 +125,20 @@ class TabularAgent(FusedAgent):
             return
         # (`launch_events`: a pair of torch.cuda.Event recorded right around the library call —
         #  bench.py times the kernel without the host's preparation of its arguments)
+        #  (a LIST that gets one pair appended per launch: a train() call may issue several)
         ev = getattr(self, 'launch_events', None)
+        pair = None
         if ev is not None:
-            ev[0].record()
-        _lib.check(_lib.lib().cobel_tab_run(interface.handle.ptr, C.byref(run),
-                                            _lib.current_stream(self.device)))
-        if ev is not None:
-            ev[1].record()
+            import torch
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+        # (the entry point SURVEY.md section 8b names for this agent: cobel_tab_run with the kind checked)
+        entry = (_lib.lib().cobel_dynaq_run if self.agent_kind == _lib.AGENT_DYNAQ
+                 else _lib.lib().cobel_q_run)
+        _lib.check(entry(interface.handle.ptr, C.byref(run), _lib.current_stream(self.device)))
+        if pair is not None:
+            pair[1].record()
+            ev.append(pair)
 
     def check_launches(self) -> None:
         """Waits for this agent's launches and raises ``CobelHipError`` if a sliced launch of the

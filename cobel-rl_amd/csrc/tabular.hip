@@ -1536,6 +1536,18 @@ extern "C" int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* 
   return tab_run_impl(world, run, stream, nullptr);
 }
 
+extern "C" int cobel_dynaq_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream) {
+  COBEL_REQUIRE(run && run->agent == COBEL_AGENT_DYNAQ, COBEL_E_ARG,
+                "cobel_dynaq_run: run->agent is not COBEL_AGENT_DYNAQ");
+  return tab_run_impl(world, run, stream, nullptr);
+}
+
+extern "C" int cobel_q_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream) {
+  COBEL_REQUIRE(run && run->agent == COBEL_AGENT_Q, COBEL_E_ARG,
+                "cobel_q_run: run->agent is not COBEL_AGENT_Q");
+  return tab_run_impl(world, run, stream, nullptr);
+}
+
 extern "C" int cobel_tab_scratch_check(const void* scratch, int64_t scratch_bytes, void* stream) {
   if (!scratch || scratch_bytes < (int64_t)COBEL_TAB_SCRATCH_BYTES(1)) return COBEL_OK;
   uint32_t word = 0;

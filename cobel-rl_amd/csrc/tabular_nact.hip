@@ -631,6 +631,8 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
       }
     }
   }
+  // (few instances: rather a workgroup on every CU than full workgroups on a few of them)
+  while (wpg > 1 && (r.n + wpg - 1) / wpg < n_cu) wpg >>= 1;
   const size_t lds = nact_lds_bytes(S, A, wpg, shared, masked || r.param_index != nullptr);
   if (lds > lds_cu) return false;
   *wpg_out = wpg;

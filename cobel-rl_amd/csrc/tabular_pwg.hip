@@ -1090,8 +1090,11 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   lds += 1024;
   COBEL_HIP_TRY(hipMemsetAsync(base, 0, (256 + (size_t)8 * A.ring_stride + (size_t)8 * grid * waves) * 4, st));
 #else
-  COBEL_HIP_TRY(hipMemsetAsync(base, 0, A.n_slices > 1 ? (256 + (size_t)8 * A.ring_stride) * 4
-                                                       : (size_t)256, st));
+  // (the abort word — word 255 of a scratch area — is STICKY: no launch clears it, so a wave that
+  //  gave up is reported by every later cobel_tab_scratch_check, whichever launches followed)
+  COBEL_HIP_TRY(hipMemsetAsync(base, 0, scratch ? (size_t)kAbortWord * 4 : (size_t)256, st));
+  if (A.n_slices > 1)
+    COBEL_HIP_TRY(hipMemsetAsync(A.ring, 0, (size_t)8 * A.ring_stride * 4, st));
 #endif
   if (lds > 64 * 1024)
     COBEL_HIP_TRY(hipFuncSetAttribute(A.n_slices > 1 ? reinterpret_cast<const void*>(&k_tab_pwg<true>)

@@ -71,7 +71,7 @@ int cobel_device_limits(int device, int* n_cu, size_t* lds_per_cu) {
 }
 
 extern "C" const char* cobel_last_error(void) { return g_err; }
-extern "C" int cobel_abi_version(void) { return 1016; }
+extern "C" int cobel_abi_version(void) { return 1017; }
 
 extern "C" int cobel_param_set_fill(double alpha, double gamma, double epsilon, double model_lr,
                                     cobel_param_set_t* out) {

@@ -393,6 +393,11 @@ typedef struct {
 COBEL_API int cobel_tab_query(int32_t n_states, int32_t agent, int32_t batch, int32_t* lds_bytes,
                     int32_t* instances_per_block);
 COBEL_API int cobel_tab_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream);
+/* SURVEY.md section 8b names the two agents' entry points separately; they are cobel_tab_run with
+ * run->agent checked: COBEL_E_ARG unless it is COBEL_AGENT_DYNAQ (agent/dyna_q.py:140-330) /
+ * COBEL_AGENT_Q (agent/q.py:115-354).  Same arguments, same kernels, same results. */
+COBEL_API int cobel_dynaq_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream);
+COBEL_API int cobel_q_run(const cobel_world_t* world, const cobel_tab_run_t* run, void* stream);
 /* Which kernel cobel_tab_run would take for this run, without launching anything (same argument
  * checks): out[0] = COBEL_TAB_KERNEL_*, out[1] = LDS bytes per workgroup, out[2] = workgroups a CU
  * can hold by LDS (1 280-byte blocks, 128 per CU), out[3] = instances per workgroup.  For tests
@@ -416,7 +421,9 @@ COBEL_API int cobel_tab_describe(const cobel_world_t* world, const cobel_tab_run
 
 /* After a cobel_tab_run call that was given a scratch area: waits for `stream`, reads the area's
  * abort word and returns COBEL_OK, or COBEL_E_HIP when a sliced launch gave up (the tables of the
- * call are then incomplete and must be discarded).  scratch NULL or smaller than
+ * call are then incomplete and must be discarded).  The word is STICKY: a launch zeroes its
+ * counters and rings but never this word (only the caller does, by zeroing the area it owns), so
+ * the check may be made once after any number of launches and reports an abort in ANY of them.  scratch NULL or smaller than
  * COBEL_TAB_SCRATCH_BYTES(1): COBEL_OK (nothing was sliced).  The reference has no counterpart:
  * its loop cannot lose a producer (agent/dyna_q.py:140-215 is one thread). */
 COBEL_API int cobel_tab_scratch_check(const void* scratch /* [dev] */, int64_t scratch_bytes,

@@ -57,6 +57,34 @@ def scan(asm_path, window):
     return out
 
 
+def dpp_hazards(asm_path):
+    """The hand-written `v_max_f32_dpp` blocks (tabular.hip, tabular_pwg.hip, tabular_nact.hip) place
+    their own wait states: the compiler's hazard recognizer does not look inside an asm block.  What
+    the blocks cover is a VALU write of the SOURCE register (two wait states: `s_nop 1`).  What they
+    do not: a VALU write of EXEC (`v_cmpx_*`) within five wait states ahead of a DPP instruction.
+    Reports every DPP instruction with a `v_cmpx` closer than that in the shipped code."""
+    lines = open(asm_path).read().split('\n')
+    out, kernel = [], None
+    for i, l in enumerate(lines):
+        m = re.match(r'^(_Z\w+):', l)
+        if m:
+            kernel = m.group(1)
+        if kernel is None or '_dpp' not in l or not re.match(r'\tv_', l):
+            continue
+        states, j = 0, i - 1
+        while j >= 0 and states < 5:
+            t = lines[j].strip()
+            j -= 1
+            if not t or t.startswith(';') or t.startswith('.') or t.endswith(':'):
+                continue
+            if t.startswith('v_cmpx'):
+                out.append((kernel, i + 1, l.strip(), t, states))
+                break
+            nop = re.match(r's_nop (\d+)', t)
+            states += int(nop.group(1)) + 1 if nop else 1
+    return out
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     window = 6
@@ -71,6 +99,9 @@ def main():
             subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + ['-S', '--cuda-device-only', '-o', asm, src],
                            check=True, capture_output=True)
             hits = scan(asm, window)
+            for k, line, dpp, cmpx, st in dpp_hazards(asm):
+                print('%-12s DPP HAZARD line %d: %s only %d wait states behind %s' % (
+                    os.path.basename(f)[:-4], line, dpp, st, cmpx))
         if not hits:
             continue
         dm = demangle(sorted({h[0] for h in hits}))

@@ -611,3 +611,35 @@ def test_pickled_worlddict_steps_and_learns_like_the_oracle(cobel):
         ref.train(renv, trials, steps, batch, trace=tr)
         assert np.array_equal(lat[i, :trials], np.array(tr['steps'])), i
         assert np.array_equal(q[i], ref.Q), i
+
+
+def test_agent_entry_points_check_the_agent_kind():
+    """SURVEY.md section 8b's `cobel_dynaq_run` / `cobel_q_run`: cobel_tab_run with run->agent
+    checked (the Python classes call them: every Dyna-Q / QAgent test goes through them) — the wrong
+    kind is COBEL_E_ARG and launches nothing."""
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_open_field
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld(make_open_field(5, 5, 0, 1), n_envs=8, seed=3)
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    agent.train(env, 2, 10, 8)
+    steps = agent.env_steps()
+    assert steps > 0
+    seen = {}
+    real = _lib.lib().cobel_dynaq_run
+
+    def spy(world, run, stream):        # the very struct the class hands over, to the OTHER entry
+        seen['rc'] = _lib.lib().cobel_q_run(world, run, stream)
+        seen['msg'] = _lib.lib().cobel_last_error().decode()
+        return real(world, run, stream)
+
+    lib = _lib.lib()
+    try:
+        lib.cobel_dynaq_run = spy
+        agent.train(env, 1, 10, 8)
+    finally:
+        lib.cobel_dynaq_run = real
+    assert seen['rc'] == _lib.E_ARG and 'COBEL_AGENT_Q' in seen['msg']
+    assert agent.env_steps() > steps

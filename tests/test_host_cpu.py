@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'missing export ' + name
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.cobel_abi_version() == 1016
+    assert lib.cobel_abi_version() == 1017
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = set(re.findall(r'\bT (cobel_\w+)', out))
     assert exported == declared
