@@ -565,19 +565,22 @@ class Runner:
 
 
 # rate of the port / rate of the real reference, one core, alternating 2-second slices in the build
-# container where both exist (scripts/calibrate_cpu_baseline.py)
-PORT_OVER_REFERENCE = {'C1': 1.11, 'C2': 1.11, 'C3': 1.13, 'C4': 1.35, 'C6': 1.08}
+# container where both exist (scripts/calibrate_cpu_baseline.py): the RANGE
+# of the sessions so far (round 2, the round-5 review's run, round 6 on 2026-10-05: C1 1.11 / 1.11 /
+# 1.07, C3 1.13 / 1.18 / 1.09, C4 1.35 / 1.07 / 1.15, C6 1.08 / 1.04 / 1.08) — sandbox noise of +-10 %
+# around "the port is a little faster, never slower"; no derived reference figure is quoted.
+PORT_OVER_REFERENCE = {'C1': (1.07, 1.11), 'C2': (1.07, 1.11), 'C3': (1.09, 1.18), 'C4': (1.07, 1.35),
+                       'C6': (1.04, 1.08)}
 
 
 def cpu_baseline(cfg_name, cfg, seconds=12.0):
     """NumPy restatement of the reference loop, 1 core, bounded sample of the same workload."""
     r = _cpu_baseline(cfg_name, cfg, seconds)
-    r['port_over_reference'] = PORT_OVER_REFERENCE.get(cfg_name)
-    r['calibration'] = ('the port runs at %.2f x the rate of the real reference on this leg '
-                        '(measured where both exist: BASELINE.md section 4), so the reference '
-                        'itself would read ~%.0f %s here'
-                        % (r['port_over_reference'], r['value'] / r['port_over_reference'], r['unit'])
-                        if r['port_over_reference'] else None)
+    rng = PORT_OVER_REFERENCE.get(cfg_name)
+    r['port_over_reference'] = list(rng) if rng else None
+    r['calibration'] = ('the port ran at %.2f-%.2f x the rate of the real reference on this leg in the '
+                        'sessions where both exist (BASELINE.md section 4): never slower'
+                        % rng if rng else None)
     return r
 
 
