@@ -133,8 +133,10 @@ __device__ __forceinline__ pwg_kargs rare_args() {
 #endif
 }
 
-// One instance, all the steps of the call.  QG: the Q table stays in global memory.
-template <bool QG>
+// One instance, all the steps of the call.  QG: the Q table stays in global memory.  POW2: the
+// state count is a power of two — a bounded draw mulhi32(x, 4 S) is then a shift (v_mul_hi_u32
+// holds a SIMD four times as long as a shift).
+template <bool QG, bool POW2>
 __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, const int step_budget,
                                              unsigned char* const lds, const int lane,
                                              const uint64_t thr_mine, const uint32_t stripe
@@ -159,7 +161,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   // (the step loop is short of those: masks it spilled were reloaded in every step): lane l reads
   // successor l % 4 of a packed record pair as bfe(bfi(sel, w1, w0), sh, 16).
   uint32_t succ_sel = (lane & 2) ? 0xffffffffu : 0u, succ_sh = (uint32_t)(lane & 1) * 16u;
-  uint32_t SAv = SA;
+  uint32_t SAv = POW2 ? (uint32_t)__builtin_clz(SA) + 1u : SA;   // (POW2: the shift)
   uint32_t qlane = (uint32_t)(lane & 3);
   asm volatile("" : "+v"(succ_sel), "+v"(succ_sh), "+v"(SAv), "+v"(qlane));
   auto succ_of = [&](uint32_t w0, uint32_t w1) -> uint32_t {
@@ -595,7 +597,8 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       const uint32_t m = (idx_cur == fresh_idx) ? fresh_m : mg_cur;
       if (lane < B) {
         float rj = 0.0f;
-        idx_next = cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SAv);
+        idx_next = POW2 ? cobel_word(blk, (cm + 1u) & 3u) >> SAv
+                        : cobel_bounded(cobel_word(blk, (cm + 1u) & 3u), SAv);
         mg_next = (uint32_t)Mg[idx_next];
         if (iflags & 2u) {
           batches += 1u;
@@ -700,7 +703,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
 // SLICED: the launch's tickets are slices (n_slices > 1).  Its own instantiation: what the ticket
 // loop carries for slices and whole-instance tickets costs the step loop of the UNSLICED launch —
 // the headline — a per cent through the register allocation alone (11.55 -> 11.66 ms, same box).
-template <bool SLICED>
+template <bool SLICED, bool POW2>
 __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int lane = (int)(threadIdx.x & 63u);
@@ -874,12 +877,12 @@ __global__ __launch_bounds__(1024) void k_tab_pwg(const pwg_args A) {
 #if defined(COBEL_PWG_STAMPS)
     PWG_STAMP(0);   // ticket
     if (lane == 0) atomicAdd(stamps + 4, 1u);
-    if (qg) pwg_instance<true>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
-    else pwg_instance<false>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
+    if (qg) pwg_instance<true, POW2>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
+    else pwg_instance<false, POW2>(A, i, budget, lds, lane, thr_mine, stripe, stamps, stamp_prev);
     PWG_STAMP(3);   // write-back issued
 #else
-    if (qg) pwg_instance<true>(A, i, budget, lds, lane, thr_mine, stripe);
-    else pwg_instance<false>(A, i, budget, lds, lane, thr_mine, stripe);
+    if (qg) pwg_instance<true, POW2>(A, i, budget, lds, lane, thr_mine, stripe);
+    else pwg_instance<false, POW2>(A, i, budget, lds, lane, thr_mine, stripe);
 #endif
     if (SLICED) {
       // the instance's next slice becomes a ticket; this wave's next ticket is drawn in the same
@@ -1096,12 +1099,14 @@ int cobel_tab_pwg_launch(const cobel_world* world, const cobel_tab_run_t& r, hip
   if (A.n_slices > 1)
     COBEL_HIP_TRY(hipMemsetAsync(A.ring, 0, (size_t)8 * A.ring_stride * 4, st));
 #endif
+  const bool pow2 = (A.S & (A.S - 1)) == 0;
+  void (*const kernel)(const pwg_args) =
+      A.n_slices > 1 ? (pow2 ? &k_tab_pwg<true, true> : &k_tab_pwg<true, false>)
+                     : (pow2 ? &k_tab_pwg<false, true> : &k_tab_pwg<false, false>);
   if (lds > 64 * 1024)
-    COBEL_HIP_TRY(hipFuncSetAttribute(A.n_slices > 1 ? reinterpret_cast<const void*>(&k_tab_pwg<true>)
-                                                     : reinterpret_cast<const void*>(&k_tab_pwg<false>),
+    COBEL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (A.n_slices > 1) hipLaunchKernelGGL(k_tab_pwg<true>, dim3(grid), dim3(64 * waves), lds, st, A);
-  else hipLaunchKernelGGL(k_tab_pwg<false>, dim3(grid), dim3(64 * waves), lds, st, A);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * waves), lds, st, A);
   COBEL_HIP_TRY(hipGetLastError());
   return COBEL_OK;
 }
