@@ -38,9 +38,6 @@ struct tab_args {
   cobel_tab_run_t r;
   cobel_eps_consts eps;
   float alpha_f, gamma_f, model_lr_f;
-  int32_t use_hash;  // LDS holds the replay dependency hash table
-  int32_t hash_buckets;
-  int32_t hash_exact;  // S * 4 <= 4096: the two-table exact dependency lookup applies
   int32_t lpw;         // lane-per-instance kernel: instances per wave (64, 32 or 16)
   // transition rows that are distributions (cobel_world_set_transitions): the generic
   // (!FAST) instantiations of k_tab_wpi draw the successor in the step, else NULL
@@ -79,18 +76,16 @@ struct tab_lds {
   float4* Qs;
   float* Qf;
   uint16_t* M16;
-  unsigned long long* H;
   uint4* Wl;
   uint32_t* occ;
 };
 constexpr int kThrBytes = 16 * 3 * 8;
 constexpr int kPassLanes = COBEL_MAX_BATCH;   // planning updates one wavefront takes per pass
-constexpr int kHashBuckets = 256;
-constexpr int kHashBucketsSmall = 128;   // with MIDX: keeps the footprint at 17 KiB (nine per CU)
 
 // LDS is handed out in blocks of 1 280 bytes, 128 per CU — not in KiB (measured on MI355X with
 // scripts/experiments/exp_occupancy.py: the launch time of k_tab_wpi steps down at 15 360 and at 14 080 bytes
-// per workgroup and is flat in between; 17 408 B, a 32 x 32 world, are 14 blocks: nine per CU).
+// per workgroup and is flat in between; 16 384 B, a 32 x 32 world, are 13 blocks: nine per CU —
+// k_tab_pwg's ONE workgroup per CU takes all 128 blocks for ten).
 inline int lds_workgroups_per_cu(size_t bytes) {
   const size_t blocks = (bytes + 1279) / 1280;
   return blocks ? (int)(128 / blocks) : 128;
@@ -100,7 +95,7 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
                                                          bool occ, bool midx = false) {
   size_t b = (size_t)S * 16;
   if (agent == COBEL_AGENT_DYNAQ && !midx) b += (size_t)S * 8;
-  if (replay) b += (midx ? kHashBucketsSmall : kHashBuckets) * 8;
+  (void)replay;   // (round 6: a batch's dependencies are found in the Q table itself — no tables of lane masks)
   if (wlds) b += (size_t)S * 16;
   if (occ) b += (size_t)S * 4;
   return b;
@@ -127,7 +122,7 @@ __host__ __device__ __forceinline__ size_t tab_lds_bytes(int S, int agent, bool 
 // MIDX (with FAST): the 16-bit model entries live in a caller-provided HBM table instead of LDS
 // (run.model_index, 8 B per state, L2 resident for the instances in flight).  The memory stream is
 // counter based, so the entries a step will sample are gathered one step ahead and patched in
-// registers with the one entry that step itself writes.  LDS shrinks to Q + hash = 17 KiB and
+// registers with the one entry that step itself writes.  LDS shrinks to Q = 16 KiB and
 // nine instances fit on a CU instead of six.
 // PSETS: hyper-parameters come from per-instance parameter sets (run.param_index).  A template
 // switch rather than a run-time one: the mere possibility of taking the loop constants from
@@ -151,8 +146,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     off += (size_t)S * 16;
     L.M16 = reinterpret_cast<uint16_t*>(lds_raw + off);
     if (AGENT == COBEL_AGENT_DYNAQ && !MIDX) off += (size_t)S * 8;
-    L.H = reinterpret_cast<unsigned long long*>(lds_raw + off);
-    if (A.use_hash) off += (size_t)A.hash_buckets * 8;
     L.Wl = reinterpret_cast<uint4*>(lds_raw + off);
     if (WLDS) off += (size_t)S * 16;
     L.occ = reinterpret_cast<uint32_t*>(lds_raw + off);
@@ -173,7 +166,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
                                                  : nullptr;
   const uint32_t SA = (uint32_t)S * 4u;
   uint16_t* const Mg = MIDX ? A.r.model_index + (size_t)i * SA : nullptr;
-  const uint32_t hmask = (uint32_t)A.hash_buckets - 1u;
 
   // ---- stage the instance: Q, compact model, world records --------------------------------
   // (nonzero: does anything that planning could propagate exist yet — a Q cell or a reward
@@ -197,8 +189,6 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       nonzero |= lo;
     }
   }
-  if (A.use_hash)
-    for (int b = lane; b < A.hash_buckets; b += 64) L.H[b] = 0ull;
   __syncthreads();
 
   int32_t* const inst = A.r.inst + (size_t)i * COBEL_I_WORDS;
@@ -340,162 +330,90 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   //  one per table access)
   auto run_batch = [&](uint32_t idx, uint32_t ns, uint32_t nt, float r, bool inside = false) {
     const bool on = inside || lane < BP;
-    const uint32_t sj = idx >> 2;
 #if defined(COBEL_ABLATE) && COBEL_ABLATE == 3
     return;
 #endif
-    int dep = -1;  // latest earlier lane this lane must wait for
-    unsigned long long conf = 0ull;   // exact lookup: ALL earlier lanes that write a cell I read
-    // S * 4 <= 4096: two 64-bucket tables of lane masks, keyed by bits 0-5 (H1) and 6-11 (H2)
-    // of the pair index.  A lane is in both of my buckets only if its pair IS mine; the lanes
-    // that write into row ns are those in one of the four H1 buckets of (ns & 15) and in the
-    // H2 bucket of ns >> 4.  No false candidates, nothing to verify.
-    auto conflict_sets = [&]() {
-      unsigned long long* const H1 = L.H;
-      unsigned long long* const H2 = L.H + 64;
-      const uint32_t h1 = idx & 63u, h2 = idx >> 6;
-      const unsigned long long bit = 1ull << lane;
-      if (on) {
-        atomicOr(&H1[h1], bit);
-        atomicOr(&H2[h2], bit);
+    // The rounds are speculative: every remaining lane computes its update from the table as it
+    // stands; a lane's result holds unless an earlier lane of this round that writes a cell it
+    // reads has CHANGED that cell — an update that leaves its cell as it was (all-zero regions
+    // of Q, converged entries) blocks nobody.  The lanes before the first one whose inputs moved
+    // are committed (only changed cells are written, so two lanes of one round never write the
+    // same cell), the rest goes again.  Same order of effects as the reference's loop; never
+    // fewer lanes per round than the conflict-free prefix.
+    // Who is held back is found IN the table (round 6, as in k_tab_pwg; until then two tables of
+    // lane masks keyed by the pair index, exact up to 1 024 states, and buckets with a verifying
+    // loop beyond): a lane that changes its cell raises it to the TAG ~lane with ds_max_u32 —
+    // tags are the bit patterns 0xffffffc0 .. 0xffffffff, above every float that is not a NaN of
+    // exactly that payload, so the cell then holds the tag of the EARLIEST lane that writes it —,
+    // every lane reads its five inputs again and is held back iff one of them is a tag above its
+    // own: an earlier writer of a cell it reads.  The earliest writer of a cell then stores the new
+    // value (committed) or puts the old one back (held back).  Exact for any state count, no byte
+    // of LDS beside the table.
+    auto td_of = [&](float q, float m) -> float {
+      if (AGENT == COBEL_AGENT_DYNAQ) {
+        // planning TD in float64, one rounding on store (NumPy promotion of the reference's
+        // expression with a float32 table; see include/cobel_hip.h)
+        const double gnt = gamma * (double)nt;
+        double td = (double)r + gnt * (double)m;
+        td = td - (double)q;
+        return (float)((double)q + alpha * td);
       }
-      __builtin_amdgcn_wave_barrier();
-      unsigned long long cnd = 0ull;
-      if (on) {
-        const ulonglong2* const r4 = reinterpret_cast<const ulonglong2*>(&H1[(ns & 15u) * 4u]);
-        const ulonglong2 ra = r4[0], rb = r4[1];
-        const unsigned long long cell = H1[h1] & H2[h2];
-        const unsigned long long row = ((ra.x | ra.y) | (rb.x | rb.y)) & H2[ns >> 4];
-        cnd = (cell | row) & (bit - 1ull);
-      }
-#if defined(COBEL_ABLATE) && COBEL_ABLATE == 1
-      cnd = 0ull;
-#endif
-      __builtin_amdgcn_wave_barrier();
-      if (on) {
-        H1[h1] = 0ull;
-        H2[h2] = 0ull;
-      }
-      conf = cnd;
+      const float gnt = nt ? gamma_f : 0.0f;
+      float td = r + gnt * m;
+      td = td - q;
+      return q + alpha_f * td;
     };
-    if (__builtin_expect(A.hash_exact == 0, 0)) {
-    // candidates: earlier lanes whose state shares a hash bucket with my ns or my s
-    const uint32_t bs = sj & hmask, bn = ns & hmask;
-    if (on) atomicOr(&L.H[bs], 1ull << lane);
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long cnd = on ? ((L.H[bn] | L.H[bs]) & ((1ull << lane) - 1ull)) : 0ull;
-#if defined(COBEL_ABLATE) && COBEL_ABLATE == 1
-    cnd = 0ull;
-#endif
-    __builtin_amdgcn_wave_barrier();
-    if (on) L.H[bs] = 0ull;
-    STAMP(2);
-    // verify candidates, latest first: a hit ends the lane's search
-    while (__ballot(cnd != 0ull)) {
-      const int e = cnd ? (63 - __clzll((long long)cnd)) : 0;
-      const uint32_t se = (uint32_t)__shfl((int)sj, e), ie = (uint32_t)__shfl((int)idx, e);
-      const bool hit = cnd && (ns == se || idx == ie);
-      if (hit) {
-        dep = e;
-        cnd = 0ull;
-      } else if (cnd) {
-        cnd &= ~(1ull << e);
-      }
-    }
-    STAMP(3);
-    }
-    int first = 0;
-    if (__builtin_expect(A.hash_exact != 0, 1)) {
-      // The rounds are speculative: every remaining lane computes its update from the table as it
-      // stands; a lane's result holds unless an earlier lane of this round that writes a cell it
-      // reads has CHANGED that cell — an update that leaves its cell as it was (all-zero regions
-      // of Q, converged entries) blocks nobody.  The lanes before the first one whose inputs moved
-      // are committed (only changed cells are written, so two lanes of one round never write the
-      // same cell), the rest goes again.  Same order of effects as the reference's loop; never
-      // fewer lanes per round than the conflict-free prefix.  Who conflicts with whom is only
-      // looked up — once per batch — when something changes.
-      auto td_of = [&](float q, float m) -> float {
-        if (AGENT == COBEL_AGENT_DYNAQ) {
-          const double gnt = gamma * (double)nt;
-          double td = (double)r + gnt * (double)m;
-          td = td - (double)q;
-          return (float)((double)q + alpha * td);
-        }
-        const float gnt = nt ? gamma_f : 0.0f;
-        float td = r + gnt * m;
-        td = td - q;
-        return q + alpha_f * td;
-      };
-      // (the first round written out in front of the loop over the rounds — most batches end with
-      //  it —, as in k_tab_pwg §4.1d: trained agents on 16 x 16 / 24 x 24 mazes +1.3 / +0.7 %,
-      //  scripts/experiments/exp_occ_trained.py)
-      {
-        float q = 0.0f, qn = 0.0f;
-        if (on) {
-          const float4 row = Qs[ns];
-          q = Qf[idx];
-          qn = td_of(q, max4(row));
-        }
-        const bool ch = on && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
-        const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
-        if (!changed) {
-          STAMP(4);
-          return;
-        }
-        conflict_sets();
-        const unsigned long long blocked = __builtin_amdgcn_ballot_w64(on && (conf & changed) != 0ull);
-        first = blocked ? (__ffsll((long long)blocked) - 1) : BP;
-        if (ch && lane < first) Qf[idx] = qn;
-        __builtin_amdgcn_wave_barrier();
-      }
-      while (first < BP) {
-        const bool act = on && lane >= first;
-        float q = 0.0f, qn = 0.0f;
-        if (act) {
-          const float4 row = Qs[ns];
-          q = Qf[idx];
-          qn = td_of(q, max4(row));
-        }
-        const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
-        const unsigned long long changed = __ballot(ch);
-        int stop = BP;
-        if (changed) {
-          const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
-          if (blocked) stop = __ffsll((long long)blocked) - 1;
-          if (ch && lane < stop) Qf[idx] = qn;
-          __builtin_amdgcn_wave_barrier();
-        }
-        first = stop;
-      }
-      STAMP(4);
-      return;
-    }
-    do {   // (B >= 1 here; most batches need one or two rounds)
-      const unsigned long long blocked = __ballot(on && dep >= first);
-      const int stop = blocked ? (__ffsll((long long)blocked) - 1) : BP;
-      if (lane >= first && lane < stop) {
-        const float4 row = Qs[ns];
-        const float q = Qf[idx];
-        const float m = max4(row);
-        float qn;
-        if (AGENT == COBEL_AGENT_DYNAQ) {
-          // planning TD in float64, one rounding on store (NumPy promotion of the reference's
-          // expression with a float32 table; see include/cobel_hip.h)
-          const double gnt = gamma * (double)nt;
-          double td = (double)r + gnt * (double)m;
-          td = td - (double)q;
-          qn = (float)((double)q + alpha * td);
-        } else {
-          const float gnt = nt ? gamma_f : 0.0f;
-          float td = r + gnt * m;
-          td = td - q;
-          qn = q + alpha_f * td;
-        }
-        Qf[idx] = qn;
-      }
+    uint32_t* const Qu = reinterpret_cast<uint32_t*>(Qf);
+    const uint4* const Qs4u = reinterpret_cast<const uint4*>(Qs);
+    const uint32_t tag_mine = ~(uint32_t)lane;
+    auto tag_round = [&](bool act, bool ch, float q, float qn) -> int {
+      if (ch) atomicMax(&Qu[idx], tag_mine);
       __builtin_amdgcn_wave_barrier();
-      first = stop;
-    } while (first < BP);
+      uint32_t t = 0u, c2 = 0u;
+      if (act) {
+        const uint4 r2 = Qs4u[ns];
+        c2 = Qu[idx];
+        t = max(max(max(r2.x, r2.y), r2.z), max(r2.w, c2));
+      }
+#if defined(COBEL_ABLATE) && COBEL_ABLATE == 1
+      t = 0u;
+#endif
+      const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
+      const int stop = blocked ? __ffsll((long long)blocked) - 1 : BP;
+      if (ch && c2 == tag_mine) Qf[idx] = lane < stop ? qn : q;
+      __builtin_amdgcn_wave_barrier();
+      return stop;
+    };
+    // (the first round written out in front of the loop over the rounds — most batches end with
+    //  it —, as in k_tab_pwg §4.1d: trained agents on 16 x 16 / 24 x 24 mazes +1.3 / +0.7 %,
+    //  scripts/experiments/exp_occ_trained.py)
+    int first;
+    {
+      float q = 0.0f, qn = 0.0f;
+      if (on) {
+        const float4 row = Qs[ns];
+        q = Qf[idx];
+        qn = td_of(q, max4(row));
+      }
+      const bool ch = on && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
+      if (!__builtin_amdgcn_ballot_w64(ch)) {
+        STAMP(4);
+        return;
+      }
+      first = tag_round(on, ch, q, qn);
+    }
+    while (first < BP) {
+      const bool act = on && lane >= first;
+      float q = 0.0f, qn = 0.0f;
+      if (act) {
+        const float4 row = Qs[ns];
+        q = Qf[idx];
+        qn = td_of(q, max4(row));
+      }
+      const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
+      if (!__ballot(ch)) break;
+      first = tag_round(act, ch, q, qn);
+    }
     STAMP(4);
   };
   // Dyna-Q batch drawn with x: model entries from LDS, reward estimates from HBM where flagged.
@@ -1419,7 +1337,6 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   const bool wlds = world->n_states <= kWorldLdsStates;
   const bool replay = (r.flags & COBEL_F_LEARN) && !(r.flags & COBEL_F_NO_REPLAY) && r.batch > 0 &&
                       (r.agent == COBEL_AGENT_DYNAQ || r.replay_log != nullptr);
-  A.use_hash = replay ? 1 : 0;
   // (more than COBEL_MAX_BATCH updates per step: plain training takes them in passes only with the
   //  digest in HBM — the MULTI instantiations)
   const bool digest = r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
@@ -1427,12 +1344,8 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
                     (r.batch <= COBEL_MAX_BATCH || digest) &&
                     !(r.flags & (COBEL_F_MASK_ACTIONS | COBEL_F_TEST_STREAM)) && !r.last_exp;
   const bool midx = fast && r.model_index != nullptr && !(r.flags & COBEL_F_FORCE_LDS_MODEL);
-  A.hash_buckets = midx ? kHashBucketsSmall : kHashBuckets;
-  // (debug switches are read once per process, not per launch)
-  static const bool no_exact_hash = cobel_debug_env("COBEL_DEBUG_NO_EXACT_HASH") != nullptr;
   // (per launch: scripts/experiments/exp_occupancy.py; validated against the limit below)
   static const char* const lpw_env = cobel_debug_env("COBEL_DEBUG_LPW");
-  A.hash_exact = (world->n_states * 4 <= 4096 && !no_exact_hash) ? 1 : 0;
   size_t lds = tab_lds_bytes(world->n_states, r.agent, replay, wlds, occ, midx);
   const size_t lds_pad = cobel_debug_lds_pad(lds, (size_t)kLdsLimit);   // occupancy experiments
   lds += lds_pad;

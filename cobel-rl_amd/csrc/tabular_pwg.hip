@@ -950,7 +950,8 @@ bool cobel_tab_pwg_plan(const cobel_world* world, const cobel_tab_run_t& r, int*
   } else if (r.flags & COBEL_F_PWG_GLOBAL) {
     nl = 0;
     ng = 16;
-  } else if (total / (slice_l + 1024) >= 16) {
+  } else if (128 / ((slice_l + 1279) / 1280) >= 16) {
+    // (LDS comes in blocks of 1 280 B, 128 per CU: tabular.hip lds_workgroups_per_cu)
     return false;   // LDS is not what limits the resident instances: k_tab_wpi as it is
   }
   *nl_out = nl;

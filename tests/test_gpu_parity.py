@@ -1734,10 +1734,10 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
     from cobel_amd import _lib
     dev = torch.device('cuda', 0)
     # (C3: one persistent workgroup per CU — ten wavefronts, each with its instance's Q table in LDS,
-    #  16 384 B, which is all of it; F_NO_PWG: one workgroup per instance, tables of lane masks beside Q)
+    #  16 384 B, which is all of it; F_NO_PWG: one workgroup per instance, nine per CU — LDS comes in blocks of 1 280 B)
     for name, n, kernel, lds, per_cu, per_wg, extra in [
             ('C3', 256, _lib.TAB_KERNEL_PWG, None, 1, None, 0),
-            ('C3', 256, _lib.TAB_KERNEL_WPI_INDEX, 1024 * 16 + 1024, 9, 1, _lib.F_NO_PWG),
+            ('C3', 256, _lib.TAB_KERNEL_WPI_INDEX, 1024 * 16, 9, 1, _lib.F_NO_PWG),
             ('C2', 256, _lib.TAB_KERNEL_LPI, None, None, 64, 0)]:
         cfg = dict(bench.CONFIGS[name], instances=n)
         env, ag = bench.build_agent(name, cfg, n, 0, dev)
@@ -1762,7 +1762,7 @@ def test_describe_reports_the_kernel_a_run_takes(torch_cuda):
     ag.mask_actions = True
     r = bench.Runner(cfg, env, ag)
     got = ag.describe_launch(env, ag.policy, r.flags | _lib.F_MASK_ACTIONS, 0x7fffffff, 200, 16, 50)
-    assert got['kernel'] == _lib.TAB_KERNEL_WPI and got['lds_bytes'] == 1024 * 24 + 2048
+    assert got['kernel'] == _lib.TAB_KERNEL_WPI and got['lds_bytes'] == 1024 * 24
 
 
 # ---------------------------------------------------------------------------------------------

@@ -161,7 +161,7 @@ def test_argument_errors_map_to_reference_exceptions():
     with pytest.raises(AssertionError):            # NULL tensors are refused before any launch
         _lib.check(lib.cobel_dqn_replay(C.byref(run), None))
     _lib.check(lib.cobel_tab_query(1024, 1, 50, C.byref(lds), None))
-    assert lds.value == 1024 * (16 + 8 + 4) + 2048   # Q, compact model, visit counters, hash
+    assert lds.value == 1024 * (16 + 8 + 4)   # Q, compact model, visit counters
     r, s, t = C.c_float(), C.c_uint16(), C.c_uint8()
     rec = lib.cobel_pack_model(C.c_float(0.75), 321, 1)
     lib.cobel_unpack_model(rec, C.byref(r), C.byref(s), C.byref(t))
