@@ -20,19 +20,20 @@
 //   * the replay batch (agent/q.py:344-354: B indices into the experience log, one vector draw) is
 //     one lane per update; the logged records are gathered from HBM one step ahead (the memory
 //     stream is counter based) and patched with the two records the gather cannot have seen; the
-//     B sequential float32 TD updates run as speculative rounds over exact conflict sets (two
-//     tables of lane masks keyed by the bits of s * 8 + a), as in k_tab_wpi.
+//     B sequential float32 TD updates run as speculative rounds, the lanes to hold back found in
+//     the Q table itself (tags, round 6), as in k_tab_wpi / k_tab_pwg.
 // Same streams, counters, arithmetic and order of effects as k_tab_general: identical Q tables,
 // logs, counters and monitors (tests/test_gpu_general.py, scripts/fuzz_topology.py).
 //
-// Round 5: nine to 32 actions on the same kernel with rows of 16 / 32 values (template W) while a
-// cell's key s W + a fits the conflict tables' 14 bits (1 024 / 512 states).  No threshold table
+// Round 5: nine to 32 actions on the same kernel with rows of 16 / 32 values (template W; up to
+// 1 024 / 512 states).  No threshold table
 // there (2^A tie patterns): the wave works the selection's float64 CDF out itself, in the order
 // cobel_eps_greedy_select_n (cobel_policy.h) states it — lane k holds value k, the cumulative sum is
 // ONE chain of W additions every lane runs, lane k keeps entry k, divides by the last entry and
 // compares with the draw — and action masks (an LDS copy) and per-instance parameter sets take part
 // in it (such runs on rows of 8 take this path too); the
-// replayed updates read a row's maximum with W / 4 LDS reads, the conflict sets OR W buckets.
+// replayed updates read a row's maximum with W / 4 LDS reads (and once more, as unsigned integers,
+// when a cell changed: the tag test).
 // Masked twelve-action QAgent on a 256-node graph, B 32: 8.1e8 env-steps/s against the 1.9e8 of
 // k_tab_general (bench.py general_wide_q / general_wide_q_lane).
 //
@@ -59,9 +60,6 @@ struct nact_args {
   float alpha_f, gamma_f;
 };
 
-// H1: bits 0-5 of a cell's key s W + a; H2: the bits above — 6-12 on rows of 8 (1 024 states), 6-13 on
-// the wider rows (1 024 / 512 states)
-__host__ __device__ constexpr int nact_hash_words(int W) { return 64 + (W == 8 ? 128 : 256); }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -93,7 +91,7 @@ __host__ __device__ inline size_t nact_lds_bytes(int S, int A, int wpg, bool sha
   const size_t thr = (W == 8 && !masked) ? (nact_thr_words(A) * 8 + 15) & ~(size_t)15
                                          : (((size_t)S * 4 + 15) & ~(size_t)15);
   const size_t world = (size_t)S * (2 * W + 8);
-  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4 + nact_hash_words(W) * 8);
+  return thr + (shared ? world : world * wpg) + (size_t)wpg * ((size_t)S * W * 4);
 }
 // QAgent replay record of nine to 32 actions (general.hip): hi = s | ns << 13 | action << 26 | nt << 31
 __device__ __forceinline__ uint64_t log_pack32(float r, uint32_t s, uint32_t a, uint32_t ns, uint32_t nt) {
@@ -131,11 +129,9 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   off += G.shared_world ? wbytes : wbytes * (size_t)G.wpg;
   uint16_t* const nextL = reinterpret_cast<uint16_t*>(wl);               // [S][W]
   uint2* const RT = reinterpret_cast<uint2*>(wl + (size_t)S * 2 * W);    // [S] {reward bits, terminal}
-  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * W * 4 + nact_hash_words(W) * 8);
+  unsigned char* const mine = lds_raw + off + (size_t)wave * ((size_t)S * W * 4);
   float4* const Qs = reinterpret_cast<float4*>(mine);                    // [S][W / 4]
   float* const Qf = reinterpret_cast<float*>(mine);
-  unsigned long long* const H1 = reinterpret_cast<unsigned long long*>(mine + (size_t)S * W * 4);
-  unsigned long long* const H2 = H1 + 64;
 
   // ---- the threshold table (whole workgroup) ----------------------------------------------------
   // thr[t * (A - 1) + k] = ceil(cdf_k * 2^53) of the tie pattern t (bit a set: action a attains
@@ -192,7 +188,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         RT[s] = make_uint2(fbits(G.reward_s[wbase + s]), (uint32_t)G.terminal_s[wbase + s]);
     }
   }
-  // ---- this instance's Q table (pad cells: -inf) and conflict tables ----------------------------
+  // ---- this instance's Q table (pad cells: -inf) -------------------------------------------------
   float* const Qg = G.r.q + (size_t)(present ? i : 0) * S * A;
   if (present) {
     for (int e0 = 0; e0 < S * W; e0 += 512) {
@@ -211,7 +207,6 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         if (e < S * W) Qf[e] = v[j];
       }
     }
-    for (int b = lane; b < nact_hash_words(W); b += 64) H1[b] = 0ull;
   }
   __syncthreads();
   if (!present) return;
@@ -303,8 +298,6 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
     const float r = __builtin_bit_cast(float, lo);
     const uint32_t p = s * WU + a;
     const bool on = lane < B;
-    int first = B;
-    unsigned long long conf = 0ull;
     auto td_of = [&](float q) -> float {
       const float m = W == 8 ? max8(Qs[ns * 2u], Qs[ns * 2u + 1u]) : row_max(ns);
       const float gnt = nt ? gamma_f : 0.0f;
@@ -312,8 +305,38 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
       td = td - q;
       return q + alpha_f * td;
     };
+    // Who is held back is found IN the table (round 6, as in k_tab_pwg / k_tab_wpi; until then two
+    // tables of lane masks beside every Q table): a lane that changes its cell raises it to the TAG
+    // ~lane with ds_max_u32 (bit patterns 0xffffffc0 .. 0xffffffff: above every float, the pad
+    // cells' -inf included, that is not a NaN of exactly that payload) — the cell then holds the
+    // tag of the EARLIEST lane that writes it; every lane reads its row and its cell again and is
+    // held back iff one of them is a tag above its own.  The earliest writer of a cell stores the
+    // new value (committed) or puts the old one back (held back).
+    uint32_t* const Qu = reinterpret_cast<uint32_t*>(Qf);
+    const uint4* const Qs4u = reinterpret_cast<const uint4*>(Qs);
+    const uint32_t tag_mine = ~(uint32_t)lane;
+    auto tag_round = [&](bool act, bool ch, float q, float qn) -> int {
+      if (ch) atomicMax(&Qu[p], tag_mine);
+      __builtin_amdgcn_wave_barrier();
+      uint32_t t = 0u, c2 = 0u;
+      if (act) {
+        c2 = Qu[p];
+        t = c2;
+#pragma unroll
+        for (uint32_t j = 0; j < WU / 4u; ++j) {
+          const uint4 v = Qs4u[ns * (WU / 4u) + j];
+          t = max(max(max(v.x, v.y), max(v.z, v.w)), t);
+        }
+      }
+      const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
+      const int stop = blocked ? __ffsll((long long)blocked) - 1 : B;
+      if (ch && c2 == tag_mine) Qf[p] = lane < stop ? qn : q;
+      __builtin_amdgcn_wave_barrier();
+      return stop;
+    };
     // (the first round on its own, in front of the loop over the rounds — most batches end with
     //  it —, as in k_tab_pwg)
+    int first;
     {
       float q = 0.0f, qn = 0.0f;
       if (on) {
@@ -321,41 +344,8 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         qn = td_of(q);
       }
       const bool ch = on && fbits(qn) != fbits(q);
-      const unsigned long long changed = __builtin_amdgcn_ballot_w64(ch);
-      if (!changed) return;
-      {
-        // exact conflict sets: all EARLIER lanes that write a cell this lane reads — its own
-        // cell (both buckets of p) or a cell of row ns (the W H1 buckets from (ns W) % 64, the H2
-        // bucket (ns W) / 64; W = 8: the eight buckets of ns % 8, bucket ns / 8)
-        const uint32_t h1 = p & 63u, h2 = p >> 6;
-        const unsigned long long bit = 1ull << lane;
-        if (on) {
-          atomicOr(&H1[h1], bit);
-          atomicOr(&H2[h2], bit);
-        }
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long cnd = 0ull;
-        if (on) {
-          const ulonglong2* const r8 = reinterpret_cast<const ulonglong2*>(&H1[(ns * WU) & 63u]);
-          const ulonglong2 ra = r8[0], rb = r8[1], rc = r8[2], rd = r8[3];
-          const unsigned long long cell = H1[h1] & H2[h2];
-          unsigned long long any = ((ra.x | ra.y) | (rb.x | rb.y)) | ((rc.x | rc.y) | (rd.x | rd.y));
-#pragma unroll
-          for (uint32_t j = 4; j < WU / 2u; ++j) any |= r8[j].x | r8[j].y;
-          const unsigned long long row = any & H2[(ns * WU) >> 6];
-          cnd = (cell | row) & (bit - 1ull);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (on) {
-          H1[h1] = 0ull;
-          H2[h2] = 0ull;
-        }
-        conf = cnd;
-      }
-      const unsigned long long blocked = __builtin_amdgcn_ballot_w64(on && (conf & changed) != 0ull);
-      if (blocked) first = __ffsll((long long)blocked) - 1;
-      if (ch && lane < first) Qf[p] = qn;
-      __builtin_amdgcn_wave_barrier();
+      if (!__builtin_amdgcn_ballot_w64(ch)) return;
+      first = tag_round(on, ch, q, qn);
     }
     while (first < B) {
       const bool act = on && lane >= first;
@@ -365,15 +355,8 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         qn = td_of(q);
       }
       const bool ch = act && fbits(qn) != fbits(q);
-      const unsigned long long changed = __ballot(ch);
-      int stop = B;
-      if (changed) {
-        const unsigned long long blocked = __ballot(act && (conf & changed) != 0ull);
-        if (blocked) stop = __ffsll((long long)blocked) - 1;
-        if (ch && lane < stop) Qf[p] = qn;
-        __builtin_amdgcn_wave_barrier();
-      }
-      first = stop;
+      if (!__ballot(ch)) return;
+      first = tag_round(act, ch, q, qn);
     }
   };
 
@@ -601,8 +584,8 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   const int S = world->n_states, A = world->n_actions;
   const int W = nact_width(A);
   const bool masked = (r.flags & COBEL_F_MASK_ACTIONS) != 0;
-  // (the conflict tables key a cell by s W + a in 13 bits, 14 on the wide rows; their packed log
-  //  record holds 13-bit states)
+  // (the packed log record holds 14-bit states on rows of 8, 13-bit states beyond; the table sizes
+  //  below are the tested ones)
   if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
       r.last_exp || (r.param_index && !r.param_sets) ||
       (masked && (!r.action_mask || (W > 8 && ((uintptr_t)r.action_mask & 3u)))) ||
