@@ -12,6 +12,11 @@ import bench  # noqa: E402
 from cobel_amd import _lib  # noqa: E402
 if os.environ.get('COBEL_LIB'):      # A/B builds of the library
     _lib.LIB_PATH = os.path.join(ROOT, 'cobel-rl_amd', 'lib', os.environ['COBEL_LIB'])
+if os.environ.get('PWG_SIDE'):       # (occupancy experiments: the same mazes on another grid)
+    _side = int(os.environ['PWG_SIDE'])
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze as _mk
+    _orig = bench.make_worlds
+    bench.make_worlds = lambda name: ([_mk(_side, _side, 1234 + k) for k in range(64)] if name == 'C3' else _orig(name))
 dev = torch.device('cuda', 0)
 pre = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cfg = dict(bench.CONFIGS['C3'])
