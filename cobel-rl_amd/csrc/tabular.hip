@@ -366,7 +366,10 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
     uint32_t* const Qu = reinterpret_cast<uint32_t*>(Qf);
     const uint4* const Qs4u = reinterpret_cast<const uint4*>(Qs);
     const uint32_t tag_mine = ~(uint32_t)lane;
-    auto tag_round = [&](bool act, bool ch, float q, float qn) -> int {
+    // (`lo` = the first lane of the round: only a table that held a tag pattern to begin with — a NaN
+    //  no arithmetic produces — can hold it back; it is committed regardless, so every round ends
+    //  one lane further: garbage in, garbage out, never a batch that does not end)
+    auto tag_round = [&](bool act, bool ch, float q, float qn, int lo) -> int {
       if (ch) atomicMax(&Qu[idx], tag_mine);
       __builtin_amdgcn_wave_barrier();
       uint32_t t = 0u, c2 = 0u;
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       t = 0u;
 #endif
       const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
-      const int stop = blocked ? __ffsll((long long)blocked) - 1 : BP;
+      const int stop = max(blocked ? __ffsll((long long)blocked) - 1 : BP, lo + 1);
       if (ch && c2 == tag_mine) Qf[idx] = lane < stop ? qn : q;
       __builtin_amdgcn_wave_barrier();
       return stop;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         STAMP(4);
         return;
       }
-      first = tag_round(on, ch, q, qn);
+      first = tag_round(on, ch, q, qn, 0);
     }
     while (first < BP) {
       const bool act = on && lane >= first;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
       }
       const bool ch = act && __builtin_bit_cast(uint32_t, qn) != __builtin_bit_cast(uint32_t, q);
       if (!__ballot(ch)) break;
-      first = tag_round(act, ch, q, qn);
+      first = tag_round(act, ch, q, qn, first);
     }
     STAMP(4);
   };

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
     uint32_t* const Qu = reinterpret_cast<uint32_t*>(Qf);
     const uint4* const Qs4u = reinterpret_cast<const uint4*>(Qs);
     const uint32_t tag_mine = ~(uint32_t)lane;
-    auto tag_round = [&](bool act, bool ch, float q, float qn) -> int {
+    // (`lo` = the first lane of the round: committed regardless — only a table that held a tag
+    //  pattern to begin with could hold it back —, so every round ends one lane further)
+    auto tag_round = [&](bool act, bool ch, float q, float qn, int lo) -> int {
       if (ch) atomicMax(&Qu[p], tag_mine);
       __builtin_amdgcn_wave_barrier();
       uint32_t t = 0u, c2 = 0u;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         }
       }
       const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
-      const int stop = blocked ? __ffsll((long long)blocked) - 1 : B;
+      const int stop = max(blocked ? __ffsll((long long)blocked) - 1 : B, lo + 1);
       if (ch && c2 == tag_mine) Qf[p] = lane < stop ? qn : q;
       __builtin_amdgcn_wave_barrier();
       return stop;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
       }
       const bool ch = on && fbits(qn) != fbits(q);
       if (!__builtin_amdgcn_ballot_w64(ch)) return;
-      first = tag_round(on, ch, q, qn);
+      first = tag_round(on, ch, q, qn, 0);
     }
     while (first < B) {
       const bool act = on && lane >= first;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
       }
       const bool ch = act && fbits(qn) != fbits(q);
       if (!__ballot(ch)) return;
-      first = tag_round(act, ch, q, qn);
+      first = tag_round(act, ch, q, qn, first);
     }
   };
 

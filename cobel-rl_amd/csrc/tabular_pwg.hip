@@ -310,7 +310,11 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
   uint32_t* const Qu = reinterpret_cast<uint32_t*>(lds);
   const uint4* const Qs4u = reinterpret_cast<const uint4*>(lds);
   uint32_t tag_mine = ~(uint32_t)lane;
-  auto tag_round = [&](uint32_t idx, uint32_t ns, bool act, bool ch, float q, float qn) -> int {
+  // (`lo` = the first lane of the round: nothing can hold it back — tags are raised by lanes of the
+  //  round only — unless the table held one of the tag patterns to begin with, a NaN no arithmetic
+  //  produces; the round then commits that lane regardless: garbage in, garbage out, but every
+  //  round ends one lane further and the batch ends)
+  auto tag_round = [&](uint32_t idx, uint32_t ns, bool act, bool ch, float q, float qn, int lo) -> int {
     if (ch) atomicMax(&Qu[idx], tag_mine);
     __builtin_amdgcn_wave_barrier();
     uint32_t t = 0u, c2 = 0u;
@@ -320,7 +324,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       t = max(max(max(r2.x, r2.y), r2.z), max(r2.w, c2));
     }
     const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
-    const int stop = blocked ? __ffsll((long long)blocked) - 1 : B;
+    const int stop = max(blocked ? __ffsll((long long)blocked) - 1 : B, lo + 1);
     if (ch && c2 == tag_mine) Qf[idx] = lane < stop ? qn : q;
     __builtin_amdgcn_wave_barrier();
     return stop;
@@ -337,7 +341,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       const float qn = plan_td(q, max4(row), r, nt);
       const bool ch = fbits(qn) != fbits(q);
       if (!__builtin_amdgcn_ballot_w64(ch)) return;
-      first = tag_round(idx, ns, true, ch, q, qn);
+      first = tag_round(idx, ns, true, ch, q, qn, 0);
     }
     // Later rounds (a lane was held back): the lanes from `first` on.
     while (first < B) {
@@ -350,7 +354,7 @@ __device__ __forceinline__ void pwg_instance(const pwg_args& A, const int i, con
       }
       const bool ch = act && fbits(qn) != fbits(q);
       if (!__ballot(ch)) return;
-      first = tag_round(idx, ns, act, ch, q, qn);
+      first = tag_round(idx, ns, act, ch, q, qn, first);
     }
   };
   // ---- one batch, Q in global memory: inputs (row, q) already in registers -------------------

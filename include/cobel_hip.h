@@ -289,7 +289,12 @@ COBEL_API int cobel_param_set_fill(double alpha, double gamma, double epsilon, d
 
 typedef struct {
   /* tables, all caller-owned device memory */
-  float* q;              /* [N][S][4] float32 Q                                              */
+  float* q;              /* [N][S][4] float32 Q.  The replayed updates of a step use the bit
+                            patterns 0xffffffc0 .. 0xffffffff inside the table as lane tags while
+                            a batch runs (NaNs of a payload no arithmetic produces: the reference's
+                            tables never hold them).  A table that holds such a pattern — e.g.
+                            uninitialised memory — is garbage in, garbage out (the cell may be
+                            taken for a tag); every batch still ends.                           */
   uint64_t* model;       /* DYNAQ: [N][S][4] packed {f32 R; u16 NS; u8 nonterminal; u8 0}    */
   uint16_t* model_index; /* DYNAQ, optional: [N][S][4] 16-bit digest of `model`
                             (next | nonterminal << 14 | (R != +0) << 15, cobel_model_index_build),

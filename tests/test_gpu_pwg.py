@@ -220,3 +220,28 @@ def test_scratch_check_reports_a_raised_abort_word():
     assert 'sliced launch' in str(err.value)
     agent._scratch[255] = 0
     agent.check_launches()
+
+
+@pytest.mark.parametrize('side,flags_name', [(8, None), (32, None), (32, 'F_NO_PWG')])
+def test_tables_full_of_tag_patterns_end_the_batch(side, flags_name):
+    """The dependency test of the planning batch raises cells to tags 0xffffffc0 .. 0xffffffff — NaN
+    payloads no arithmetic produces.  A caller's table that HOLDS such patterns (uninitialised
+    memory, 0xff fill) is garbage in, garbage out, but it must not hold a lane back for ever: the
+    first lane of a round is committed regardless, so every batch ends (k_tab_wpi at 8 x 8,
+    k_tab_pwg and k_tab_wpi at 32 x 32)."""
+    from cobel_amd import _lib
+    from cobel_amd.agent import DynaQ
+    from cobel_amd.interface import Gridworld
+    from cobel_amd.misc.gridworld_tools import make_obstacle_maze
+    from cobel_amd.policy import EpsilonGreedy
+    env = Gridworld([make_obstacle_maze(side, side, 1234)], n_envs=96, seed=SEED,
+                    device=torch.device('cuda', 0))
+    agent = DynaQ(env.observation_space, env.action_space, EpsilonGreedy(0.1))
+    if flags_name:
+        agent.extra_flags = getattr(_lib, flags_name)
+    agent._bind(env)
+    agent._q.view(torch.int32).fill_(-1)                       # every cell 0xffffffff
+    agent._q.view(torch.int32)[:, ::3, :] = -64                # ... or 0xffffffc0
+    agent.train(env, 2, 30, 50)
+    torch.cuda.synchronize()
+    assert 0 < agent.env_steps() <= 96 * 60
