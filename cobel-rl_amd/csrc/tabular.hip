@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
   };
   auto log_gather = [&](uint32_t x, uint32_t bound, uint32_t have) -> uint64_t {
     uint64_t rec = 0;
-    if (lane < B && bound > 0u) {
+    if (lane < BP && bound > 0u) {
       const uint32_t idx = cobel_bounded(x, bound);
       if (idx < have) rec = rlog[idx];
     }
@@ -775,14 +775,30 @@ __global__ __launch_bounds__(64) void k_tab_wpi(const tab_args A) {
         const uint32_t bound_next = loglen + room;
         uint64_t qrec_next = log_gather(qx_next, bound_next, loglen);
         if (bound_now > 0u) {
-          if (lane < B && cobel_bounded(qx, bound_now) == fresh_idx) qrec = fresh_rec;
+          if (lane < BP && cobel_bounded(qx, bound_now) == fresh_idx) qrec = fresh_rec;
           replay_log(qrec);
+          // updates kPassLanes .. B - 1 of this step's batch (agent/q.py:344-354 draws ONE vector
+          // of indices: element j comes from sub-stream j), gathered here — the log as it stands,
+          // this step's own record from registers — and applied pass by pass, in order
+          if (__builtin_expect(B > kPassLanes, 0)) {
+            for (int j0 = kPassLanes; j0 < B; j0 += kPassLanes) {
+              Bp = B - j0 < kPassLanes ? B - j0 : kPassLanes;
+              const cobel_u4 b = cobel_philox(cm >> 2, (uint32_t)(j0 + lane), g, COBEL_STREAM_MEMORY, seed);
+              uint64_t rec2 = 0;
+              if (lane < Bp) {
+                const uint32_t idx2 = cobel_bounded(cobel_word(b, cm & 3u), bound_now);
+                rec2 = idx2 == fresh_idx ? fresh_rec : rlog[idx2];
+              }
+              replay_log(rec2);
+            }
+            Bp = kPassLanes;
+          }
           batches += 1u;
         }
         cm += 1u;
         qx = qx_next;
         // the gather may have passed this step's own append
-        if (lane < B && bound_next > 0u && cobel_bounded(qx, bound_next) == fresh_idx)
+        if (lane < BP && bound_next > 0u && cobel_bounded(qx, bound_next) == fresh_idx)
           qrec_next = fresh_rec;
         qrec = qrec_next;
       }
@@ -1276,8 +1292,8 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   // more than COBEL_MAX_BATCH updates per step, tables beyond LDS — take
   // the general kernel (general.hip: one lane per instance, every update in sequence).
   int32_t lds_max = 0;
-  // (Dyna-Q plans batches above COBEL_MAX_BATCH in several passes of the generic wavefront
-  //  kernel; QAgent's log replay gathers its records a step ahead, one lane each: general kernel)
+  // (batches above COBEL_MAX_BATCH run as several passes of the wavefront kernels: Dyna-Q's pairs
+  //  and — round 6 — QAgent's log records beyond the first pass are drawn and gathered in the step)
   const int32_t pass = r.batch > COBEL_MAX_BATCH ? COBEL_MAX_BATCH : r.batch;
   // (worlds whose transition rows are distributions: the generic wavefront kernels draw the
   //  successor in the step — no fast / digest / lane-per-instance / persistent form for them)
@@ -1289,7 +1305,8 @@ static int tab_run_impl(const cobel_world_t* world, const cobel_tab_run_t* run, 
   //  Q-learning 6.0 / 6.3 ms on k_tab_general against 11.4 / 20.8 on the wavefront kernel, Dyna-Q
   //  B 32 44 / 72 ms against 14.6 / 34.9: scripts/experiments/exp_tab_slippery.py)
   const bool general = world->n_actions != 4 || (draws && !replays) ||
-                       (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ) ||
+                       (r.batch > COBEL_MAX_BATCH && r.agent != COBEL_AGENT_DYNAQ &&
+                        (r.flags & COBEL_F_EPISODIC)) ||
                        (r.flags & COBEL_F_TAB_GENERAL) ||
                        cobel_tab_query(world->n_states, r.agent, pass, &lds_max, nullptr) != COBEL_OK;
   // Q-learning on worlds of other action counts whose tables fit the LDS: one wavefront per instance

@@ -228,8 +228,11 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   const bool learn = PLAIN || (flags & COBEL_F_LEARN) != 0;
   uint64_t* const rlog = G.r.replay_log ? G.r.replay_log + (size_t)i * G.r.log_cap : nullptr;
   const uint32_t cap = rlog ? (uint32_t)G.r.log_cap : 0u;
-  const int B = PLAIN ? max(G.r.batch, 1)
-                      : ((learn && !(flags & COBEL_F_NO_REPLAY) && rlog) ? G.r.batch : 0);
+  // (BT = the batch; B = the updates one pass of the wavefront takes — lane j < B owns update j —,
+  //  batches beyond COBEL_MAX_BATCH run as further passes behind the first: see the replay below)
+  const int BT = PLAIN ? max(G.r.batch, 1)
+                       : ((learn && !(flags & COBEL_F_NO_REPLAY) && rlog) ? G.r.batch : 0);
+  const int B = BT > COBEL_MAX_BATCH ? COBEL_MAX_BATCH : BT;
   const uint32_t pol_stream =
       (flags & COBEL_F_TEST_STREAM) ? COBEL_STREAM_POLICY_TEST : COBEL_STREAM_POLICY;
   uint64_t seed = G.r.seed;
@@ -289,7 +292,8 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
   };
 
   // ---- B sequential float32 TD updates (q.py:305-313), speculative rounds ------------------------
-  auto run_batch = [&](uint64_t rec) {
+  // (nb = the updates of this pass: B, fewer in the last of several passes)
+  auto run_batch = [&](uint64_t rec, const int nb) {
     const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
     const uint32_t s = W == 8 ? hi & 0x3fffu : hi & 0x1fffu;
     const uint32_t ns = W == 8 ? (hi >> 14) & 0x3fffu : (hi >> 13) & 0x1fffu;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
     const uint32_t nt = W == 8 ? (hi >> nt_shift) & 1u : hi >> 31;
     const float r = __builtin_bit_cast(float, lo);
     const uint32_t p = s * WU + a;
-    const bool on = lane < B;
+    const bool on = lane < nb;
     auto td_of = [&](float q) -> float {
       const float m = W == 8 ? max8(Qs[ns * 2u], Qs[ns * 2u + 1u]) : row_max(ns);
       const float gnt = nt ? gamma_f : 0.0f;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         }
       }
       const unsigned long long blocked = __builtin_amdgcn_ballot_w64(act && t > tag_mine);
-      const int stop = max(blocked ? __ffsll((long long)blocked) - 1 : B, lo + 1);
+      const int stop = max(blocked ? __ffsll((long long)blocked) - 1 : nb, lo + 1);
       if (ch && c2 == tag_mine) Qf[p] = lane < stop ? qn : q;
       __builtin_amdgcn_wave_barrier();
       return stop;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
       if (!__builtin_amdgcn_ballot_w64(ch)) return;
       first = tag_round(on, ch, q, qn, 0);
     }
-    while (first < B) {
+    while (first < nb) {
       const bool act = on && lane >= first;
       float q = 0.0f, qn = 0.0f;
       if (act) {
@@ -532,7 +536,22 @@ __global__ __launch_bounds__(512) void k_tab_wqn(const nact_args G) {
         } else if (idx_cur + 1u == loglen && have_prev) {
           rec = fresh_prev;
         }
-        run_batch(rec);
+        run_batch(rec, B);
+        // updates COBEL_MAX_BATCH .. BT - 1 of this step's batch (agent/q.py:344-354 draws ONE vector of
+        // indices: element j comes from sub-stream j), gathered here — the log as it stands, this
+        // step's own record from registers — and applied pass by pass, in order
+        if (__builtin_expect(BT > COBEL_MAX_BATCH, 0)) {
+          for (int j0 = COBEL_MAX_BATCH; j0 < BT; j0 += COBEL_MAX_BATCH) {
+            const int nb = BT - j0 < COBEL_MAX_BATCH ? BT - j0 : COBEL_MAX_BATCH;
+            const cobel_u4 b = cobel_philox(cm >> 2, (uint32_t)(j0 + lane), g, COBEL_STREAM_MEMORY, seed);
+            uint64_t rec2 = 0;
+            if (lane < nb) {
+              const uint32_t idx2 = cobel_bounded(cobel_word(b, cm & 3u), loglen);
+              rec2 = (appended && idx2 + 1u == loglen) ? fresh_cur : rlog[idx2];
+            }
+            run_batch(rec2, nb);
+          }
+        }
       }
       cm += 1u;
       rec_cur = rec_next;
@@ -591,7 +610,7 @@ bool nact_plan(const cobel_world* world, const cobel_tab_run_t& r, int* wpg_out,
   if (r.agent != COBEL_AGENT_Q || A == 4 || A < 1 || A > 32 || !world->next_n || world->succ_off ||
       r.last_exp || (r.param_index && !r.param_sets) ||
       (masked && (!r.action_mask || (W > 8 && ((uintptr_t)r.action_mask & 3u)))) ||
-      (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) || r.batch > COBEL_MAX_BATCH ||
+      (r.flags & (COBEL_F_TAB_GENERAL | COBEL_F_EPISODIC)) ||
       S > 1024 || (size_t)S * W > (W == 8 ? 8192u : 16384u) || r.n < 1)
     return false;
   const bool shared = world->n_worlds == 1;

@@ -384,10 +384,10 @@ typedef struct {
 
 /* Largest batch the wavefront kernels plan in one pass (one lane per update).  Larger batches —
  * the reference has no limit (agent/dyna_q.py:319-330, memory/dyna_q.py:137) — are planned by
- * Dyna-Q in ceil(batch / 62) passes per step (the passes run one after the other, so the
- * sequential order of the reference's loop is kept); QAgent's log replay beyond 62 runs on the
- * general kernel: one lane per instance, every update in the reference's sequential order, tables
- * in HBM / L2; that kernel is also taken where no wavefront kernel covers a world with an action
+ * Dyna-Q and QAgent in ceil(batch / 62) passes per step (the passes run one after the other, so
+ * the sequential order of the reference's loop is kept).  The general kernel — one lane per
+ * instance, every update in the reference's sequential order, tables in HBM / L2 — is taken where
+ * no wavefront kernel covers a world with an action
  * count other than four (Q is then [N][S][n_actions], replay records carry the action in bits 28-30
  * and the nonterminal flag in bit 31 of the high word; QAgent runs one wavefront per instance on
  * 1 .. 32 actions) and for state counts whose tables

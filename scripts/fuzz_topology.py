@@ -2,7 +2,7 @@
 from 2 * 10^6 on: 1..32 with a random action mask in half of the cases — bytes up to eight actions,
 32-bit words beyond) — random directed graphs
 (every node the same neighbour count, as `Topology` requires), random rewards / terminals / start
-nodes, replay batches 0..70 — against the NumPy restatement of the reference's loop
+nodes, replay batches 0..130 — against the NumPy restatement of the reference's loop
 (oracle/ref_loop.py, fed with the build's streams through TapeRNG).
 
     python scripts/fuzz_topology.py [first_seed] [count]
@@ -51,7 +51,7 @@ def draw_case(seed: int) -> dict:
     return dict(seed=seed, S=S, A=A, nbr=nbr, terminal=terminal, reward=reward, starts=starts, mask=mask,
                 n=int(r.choice([1, 2, 64, 130])), base=int(r.choice([0, 3, 1 << 16])),
                 trials=int(r.integers(1, 6)), steps=int(r.integers(1, 41)),
-                batch=int(r.choice([0, 0, 1, 8, 24, 62, 63, 70])),
+                batch=int(r.choice([0, 0, 1, 8, 24, 62, 63, 70, 130])),
                 alpha=float(r.choice([0.9, 0.5, 1.0, 0.1])), gamma=float(r.choice([0.8, 0.99, 0.0])),
                 eps=float(r.choice([0.1, 0.3, 0.0, 1.0])), second=bool(r.random() < 0.3))
 

@@ -169,7 +169,7 @@ def test_general_kernel_equals_wavefront_kernels(torch_cuda, golden_worlds):
 @pytest.mark.parametrize('agent_name', ['dynaq', 'q'])
 def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
     """batch_size = 100 (the reference has no limit; one wavefront plans at most 62 per pass):
-    Dyna-Q in two passes of the wavefront kernel, QAgent on the general kernel, against the C
+    Dyna-Q and — since round 6 — QAgent in two passes of the wavefront kernel, against the C
     oracle — Q, model tables, replay counters, latencies."""
     torch = torch_cuda
     from oracle import c_oracle
@@ -201,6 +201,8 @@ def test_batch_of_100_updates_vs_oracle(torch_cuda, golden_worlds, agent_name):
         ag = QAgent(env.observation_space, env.action_space, EpsilonGreedy(0.1))
         ag.track_instances = True
         ag.train(env, trials, steps, B)
+        assert ag.describe_launch(env, ag.policy, _lib.F_LEARN, trials, steps, 0, B)['kernel'] == \
+            _lib.TAB_KERNEL_WPI
         o = c_oracle.TabOracle(w, n, c_oracle.AG_Q, SEED, True, alpha=0.9, gamma=0.8,
                                trial_cap=trials, log_cap=trials * steps)
         o.run(trials, steps, B)
