@@ -320,7 +320,9 @@ def test_batches_done_counts_what_planning_evaluates(torch_cuda):
                           (1, 1, 4, False), (6, 1, 32, True), (8, 1, 20, True), (3, 1, 0, True),
                           (12, 1, 32, True), (20, 1, 16, False), (12, 2, 16, True), (30, 3, 9, False),
                           (6, 1, 32, 'psets'), (12, 1, 16, 'psets'), (6, 2, 8, 'occupancy'),
-                          (12, 1, 32, 'occupancy')])
+                          (12, 1, 32, 'occupancy'),
+                          # batches above 62: further passes of the wavefront kernel (round 6)
+                          (6, 1, 100, False), (12, 1, 70, True), (5, 2, 130, False)])
 def test_wavefront_kernel_for_other_action_counts_equals_the_general_kernel(torch_cuda, A, n_worlds, batch,
                                                                             masked):
     """Q-learning on worlds of 1..32 (not four) actions, with an action mask or without, runs one
