@@ -1,3 +1,4 @@
+# (with staggered_split.patch applied: COBEL_DEBUG_PWG_SPLIT exists only there)
 # (on the GPU box) split launches against whole instances on C3 and its shards
 export COBEL_DEBUG=1
 E=scripts/experiments/exp_pwg.py
