@@ -923,6 +923,13 @@ def run_config(cfg_name, args, rank, world_size, device, dist, repeat_for=0.0):
         res['roofline']['issue'] = iss
     if cfg_name in ('C2', 'C6'):
         res['roofline'] = to_issue_bound(res['roofline'])
+    elif cfg_name == 'C3':
+        res['roofline']['note'] = (
+            'frac = SURVEY 8d bytes of the work done / launch time / 8 TB/s: the north-star\'s '
+            'accounting.  Since round 6 the kernel keeps every Q table in LDS for the whole launch '
+            '(ten per CU): `traffic` — the L2 <-> fabric bytes of the counter passes, staging, '
+            'write-back and digest gathers — is a tenth of the accounted bytes, and what bounds the '
+            'kernel is the chain of one wave\'s step (`limiter`, `issue`; DESIGN.md section 4.1d)')
     if dynaq:
         # (this rank's instances; counted by the kernel: cobel_tab_run_t.batches_done)
         drawn = steps_per_launch * args.steps
