@@ -333,6 +333,8 @@ def gen_dynaq(worlds):
         'walls8_mask_f32': ('walls_8x8', 4, True, 25, 60, 8, {'mask': True}),
         'walls8_traintest_f32': ('walls_8x8', 5, True, 20, 40, 12, {'test_trials': 10}),
         'maze32_b50_f32': ('maze_32x32_1234', 6, True, 3, 200, 50, {}),
+        # more updates per step than one wavefront takes in a pass (round 6: 62 + 62 + 6)
+        'walls8_b130_f32': ('walls_8x8', 7, True, 10, 40, 130, {}),
     }
     out = {}
     for name, (wname, inst, f32, trials, steps, B, kw) in cases.items():
@@ -527,6 +529,8 @@ def gen_qagent(worlds):
         'open5_b8_f32': ('open_5x5', 1, True, 30, 50, 8),
         'walls8_b16_f32': ('walls_8x8', 2, True, 20, 60, 16),
         'walls8_b16_f64': ('walls_8x8', 2, False, 20, 60, 16),
+        # more replayed experiences per step than one wavefront takes in a pass (round 6: 62 + 38)
+        'walls8_b100_f32': ('walls_8x8', 3, True, 10, 40, 100),
     }
     out = {}
     for name, (wname, inst, f32, trials, steps, B) in cases.items():

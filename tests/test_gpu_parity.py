@@ -167,7 +167,8 @@ def _dynaq(golden, golden_worlds, name, n_envs, base, callbacks=None):
 
 
 DYNAQ_F32 = ['open5_b32_f32', 'open5_b50_f32_i7', 'open5_noreplay_f32', 'open5_episodic_f32',
-             'walls8_b8_f32', 'walls8_mask_f32', 'walls8_traintest_f32', 'maze32_b50_f32']
+             'walls8_b8_f32', 'walls8_mask_f32', 'walls8_traintest_f32', 'maze32_b50_f32',
+             'walls8_b130_f32']
 
 
 @pytest.mark.parametrize('name', DYNAQ_F32)
@@ -263,7 +264,7 @@ def test_dynaq_chunking_and_sharding_invariance(torch_cuda, golden, golden_world
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name', ['open5_b0_f32', 'open5_b8_f32', 'walls8_b16_f32'])
+@pytest.mark.parametrize('name', ['open5_b0_f32', 'open5_b8_f32', 'walls8_b16_f32', 'walls8_b100_f32'])
 def test_qagent_golden(torch_cuda, golden, golden_worlds, name):
     from cobel_amd.agent import QAgent
     from cobel_amd.interface import Gridworld

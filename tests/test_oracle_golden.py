@@ -105,7 +105,7 @@ def _dq(golden):
 @pytest.mark.parametrize('name', ['maze32_b50_f32', 'open5_b32_f32', 'open5_b32_f64',
                                   'open5_b50_f32_i7', 'open5_episodic_f32', 'open5_noreplay_f32',
                                   'walls8_b8_f32', 'walls8_b8_f64', 'walls8_mask_f32',
-                                  'walls8_traintest_f32'])
+                                  'walls8_traintest_f32', 'walls8_b130_f32'])
 def test_dynaq_golden(golden, golden_worlds, name):
     D = _dq(golden)
     inst, f32, trials, steps, B, norep, epi, mask, tt, nts = [int(x) for x in D[name + '/cfg']]
@@ -155,7 +155,7 @@ def test_dynaq_golden(golden, golden_worlds, name):
 
 
 @pytest.mark.parametrize('name', ['open5_b0_f32', 'open5_b0_f64', 'open5_b8_f32',
-                                  'walls8_b16_f32', 'walls8_b16_f64'])
+                                  'walls8_b16_f32', 'walls8_b16_f64', 'walls8_b100_f32'])
 def test_qagent_golden(golden, golden_worlds, name):
     D = golden('qagent_traces')
     inst, f32, trials, steps, B = [int(x) for x in D[name + '/cfg']]
